@@ -1,0 +1,168 @@
+/*
+ * hdsm.h — C ABI of the MI355X-native batched trajectory-optimisation solver.
+ *
+ * This is the drop-in boundary for ONE hot path of lis-epfl/multi_agent_pkgs: the per-agent
+ * receding-horizon MIQP that `multi_agent_planner::Agent` builds and hands to Gurobi every 100 ms.
+ * Citations are relative to the reference repo; AC = multi_agent_planner/src/agent_class.cpp,
+ * AH = multi_agent_planner/include/multi_agent_planner/agent_class.hpp.
+ *
+ * The reference has no plugin/FFI interface for this path: the seam is the set of Gurobi C++ calls inside
+ * the private method Agent::SolveOptimizationProblem() (AC:858-1023), which communicates only through
+ * member variables. Each entry point below names the reference code it replaces. INTEGRATION.md shows the
+ * few lines a maintainer of the reference adds to agent_class.cpp to call it.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; all reals are IEEE double (decimal_t = double in the reference,
+ *     decomp_basis/data_type.h:50; ROS float64; Gurobi doubles);
+ *   - every function returns 0 on success and a negative hdsm_error on API misuse / device error; nothing
+ *     throws (the reference swallows every Gurobi exception too, AC:988-995);
+ *   - per-instance solver outcome is reported in `status[]` (hdsm_status), never through the return code;
+ *   - one handle per calling thread; a handle is not thread-safe (the reference calls the solver from one
+ *     dedicated thread per agent, AC:119);
+ *   - the library needs a gfx950 device: there is NO CPU fallback. hdsm_create() fails with
+ *     HDSM_ERR_NO_DEVICE when no HIP device is present.
+ *
+ * Array layouts (row-major, C order). N = n_hor, P = poly_hor, RS = max_rows_static:
+ *   state_curr  [n_inst][9]          (px,py,pz, vx,vy,vz, ax,ay,az)           state_curr_   AH:446
+ *   traj_ref    [n_inst][N][6]       rows 0..N-1 of traj_ref_curr_ (p, v)       AC:864-883
+ *   traj_out    [n_inst][N+1][9]     traj_curr_                                 AH:459, AC:962-971
+ *   ctrl_out    [n_inst][N][3]       control_curr_                              AH:461, AC:973-977
+ *   poly_used   [n_inst][P]  uint8   poly_used_idx_                             AH:483, AC:979-985
+ *   plans_all   [n_rob][N+1][9]      the all-gathered traj_full of every agent  Trajectory.msg, AC:645-677
+ *   has_plan    [n_rob]      uint8   0 = no message received from that agent yet (AC:1134)
+ */
+#ifndef HDSM_H
+#define HDSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDSM_MAX_HOR 16         /* largest supported n_hor (reference ships 9, BASELINE uses 10 and 15)   */
+#define HDSM_MAX_POLY 8         /* largest supported poly_hor (reference ships 3 or 4)                    */
+#define HDSM_MAX_ROWS_STATIC 32 /* largest supported rows per static polyhedron (GetPolyOcta3D emits <=18)*/
+#define HDSM_INF 1e100          /* GRB_INFINITY: bounds with |value| >= 1e20 are treated as absent        */
+
+typedef enum hdsm_error {
+  HDSM_OK = 0,
+  HDSM_ERR_BAD_ARG = -1,    /* null pointer, size out of range, unsupported parameter combination        */
+  HDSM_ERR_NO_DEVICE = -2,  /* no gfx950 HIP device / device index out of range                           */
+  HDSM_ERR_DEVICE = -3,     /* HIP runtime error (allocation, launch, copy); see hdsm_last_error()       */
+  HDSM_ERR_CAPACITY = -4    /* n_inst > max_instances or n_rob > handle capacity                         */
+} hdsm_error;
+
+/* Per-instance outcome. The reference never inspects Gurobi's status (AC:959-995): a time-limit WITH an
+ * incumbent is silently accepted as success, everything else surfaces as an exception -> fallback.       */
+typedef enum hdsm_status {
+  HDSM_OPTIMAL = 0,    /* proven optimal assignment + KKT point (residuals <= solver tolerance)            */
+  HDSM_LIMIT = 1,      /* node/iteration limit hit, incumbent returned (Gurobi TimeLimit with incumbent)   */
+  HDSM_NO_SOLUTION = 2 /* infeasible, limit without incumbent, or degenerate input (NaN plane): the caller
+                          applies the shift-by-one fallback of AC:1000-1019; outputs are left untouched    */
+} hdsm_status;
+
+/* Mirrors the Agent members the solve reads (AH:297-357, AH:426-432); filled from the ROS parameters
+ * exactly as InitializePlannerParameters does (AC:2169-2188).                                             */
+typedef struct hdsm_params {
+  int32_t n_hor;            /* N, n_hor_                                       AH:297                      */
+  int32_t poly_hor;         /* P, poly_hor_                                    AH:373                      */
+  int32_t rk4;              /* rk4_: 0 forward Euler, 1 classical RK4          AC:2115-2152                */
+  int32_t max_rows_static;  /* RS: row capacity of one static polyhedron in A_static (<= HDSM_MAX_ROWS_STATIC) */
+  double dt;                /* dt_                                                                          */
+  double drag[3];           /* drag_coeff_                                     AC:2157-2165                */
+  double r_u;               /* r_u_  jerk weight                               AC:2098                     */
+  double r_x[9];            /* r_x_  running state weights (only [0..5] used)  AC:871-883                  */
+  double r_n[9];            /* r_n_  terminal state weights (only [0..5] used)                             */
+  double x_lb[9], x_ub[9];  /* x_lb_/x_ub_ (positions +-HDSM_INF)              AC:2179-2184                */
+  double u_lb[3], u_ub[3];  /* u_lb_/u_ub_                                     AC:2185-2186                */
+  double drone_radius;      /* drone_radius_                                   AH:342                      */
+  double drone_z_offset;    /* drone_z_offset_                                 AH:344                      */
+  double plane_perturb;     /* var_tmp = 0.1 hard-coded in the reference       AC:1180                     */
+  /* Deterministic stand-ins for Gurobi's wall-clock TimeLimit = 0.08 s (AC:952): a time-limited solve is
+   * not reproducible, so limits are expressed in work units. 0 = library default.                         */
+  int32_t max_nodes;        /* branch-and-bound node budget per instance                                   */
+  int32_t max_qp_iters;     /* active-set iteration budget per instance (summed over nodes)                */
+  double feas_tol_fixed;    /* tolerance for rows on the pinned point p_0 (Gurobi FeasibilityTol 1e-6)     */
+  double solver_tol;        /* primal feasibility tolerance of the exact active-set solver (default 1e-9)  */
+} hdsm_params;
+
+/* Fills `p` with the agile configuration shipped by the reference
+ * (multi_agent_planner/config/agent_agile_config.yaml) with n_hor overridden by the caller.               */
+void hdsm_default_params(hdsm_params* p, int32_t n_hor);
+
+/* Replaces: GRBEnv/GRBModel construction + Agent::CreateGurobiModel() (AC:5, AC:32, AC:2063-2153), done
+ * once per process in the reference. Builds the condensed dynamics, the Hessian factor and every
+ * config-level constant on the host, uploads them, allocates per-instance device scratch.
+ * `n_rob_max` bounds the n_rob later passed to hdsm_replan / hdsm_replan_device. `device` = HIP device ordinal.               */
+int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_max, int32_t device,
+                void** handle);
+void hdsm_destroy(void* handle);
+
+/* Level 2 — fused stand-in for Agent::GenerateTimeAwareSafeCorridor() (AC:1086-1215, AddHyperplane
+ * AC:1217-1234) followed by Agent::SolveOptimizationProblem() (AC:858-1023): the caller passes the static
+ * polyhedra (poly_const_vec_, AH:469) and the all-gathered plans of every agent; the separating planes
+ * are generated on the device and never materialised.
+ *
+ *   agent_id      [n_inst]  id_ of each instance: its own previous plan is plans_all[agent_id] when
+ *                 has_plan[agent_id] != 0 (traj_curr_), else state_curr (state_ini_, AC:1103-1110); it
+ *                 never builds a plane against itself (AC:617).
+ *   n_poly        [n_inst]  poly_const_vec_.size(); only the first min(P, n_poly) are used (AC:913).
+ *   n_rows_static [n_inst][P]
+ *   A_static      [n_inst][P][RS][3], b_static [n_inst][P][RS]   rows A x <= b (polyhedron.h:98-147)
+ *
+ * Host-pointer form: copies inputs to the device, runs, copies results back (PCIe-inclusive).             */
+int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
+                uint8_t* poly_used, int32_t* status, double* obj);
+
+/* Same contract, every pointer is a DEVICE pointer, the launch is asynchronous on `hip_stream`
+ * (a hipStream_t passed as void*; NULL = the default stream). Nothing is copied or synchronised: this is
+ * the form the batched harness and bench.py time, with inputs resident in HBM. `traj_out` may alias the
+ * caller's shard of the NEXT round's plans buffer (it must not alias `plans_all` of this call).           */
+int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                       const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                       const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                       const double* plans_all, const uint8_t* has_plan, double* traj_out,
+                       double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
+                       void* hip_stream);
+
+/* Level 1 — exact stand-in for the Gurobi part alone (AC:870-1019): the caller passes the fully formed
+ * per-step polyhedra poly_const_final_vec_[N][<=P] (AH:471), i.e. static rows followed by the neighbour
+ * planes AddHyperplane appended.
+ *
+ *   n_poly  [n_inst][N]          poly_const_final_vec_[i].size()
+ *   n_rows  [n_inst][N][P]       rows of polyhedron (i, j)
+ *   A       [n_inst][N][P][r_max][3],  b [n_inst][N][P][r_max]
+ * Host pointers; PCIe-inclusive.                                                                          */
+int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_curr,
+               const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows, const double* A,
+               const double* b, double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status,
+               double* obj);
+
+/* Stand-alone plane generator = Agent::GenerateTimeAwareSafeCorridor's inner maths (AC:1100-1205) for one
+ * batch: planes[n_inst][N][n_rob][4] = (n_f.x, n_f.y, n_f.z, n_f . q), rows of absent/self agents are
+ * filled with zeros. Host pointers. Used by tests and by callers that want the level-1 input.             */
+int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                     const double* state_curr, const double* plans_all, const uint8_t* has_plan,
+                     double* planes);
+
+/* Diagnostics of the last hdsm_replan / hdsm_replan_device / hdsm_solve call on this handle (host arrays, may be NULL):
+ *   qp_iters[n_inst]  active-set iterations, nodes[n_inst]  branch-and-bound nodes,
+ *   sweeps[n_inst]    full passes over the neighbour buffer, cand[n_inst] neighbour rows ever staged.
+ * Synchronises the handle's stream.                                                                       */
+int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
+                    int32_t* cand);
+
+/* Text of the last error on this thread (HIP error string or argument check that failed).                 */
+const char* hdsm_last_error(void);
+
+/* Library/ABI version: (major << 16) | minor.                                                             */
+int32_t hdsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HDSM_H */

@@ -1,0 +1,83 @@
+"""ctypes mirror of `hdsm_params` (include/hdsm.h) and the reference's shipped configurations.
+
+The field values of :func:`agile_params` are the ROS parameters of
+``multi_agent_planner/config/agent_agile_config.yaml`` of the reference, turned into solver bounds the way
+``Agent::InitializePlannerParameters`` does (agent_class.cpp:2169-2188).
+"""
+import ctypes as C
+
+HDSM_MAX_HOR = 16
+HDSM_MAX_POLY = 8
+HDSM_MAX_ROWS_STATIC = 32
+HDSM_INF = 1e100
+
+HDSM_OPTIMAL, HDSM_LIMIT, HDSM_NO_SOLUTION = 0, 1, 2
+
+
+class HdsmParams(C.Structure):
+    _fields_ = [
+        ("n_hor", C.c_int32),
+        ("poly_hor", C.c_int32),
+        ("rk4", C.c_int32),
+        ("max_rows_static", C.c_int32),
+        ("dt", C.c_double),
+        ("drag", C.c_double * 3),
+        ("r_u", C.c_double),
+        ("r_x", C.c_double * 9),
+        ("r_n", C.c_double * 9),
+        ("x_lb", C.c_double * 9),
+        ("x_ub", C.c_double * 9),
+        ("u_lb", C.c_double * 3),
+        ("u_ub", C.c_double * 3),
+        ("drone_radius", C.c_double),
+        ("drone_z_offset", C.c_double),
+        ("plane_perturb", C.c_double),
+        ("max_nodes", C.c_int32),
+        ("max_qp_iters", C.c_int32),
+        ("feas_tol_fixed", C.c_double),
+        ("solver_tol", C.c_double),
+    ]
+
+    def copy(self):
+        other = HdsmParams()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(self))
+        return other
+
+
+def make_params(n_hor=10, poly_hor=4, rk4=False, dt=0.1, drag=(0.0, 0.0, 0.0), r_u=0.01,
+                r_x=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0),
+                r_n=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0),
+                max_vel=20.0, max_acc_xy=15.0, min_acc_xy=-15.0, max_acc_z=15.0, min_acc_z=-15.0,
+                max_jerk=60.0, drone_radius=0.25, drone_z_offset=0.25, plane_perturb=0.1,
+                max_rows_static=18, max_nodes=0, max_qp_iters=0, feas_tol_fixed=1e-6, solver_tol=1e-9):
+    """Build an HdsmParams the way InitializePlannerParameters builds x_lb_/x_ub_/u_lb_/u_ub_ (n_x = 9)."""
+    p = HdsmParams()
+    p.n_hor, p.poly_hor, p.rk4, p.max_rows_static = n_hor, poly_hor, int(bool(rk4)), max_rows_static
+    p.dt, p.r_u = dt, r_u
+    for k in range(3):
+        p.drag[k] = drag[k]
+    for k in range(9):
+        p.r_x[k], p.r_n[k] = r_x[k], r_n[k]
+    lb = [-HDSM_INF] * 3 + [-max_vel] * 3 + [min_acc_xy, min_acc_xy, min_acc_z]
+    ub = [HDSM_INF] * 3 + [max_vel] * 3 + [max_acc_xy, max_acc_xy, max_acc_z]
+    for k in range(9):
+        p.x_lb[k], p.x_ub[k] = lb[k], ub[k]
+    for k in range(3):
+        p.u_lb[k], p.u_ub[k] = -max_jerk, max_jerk
+    p.drone_radius, p.drone_z_offset, p.plane_perturb = drone_radius, drone_z_offset, plane_perturb
+    p.max_nodes, p.max_qp_iters = max_nodes, max_qp_iters
+    p.feas_tol_fixed, p.solver_tol = feas_tol_fixed, solver_tol
+    return p
+
+
+def agile_params(n_hor=10, **over):
+    """agent_agile_config.yaml (poly_hor 4, dt 0.1, jerk control) with n_hor overridden (BASELINE: 10 / 15)."""
+    return make_params(n_hor=n_hor, **over)
+
+
+def default_params(n_hor=9, **over):
+    """agent_default_config.yaml: poly_hor 3, max_vel 9.5, acc +-20, jerk 30, drone radius 0.125."""
+    kw = dict(poly_hor=3, max_vel=9.5, max_acc_xy=20.0, min_acc_xy=-20.0, max_acc_z=20.0, min_acc_z=-20.0,
+              max_jerk=30.0, drone_radius=0.125, drone_z_offset=0.125)
+    kw.update(over)
+    return make_params(n_hor=n_hor, **kw)
