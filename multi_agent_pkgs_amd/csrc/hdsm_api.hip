@@ -1,0 +1,374 @@
+// hdsm_api.hip — gfx950 kernels and the extern "C" boundary declared in include/hdsm.h.
+//
+// One workgroup solves one agent-replan (hdsm_core.h); the launch is a plain 1-D grid of n_inst blocks.
+// There is no CPU path in this library: without a HIP device hdsm_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/hdsm.h"
+#include "hdsm_consts.h"
+#include "hdsm_core.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return set_err(HDSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+
+constexpr int CMAX_DEFAULT = 768;
+
+template <int NV, int CMAX, int NT>
+__global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sol = hdsm::Solver<NV, CMAX>;
+  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
+  Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
+}
+
+// planes[n_inst][N][n_rob][4] for tests / level-1 callers (AC:1100-1205)
+__global__ __launch_bounds__(256) void k_tasc_planes(const hdsm::Consts* __restrict__ cp, int n_inst, int n_rob,
+                                                     const int32_t* agent_id, const double* state,
+                                                     const double* plans, const uint8_t* has_plan,
+                                                     double* planes) {
+  const hdsm::Consts& c = *cp;
+  const int N = c.N;
+  const int64_t total = (int64_t)n_inst * N * n_rob;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % n_rob);
+    const int i = (int)((idx / n_rob) % N);
+    const int inst = (int)(idx / ((int64_t)n_rob * N));
+    const int self = agent_id[inst];
+    double row[4] = {0, 0, 0, 0};
+    if (k != self && has_plan[k]) {
+      double cp3[3];
+      const bool own = self >= 0 && self < n_rob && has_plan[self];
+      for (int ax = 0; ax < 3; ++ax)
+        cp3[ax] = own ? plans[((int64_t)self * (N + 1) + (i + 1)) * 9 + ax] : state[(int64_t)inst * 9 + ax];
+      double tmp[4];
+      if (hdsm::Solver<30, 16>::tasc_plane(c, cp3, plans + ((int64_t)k * (N + 1) + (i + 1)) * 9, tmp))
+        row[0] = tmp[0], row[1] = tmp[1], row[2] = tmp[2], row[3] = tmp[3];
+    }
+    double* out = planes + idx * 4;
+    out[0] = row[0], out[1] = row[1], out[2] = row[2], out[3] = row[3];
+  }
+}
+
+struct Handle {
+  int device = 0;
+  int max_inst = 0, n_rob_max = 0;
+  int N = 0, P = 0, RS = 0, n = 0;
+  int threads = 64;
+  hdsm_params prm{};
+  hdsm::Consts* d_consts = nullptr;
+  double* d_scratch = nullptr;
+  int64_t scratch_stride = 0;
+  int32_t* d_stats = nullptr;  // 4 * max_inst
+  // staging for the host-pointer entry points
+  int32_t *d_agent = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr;
+  double *d_state = nullptr, *d_ref = nullptr, *d_A = nullptr, *d_b = nullptr, *d_plans = nullptr;
+  double *d_traj = nullptr, *d_ctrl = nullptr, *d_obj = nullptr;
+  uint8_t *d_has = nullptr, *d_used = nullptr;
+  hipStream_t stream = nullptr;
+  hipStream_t last_stream = nullptr;
+};
+
+template <int NV, int NT>
+int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
+  using Sol = hdsm::Solver<NV, CMAX_DEFAULT>;
+  const size_t shm = sizeof(typename Sol::S);
+  auto kern = k_replan<NV, CMAX_DEFAULT, NT>;
+  static thread_local int attr_dev = -1;
+  if (attr_dev != h->device) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    attr_dev = h->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(NT), shm, st, h->d_consts, a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
+int launch(Handle* h, hdsm::Args a, hipStream_t st) {
+  a.scratch = h->d_scratch;
+  a.scratch_stride = h->scratch_stride;
+  a.st_iters = h->d_stats;
+  a.st_nodes = h->d_stats + h->max_inst;
+  a.st_sweeps = h->d_stats + 2 * h->max_inst;
+  a.st_cand = h->d_stats + 3 * h->max_inst;
+  h->last_stream = st;
+  if (h->n <= 30) {
+    if (h->threads == 256) return launch_nv<30, 256>(h, a, st);
+    if (h->threads == 128) return launch_nv<30, 128>(h, a, st);
+    return launch_nv<30, 64>(h, a, st);
+  }
+  if (h->threads == 256) return launch_nv<48, 256>(h, a, st);
+  if (h->threads == 128) return launch_nv<48, 128>(h, a, st);
+  return launch_nv<48, 64>(h, a, st);
+}
+
+int64_t scratch_stride_for(int n) {
+  return n <= 30 ? (int64_t)hdsm::Solver<30, CMAX_DEFAULT>::SNAP_STRIDE * hdsm::MAXH
+                 : (int64_t)hdsm::Solver<48, CMAX_DEFAULT>::SNAP_STRIDE * hdsm::MAXH;
+}
+
+template <class T>
+hipError_t dmalloc(T** p, size_t count) {
+  return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T));
+}
+
+void free_all(Handle* h) {
+  void* ptrs[] = {h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
+                  h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_traj,  h->d_ctrl,
+                  h->d_obj,    h->d_has,     h->d_used};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+int check_common(Handle* h, int n_inst, int n_rob) {
+  if (!h) return set_err(HDSM_ERR_BAD_ARG, "null handle");
+  if (n_inst < 0 || n_rob < 0) return set_err(HDSM_ERR_BAD_ARG, "negative size");
+  if (n_inst > h->max_inst) return set_err(HDSM_ERR_CAPACITY, "n_inst exceeds max_instances of the handle");
+  if (n_rob > h->n_rob_max) return set_err(HDSM_ERR_CAPACITY, "n_rob exceeds n_rob_max of the handle");
+  return HDSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t hdsm_version(void) { return (1 << 16) | 0; }
+
+const char* hdsm_last_error(void) { return g_err.c_str(); }
+
+void hdsm_default_params(hdsm_params* p, int32_t n_hor) {
+  if (!p) return;
+  std::memset(p, 0, sizeof *p);
+  // multi_agent_planner/config/agent_agile_config.yaml -> InitializePlannerParameters (AC:2169-2188)
+  p->n_hor = n_hor, p->poly_hor = 4, p->rk4 = 0, p->max_rows_static = 18;
+  p->dt = 0.1, p->r_u = 0.01;
+  const double w[9] = {100, 100, 100, 1, 1, 1, 0, 0, 0};
+  for (int k = 0; k < 9; ++k) p->r_x[k] = p->r_n[k] = w[k];
+  const double max_vel = 20.0, max_acc = 15.0, max_jerk = 60.0;
+  for (int k = 0; k < 3; ++k) {
+    p->x_lb[k] = -HDSM_INF, p->x_ub[k] = HDSM_INF;
+    p->x_lb[3 + k] = -max_vel, p->x_ub[3 + k] = max_vel;
+    p->x_lb[6 + k] = -max_acc, p->x_ub[6 + k] = max_acc;
+    p->u_lb[k] = -max_jerk, p->u_ub[k] = max_jerk;
+  }
+  p->drone_radius = 0.25, p->drone_z_offset = 0.25, p->plane_perturb = 0.1;
+  p->max_nodes = 0, p->max_qp_iters = 0, p->feas_tol_fixed = 1e-6, p->solver_tol = 1e-9;
+}
+
+int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_max, int32_t device,
+                void** handle) {
+  if (!params || !handle) return set_err(HDSM_ERR_BAD_ARG, "null argument");
+  if (max_instances < 1 || n_rob_max < 1) return set_err(HDSM_ERR_BAD_ARG, "max_instances/n_rob_max must be >= 1");
+  *handle = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(HDSM_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return set_err(HDSM_ERR_NO_DEVICE, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+
+  hdsm::Consts* hc = new (std::nothrow) hdsm::Consts;
+  if (!hc) return set_err(HDSM_ERR_DEVICE, "out of host memory");
+  const char* msg = nullptr;
+  int rc = hdsm::build_consts(params, hc, &msg);
+  if (rc) {
+    delete hc;
+    return set_err(rc, msg ? msg : "bad params");
+  }
+  Handle* h = new (std::nothrow) Handle;
+  if (!h) {
+    delete hc;
+    return set_err(HDSM_ERR_DEVICE, "out of host memory");
+  }
+  h->device = device, h->max_inst = max_instances, h->n_rob_max = n_rob_max, h->prm = *params;
+  h->N = hc->N, h->P = hc->P, h->RS = hc->RS, h->n = hc->n;
+  if (const char* e = std::getenv("HDSM_THREADS")) {
+    const int t = std::atoi(e);
+    if (t == 64 || t == 128 || t == 256) h->threads = t;
+  }
+  h->scratch_stride = scratch_stride_for(h->n);
+  const size_t I = (size_t)max_instances, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  ok(dmalloc(&h->d_consts, 1));
+  ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
+  ok(dmalloc(&h->d_stats, 4 * I));
+  ok(dmalloc(&h->d_agent, I));
+  ok(dmalloc(&h->d_npoly, I));
+  ok(dmalloc(&h->d_nrows, I * P));
+  ok(dmalloc(&h->d_status, I));
+  ok(dmalloc(&h->d_state, I * 9));
+  ok(dmalloc(&h->d_ref, I * N * 6));
+  ok(dmalloc(&h->d_A, I * P * RS * 3));
+  ok(dmalloc(&h->d_b, I * P * RS));
+  ok(dmalloc(&h->d_plans, (size_t)n_rob_max * (N + 1) * 9));
+  ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
+  ok(dmalloc(&h->d_ctrl, I * N * 3));
+  ok(dmalloc(&h->d_obj, I));
+  ok(dmalloc(&h->d_has, (size_t)n_rob_max));
+  ok(dmalloc(&h->d_used, I * P));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 4 * I * sizeof(int32_t));
+  delete hc;
+  if (e != hipSuccess) {
+    free_all(h);
+    delete h;
+    return set_err(HDSM_ERR_DEVICE, std::string("hdsm_create: ") + hipGetErrorString(e));
+  }
+  *handle = h;
+  return HDSM_OK;
+}
+
+void hdsm_destroy(void* handle) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  free_all(h);
+  delete h;
+}
+
+int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                       const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                       const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                       const double* plans_all, const uint8_t* has_plan, double* traj_out,
+                       double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
+                       void* hip_stream) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, n_rob)) return rc;
+  if (n_inst == 0) return HDSM_OK;
+  if (!agent_id || !state_curr || !traj_ref || !n_poly || !n_rows_static || !A_static || !b_static ||
+      !plans_all || !has_plan || !traj_out || !ctrl_out || !poly_used || !status || !obj)
+    return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  if (traj_out == plans_all) return set_err(HDSM_ERR_BAD_ARG, "traj_out must not alias plans_all");
+  hdsm::Args a{};
+  a.n_inst = n_inst, a.n_rob = n_rob, a.agent_id = agent_id, a.state = state_curr, a.ref = traj_ref;
+  a.n_poly = n_poly, a.n_rows = n_rows_static, a.A = A_static, a.b = b_static, a.plans = plans_all;
+  a.has_plan = has_plan, a.traj = traj_out, a.ctrl = ctrl_out, a.used = poly_used, a.status = status;
+  a.obj = obj;
+  return launch(h, a, static_cast<hipStream_t>(hip_stream));
+}
+
+int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
+                uint8_t* poly_used, int32_t* status, double* obj) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, n_rob)) return rc;
+  if (n_inst == 0) return HDSM_OK;
+  if (!agent_id || !state_curr || !traj_ref || !n_poly || !n_rows_static || !A_static || !b_static ||
+      !plans_all || !has_plan || !traj_out || !ctrl_out || !poly_used || !status || !obj)
+    return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t I = (size_t)n_inst, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
+  hipStream_t st = h->stream;
+  const auto H2D = hipMemcpyHostToDevice;
+  const auto D2H = hipMemcpyDeviceToHost;
+  HIP_TRY(hipMemcpyAsync(h->d_agent, agent_id, I * 4, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_ref, traj_ref, I * N * 6 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_npoly, n_poly, I * 4, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_nrows, n_rows_static, I * P * 4, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_A, A_static, I * P * RS * 3 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_b, b_static, I * P * RS * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_has, has_plan, (size_t)n_rob, H2D, st));
+  // outputs are "left untouched" for instances without a solution: seed the device copies with the
+  // caller's current contents
+  HIP_TRY(hipMemcpyAsync(h->d_traj, traj_out, I * (N + 1) * 9 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_ctrl, ctrl_out, I * N * 3 * 8, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_used, poly_used, I * P, H2D, st));
+  HIP_TRY(hipMemcpyAsync(h->d_obj, obj, I * 8, H2D, st));
+  int rc = hdsm_replan_device(handle, n_inst, n_rob, h->d_agent, h->d_state, h->d_ref, h->d_npoly, h->d_nrows,
+                              h->d_A, h->d_b, h->d_plans, h->d_has, h->d_traj, h->d_ctrl, h->d_used,
+                              h->d_status, h->d_obj, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(traj_out, h->d_traj, I * (N + 1) * 9 * 8, D2H, st));
+  HIP_TRY(hipMemcpyAsync(ctrl_out, h->d_ctrl, I * N * 3 * 8, D2H, st));
+  HIP_TRY(hipMemcpyAsync(poly_used, h->d_used, I * P, D2H, st));
+  HIP_TRY(hipMemcpyAsync(status, h->d_status, I * 4, D2H, st));
+  HIP_TRY(hipMemcpyAsync(obj, h->d_obj, I * 8, D2H, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return HDSM_OK;
+}
+
+int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                     const double* state_curr, const double* plans_all, const uint8_t* has_plan,
+                     double* planes) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, n_rob)) return rc;
+  if (n_inst == 0 || n_rob == 0) return HDSM_OK;
+  if (!agent_id || !state_curr || !plans_all || !has_plan || !planes)
+    return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t I = (size_t)n_inst, N = (size_t)h->N;
+  const size_t total = I * N * (size_t)n_rob * 4;
+  double* d_planes = nullptr;
+  HIP_TRY(dmalloc(&d_planes, total));
+  hipStream_t st = h->stream;
+  hipError_t e = hipMemcpyAsync(h->d_agent, agent_id, I * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->d_has, has_plan, (size_t)n_rob, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    const int64_t items = (int64_t)(total / 4);
+    const int blocks = (int)((items + 255) / 256 > 4096 ? 4096 : (items + 255) / 256);
+    hipLaunchKernelGGL(k_tasc_planes, dim3(blocks), dim3(256), 0, st, h->d_consts, n_inst, n_rob, h->d_agent,
+                       h->d_state, h->d_plans, h->d_has, d_planes);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(planes, d_planes, total * 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_planes);
+  if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_tasc_planes: ") + hipGetErrorString(e));
+  return HDSM_OK;
+}
+
+int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
+                    int32_t* cand) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, 0)) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  int32_t* dst[4] = {qp_iters, nodes, sweeps, cand};
+  for (int k = 0; k < 4; ++k)
+    if (dst[k])
+      HIP_TRY(hipMemcpy(dst[k], h->d_stats + (size_t)k * h->max_inst, (size_t)n_inst * 4, hipMemcpyDeviceToHost));
+  return HDSM_OK;
+}
+
+int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_curr,
+               const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows, const double* A,
+               const double* b, double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status,
+               double* obj) {
+  (void)handle, (void)n_inst, (void)r_max, (void)state_curr, (void)traj_ref, (void)n_poly, (void)n_rows;
+  (void)A, (void)b, (void)traj_out, (void)ctrl_out, (void)poly_used, (void)status, (void)obj;
+  return set_err(HDSM_ERR_BAD_ARG, "hdsm_solve (level 1) is not available in this build");
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// hdsm_consts.cpp — see hdsm_consts.h. Pure host code, no device dependency.
+#include "hdsm_consts.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace hdsm {
+namespace {
+
+struct M3 {
+  double m[3][3];
+};
+M3 eye() {
+  M3 r{};
+  for (int i = 0; i < 3; ++i) r.m[i][i] = 1;
+  return r;
+}
+M3 mul(const M3& a, const M3& b) {
+  M3 r{};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) r.m[i][j] += a.m[i][k] * b.m[k][j];
+  return r;
+}
+M3 axpy(const M3& a, double s, const M3& b) {  // a + s b
+  M3 r = a;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[i][j] += s * b.m[i][j];
+  return r;
+}
+
+int fail(const char** err, const char* msg) {
+  if (err) *err = msg;
+  return HDSM_ERR_BAD_ARG;
+}
+
+}  // namespace
+
+int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
+  if (!prm || !c) return fail(err, "null params");
+  const int N = prm->n_hor, P = prm->poly_hor, RS = prm->max_rows_static;
+  if (N < 2 || N > MAXH) return fail(err, "n_hor must be in [2, HDSM_MAX_HOR]");
+  if (P < 1 || P > MAXP) return fail(err, "poly_hor must be in [1, HDSM_MAX_POLY]");
+  if (RS < 1 || RS > MAXRS) return fail(err, "max_rows_static must be in [1, HDSM_MAX_ROWS_STATIC]");
+  if (!(prm->dt > 0)) return fail(err, "dt must be positive");
+  if (!(prm->r_u > 0)) return fail(err, "r_u must be positive (strict convexity, AC:2098)");
+  if (!(prm->drone_radius > 0) || !(prm->drone_z_offset > 0)) return fail(err, "drone_radius/drone_z_offset must be positive");
+  for (int k = 0; k < 3; ++k)
+    if (std::fabs(prm->x_lb[k]) < ABSENT || std::fabs(prm->x_ub[k]) < ABSENT)
+      return fail(err, "position bounds must be +-HDSM_INF (AC:2179-2182 leaves positions free)");
+  for (int k = 0; k < 6; ++k)
+    if (prm->r_x[k] < 0 || prm->r_n[k] < 0) return fail(err, "negative tracking weight");
+
+  std::memset(c, 0, sizeof *c);
+  const int n = 3 * N;
+  c->N = N, c->n = n, c->P = P, c->RS = RS;
+  c->max_nodes = prm->max_nodes > 0 ? prm->max_nodes : 2000;
+  c->max_iters = prm->max_qp_iters > 0 ? prm->max_qp_iters : 100000;
+  c->tol = prm->solver_tol > 0 ? prm->solver_tol : 1e-9;
+  c->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
+  c->cand_tau = 1.5;  // [m] rows whose slack at the first converged iterate is below this are staged
+  if (const char* e = std::getenv("HDSM_CAND_TAU")) c->cand_tau = std::atof(e);
+  c->r_u = prm->r_u;
+  for (int k = 0; k < 6; ++k) c->wx[k] = prm->r_x[k], c->wn[k] = prm->r_n[k];
+  for (int ax = 0; ax < 3; ++ax) {
+    c->lbu[ax] = prm->u_lb[ax], c->ubu[ax] = prm->u_ub[ax];
+    for (int comp = 1; comp < 3; ++comp) {
+      c->lbs[comp][ax] = prm->x_lb[3 * comp + ax];
+      c->ubs[comp][ax] = prm->x_ub[3 * comp + ax];
+    }
+  }
+  c->radius = prm->drone_radius;
+  const double kk = prm->drone_radius / prm->drone_z_offset;
+  c->k2m1 = kk * kk - 1.0;
+  c->pert = prm->plane_perturb;
+
+  // ---- discrete dynamics per axis. Continuous model (ModelODE, AC:2155-2167): d/dt (p,v,a) = Ac x + Bc u.
+  for (int ax = 0; ax < 3; ++ax) {
+    M3 Ac{};
+    Ac.m[0][1] = 1, Ac.m[1][1] = -prm->drag[ax], Ac.m[1][2] = 1;
+    const double dt = prm->dt;
+    M3 Ad, Bm;  // x+ = Ad x + (Bm Bc) u
+    if (!prm->rk4) {  // forward Euler, AC:2140-2151
+      Ad = axpy(eye(), dt, Ac);
+      Bm = eye();
+      for (auto& row : Bm.m)
+        for (double& v : row) v *= dt;
+    } else {  // classical RK4 on a linear system with the input held: truncated exponential series
+      const M3 A1 = Ac, A2 = mul(Ac, Ac), A3 = mul(A2, Ac), A4 = mul(A3, Ac);
+      Ad = axpy(axpy(axpy(axpy(eye(), dt, A1), dt * dt / 2, A2), dt * dt * dt / 6, A3), dt * dt * dt * dt / 24, A4);
+      M3 I = eye();
+      for (auto& row : I.m)
+        for (double& v : row) v *= dt;
+      Bm = axpy(axpy(axpy(I, dt * dt / 2, A1), dt * dt * dt / 6, A2), dt * dt * dt * dt / 24, A3);
+    }
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) c->Ad[ax][i][j] = Ad.m[i][j];
+      c->Bd[ax][i] = Bm.m[i][2];  // Bc = e_3
+    }
+    M3 pw = eye();
+    double v[3] = {c->Bd[ax][0], c->Bd[ax][1], c->Bd[ax][2]};
+    for (int i = 0; i <= N; ++i) {
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) c->phi[ax][i][r][cc] = pw.m[r][cc];
+      pw = mul(Ad, pw);
+    }
+    for (int lag = 0; lag < N; ++lag) {
+      for (int s = 0; s < 3; ++s) c->g[ax][s][lag] = v[s];
+      double vn[3];
+      for (int r = 0; r < 3; ++r) vn[r] = Ad.m[r][0] * v[0] + Ad.m[r][1] * v[1] + Ad.m[r][2] * v[2];
+      for (int r = 0; r < 3; ++r) v[r] = vn[r];
+    }
+  }
+
+  // ---- Hessian of the tracking objective (AC:870-883, AC:2098) in u, its Cholesky factor and inverse
+  std::vector<double> H(n * n, 0.0), L(n * n, 0.0);
+  for (int ax = 0; ax < 3; ++ax)
+    for (int k = 0; k < N; ++k)
+      for (int l = 0; l < N; ++l) {
+        double h = (k == l) ? 2 * prm->r_u : 0.0;
+        for (int i = (k > l ? k : l) + 1; i <= N; ++i) {
+          const double* w = (i == N) ? prm->r_n : prm->r_x;
+          for (int comp = 0; comp < 2; ++comp)
+            h += 2 * w[3 * comp + ax] * c->g[ax][comp][i - 1 - k] * c->g[ax][comp][i - 1 - l];
+        }
+        H[(ax * N + k) * n + ax * N + l] = h;
+      }
+  for (int j = 0; j < n; ++j) {
+    double d = H[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0)) return fail(err, "Hessian not positive definite");
+    d = std::sqrt(d);
+    L[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = H[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s / d;
+    }
+  }
+  for (int j = 0; j < n; ++j)  // J0 = L^{-T}
+    for (int i = n - 1; i >= 0; --i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * c->J0[k * n + j];
+      c->J0[i * n + j] = s / L[i * n + i];
+    }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      for (int k = 0; k < n; ++k) s += c->J0[i * n + k] * c->J0[j * n + k];
+      c->Hinv[i * n + j] = s;
+    }
+  return HDSM_OK;
+}
+
+}  // namespace hdsm

@@ -1,0 +1,806 @@
+// hdsm_core.h — per-instance MIQP solver: ONE agent-replan per workgroup, all solver state in LDS.
+//
+// Replaces, for one agent and one replan, Agent::GenerateTimeAwareSafeCorridor (AC:1086-1215) +
+// Agent::SolveOptimizationProblem (AC:858-1023) of lis-epfl/multi_agent_pkgs
+// (AC = multi_agent_planner/src/agent_class.cpp). Design notes: DESIGN.md.
+//
+//   * decision vector u = jerk inputs, condensed (states eliminated), n = 3 N, index ax*N + k;
+//   * exact dual active-set QP (Goldfarb-Idnani) with J = L^{-T} Q and R kept in LDS, parallel over the
+//     lanes of the workgroup: lane j owns column j of J for d = J^T a, lane i owns row i for z = J2 d2 and
+//     for the Givens sweeps; the Givens coefficients of an "add" come from a suffix sum of d^2 so that no
+//     sequential sqrt chain is needed;
+//   * the n_rob-1 neighbour planes per step are NEVER materialised: a sweep over the all-gathered plans
+//     buffer generates each plane on the fly (trig-free closed form of the ellipsoid support distance)
+//     and stages only the rows close to the current iterate in LDS; after convergence a verification sweep
+//     re-checks every row, stages the violated ones and the dual method simply continues (it stays dual
+//     feasible when rows are added), so the result is exact;
+//   * the one-hot polyhedron choice is handled by a lazy depth-first branch-and-bound: a node branches
+//     only on a step whose segment lies in no polyhedron; children continue the parent's factorisation
+//     (snapshots of the solver state live in a per-instance global scratch, one per depth).
+//
+// The file compiles in two modes:
+//   - device mode (hipcc, gfx950): PAR_FOR distributes a loop over the threads of the workgroup,
+//     SYNC() is __syncthreads();
+//   - HDSM_EMU (g++): the same statements executed sequentially by one host thread. This build exists only
+//     for the CPU test-suite (tests/emu/) to check the kernel LOGIC without a GPU; it is never part of
+//     libhdsm.so and is not a fallback.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef HDSM_EMU
+#define HD inline
+#define HDN inline
+#define PAR_FOR(i, cnt) for (int i = 0; i < (cnt); ++i)
+#define SYNC() ((void)0)
+#define IS_T0 (true)
+#define HDSM_NT 1
+namespace hdsm {
+static inline int atomic_inc_i32(int* p) { return (*p)++; }
+}  // namespace hdsm
+#else
+#include <hip/hip_runtime.h>
+#define HD __device__ __forceinline__
+#define HDN __device__ __noinline__
+#define PAR_FOR(i, cnt) for (int i = (int)threadIdx.x; i < (cnt); i += (int)blockDim.x)
+#define SYNC() __syncthreads()
+#define IS_T0 (threadIdx.x == 0)
+namespace hdsm {
+__device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); }
+}  // namespace hdsm
+#endif
+
+#include "hdsm_types.h"
+
+namespace hdsm {
+
+enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4 };
+enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
+
+// constraint ids: kind in bits 28..30
+enum { K_U = 0, K_S = 1, K_P = 2, K_C = 3, K_E = 4 };
+HD int mk_id(int kind, int payload) { return (kind << 28) | payload; }
+HD int id_kind(int id) { return (id >> 28) & 7; }
+HD int id_payload(int id) { return id & 0x0fffffff; }
+
+// ---------------------------------------------------------------------------------------------------------
+// All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
+template <int NV, int CMAX>
+struct Shm {
+  static constexpr int LD = NV + 1;  // odd leading dimension: row- and column-walks are bank-conflict free
+  double J[NV * LD];
+  double R[NV * LD];
+  double x[NV], lam[NV], d[NV], w[NV], z[NV], r[NV], a[NV], suf[NV + 1], gc[NV], gs[NV], grad[NV];
+  double inc_x[NV];
+  double g[3][3][MAXH];
+  double fr[3][MAXH + 1][3];
+  double ref[MAXH][6];
+  double st[MAXH + 1][9];
+  double cprev[MAXH][3];
+  double sp[MAXP][MAXRS][4];
+  double keys[MAXH][MAXP];
+  double cand[CMAX][4];
+  double red_v[MAXT];
+  double br_f[MAXH];
+  double state0[9];
+  double f, inc_f, f0;
+  int32_t red_i[MAXT];
+  int32_t red_j[MAXT];
+  int32_t cand_m[CMAX];
+  int32_t act[NV];
+  int32_t sp_rows[MAXP];
+  int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
+  int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
+  int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
+};
+
+template <int NV, int CMAX>
+struct Solver {
+  using S = Shm<NV, CMAX>;
+  static constexpr int LD = S::LD;
+
+  // ---- block-wide reductions -----------------------------------------------------------------------------
+  // argmax over idx in [0,cnt) of f(idx) -> (value, id); only values > v0 qualify; ties -> lowest idx.
+  template <class F>
+  static HD void block_argmax(S& s, int cnt, double v0, F f, double& vbest, int& ibest) {
+#ifdef HDSM_EMU
+    vbest = v0;
+    ibest = -1;
+    for (int i = 0; i < cnt; ++i) {
+      double v;
+      int id;
+      f(i, v, id);
+      if (v > vbest) vbest = v, ibest = id;
+    }
+#else
+    double v = v0;
+    int bi = -1, bidx = 0x7fffffff;
+    for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) {
+      double vi;
+      int id;
+      f(i, vi, id);
+      if (vi > v) v = vi, bi = id, bidx = i;
+    }
+    s.red_v[threadIdx.x] = v;
+    s.red_i[threadIdx.x] = bi;
+    s.red_j[threadIdx.x] = bidx;
+    __syncthreads();
+    // tree over the workgroup; equal values resolve to the smallest loop index, i.e. exactly the result
+    // of a sequential scan (keeps the device path and the CPU logic build bit-identical)
+    for (int off = (int)blockDim.x >> 1; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) {
+        const double v2 = s.red_v[threadIdx.x + off];
+        const int j2 = s.red_j[threadIdx.x + off];
+        const double v1 = s.red_v[threadIdx.x];
+        if (v2 > v1 || (v2 == v1 && j2 < s.red_j[threadIdx.x])) {
+          s.red_v[threadIdx.x] = v2;
+          s.red_i[threadIdx.x] = s.red_i[threadIdx.x + off];
+          s.red_j[threadIdx.x] = j2;
+        }
+      }
+      __syncthreads();
+    }
+    vbest = s.red_v[0];
+    ibest = s.red_i[0];
+    __syncthreads();
+#endif
+  }
+
+  // ---- trajectory from the current iterate ---------------------------------------------------------------
+  static HD void compute_states(S& s, const Consts& c) {
+    const int N = c.N;
+    PAR_FOR(idx, 9 * N) {
+      const int i = idx / 9 + 1, k = idx % 9, comp = k / 3, ax = k % 3;
+      double v = s.fr[ax][i][comp];
+      const double* gg = s.g[ax][comp];
+      const double* xx = s.x + ax * N;
+      for (int kk = 0; kk < i; ++kk) v += gg[i - 1 - kk] * xx[kk];
+      s.st[i][k] = v;
+    }
+    SYNC();
+  }
+
+  // value - rhs of a constraint (positive = violated); uniform call (all threads, same id)
+  static HD double resid(const S& s, const Consts& c, int id) {
+    const int N = c.N, kind = id_kind(id), p = id_payload(id);
+    if (kind == K_U) {
+      const int var = p >> 1, ax = var / N;
+      return (p & 1) ? (c.lbu[ax] - s.x[var]) : (s.x[var] - c.ubu[ax]);
+    }
+    if (kind == K_S) {
+      const int sg = p & 1, ax = (p >> 1) & 3, comp = (p >> 3) & 3, i = p >> 5;
+      const double v = s.st[i][3 * comp + ax];
+      return sg ? (c.lbs[comp][ax] - v) : (v - c.ubs[comp][ax]);
+    }
+    if (kind == K_E) {
+      const int ax = p % 3, comp = 1 + p / 3;
+      return s.st[N][3 * comp + ax];
+    }
+    if (kind == K_P) {
+      const int r = p & 63, e = (p >> 6) & 1, i = p >> 7;
+      const double* row = s.sp[s.assign[i]][r];
+      const double* pm = s.st[i + e];
+      return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+    }
+    const double* row = s.cand[p];
+    const double* pm = s.st[s.cand_m[p]];
+    return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+  }
+
+  // most violated inequality over: input box, state boxes, rows of assigned polyhedra, staged neighbour rows
+  static HD void select_violated(S& s, const Consts& c, double& vbest, int& ibest) {
+    const int N = c.N, n = c.n, RS = c.RS;
+    const int n_sb = 6 * (N - 1), n_sp = N * 2 * RS, n_c = s.ncand;
+    block_argmax(
+        s, n + n_sb + n_sp + n_c, c.tol,
+        [&](int idx, double& v, int& id) {
+          v = -DINF;
+          id = -1;
+          if (idx < n) {
+            const int ax = idx / N;
+            const double xv = s.x[idx];
+            const double vu = (fabs(c.ubu[ax]) < ABSENT) ? xv - c.ubu[ax] : -DINF;
+            const double vl = (fabs(c.lbu[ax]) < ABSENT) ? c.lbu[ax] - xv : -DINF;
+            if (vu >= vl) v = vu, id = mk_id(K_U, idx << 1);
+            else v = vl, id = mk_id(K_U, (idx << 1) | 1);
+            return;
+          }
+          idx -= n;
+          if (idx < n_sb) {
+            const int i = idx / 6 + 1, k = idx % 6, comp = 1 + k / 3, ax = k % 3;
+            const double sv = s.st[i][3 * comp + ax];
+            const double vu = (fabs(c.ubs[comp][ax]) < ABSENT) ? sv - c.ubs[comp][ax] : -DINF;
+            const double vl = (fabs(c.lbs[comp][ax]) < ABSENT) ? c.lbs[comp][ax] - sv : -DINF;
+            const int base = (i << 5) | (comp << 3) | (ax << 1);
+            if (vu >= vl) v = vu, id = mk_id(K_S, base);
+            else v = vl, id = mk_id(K_S, base | 1);
+            return;
+          }
+          idx -= n_sb;
+          if (idx < n_sp) {
+            const int i = idx / (2 * RS), rem = idx % (2 * RS), e = rem / RS, r = rem % RS;
+            const int j = s.assign[i];
+            if (j < 0 || r >= s.sp_rows[j] || i + e == 0) return;
+            const double* row = s.sp[j][r];
+            const double* pm = s.st[i + e];
+            v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+            id = mk_id(K_P, (i << 7) | (e << 6) | r);
+            return;
+          }
+          idx -= n_sp;
+          const double* row = s.cand[idx];
+          const double* pm = s.st[s.cand_m[idx]];
+          v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+          id = mk_id(K_C, idx);
+        },
+        vbest, ibest);
+  }
+
+  // dense normal a (in u-space) of constraint id:  a . u  (<= | ==)  rhs'
+  static HD void build_normal(S& s, const Consts& c, int id) {
+    const int N = c.N, n = c.n, kind = id_kind(id), p = id_payload(id);
+    int m = 0, comp = 0, cax = -1;
+    double nx = 0, ny = 0, nz = 0, sg = 1;
+    if (kind == K_U) {
+      sg = (p & 1) ? -1.0 : 1.0;
+    } else if (kind == K_S) {
+      sg = (p & 1) ? -1.0 : 1.0;
+      cax = (p >> 1) & 3, comp = (p >> 3) & 3, m = p >> 5;
+    } else if (kind == K_E) {
+      cax = p % 3, comp = 1 + p / 3, m = N;
+    } else if (kind == K_P) {
+      const int r = p & 63, e = (p >> 6) & 1, i = p >> 7;
+      const double* row = s.sp[s.assign[i]][r];
+      nx = row[0], ny = row[1], nz = row[2], m = i + e;
+    } else {
+      const double* row = s.cand[p];
+      nx = row[0], ny = row[1], nz = row[2], m = s.cand_m[p];
+    }
+    PAR_FOR(k, n) {
+      const int ax = k / N, kk = k % N;
+      double v = 0;
+      if (kind == K_U) {
+        v = (k == (p >> 1)) ? sg : 0.0;
+      } else if (kind == K_S || kind == K_E) {
+        if (ax == cax && kk < m) v = sg * s.g[ax][comp][m - 1 - kk];
+      } else if (kk < m) {
+        v = (ax == 0 ? nx : (ax == 1 ? ny : nz)) * s.g[ax][0][m - 1 - kk];
+      }
+      s.a[k] = v;
+    }
+    SYNC();
+  }
+
+  // ---- factor updates -----------------------------------------------------------------------------------
+  // Append the incoming constraint (whose transformed normal is s.d, suffix sums of d^2 in s.suf) to the
+  // working set: Givens sweep on the columns q..n-1 of J, new column of R.
+  static HD void add_constraint(S& s, const Consts& c, int id, double lam_p) {
+    const int n = c.n, q = s.q;
+    PAR_FOR(j, n) {
+      if (j > q) {
+        const double h = sqrt(s.suf[j - 1]);
+        double cc = 1.0, ss = 0.0;
+        if (h > 0) {
+          cc = s.d[j - 1] / h;
+          ss = (j == n - 1 ? s.d[j] : sqrt(s.suf[j])) / h;
+        }
+        s.gc[j] = cc;
+        s.gs[j] = ss;
+      }
+    }
+    SYNC();
+    PAR_FOR(i, n) {
+      double* Ji = s.J + i * LD;
+      double carry = Ji[n - 1];
+      for (int j = n - 1; j > q; --j) {
+        const double t1 = Ji[j - 1];
+        Ji[j] = -s.gs[j] * t1 + s.gc[j] * carry;
+        carry = s.gc[j] * t1 + s.gs[j] * carry;
+      }
+      Ji[q] = carry;
+    }
+    PAR_FOR(i, q) s.R[i * LD + q] = s.d[i];
+    if (IS_T0) {
+      s.R[q * LD + q] = (q == n - 1) ? s.d[q] : sqrt(s.suf[q]);
+      s.act[q] = id;
+      s.lam[q] = lam_p;
+      s.q = q + 1;
+      if (id_kind(id) == K_E) s.neq_done++;
+    }
+    SYNC();
+  }
+
+  // Remove the constraint at position l of the working set.
+  static HD void drop_constraint(S& s, const Consts& c, int l) {
+    const int n = c.n, q = s.q;
+    PAR_FOR(i, q) {
+      double* Ri = s.R + i * LD;
+      for (int j = l; j < q - 1; ++j) Ri[j] = Ri[j + 1];
+    }
+    if (IS_T0) {
+      for (int j = l; j < q - 1; ++j) {
+        s.act[j] = s.act[j + 1];
+        s.lam[j] = s.lam[j + 1];
+      }
+      s.q = q - 1;
+    }
+    SYNC();
+    const int qn = q - 1;
+    for (int j = l; j < qn; ++j) {
+      const double a1 = s.R[j * LD + j], a2 = s.R[(j + 1) * LD + j];
+      const double h = sqrt(a1 * a1 + a2 * a2);
+      SYNC();  // every thread has read a1, a2 before anybody rewrites them
+      if (h == 0) continue;
+      const double cc = a1 / h, ss = a2 / h;
+      PAR_FOR(k, qn - j) {
+        const int col = j + k;
+        const double t1 = s.R[j * LD + col], t2 = s.R[(j + 1) * LD + col];
+        s.R[j * LD + col] = cc * t1 + ss * t2;
+        s.R[(j + 1) * LD + col] = -ss * t1 + cc * t2;
+      }
+      PAR_FOR(i, n) {
+        const double t1 = s.J[i * LD + j], t2 = s.J[i * LD + j + 1];
+        s.J[i * LD + j] = cc * t1 + ss * t2;
+        s.J[i * LD + j + 1] = -ss * t1 + cc * t2;
+      }
+      SYNC();
+    }
+  }
+
+  // ---- the dual active-set loop --------------------------------------------------------------------------
+  // Continues from the current (dual feasible) state until no row of the current node is violated.
+  static HD int gi_run(S& s, const Consts& c, double f_cut, int& iters) {
+    const int N = c.N, n = c.n;
+    double f = s.f;
+    int rc = GI_OK;
+    for (;;) {
+      compute_states(s, c);
+      int ip;
+      double vip;
+      if (s.neq_done < 6) {
+        ip = mk_id(K_E, s.neq_done);
+        vip = resid(s, c, ip);
+      } else {
+        select_violated(s, c, vip, ip);
+        if (ip < 0) break;
+      }
+      const bool is_eq = id_kind(ip) == K_E;
+      build_normal(s, c, ip);
+      double lam_p = 0;
+      bool stop = false;
+      for (;;) {
+        if (iters >= c.max_iters) {
+          rc = GI_ITERLIM;
+          stop = true;
+          break;
+        }
+        ++iters;
+        const int q = s.q;
+        PAR_FOR(j, n) {  // d = J^T (-a)
+          double t = 0;
+          for (int i = 0; i < n; ++i) t -= s.J[i * LD + j] * s.a[i];
+          s.d[j] = t;
+          s.w[j] = t;
+        }
+        SYNC();
+        PAR_FOR(j, n + 1) {  // suffix sums of d^2
+          double t = 0;
+          for (int k = j; k < n; ++k) t += s.d[k] * s.d[k];
+          s.suf[j] = t;
+        }
+        PAR_FOR(i, n) {  // z = J2 d2
+          double t = 0;
+          for (int j = q; j < n; ++j) t += s.J[i * LD + j] * s.d[j];
+          s.z[i] = t;
+        }
+        SYNC();
+        for (int j = q - 1; j > 0; --j) {  // back substitution R r = d1 (w is the work copy)
+          const double rj = s.w[j] / s.R[j * LD + j];
+          PAR_FOR(i, j) s.w[i] -= s.R[i * LD + j] * rj;
+          SYNC();
+        }
+        PAR_FOR(k, q) s.r[k] = s.w[k] / s.R[k * LD + k];
+        SYNC();
+        const double dd = s.suf[0], zz = s.suf[q];
+        const bool dependent = !(zz > 1e-20 * dd) || q >= n;
+        double t1 = DINF;
+        int l = -1;
+        if (!is_eq) {  // ratio test over the active inequalities
+          double nb;
+          block_argmax(
+              s, q, -DINF,
+              [&](int k, double& v, int& id) {
+                v = -DINF, id = -1;
+                if (id_kind(s.act[k]) != K_E && s.r[k] > 0) v = -(s.lam[k] / s.r[k]), id = k;
+              },
+              nb, l);
+          if (l >= 0) t1 = -nb;
+        }
+        if (dependent && l < 0) {
+          rc = GI_INFEASIBLE;
+          stop = true;
+          break;
+        }
+        if (dependent) {  // dual step only; constraint l leaves
+          PAR_FOR(k, q) s.lam[k] -= t1 * s.r[k];
+          lam_p += t1;
+          SYNC();
+          drop_constraint(s, c, l);
+          continue;
+        }
+        const double t2 = vip / zz;
+        const bool full = is_eq || t2 <= t1;
+        const double t = full ? t2 : t1;
+        PAR_FOR(i, n) s.x[i] += t * s.z[i];
+        PAR_FOR(k, q) s.lam[k] -= t * s.r[k];
+        f += t * zz * (0.5 * t + lam_p);
+        lam_p += t;
+        SYNC();
+        if (full) {
+          add_constraint(s, c, ip, lam_p);
+          break;
+        }
+        drop_constraint(s, c, l);
+        compute_states(s, c);
+        vip = resid(s, c, ip);
+        if (f >= f_cut) {
+          rc = GI_CUTOFF;
+          stop = true;
+          break;
+        }
+      }
+      if (stop) break;
+      if (f >= f_cut) {
+        rc = GI_CUTOFF;
+        break;
+      }
+    }
+    if (IS_T0) s.f = f;
+    SYNC();
+    (void)N;
+    return rc;
+  }
+
+  // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
+  static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
+    const double dx = op[0] - cp[0], dy = op[1] - cp[1], dz = op[2] - cp[2];
+    const double n2 = dx * dx + dy * dy + dz * dz;
+    if (!(n2 > 0)) return false;  // Eigen normalized() keeps a zero vector: the row is 0.p <= 0
+    const double nrm = sqrt(n2), inv = 1.0 / nrm;
+    const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
+    // ellipsoid support distance: hypot(r cos t, h sin t), t = atan((r/h) tan(pi/2 - |acos hz|))
+    //   == r / sqrt(1 + ((r/h)^2 - 1) hz^2)
+    const double sd = c.radius / sqrt(1.0 + c.k2m1 * hz * hz);
+    const double back = 0.5 * fmin(2.0 * sd, nrm);
+    const double qx = 0.5 * (cp[0] + op[0]) - back * hx;
+    const double qy = 0.5 * (cp[1] + op[1]) - back * hy;
+    const double qz = 0.5 * (cp[2] + op[2]) - back * hz;
+    // n x (0,0,1) = (hy,-hx,0);  n x (0,1,0) = (-hz,0,hx);  n_f = n + pert*(c1+c2) + pert*c2
+    const double fx = hx + c.pert * (hy - hz) - c.pert * hz;
+    const double fy = hy - c.pert * hx;
+    const double fz = hz + c.pert * hx + c.pert * hx;
+    out[0] = fx, out[1] = fy, out[2] = fz;
+    out[3] = fx * qx + fy * qy + fz * qz;
+    return true;
+  }
+
+  static HD void sweep(S& s, const Consts& c, const Args& a, int self, double thresh, bool check_fixed) {
+    const int N = c.N, total = a.n_rob * N;
+    PAR_FOR(idx, total) {
+      const int k = idx / N, i = idx % N;
+      if (k == self || !a.has_plan[k]) continue;
+      const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+      double row[4];
+      if (!tasc_plane(c, s.cprev[i], op, row)) continue;
+      for (int e = 0; e < 2; ++e) {
+        const int m = i + e;
+        const double* pm = s.st[m];
+        const double v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+        if (m == 0) {
+          if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
+          continue;
+        }
+        if (-v < thresh) {
+          const int slot = atomic_inc_i32(&s.ncand);
+          if (slot < CMAX) {
+            s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
+            s.cand[slot][3] = row[3];
+            s.cand_m[slot] = m;
+          } else {
+            s.overflow = 1;
+          }
+        }
+      }
+    }
+    SYNC();
+    if (IS_T0 && s.ncand > CMAX) s.ncand = CMAX;
+    SYNC();
+  }
+
+  // ---- leaf test: which unassigned steps lie in no polyhedron -----------------------------------------------
+  // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if the pinned p_0 is outside.
+  static HD int leaf_check(S& s, const Consts& c) {
+    const int N = c.N, np = s.n_poly;
+    PAR_FOR(idx, N * np) {
+      const int i = idx / np, j = idx % np;
+      double vmax = -DINF;
+      if (s.assign[i] < 0) {
+        for (int r = 0; r < s.sp_rows[j]; ++r) {
+          const double* row = s.sp[j][r];
+          for (int e = 0; e < 2; ++e) {
+            const double* pm = s.st[i + e];
+            const double v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+            if (i + e == 0) {
+              if (v > c.ftol_fixed) vmax = DINF;
+            } else if (v > vmax) {
+              vmax = v;
+            }
+          }
+        }
+      }
+      s.keys[i][j] = vmax;
+    }
+    SYNC();
+    int first = -1;
+    for (int i = 0; i < N; ++i) {  // uniform scan (N*P <= 128 LDS reads)
+      int cont = -1;
+      if (s.assign[i] >= 0) {
+        cont = s.assign[i];
+      } else {
+        for (int j = 0; j < np; ++j)
+          if (s.keys[i][j] <= c.tol) {
+            cont = j;
+            break;
+          }
+      }
+      if (IS_T0) s.contain[i] = cont;
+      if (cont < 0 && first < 0) first = i;
+    }
+    SYNC();
+    return first;
+  }
+
+  // ---- snapshots of the solver state (global scratch), one per branching depth ----------------------------------
+  static constexpr int SNAP_DOUBLES = 2 * NV * LD + 2 * NV + 2;
+  static HD void snapshot_io(S& s, const Consts& c, double* buf, bool save) {
+    const int n = c.n;
+    double* bJ = buf;
+    double* bR = buf + NV * LD;
+    double* bx = bR + NV * LD;
+    double* bl = bx + NV;
+    double* bs = bl + NV;
+    int32_t* bi = (int32_t*)(buf + SNAP_DOUBLES);
+    if (save) {
+      PAR_FOR(k, n * LD) bJ[k] = s.J[k], bR[k] = s.R[k];
+      PAR_FOR(k, n) bx[k] = s.x[k], bl[k] = s.lam[k], bi[k] = s.act[k];
+      if (IS_T0) bs[0] = s.f, bi[NV] = s.q;
+    } else {
+      PAR_FOR(k, n * LD) s.J[k] = bJ[k], s.R[k] = bR[k];
+      PAR_FOR(k, n) s.x[k] = bx[k], s.lam[k] = bl[k], s.act[k] = bi[k];
+      if (IS_T0) s.f = bs[0], s.q = bi[NV];
+    }
+    SYNC();
+  }
+  static constexpr int SNAP_STRIDE = SNAP_DOUBLES + (NV + 2) / 2 + 1;  // doubles per level
+
+  static HD double cutoff(const S& s) {
+    return s.have_inc ? s.inc_f - 1e-9 * fmax(1.0, fabs(s.inc_f)) : DINF;
+  }
+
+  // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
+  // assigns the child's polyhedron. Returns false when the tree is exhausted (or the node budget is).
+  static HD bool select_child(S& s, const Consts& c, double* snap, int& nodes, bool& limit) {
+    for (;;) {
+      const int level = s.level;
+      if (level == 0) return false;
+      const int L = level - 1;
+      const int pos = s.br_pos[L];
+      if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s))) {
+        if (nodes >= c.max_nodes) {
+          limit = true;
+          return false;
+        }
+        ++nodes;
+        const int j = s.br_order[L][pos];
+        SYNC();
+        if (pos > 0) snapshot_io(s, c, snap + (int64_t)L * SNAP_STRIDE, false);
+        if (IS_T0) {
+          s.br_pos[L] = pos + 1;
+          s.assign[s.br_step[L]] = j;
+        }
+        SYNC();
+        return true;
+      }
+      SYNC();
+      if (IS_T0) {
+        s.assign[s.br_step[L]] = -1;
+        s.level = L;
+      }
+      SYNC();
+    }
+  }
+
+  // ---- one instance, start to finish ------------------------------------------------------------------------
+  static HD void solve_instance(S& s, const Consts& c, const Args& a, int inst) {
+    const int N = c.N, n = c.n, P = c.P, RS = c.RS;
+    const int self = a.agent_id[inst];
+    double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
+
+    // ---- stage the instance in LDS
+    PAR_FOR(k, 9) s.state0[k] = a.state[(int64_t)inst * 9 + k];
+    PAR_FOR(k, 6 * N) s.ref[k / 6][k % 6] = a.ref[(int64_t)inst * 6 * N + k];
+    PAR_FOR(k, 9 * MAXH) s.g[k / (3 * MAXH)][(k / MAXH) % 3][k % MAXH] = c.g[k / (3 * MAXH)][(k / MAXH) % 3][k % MAXH];
+    const int np = min_i(a.n_poly[inst], P);
+    PAR_FOR(k, P) s.sp_rows[k] = (k < np) ? min_i(a.n_rows[(int64_t)inst * P + k], RS) : 0;
+    PAR_FOR(k, P * RS) {
+      const int j = k / RS, r = k % RS;
+      const double* Ar = a.A + (((int64_t)inst * P + j) * RS + r) * 3;
+      s.sp[j][r][0] = Ar[0], s.sp[j][r][1] = Ar[1], s.sp[j][r][2] = Ar[2];
+      s.sp[j][r][3] = a.b[((int64_t)inst * P + j) * RS + r];
+    }
+    const bool own_plan = self >= 0 && self < a.n_rob && a.has_plan[self];
+    PAR_FOR(k, 3 * N) {
+      const int i = k / 3, ax = k % 3;
+      s.cprev[i][ax] = own_plan ? a.plans[((int64_t)self * (N + 1) + (i + 1)) * 9 + ax]
+                                : a.state[(int64_t)inst * 9 + ax];
+    }
+    PAR_FOR(k, MAXH) s.assign[k] = -1;
+    if (IS_T0) {
+      s.n_poly = np, s.q = 0, s.neq_done = 0, s.ncand = 0, s.level = 0, s.have_inc = 0;
+      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF;
+    }
+    SYNC();
+    // free response + st[0]
+    PAR_FOR(k, 9 * (N + 1)) {
+      const int i = k / 9, comp = (k % 9) / 3, ax = k % 3;
+      double v = 0;
+      for (int cc = 0; cc < 3; ++cc) v += c.phi[ax][i][comp][cc] * s.state0[3 * cc + ax];
+      s.fr[ax][i][comp] = v;
+      if (i == 0) s.st[0][3 * comp + ax] = s.state0[3 * comp + ax];
+    }
+    SYNC();
+    // gradient of J at u = 0 and the constant term
+    PAR_FOR(k, n) {
+      const int ax = k / N, kk = k % N;
+      double gsum = 0;
+      for (int i = kk + 1; i <= N; ++i) {
+        const double* w = (i == N) ? c.wn : c.wx;
+        for (int comp = 0; comp < 2; ++comp) {
+          const double e = s.fr[ax][i][comp] - s.ref[i - 1][3 * comp + ax];
+          gsum += 2.0 * w[3 * comp + ax] * s.g[ax][comp][i - 1 - kk] * e;
+        }
+      }
+      s.grad[k] = gsum;
+    }
+    SYNC();
+    PAR_FOR(k, n) {  // x0 = -H^{-1} grad
+      double t = 0;
+      for (int j = 0; j < n; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
+      s.x[k] = t;
+    }
+    PAR_FOR(k, n * n) {
+      const int i = k / n, j = k % n;
+      s.J[i * LD + j] = c.J0[k];
+      s.R[i * LD + j] = 0;
+    }
+    SYNC();
+    if (IS_T0) {
+      double f0 = 0;
+      for (int i = 1; i <= N; ++i) {
+        const double* w = (i == N) ? c.wn : c.wx;
+        for (int k = 0; k < 6; ++k) {
+          const double e = s.fr[k % 3][i][k / 3] - s.ref[i - 1][k];
+          f0 += w[k] * e * e;
+        }
+      }
+      double f = f0;
+      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.x[k];
+      s.f0 = f0;
+      s.f = f;
+    }
+    SYNC();
+
+    // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
+    int iters = 0, nodes = 1, sweeps = 0;
+    bool limit = false;
+    bool run = np > 0;
+    while (run) {
+      const int rc = gi_run(s, c, cutoff(s), iters);
+      if (rc == GI_ITERLIM) {
+        limit = true;
+        break;
+      }
+      if (rc == GI_OK) {
+        const int bstep = leaf_check(s, c);
+        if (bstep < 0) {
+          // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
+          const int before = s.ncand;
+          SYNC();
+          sweep(s, c, a, self, sweeps == 0 ? c.cand_tau : -c.tol, sweeps == 0);
+          ++sweeps;
+          if (s.fixed_bad) break;  // a common row is violated at the pinned point: infeasible whatever j
+          if (s.ncand > before) continue;  // rows were staged: the dual method continues on this node
+          if (s.overflow) {  // staging capacity exhausted, a violated row could not be staged
+            limit = true;
+            break;
+          }
+          PAR_FOR(k, n) s.inc_x[k] = s.x[k];
+          PAR_FOR(i, N) s.inc_assign[i] = s.contain[i];
+          if (IS_T0) s.inc_f = s.f, s.have_inc = 1;
+          SYNC();
+        } else {  // open a new level on the first step that lies in no polyhedron
+          const int L = s.level;
+          snapshot_io(s, c, snap + (int64_t)L * SNAP_STRIDE, true);
+          if (IS_T0) {
+            int cnt = 0;
+            for (int j = 0; j < np; ++j)
+              if (s.keys[bstep][j] < DINF) s.br_order[L][cnt++] = j;
+            for (int x1 = 1; x1 < cnt; ++x1)  // insertion sort, ascending violation, stable in j
+              for (int y = x1; y > 0 && s.keys[bstep][s.br_order[L][y]] < s.keys[bstep][s.br_order[L][y - 1]]; --y) {
+                const int t = s.br_order[L][y];
+                s.br_order[L][y] = s.br_order[L][y - 1];
+                s.br_order[L][y - 1] = t;
+              }
+            s.br_cnt[L] = cnt, s.br_pos[L] = 0, s.br_step[L] = bstep, s.br_f[L] = s.f;
+            s.level = L + 1;
+          }
+          SYNC();
+        }
+      }
+      // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
+      run = select_child(s, c, snap, nodes, limit);
+    }
+
+    // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective
+    const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
+    if (s.have_inc) {
+      double* tr = a.traj + (int64_t)inst * 9 * (N + 1);
+      double* cu = a.ctrl + (int64_t)inst * 3 * N;
+      PAR_FOR(k, 3 * N) cu[k] = s.inc_x[(k % 3) * N + k / 3];
+      PAR_FOR(ax, 3) {
+        double xs[3] = {s.state0[ax], s.state0[3 + ax], s.state0[6 + ax]};
+        for (int comp = 0; comp < 3; ++comp) s.st[0][3 * comp + ax] = xs[comp];
+        for (int i = 0; i < N; ++i) {
+          const double u = s.inc_x[ax * N + i];
+          double xn[3];
+          for (int r = 0; r < 3; ++r)
+            xn[r] = c.Ad[ax][r][0] * xs[0] + c.Ad[ax][r][1] * xs[1] + c.Ad[ax][r][2] * xs[2] + c.Bd[ax][r] * u;
+          for (int r = 0; r < 3; ++r) {
+            xs[r] = xn[r];
+            s.st[i + 1][3 * r + ax] = xn[r];
+          }
+        }
+      }
+      SYNC();
+      PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
+      if (IS_T0) {
+        double Jv = 0;
+        for (int k = 0; k < n; ++k) Jv += c.r_u * s.inc_x[k] * s.inc_x[k];
+        for (int i = 1; i <= N; ++i) {
+          const double* w = (i == N) ? c.wn : c.wx;
+          for (int k = 0; k < 6; ++k) {
+            const double e = s.st[i][k] - s.ref[i - 1][k];
+            Jv += w[k] * e * e;
+          }
+        }
+        a.obj[inst] = Jv;
+        uint8_t* us = a.used + (int64_t)inst * P;
+        for (int j = 0; j < P; ++j) us[j] = 0;
+        for (int i = 0; i < N; ++i)
+          if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
+      }
+    }
+    if (IS_T0) {
+      a.status[inst] = status;
+      if (a.st_iters) a.st_iters[inst] = iters;
+      if (a.st_nodes) a.st_nodes[inst] = nodes;
+      if (a.st_sweeps) a.st_sweeps[inst] = sweeps;
+      if (a.st_cand) a.st_cand[inst] = s.ncand;
+    }
+    SYNC();
+  }
+
+  static HD int min_i(int x, int y) { return x < y ? x : y; }
+};
+
+}  // namespace hdsm

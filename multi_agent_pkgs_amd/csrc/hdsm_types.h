@@ -1,0 +1,58 @@
+// hdsm_types.h — plain structs shared by the host code and the device code (no HIP dependency).
+#pragma once
+#include <stdint.h>
+
+namespace hdsm {
+
+constexpr int MAXH = 16;   // HDSM_MAX_HOR
+constexpr int MAXP = 8;    // HDSM_MAX_POLY
+constexpr int MAXRS = 32;  // HDSM_MAX_ROWS_STATIC
+constexpr int MAXNV = 3 * MAXH;
+constexpr int MAXT = 256;  // largest workgroup
+constexpr double ABSENT = 1e20;
+constexpr double DINF = 1e300;
+
+// ---------------------------------------------------------------------------------------------------------
+// Config-level constants, built once on the host by hdsm_build_consts() (the counterpart of
+// Agent::CreateGurobiModel, AC:2071-2153) and kept in device memory.
+struct Consts {
+  int32_t N, n, P, RS;
+  int32_t max_nodes, max_iters, pad0, pad1;
+  double tol, ftol_fixed, cand_tau;
+  double r_u, wx[6], wn[6];
+  double lbu[3], ubu[3];       // input box (absent if |.| >= ABSENT)
+  double lbs[3][3], ubs[3][3]; // state box [comp][ax], comp 1 = v, 2 = a
+  double radius, k2m1, pert;   // drone_radius, (r/h)^2 - 1, plane perturbation
+  double Ad[3][3][3], Bd[3][3];  // one-step maps per axis: x+ = Ad x + Bd u   (Euler or RK4, AC:2115-2152)
+  double g[3][3][MAXH];          // impulse responses: g[ax][s][lag] = (Ad^lag Bd)[s]
+  double phi[3][MAXH + 1][3][3]; // Ad^i
+  double Hinv[MAXNV * MAXNV];    // inverse Hessian, dense n x n, row-major with stride n
+  double J0[MAXNV * MAXNV];      // L^{-T}, H = L L^T
+};
+
+// Per-launch arguments (device pointers), layouts of include/hdsm.h.
+struct Args {
+  int32_t n_inst, n_rob;
+  const int32_t* agent_id;
+  const double* state;
+  const double* ref;
+  const int32_t* n_poly;
+  const int32_t* n_rows;
+  const double* A;
+  const double* b;
+  const double* plans;
+  const uint8_t* has_plan;
+  double* traj;
+  double* ctrl;
+  uint8_t* used;
+  int32_t* status;
+  double* obj;
+  int32_t* st_iters;
+  int32_t* st_nodes;
+  int32_t* st_sweeps;
+  int32_t* st_cand;
+  double* scratch;        // n_inst * scratch_stride doubles
+  int64_t scratch_stride;
+};
+
+}  // namespace hdsm

@@ -1,0 +1,133 @@
+"""ctypes binding of libhdsm.so (the C ABI of include/hdsm.h).
+
+There is deliberately no fallback: if the shared library has not been built (``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C multi_agent_pkgs_amd/csrc``) importing the library raises,
+and creating a solver on a machine without a HIP device raises :class:`HdsmError` (HDSM_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import HdsmParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhdsm.so")
+
+HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACITY = 0, -1, -2, -3, -4
+
+EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
+           "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats")
+
+
+class HdsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hdsm error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libhdsm.so; raises if it is missing (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        lib = C.CDLL(SO_PATH)
+        lib.hdsm_last_error.restype = C.c_char_p
+        lib.hdsm_version.restype = C.c_int32
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HdsmError(rc, load().hdsm_last_error().decode())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Solver:
+    """One hdsm handle (= the persistent GRBModel of one planner thread, but batched)."""
+
+    def __init__(self, prm: HdsmParams, max_instances: int, n_rob_max: int, device: int = 0):
+        self.lib = load()
+        self.prm = prm.copy()
+        self.max_instances, self.n_rob_max, self.device = int(max_instances), int(n_rob_max), int(device)
+        self.h = C.c_void_p()
+        _check(self.lib.hdsm_create(C.byref(self.prm), self.max_instances, self.n_rob_max, self.device,
+                                    C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.hdsm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer entry point (PCIe inclusive) -------------------------------------------------------
+    def replan(self, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, out=None):
+        N, P = self.prm.n_hor, self.prm.poly_hor
+        agent_id, n_poly, n_rows = _i32(agent_id), _i32(n_poly), _i32(n_rows)
+        state, ref, A, b, plans, has_plan = _f64(state), _f64(ref), _f64(A), _f64(b), _f64(plans), _u8(has_plan)
+        n_inst, n_rob = state.shape[0], plans.shape[0]
+        if out is None:
+            out = dict(traj=np.zeros((n_inst, N + 1, 9)), ctrl=np.zeros((n_inst, N, 3)),
+                       used=np.zeros((n_inst, P), dtype=np.uint8), status=np.zeros(n_inst, dtype=np.int32),
+                       obj=np.zeros(n_inst))
+        d, i, u = C.c_double, C.c_int32, C.c_uint8
+        _check(self.lib.hdsm_replan(self.h, n_inst, n_rob, _p(agent_id, i), _p(state, d), _p(ref, d),
+                                    _p(n_poly, i), _p(n_rows, i), _p(A, d), _p(b, d), _p(plans, d),
+                                    _p(has_plan, u), _p(out["traj"], d), _p(out["ctrl"], d),
+                                    _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d)))
+        out.update(self.last_stats(n_inst))
+        return out
+
+    # ---- device-pointer entry point: torch tensors (already resident in HBM), async on `stream` ---------
+    def replan_device(self, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, traj, ctrl, used,
+                      status, obj, stream=None):
+        """All arguments are CUDA(HIP) torch tensors with the dtypes/layouts of include/hdsm.h."""
+        n_inst, n_rob = state.shape[0], plans.shape[0]
+        for t in (agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, traj, ctrl, used, status, obj):
+            assert t.is_cuda and t.is_contiguous()
+        sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        _check(self.lib.hdsm_replan_device(self.h, n_inst, n_rob, vp(agent_id), vp(state), vp(ref), vp(n_poly),
+                                           vp(n_rows), vp(A), vp(b), vp(plans), vp(has_plan), vp(traj),
+                                           vp(ctrl), vp(used), vp(status), vp(obj), sp))
+
+    def tasc_planes(self, agent_id, state, plans, has_plan):
+        N = self.prm.n_hor
+        agent_id, state, plans, has_plan = _i32(agent_id), _f64(state), _f64(plans), _u8(has_plan)
+        n_inst, n_rob = state.shape[0], plans.shape[0]
+        planes = np.zeros((n_inst, N, n_rob, 4))
+        _check(self.lib.hdsm_tasc_planes(self.h, n_inst, n_rob, _p(agent_id, C.c_int32), _p(state, C.c_double),
+                                         _p(plans, C.c_double), _p(has_plan, C.c_uint8),
+                                         _p(planes, C.c_double)))
+        return planes
+
+    def last_stats(self, n_inst):
+        st = {k: np.zeros(n_inst, dtype=np.int32) for k in ("qp_iters", "nodes", "sweeps", "cand")}
+        _check(self.lib.hdsm_last_stats(self.h, n_inst, _p(st["qp_iters"], C.c_int32), _p(st["nodes"], C.c_int32),
+                                        _p(st["sweeps"], C.c_int32), _p(st["cand"], C.c_int32)))
+        return st
