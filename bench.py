@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — agent-replans/s of the HIP hot path on BASELINE.json's circle-exchange workload.
+
+One "step" = one replan round of the local shard: ONE launch of the fused kernel (separating planes +
+exact MIQP for every local agent) and, for N > 1, ONE RCCL all-gather of the new plans.
+
+Workload (config.workload): BASELINE configs[1] at N=1 — 64 agents, circular exchange, empty environment,
+H = 10, agent_agile_config.yaml weights/limits. For N GPUs the swarm has 64*N agents, 64 per GPU (weak
+scaling; --agents overrides, e.g. --agents 1024 with --gpus 8 is BASELINE configs[3]).
+
+Inputs are produced by SIMULATION, not drawn from a distribution: during the untimed
+set-up the swarm is flown in closed loop with the device solver; the inputs of rounds
+[--first-round, --first-round + warmup + steps) — when the agents converge on the centre and many separating
+planes are active — are kept resident in HBM and replayed, one recorded round per step.
+
+Prints ONE JSON line (rank 0). `roofline.achieved` = algorithmic bytes per launch (SURVEY.md section 8d
+formula x agents per launch) / mean kernel duration measured with HIP events on the launch stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(n_rob, N, P, rbar):
+    """fp64 bytes one agent-replan must touch."""
+    return ((n_rob - 1) * N * 3 * 8 + (N + 1) * 3 * 8 + 9 * 8 + N * 6 * 8 + P * rbar * 4 * 8
+            + (N + 1) * 9 * 8 + N * 3 * 8 + P)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--agents", type=int, default=0, help="total agents (default 64 per GPU)")
+    ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--first-round", type=int, default=25, help="first recorded closed-loop round")
+    ap.add_argument("--cpu-sample-rounds", type=int, default=6, help="recorded rounds timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from multi_agent_pkgs_amd import lib, swarm
+    from multi_agent_pkgs_amd.params import agile_params
+
+    N = args.horizon
+    prm = agile_params(N, max_rows_static=18)
+    P, RS = prm.poly_hor, prm.max_rows_static
+    n_rob = args.agents if args.agents > 0 else 64 * world
+    first, n_local = swarm.shard_range(n_rob, rank, world)
+    per = (n_rob + world - 1) // world
+    K, W = args.steps, args.warmup
+    n_rec = K + W
+
+    solver = lib.Solver(prm, max(n_local, 1), n_rob, device=dev.index)
+    stream = torch.cuda.current_stream()
+
+    # ---------------------------------------------------------------- set-up: closed-loop flight, recording
+    def allgather_np(local):
+        t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(full, t)
+        return full.cpu().numpy()
+
+    def solve_np(inp, plans, has):
+        return solver.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"],
+                             inp["A"], inp["b"], plans, has)
+
+    cfg = swarm.default_swarm_config()
+    loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
+                           allgather=allgather_np if world > 1 else None)
+    rec, fails, total_rounds = [], 0, args.first_round + n_rec
+    for r in range(total_rounds):
+        out = loop.step(record=rec if r >= args.first_round else None)
+        if r >= args.first_round:
+            fails += int((out["status"] == 2).sum())
+
+    def stack(key, dtype):
+        return torch.from_numpy(np.ascontiguousarray(np.stack([x[key] for x in rec]), dtype=dtype)).to(dev)
+
+    d_agent = stack("agent_id", np.int32)
+    d_state, d_ref = stack("state", np.float64), stack("ref", np.float64)
+    d_npoly, d_nrows = stack("n_poly", np.int32), stack("n_rows", np.int32)
+    d_A, d_b = stack("A", np.float64), stack("b", np.float64)
+    d_plans, d_has = stack("plans", np.float64), stack("has_plan", np.uint8)
+    rows_mean = float(np.mean([x["n_rows"][x["n_rows"] > 0].mean() for x in rec]))
+    # outputs: the shard of the NEXT round's plans buffer, gathered into a full buffer when N > 1
+    d_traj = torch.zeros((per, N + 1, 9), dtype=torch.float64, device=dev)
+    d_ctrl = torch.zeros((per, N, 3), dtype=torch.float64, device=dev)
+    d_used = torch.zeros((per, P), dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(per, dtype=torch.int32, device=dev)
+    d_obj = torch.zeros(per, dtype=torch.float64, device=dev)
+    d_next = torch.zeros((world * per, N + 1, 9), dtype=torch.float64, device=dev)
+
+    def step(r):
+        solver.replan_device(d_agent[r], d_state[r], d_ref[r], d_npoly[r], d_nrows[r], d_A[r], d_b[r],
+                             d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
+                             d_status[:n_local], d_obj[:n_local], stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_next, d_traj)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- timed region (the contract)
+    for r in range(W):
+        step(r)
+    barrier()
+    t0 = time.perf_counter()
+    for r in range(W, W + K):
+        step(r)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------------------------------------------------------- second pass: per-launch kernel time
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for k, r in enumerate(range(W, W + K)):
+        ev[k][0].record(stream)
+        solver.replan_device(d_agent[r], d_state[r], d_ref[r], d_npoly[r], d_nrows[r], d_A[r], d_b[r],
+                             d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
+                             d_status[:n_local], d_obj[:n_local], stream=stream)
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    kern_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    stats = solver.last_stats(n_local)
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as orc
+        cores = os.cpu_count() or 1
+        n_s = min(args.cpu_sample_rounds, n_rec)
+        sample = [rec[W + (k * max(1, K // n_s)) % K] for k in range(n_s)]
+        t1 = time.perf_counter()
+        for x in sample:
+            orc.replan(prm, x["agent_id"], x["state"], x["ref"], x["n_poly"], x["n_rows"], x["A"], x["b"],
+                       x["plans"], x["has_plan"], n_threads=cores)
+        dt_cpu = time.perf_counter() - t1
+        cpu = {"value": n_s * n_local / dt_cpu, "unit": "agent-replans/s", "cores": cores, "kind": "port",
+               "sample": f"{n_s} recorded rounds x {n_local} agents of the same workload, CPU restatement "
+                         f"(oracle/hdsm_oracle.c, not Gurobi), one instance per thread",
+               "seconds": dt_cpu}
+
+    if rank == 0:
+        value = n_rob * K / elapsed
+        B = algorithmic_bytes(n_rob, N, P, rows_mean)
+        mean_ms = float(kern_ms.mean())
+        achieved = B * n_local / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "agent QP-replans/sec", "value": value, "unit": "agent-replans/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_rob} agents circular exchange, empty env, H={N}, "
+                                   f"poly_hor={P}, closed-loop rounds {args.first_round}..{total_rounds - 1} replayed",
+                       "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
+                       "parallelism": f"agents sharded over {world} GPU(s), one all-gather per round"},
+            "p50_solve_latency_ms": float(np.percentile(kern_ms, 50)),
+            "p95_solve_latency_ms": float(np.percentile(kern_ms, 95)),
+            "kernel_ms_mean": mean_ms,
+            "failed_instances_recorded": fails,
+            "solver_stats_last_round": {"qp_iters_max": int(stats["qp_iters"].max()),
+                                        "qp_iters_mean": float(stats["qp_iters"].mean()),
+                                        "nodes_max": int(stats["nodes"].max()),
+                                        "sweeps_max": int(stats["sweeps"].max()),
+                                        "staged_rows_max": int(stats["cand"].max())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_replan": B, "kernel": "k_replan"},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

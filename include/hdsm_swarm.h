@@ -1,0 +1,67 @@
+/*
+ * hdsm_swarm.h — host-side planner state of a shard of agents, driving hdsm_replan() in closed loop.
+ *
+ * This is the part of multi_agent_planner::Agent that sits directly around the solve in
+ * Agent::TrajPlanningIteration (AC:157-258), restated for a BATCH of agents and for the obstacle-free
+ * environments of BASELINE configs 1, 2 and 4 (circle exchange, empty world):
+ *
+ *   hdsm_swarm_prepare()  = GenerateSafeCorridor (AC:1236-1447, with the free-space polyhedron of
+ *                           convex_decomp.cpp:54-373 in closed form: SURVEY.md App. D.2)
+ *                         + GenerateReferenceTrajectory (AC:1449-1553; SamplePath AC:1591-1663,
+ *                           ComputePathVelocity's neighbour term AC:1769-1801, GetVelocityLimit AC:1805-1817)
+ *                         -> the input arrays of hdsm_replan / hdsm_replan_device
+ *   hdsm_swarm_commit()   = read-back bookkeeping (poly_used_idx_), the shift-by-one fallback on failure
+ *                           (AC:1000-1019), CheckReferenceTrajIncrement (AC:569-585, GetPathProgress
+ *                           path_tools.cpp:419-479), state advance (AC:233-238), and the record this shard
+ *                           publishes (PublishTrajectoryFull AC:645-677) for the next all-gather.
+ *
+ * Simplifications, stated: the global path is the straight segment start->goal (what JPS+DMP returns in
+ * an empty world up to voxel snapping); the voxel grid is all-free, so the potential
+ * field term of ComputePathVelocity is inactive and KeepOnlyFreeReference is the identity.
+ * Pure host code; arrays use the layouts of hdsm.h.
+ */
+#ifndef HDSM_SWARM_H
+#define HDSM_SWARM_H
+
+#include "hdsm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hdsm_swarm_config {
+  double path_vel_min, path_vel_max; /* agent_agile_config.yaml: 4.5 / 9.0                                */
+  double sens_dist, sens_pot;        /* 0.05 / 0.18                                                       */
+  double sens_other_agents;          /* default 1.0 (AC:2213)                                             */
+  double path_vel_dec;               /* 0.0                                                               */
+  double thresh_dist;                /* 1.0                                                               */
+  double voxel_size;                 /* 0.3                                                               */
+  double grid_range[3];              /* local grid extent, 20 x 20 x 6 m                                  */
+  double grid_z_min;                 /* z of the local grid origin (ground), 0.0                          */
+  int32_t n_it_decomp;               /* 42 -> 7 voxel layers per face                                     */
+  int32_t step_plan;                 /* 1                                                                 */
+} hdsm_swarm_config;
+
+void hdsm_swarm_default_config(hdsm_swarm_config* cfg);
+
+/* Agents [first_id, first_id + n_local) of a swarm of n_rob. starts/goals: [n_local][3] (state_ini, goal). */
+int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int32_t n_rob, int32_t first_id,
+                      int32_t n_local, const double* starts, const double* goals, void** swarm);
+void hdsm_swarm_destroy(void* swarm);
+
+/* Fills the solver inputs of this round for the n_local agents from the all-gathered plans of last round. */
+int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_plan, int32_t* agent_id,
+                       double* state_curr, double* traj_ref, int32_t* n_poly, int32_t* n_rows_static,
+                       double* A_static, double* b_static);
+
+/* Consumes the solver outputs; writes the shard's published plans [n_local][N+1][9] and has_plan flags. */
+int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_out, const uint8_t* poly_used,
+                      const int32_t* status, double* plans_local, uint8_t* has_plan_local);
+
+/* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
+int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

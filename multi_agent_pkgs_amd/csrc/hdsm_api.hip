@@ -30,7 +30,8 @@ int set_err(int code, const std::string& msg) {
       return set_err(HDSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
-constexpr int CMAX_DEFAULT = 768;
+constexpr int CMAX30 = 1536;  // staged neighbour rows (LDS) for n <= 30
+constexpr int CMAX48 = 1024;  // ... for n <= 48
 
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
@@ -90,9 +91,10 @@ struct Handle {
 
 template <int NV, int NT>
 int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
-  using Sol = hdsm::Solver<NV, CMAX_DEFAULT>;
+  constexpr int CM = (NV <= 30) ? CMAX30 : CMAX48;
+  using Sol = hdsm::Solver<NV, CM>;
   const size_t shm = sizeof(typename Sol::S);
-  auto kern = k_replan<NV, CMAX_DEFAULT, NT>;
+  auto kern = k_replan<NV, CM, NT>;
   static thread_local int attr_dev = -1;
   if (attr_dev != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -123,8 +125,8 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
 }
 
 int64_t scratch_stride_for(int n) {
-  return n <= 30 ? (int64_t)hdsm::Solver<30, CMAX_DEFAULT>::SNAP_STRIDE * hdsm::MAXH
-                 : (int64_t)hdsm::Solver<48, CMAX_DEFAULT>::SNAP_STRIDE * hdsm::MAXH;
+  return n <= 30 ? (int64_t)hdsm::Solver<30, CMAX30>::SNAP_STRIDE * hdsm::MAXH
+                 : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
 }
 
 template <class T>

@@ -715,9 +715,18 @@ struct Solver {
         if (bstep < 0) {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
-          SYNC();
-          sweep(s, c, a, self, sweeps == 0 ? c.cand_tau : -c.tol, sweeps == 0);
-          ++sweeps;
+          double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
+          for (;;) {
+            SYNC();
+            sweep(s, c, a, self, thresh, sweeps == 0);
+            ++sweeps;
+            if (!s.overflow || thresh <= -c.tol) break;
+            // dense neighbourhood: more rows within the staging radius than LDS slots -> tighten it
+            // (the radius only decides what is pre-staged; exactness comes from the verification sweeps)
+            SYNC();
+            if (IS_T0) s.ncand = before, s.overflow = 0;
+            thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
+          }
           if (s.fixed_bad) break;  // a common row is violated at the pinned point: infeasible whatever j
           if (s.ncand > before) continue;  // rows were staged: the dual method continues on this node
           if (s.overflow) {  // staging capacity exhausted, a violated row could not be staged

@@ -1,0 +1,409 @@
+// swarm_host.cpp — host-side planner state around the solve (see include/hdsm_swarm.h).
+// AC = multi_agent_planner/src/agent_class.cpp of lis-epfl/multi_agent_pkgs. Pure host C++.
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/hdsm_swarm.h"
+
+namespace {
+
+using V3 = std::array<double, 3>;
+
+inline V3 sub(const V3& a, const V3& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+inline V3 axpy(const V3& a, double s, const V3& b) { return {a[0] + s * b[0], a[1] + s * b[1], a[2] + s * b[2]}; }
+inline double dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double norm(const V3& a) { return std::sqrt(dot(a, a)); }
+
+struct Poly {  // LinearConstraint3D: rows A x <= b
+  int rows = 0;
+  double A[HDSM_MAX_ROWS_STATIC][3];
+  double b[HDSM_MAX_ROWS_STATIC];
+  V3 seed{};  // poly_seeds_ entry (voxel centre in world coordinates)
+  // LinearConstraint::inside (decomp_geometry/polyhedron.h:130-137): rejected when A x - b > 0
+  bool inside(const V3& p) const {
+    for (int r = 0; r < rows; ++r)
+      if (A[r][0] * p[0] + A[r][1] * p[1] + A[r][2] * p[2] - b[r] > 0) return false;
+    return true;
+  }
+};
+
+struct Agent {
+  int id = 0;
+  V3 start{}, goal{};
+  std::array<double, 9> state_curr{};
+  std::vector<std::array<double, 9>> traj_curr;    // traj_curr_     (empty before the first solve)
+  std::vector<std::array<double, 3>> control_curr; // control_curr_
+  std::vector<std::array<double, 6>> traj_ref;     // traj_ref_curr_ (N+1 rows)
+  std::vector<Poly> polys;                         // poly_const_vec_ / poly_seeds_
+  std::vector<uint8_t> poly_used;                  // poly_used_idx_
+  bool increment_traj_ref = false;
+  double path_vel = 0;
+  int n_fail = 0;
+};
+
+struct Swarm {
+  hdsm_params prm;
+  hdsm_swarm_config cfg;
+  int n_rob = 0, first_id = 0, n_local = 0;
+  std::vector<Agent> agents;
+};
+
+// GetVelocityLimit, AC:1805-1817
+double velocity_limit(const hdsm_swarm_config& c, double occ, double dist) {
+  if (occ < 0) occ = 0;
+  if (occ > 100) occ = 100;
+  const double alpha = 1 - std::pow(occ / 100, c.sens_pot) * (1 / std::exp(c.sens_dist * dist));
+  return c.path_vel_min + (c.path_vel_max - c.path_vel_min) * alpha;
+}
+
+// Free-space polyhedron of GetPolyOcta3D (convex_decomp.cpp:5-376) in closed form:
+// every face advances one voxel layer per visit, round robin, n_it/6 visits each; growth stays inside local
+// voxels 1..dim-2 and above the ground (voxels below world z = grid_z_min are unknown -> occupied).
+void free_space_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], Poly* out) {
+  const hdsm_swarm_config& c = sw.cfg;
+  const double vs = c.voxel_size;
+  const int layers = c.n_it_decomp / 6;
+  double lo[3], hi[3];
+  for (int ax = 0; ax < 3; ++ax) {
+    const int dim = (int)std::floor(c.grid_range[ax] / vs);
+    int lo_lim = 1, hi_lim = dim - 2;
+    if (ax == 2) {
+      const int first_free = (int)std::ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
+      if (first_free > lo_lim) lo_lim = first_free;
+    }
+    int a = seed[ax] - layers, b = seed[ax] + layers;
+    if (a < lo_lim) a = lo_lim;
+    if (b > hi_lim) b = hi_lim;
+    lo[ax] = a * vs + grid_origin[ax];
+    hi[ax] = (b + 1) * vs + grid_origin[ax];
+  }
+  // face order of convex_decomp.cpp:361-373: -y, +x, +y, -x, +z, -z ; rows n.x <= n.p
+  const double n[6][3] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
+  const double rhs[6] = {-lo[1], hi[0], hi[1], -lo[0], hi[2], -lo[2]};
+  out->rows = 6;
+  for (int r = 0; r < 6; ++r) {
+    for (int k = 0; k < 3; ++k) out->A[r][k] = n[r][k];
+    out->b[r] = rhs[r];
+  }
+}
+
+// GenerateSafeCorridor, AC:1236-1447
+void generate_safe_corridor(const Swarm& sw, Agent& ag) {
+  const hdsm_swarm_config& c = sw.cfg;
+  const int P = sw.prm.poly_hor;
+  std::vector<Poly> fresh;
+  if (!ag.polys.empty()) {  // AC:1253-1267: the whole previous plan inside the LAST polyhedron -> keep only it
+    bool all_in = true;
+    for (const auto& st : ag.traj_curr)
+      if (!ag.polys.back().inside({st[0], st[1], st[2]})) {
+        all_in = false;
+        break;
+      }
+    if (all_in) fresh.push_back(ag.polys.back());
+  }
+  if (!ag.polys.empty() && fresh.empty())  // AC:1273-1282: keep the polyhedra used by the last solve
+    for (size_t i = 0; i < ag.poly_used.size() && i < ag.polys.size(); ++i)
+      if (ag.poly_used[i]) fresh.push_back(ag.polys[i]);
+
+  // path: current position pushed in front of the global path (AC:1286-1290). The path thread re-plans from
+  // the kept reference points (AC:328-350), so in an empty world path_curr_ = [last reference start, goal].
+  const V3 path_head = ag.traj_ref.empty() ? ag.start : V3{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]};
+  std::vector<V3> path = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}, path_head, ag.goal};
+  // local voxel grid origin (env_builder GenerateVoxelGridMSG, environment_builder.cpp:58-67)
+  const double vs = c.voxel_size;
+  V3 origin;
+  for (int ax = 0; ax < 3; ++ax) origin[ax] = std::floor((ag.state_curr[ax] - c.grid_range[ax] / 2) / vs) * vs;
+
+  int n_poly = (int)fresh.size();
+  size_t path_idx = 1;
+  V3 curr = path[0];
+  const double samp = vs / 10;  // AC:1316
+  while (n_poly < P) {
+    const V3 next = path[path_idx];
+    const V3 diff = sub(next, curr);
+    const double dist_next = norm(diff);
+    if (dist_next > samp) {
+      curr = axpy(curr, samp / dist_next, diff);
+    } else {
+      curr = next;
+      if (++path_idx == path.size()) break;
+    }
+    bool inside_one = false;
+    for (const auto& p : fresh)
+      if (p.inside(curr)) {
+        inside_one = true;
+        break;
+      }
+    if (inside_one) continue;
+    V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
+    if (dist_next > 0) seed_pt = axpy(curr, -std::fmin(samp, dist_next) / dist_next, diff);
+    int seed[3];
+    V3 seed_world;
+    for (int ax = 0; ax < 3; ++ax) {
+      seed[ax] = (int)((seed_pt[ax] - origin[ax]) / vs);  // AC:1357-1359 (truncation)
+      seed_world[ax] = seed[ax] * vs + vs / 2 + origin[ax];
+    }
+    bool previous_seed = false;  // AC:1361-1379
+    for (const auto& p : fresh)
+      if (p.seed[0] == seed_world[0] && p.seed[1] == seed_world[1] && p.seed[2] == seed_world[2]) {
+        previous_seed = true;
+        break;
+      }
+    if (previous_seed) continue;
+    Poly np;
+    free_space_poly(sw, origin, seed, &np);
+    np.seed = seed_world;
+    fresh.push_back(np);
+    ++n_poly;
+  }
+  ag.polys.swap(fresh);
+}
+
+// ComputePathVelocity, AC:1695-1803: empty world -> only the neighbour term (AC:1769-1801) is active
+double compute_path_velocity(const Swarm& sw, const Agent& ag, const double* plans_all, const uint8_t* has_plan) {
+  const int N = sw.prm.n_hor;
+  double path_vel = sw.cfg.path_vel_max;
+  for (size_t i = 0; i < ag.traj_curr.size(); ++i) {
+    const V3 start = {ag.traj_curr[i][0], ag.traj_curr[i][1], ag.traj_curr[i][2]};
+    const double occ = 100 * std::pow(sw.cfg.sens_other_agents, (double)i);
+    for (int j = 0; j < sw.n_rob; ++j) {
+      if (j == ag.id || !has_plan[j]) continue;
+      const double* st = plans_all + ((size_t)j * (N + 1) + i) * 9;
+      const double d = norm(sub(start, {st[0], st[1], st[2]}));
+      const double v = velocity_limit(sw.cfg, occ, d);
+      if (v < path_vel) path_vel = v;
+    }
+  }
+  return path_vel;
+}
+
+// SamplePath, AC:1591-1663
+std::vector<V3> sample_path(const Swarm& sw, Agent& ag, const std::vector<V3>& path, const double* plans_all,
+                            const uint8_t* has_plan) {
+  const int N = sw.prm.n_hor;
+  std::vector<V3> ref;
+  if (path.size() < 2) {
+    for (int i = 0; i < N; ++i) ref.push_back(path[0]);
+    return ref;
+  }
+  ag.path_vel = compute_path_velocity(sw, ag, plans_all, has_plan);
+  const double samp_dist = ag.path_vel * sw.prm.dt;
+  size_t path_idx = 1;
+  int ref_idx = 0;
+  V3 curr = path[0];
+  ref.push_back(path.front());
+  double limit = samp_dist;
+  while (ref_idx < N) {
+    const V3 diff = sub(path[path_idx], curr);
+    const double dist_next = norm(diff);
+    if (dist_next > limit) {
+      curr = axpy(curr, limit / dist_next, diff);
+      ref.push_back(curr);
+      ++ref_idx;
+      limit = std::fmax(0.0, samp_dist - sw.cfg.path_vel_dec * sw.prm.dt);
+    } else {
+      curr = path[path_idx];
+      if (++path_idx == path.size()) {
+        for (int i = ref_idx; i < N; ++i) ref.push_back(path.back());
+        return ref;
+      }
+      limit -= dist_next;
+    }
+  }
+  return ref;
+}
+
+// IsOnSegment, AC:1864-1884: |pa| + |pb| == |ab| within 1e-6 and (p - a).(p - b) <= 0
+bool on_segment(const V3& p, const V3& a, const V3& b) {
+  const double d1 = norm(sub(p, a)), d2 = norm(sub(p, b)), d12 = norm(sub(a, b));
+  if (std::fabs(d1 + d2 - d12) < 1e-6) return dot(sub(p, a), sub(p, b)) <= 0;
+  return false;
+}
+
+// GenerateReferenceTrajectory, AC:1449-1553
+void generate_reference(const Swarm& sw, Agent& ag, const double* plans_all, const uint8_t* has_plan) {
+  const std::vector<V3> path_curr = {ag.start, ag.goal};
+  V3 starting;
+  if (!ag.traj_ref.empty()) {  // AC:1459-1470
+    const auto& r = ag.increment_traj_ref ? ag.traj_ref[1] : ag.traj_ref[0];
+    starting = {r[0], r[1], r[2]};
+  } else {
+    starting = path_curr[0];
+  }
+  size_t start_idx = 0;  // AC:1480-1488
+  for (size_t i = 0; i + 1 < path_curr.size(); ++i)
+    if (on_segment(starting, path_curr[i], path_curr[i + 1])) {
+      start_idx = i + 1;
+      break;
+    }
+  std::vector<V3> path_samp = {starting};
+  for (size_t i = start_idx; i < path_curr.size(); ++i) path_samp.push_back(path_curr[i]);
+  std::vector<V3> pts = sample_path(sw, ag, path_samp, plans_all, has_plan);
+  // velocity reference, AC:1527-1547 (points backwards along the path; reproduced as is)
+  ag.traj_ref.assign(pts.size(), {});
+  double v[3] = {0, 0, 0};
+  for (size_t i = 0; i < pts.size(); ++i) {
+    if (i + 1 < pts.size()) {
+      const V3 d = sub(pts[i], pts[i + 1]);
+      const double dist = norm(d);
+      for (int k = 0; k < 3; ++k) v[k] = dist > 1e-2 ? ag.path_vel * d[k] / dist : 0.0;
+    }
+    ag.traj_ref[i] = {pts[i][0], pts[i][1], pts[i][2], v[0], v[1], v[2]};
+  }
+}
+
+// GetPathProgress (path_finding_util/src/path_tools.cpp:419-479) + CheckReferenceTrajIncrement (AC:569-585)
+void check_reference_increment(const Swarm& sw, Agent& ag) {
+  ag.increment_traj_ref = false;
+  if (ag.traj_curr.size() < 2 || ag.traj_ref.size() < 2) return;
+  const V3 pt = {ag.traj_curr[1][0], ag.traj_curr[1][1], ag.traj_curr[1][2]};
+  std::vector<V3> path;
+  for (const auto& r : ag.traj_ref) path.push_back({r[0], r[1], r[2]});
+  V3 curr = path[0];
+  double dist_min = norm(sub(pt, curr)), progress = 0, progress_final = 0, proj_dist = dist_min;
+  size_t idx = 1;
+  const double samp = 0.01;
+  while (idx < path.size()) {
+    const V3 diff = sub(path[idx], curr);
+    const double dist_next = norm(diff);
+    if (dist_next > samp) {
+      curr = axpy(curr, samp / dist_next, diff);
+      progress += samp;
+    } else {
+      curr = path[idx];
+      ++idx;
+      progress += dist_next;
+    }
+    const double d = norm(sub(pt, curr));
+    if (d < dist_min) {
+      dist_min = d;
+      proj_dist = d;
+      progress_final = progress;
+    }
+  }
+  if (progress_final > 0 && proj_dist < sw.cfg.thresh_dist) ag.increment_traj_ref = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void hdsm_swarm_default_config(hdsm_swarm_config* c) {
+  if (!c) return;
+  c->path_vel_min = 4.5, c->path_vel_max = 9.0, c->sens_dist = 0.05, c->sens_pot = 0.18;
+  c->sens_other_agents = 1.0, c->path_vel_dec = 0.0, c->thresh_dist = 1.0, c->voxel_size = 0.3;
+  c->grid_range[0] = 20.0, c->grid_range[1] = 20.0, c->grid_range[2] = 6.0, c->grid_z_min = 0.0;
+  c->n_it_decomp = 42, c->step_plan = 1;
+}
+
+int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int32_t n_rob, int32_t first_id,
+                      int32_t n_local, const double* starts, const double* goals, void** swarm) {
+  if (!prm || !cfg || !starts || !goals || !swarm) return HDSM_ERR_BAD_ARG;
+  if (n_rob < 1 || n_local < 0 || first_id < 0 || first_id + n_local > n_rob) return HDSM_ERR_BAD_ARG;
+  if (prm->n_hor < 2 || prm->n_hor > HDSM_MAX_HOR || prm->poly_hor < 1 || prm->poly_hor > HDSM_MAX_POLY)
+    return HDSM_ERR_BAD_ARG;
+  if (prm->max_rows_static < 6 || cfg->step_plan < 1 || cfg->step_plan > prm->n_hor) return HDSM_ERR_BAD_ARG;
+  Swarm* sw = new (std::nothrow) Swarm;
+  if (!sw) return HDSM_ERR_DEVICE;
+  sw->prm = *prm, sw->cfg = *cfg, sw->n_rob = n_rob, sw->first_id = first_id, sw->n_local = n_local;
+  sw->agents.resize(n_local);
+  for (int k = 0; k < n_local; ++k) {
+    Agent& a = sw->agents[k];
+    a.id = first_id + k;
+    for (int ax = 0; ax < 3; ++ax) a.start[ax] = starts[3 * k + ax], a.goal[ax] = goals[3 * k + ax];
+    a.state_curr.fill(0.0);
+    for (int ax = 0; ax < 3; ++ax) a.state_curr[ax] = a.start[ax];
+  }
+  *swarm = sw;
+  return HDSM_OK;
+}
+
+void hdsm_swarm_destroy(void* swarm) { delete static_cast<Swarm*>(swarm); }
+
+int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_plan, int32_t* agent_id,
+                       double* state_curr, double* traj_ref, int32_t* n_poly, int32_t* n_rows_static,
+                       double* A_static, double* b_static) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !plans_all || !has_plan || !agent_id || !state_curr || !traj_ref || !n_poly || !n_rows_static ||
+      !A_static || !b_static)
+    return HDSM_ERR_BAD_ARG;
+  const int N = sw->prm.n_hor, P = sw->prm.poly_hor, RS = sw->prm.max_rows_static;
+  for (int k = 0; k < sw->n_local; ++k) {
+    Agent& ag = sw->agents[k];
+    generate_safe_corridor(*sw, ag);                     // AC:165
+    generate_reference(*sw, ag, plans_all, has_plan);    // AC:171
+    agent_id[k] = ag.id;
+    for (int c = 0; c < 9; ++c) state_curr[9 * k + c] = ag.state_curr[c];
+    for (int i = 0; i < N; ++i)
+      for (int c = 0; c < 6; ++c) traj_ref[((size_t)k * N + i) * 6 + c] = ag.traj_ref[i][c];
+    n_poly[k] = (int32_t)ag.polys.size();
+    for (int j = 0; j < P; ++j) {
+      const bool have = j < (int)ag.polys.size();
+      n_rows_static[k * P + j] = have ? ag.polys[j].rows : 0;
+      for (int r = 0; r < RS; ++r) {
+        const bool hr = have && r < ag.polys[j].rows;
+        for (int c = 0; c < 3; ++c) A_static[(((size_t)k * P + j) * RS + r) * 3 + c] = hr ? ag.polys[j].A[r][c] : 0.0;
+        b_static[((size_t)k * P + j) * RS + r] = hr ? ag.polys[j].b[r] : 0.0;
+      }
+    }
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_out, const uint8_t* poly_used,
+                      const int32_t* status, double* plans_local, uint8_t* has_plan_local) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !traj_out || !ctrl_out || !poly_used || !status || !plans_local || !has_plan_local)
+    return HDSM_ERR_BAD_ARG;
+  const int N = sw->prm.n_hor, P = sw->prm.poly_hor;
+  for (int k = 0; k < sw->n_local; ++k) {
+    Agent& ag = sw->agents[k];
+    if (status[k] != HDSM_NO_SOLUTION) {  // AC:960-987
+      ag.traj_curr.assign(N + 1, {});
+      ag.control_curr.assign(N, {});
+      for (int i = 0; i <= N; ++i)
+        for (int c = 0; c < 9; ++c) ag.traj_curr[i][c] = traj_out[((size_t)k * (N + 1) + i) * 9 + c];
+      for (int i = 0; i < N; ++i)
+        for (int c = 0; c < 3; ++c) ag.control_curr[i][c] = ctrl_out[((size_t)k * N + i) * 3 + c];
+      ag.poly_used.assign(P, 0);
+      for (int j = 0; j < P; ++j) ag.poly_used[j] = poly_used[k * P + j];
+    } else {  // AC:1000-1019: drop the first state/control of the previous plan, duplicate the last
+      ++ag.n_fail;
+      if (!ag.traj_curr.empty()) {
+        ag.traj_curr.erase(ag.traj_curr.begin());
+        ag.control_curr.erase(ag.control_curr.begin());
+        ag.traj_curr.push_back(ag.traj_curr.back());
+        ag.control_curr.push_back(ag.control_curr.back());
+      }
+    }
+    const bool have_plan = !ag.traj_curr.empty();
+    if (have_plan) {
+      check_reference_increment(*sw, ag);  // AC:182
+      ag.state_curr = ag.traj_curr[sw->cfg.step_plan];  // AC:233-238
+    }
+    has_plan_local[k] = have_plan ? 1 : 0;
+    for (int i = 0; i <= N; ++i)
+      for (int c = 0; c < 9; ++c)
+        plans_local[((size_t)k * (N + 1) + i) * 9 + c] = have_plan ? ag.traj_curr[i][c] : 0.0;
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw) return HDSM_ERR_BAD_ARG;
+  for (int k = 0; k < sw->n_local; ++k) {
+    const Agent& ag = sw->agents[k];
+    const V3 p = {ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]};
+    if (pos)
+      for (int c = 0; c < 3; ++c) pos[3 * k + c] = p[c];
+    if (dist_goal) dist_goal[k] = norm(sub(p, ag.goal));
+    if (n_fail) n_fail[k] = ag.n_fail;
+  }
+  return HDSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""Closed-loop driver: shards of agents replanning in lock-step, one all-gather of the new plans per round.
+
+Mirrors the sequencing of Agent::TrajPlanningIteration (agent_class.cpp:157-258) for a batch:
+
+    prepare (host: corridor + reference)  ->  solve (device: planes + MIQP)  ->  commit (host: fallback,
+    increment check, state advance)  ->  all-gather of the published plans (replaces the DDS all-to-all of
+    agent_class.cpp:610-677)  ->  next round
+
+The host-side steps live in libhdsm.so (csrc/swarm_host.cpp, include/hdsm_swarm.h). The solver is pluggable so
+that the multi-process CPU tests can drive the same loop with the oracle standing in for the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .params import HdsmParams
+
+
+class SwarmConfig(C.Structure):
+    _fields_ = [
+        ("path_vel_min", C.c_double), ("path_vel_max", C.c_double), ("sens_dist", C.c_double),
+        ("sens_pot", C.c_double), ("sens_other_agents", C.c_double), ("path_vel_dec", C.c_double),
+        ("thresh_dist", C.c_double), ("voxel_size", C.c_double), ("grid_range", C.c_double * 3),
+        ("grid_z_min", C.c_double), ("n_it_decomp", C.c_int32), ("step_plan", C.c_int32),
+    ]
+
+
+def default_swarm_config():
+    cfg = SwarmConfig()
+    _lib.load().hdsm_swarm_default_config(C.byref(cfg))
+    return cfg
+
+
+def circle_scenario(n, radius=None, cx=18.0, cy=15.0, z=1.5):
+    """start/goal of multi_agent_planner_circle.launch.py:36-44: agent k starts at angle 2 pi k / n, its goal
+    is the start of agent (k + n//2) mod n. The shipped radius (22 m) is kept while the chord between
+    neighbours stays >= 1 m; larger swarms use R = n / (2 pi)."""
+    if radius is None:
+        radius = max(22.0, n / (2 * np.pi))
+    ang = 2 * np.pi * np.arange(n) / n
+    starts = np.stack([cx + radius * np.cos(ang), cy + radius * np.sin(ang), np.full(n, z)], axis=1)
+    goals = starts[(np.arange(n) + n // 2) % n].copy()
+    return starts, goals
+
+
+def shard_range(n_rob, rank, world):
+    """Contiguous id blocks, n_rob/world per rank."""
+    per = (n_rob + world - 1) // world
+    first = min(rank * per, n_rob)
+    return first, min(per, n_rob - first)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class SwarmShard:
+    """Host planner state of agents [first_id, first_id + n_local)."""
+
+    def __init__(self, prm: HdsmParams, cfg: SwarmConfig, n_rob, first_id, starts, goals):
+        self.lib = _lib.load()
+        self.prm, self.cfg = prm.copy(), cfg
+        self.n_rob, self.first_id = int(n_rob), int(first_id)
+        starts = np.ascontiguousarray(starts, dtype=np.float64)
+        goals = np.ascontiguousarray(goals, dtype=np.float64)
+        self.n_local = starts.shape[0]
+        self.h = C.c_void_p()
+        rc = self.lib.hdsm_swarm_create(C.byref(self.prm), C.byref(self.cfg), self.n_rob, self.first_id,
+                                        self.n_local, _p(starts, C.c_double), _p(goals, C.c_double),
+                                        C.byref(self.h))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_create")
+        N, P, RS, n = prm.n_hor, prm.poly_hor, prm.max_rows_static, self.n_local
+        self.inp = dict(agent_id=np.zeros(n, np.int32), state=np.zeros((n, 9)), ref=np.zeros((n, N, 6)),
+                        n_poly=np.zeros(n, np.int32), n_rows=np.zeros((n, P), np.int32),
+                        A=np.zeros((n, P, RS, 3)), b=np.zeros((n, P, RS)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.hdsm_swarm_destroy(self.h)
+            self.h = None
+
+    def prepare(self, plans_all, has_plan):
+        i = self.inp
+        d, i32, u8 = C.c_double, C.c_int32, C.c_uint8
+        plans_all = np.ascontiguousarray(plans_all, dtype=np.float64)
+        has_plan = np.ascontiguousarray(has_plan, dtype=np.uint8)
+        rc = self.lib.hdsm_swarm_prepare(self.h, _p(plans_all, d), _p(has_plan, u8), _p(i["agent_id"], i32),
+                                         _p(i["state"], d), _p(i["ref"], d), _p(i["n_poly"], i32),
+                                         _p(i["n_rows"], i32), _p(i["A"], d), _p(i["b"], d))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_prepare")
+        return i
+
+    def commit(self, out):
+        N = self.prm.n_hor
+        plans_local = np.zeros((self.n_local, N + 1, 9))
+        has_local = np.zeros(self.n_local, np.uint8)
+        d, i32, u8 = C.c_double, C.c_int32, C.c_uint8
+        traj = np.ascontiguousarray(out["traj"], dtype=np.float64)
+        ctrl = np.ascontiguousarray(out["ctrl"], dtype=np.float64)
+        used = np.ascontiguousarray(out["used"], dtype=np.uint8)
+        status = np.ascontiguousarray(out["status"], dtype=np.int32)
+        rc = self.lib.hdsm_swarm_commit(self.h, _p(traj, d), _p(ctrl, d), _p(used, u8), _p(status, i32),
+                                        _p(plans_local, d), _p(has_local, u8))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_commit")
+        return plans_local, has_local
+
+    def state(self):
+        pos = np.zeros((self.n_local, 3))
+        dist = np.zeros(self.n_local)
+        nfail = np.zeros(self.n_local, np.int32)
+        self.lib.hdsm_swarm_state(self.h, _p(pos, C.c_double), _p(dist, C.c_double), _p(nfail, C.c_int32))
+        return pos, dist, nfail
+
+
+class SwarmLoop:
+    """One rank of the lock-step loop. `solve(inputs, plans_all, has_plan) -> out dict` is the device solver
+    (or, in CPU tests, the oracle); `allgather(local_array) -> full array` exchanges the shards."""
+
+    def __init__(self, prm, cfg, n_rob, rank=0, world=1, solve=None, allgather=None, radius=None):
+        self.prm, self.n_rob, self.rank, self.world = prm, n_rob, rank, world
+        starts, goals = circle_scenario(n_rob, radius)
+        self.first, self.n_local = shard_range(n_rob, rank, world)
+        sl = slice(self.first, self.first + self.n_local)
+        self.shard = SwarmShard(prm, cfg, n_rob, self.first, starts[sl], goals[sl])
+        self.solve, self.allgather = solve, allgather
+        N = prm.n_hor
+        self.plans_all = np.zeros((n_rob, N + 1, 9))
+        self.has_plan = np.zeros(n_rob, np.uint8)
+        self.round_idx = 0
+
+    def step(self, record=None):
+        inputs = self.shard.prepare(self.plans_all, self.has_plan)
+        if record is not None:
+            record.append(dict({k: v.copy() for k, v in inputs.items()}, plans=self.plans_all.copy(),
+                               has_plan=self.has_plan.copy()))
+        out = self.solve(inputs, self.plans_all, self.has_plan)
+        plans_local, has_local = self.shard.commit(out)
+        if self.world > 1:
+            per = (self.n_rob + self.world - 1) // self.world
+            pad = per - self.n_local  # equal-size shards for the collective
+            pl = np.concatenate([plans_local, np.zeros((pad,) + plans_local.shape[1:])]) if pad else plans_local
+            hl = np.concatenate([has_local, np.zeros(pad, np.uint8)]) if pad else has_local
+            self.plans_all = self.allgather(pl)[: self.n_rob]
+            self.has_plan = self.allgather(hl)[: self.n_rob]
+        else:
+            self.plans_all, self.has_plan = plans_local, has_local
+        self.round_idx += 1
+        return out
+
+
+def torch_allgather(group=None):
+    """all-gather of a numpy shard through torch.distributed (gloo on CPU, RCCL via 'nccl' on GPUs)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(local):
+        t = torch.from_numpy(np.ascontiguousarray(local))
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        world = dist.get_world_size(group)
+        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(full, t, group=group)
+        return full.cpu().numpy()
+
+    return fn

@@ -47,7 +47,7 @@ extern "C" int emu_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob,
   if (cmax > 0 && cmax <= 16) {  // tiny staging capacity: exercises the overflow path in tests
     if (small) run_all<30, 16>(*c, a); else run_all<48, 16>(*c, a);
   } else {
-    if (small) run_all<30, 768>(*c, a); else run_all<48, 768>(*c, a);
+    if (small) run_all<30, 1536>(*c, a); else run_all<48, 1024>(*c, a);
   }
   return 0;
 }
