@@ -114,13 +114,8 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.st_sweeps = h->d_stats + 2 * h->max_inst;
   a.st_cand = h->d_stats + 3 * h->max_inst;
   h->last_stream = st;
-  if (h->n <= 30) {
-    if (h->threads == 256) return launch_nv<30, 256>(h, a, st);
-    if (h->threads == 128) return launch_nv<30, 128>(h, a, st);
-    return launch_nv<30, 64>(h, a, st);
-  }
-  if (h->threads == 256) return launch_nv<48, 256>(h, a, st);
-  if (h->threads == 128) return launch_nv<48, 128>(h, a, st);
+  // one 64-lane wavefront per agent-replan: the factorisation lives in that wave's registers
+  if (h->n <= 30) return launch_nv<30, 64>(h, a, st);
   return launch_nv<48, 64>(h, a, st);
 }
 

@@ -68,8 +68,16 @@ HD int id_payload(int id) { return id & 0x0fffffff; }
 template <int NV, int CMAX>
 struct Shm {
   static constexpr int LD = NV + 1;  // odd leading dimension: row- and column-walks are bank-conflict free
+  static constexpr int LDT = (NV == 30) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
+#ifdef HDSM_EMU
   double J[NV * LD];
   double R[NV * LD];
+#else
+  alignas(16) double T[NV * LDT];       // transposition / row-shift buffer of the register-resident factors
+  alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
+  alignas(16) double cs[2 * NV];        // Givens pairs (c_j, s_j)
+  double gz[3][3][2 * MAXH];            // zero-padded impulse responses: gz[ax][s][MAXH + lag]
+#endif
   double x[NV], lam[NV], d[NV], w[NV], z[NV], r[NV], a[NV], suf[NV + 1], gc[NV], gs[NV], grad[NV];
   double inc_x[NV];
   double g[3][3][MAXH];
@@ -93,6 +101,10 @@ struct Shm {
   int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
 };
+
+}  // namespace hdsm
+#include "hdsm_wave_gi.h"
+namespace hdsm {
 
 template <int NV, int CMAX>
 struct Solver {
@@ -271,6 +283,7 @@ struct Solver {
     SYNC();
   }
 
+#ifdef HDSM_EMU
   // ---- factor updates -----------------------------------------------------------------------------------
   // Append the incoming constraint (whose transformed normal is s.d, suffix sums of d^2 in s.suf) to the
   // working set: Givens sweep on the columns q..n-1 of J, new column of R.
@@ -461,6 +474,8 @@ struct Solver {
     return rc;
   }
 
+#endif  // HDSM_EMU (the device build uses hdsm_wave_gi.h)
+
   // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
   static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
     const double dx = op[0] - cp[0], dy = op[1] - cp[1], dz = op[2] - cp[2];
@@ -561,6 +576,20 @@ struct Solver {
   }
 
   // ---- snapshots of the solver state (global scratch), one per branching depth ----------------------------------
+#ifndef HDSM_EMU
+  using W = WaveGI<NV, CMAX>;
+  using GIState = typename W::Regs;
+  static constexpr int SNAP_STRIDE = W::SNAP_DOUBLES + 2;  // doubles per level
+  static HD void snapshot_io(S& s, const Consts& c, GIState& R, double* buf, bool save) {
+    W::snapshot(s, R, buf, save, (int)threadIdx.x);
+  }
+  static HD int gi_run(S& s, const Consts& c, GIState& R, double f_cut, int& iters) {
+    return W::run(s, c, R, f_cut, iters);
+  }
+#else
+  struct GIState {};
+  static HD int gi_run(S& s, const Consts& c, GIState&, double f_cut, int& iters) { return gi_run(s, c, f_cut, iters); }
+  static HD void snapshot_io(S& s, const Consts& c, GIState&, double* buf, bool save) { snapshot_io(s, c, buf, save); }
   static constexpr int SNAP_DOUBLES = 2 * NV * LD + 2 * NV + 2;
   static HD void snapshot_io(S& s, const Consts& c, double* buf, bool save) {
     const int n = c.n;
@@ -582,6 +611,7 @@ struct Solver {
     SYNC();
   }
   static constexpr int SNAP_STRIDE = SNAP_DOUBLES + (NV + 2) / 2 + 1;  // doubles per level
+#endif
 
   static HD double cutoff(const S& s) {
     return s.have_inc ? s.inc_f - 1e-9 * fmax(1.0, fabs(s.inc_f)) : DINF;
@@ -589,7 +619,7 @@ struct Solver {
 
   // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
   // assigns the child's polyhedron. Returns false when the tree is exhausted (or the node budget is).
-  static HD bool select_child(S& s, const Consts& c, double* snap, int& nodes, bool& limit) {
+  static HD bool select_child(S& s, const Consts& c, GIState& R, double* snap, int& nodes, bool& limit) {
     for (;;) {
       const int level = s.level;
       if (level == 0) return false;
@@ -603,7 +633,7 @@ struct Solver {
         ++nodes;
         const int j = s.br_order[L][pos];
         SYNC();
-        if (pos > 0) snapshot_io(s, c, snap + (int64_t)L * SNAP_STRIDE, false);
+        if (pos > 0) snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, false);
         if (IS_T0) {
           s.br_pos[L] = pos + 1;
           s.assign[s.br_step[L]] = j;
@@ -678,12 +708,34 @@ struct Solver {
       for (int j = 0; j < n; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
       s.x[k] = t;
     }
+    GIState R;
+#ifdef HDSM_EMU
     PAR_FOR(k, n * n) {
       const int i = k / n, j = k % n;
       s.J[i * LD + j] = c.J0[k];
       s.R[i * LD + j] = 0;
     }
+#else
+    {  // lane i holds row i of J = L^{-T} (identity beyond n) and of U = R^{-1} (empty)
+      const int lane = (int)threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        R.Jr[j] = (lane < n && j < n) ? c.J0[lane * n + j] : ((lane == j) ? 1.0 : 0.0);
+        R.Ur[j] = 0.0;
+      }
+      R.lami = 0.0;
+      R.acti = -1;
+    }
+    PAR_FOR(k, 9 * 2 * MAXH) {
+      const int ax = k / (6 * MAXH), comp = (k / (2 * MAXH)) % 3, e = k % (2 * MAXH), lag = e - MAXH;
+      s.gz[ax][comp][e] = (lag >= 0 && lag < N) ? c.g[ax][comp][lag] : 0.0;
+    }
+    PAR_FOR(k, NV) if (k >= n) s.x[k] = 0.0;
+#endif
     SYNC();
+#ifndef HDSM_EMU
+    R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
+#endif
     if (IS_T0) {
       double f0 = 0;
       for (int i = 1; i <= N; ++i) {
@@ -705,7 +757,7 @@ struct Solver {
     bool limit = false;
     bool run = np > 0;
     while (run) {
-      const int rc = gi_run(s, c, cutoff(s), iters);
+      const int rc = gi_run(s, c, R, cutoff(s), iters);
       if (rc == GI_ITERLIM) {
         limit = true;
         break;
@@ -739,7 +791,7 @@ struct Solver {
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level;
-          snapshot_io(s, c, snap + (int64_t)L * SNAP_STRIDE, true);
+          snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, true);
           if (IS_T0) {
             int cnt = 0;
             for (int j = 0; j < np; ++j)
@@ -757,7 +809,7 @@ struct Solver {
         }
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
-      run = select_child(s, c, snap, nodes, limit);
+      run = select_child(s, c, R, snap, nodes, limit);
     }
 
     // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective
