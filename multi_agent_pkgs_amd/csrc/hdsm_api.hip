@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/hdsm.h"
 #include "hdsm_consts.h"
@@ -80,6 +81,7 @@ struct Handle {
   double* d_scratch = nullptr;
   int64_t scratch_stride = 0;
   int32_t* d_stats = nullptr;  // 4 * max_inst
+  long long* d_prof = nullptr; // 16 * max_inst (HDSM_PROFILE builds)
   // staging for the host-pointer entry points
   int32_t *d_agent = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr;
   double *d_state = nullptr, *d_ref = nullptr, *d_A = nullptr, *d_b = nullptr, *d_plans = nullptr;
@@ -113,6 +115,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.st_nodes = h->d_stats + h->max_inst;
   a.st_sweeps = h->d_stats + 2 * h->max_inst;
   a.st_cand = h->d_stats + 3 * h->max_inst;
+  a.prof = h->d_prof;
   h->last_stream = st;
   // one 64-lane wavefront per agent-replan: the factorisation lives in that wave's registers
   if (h->n <= 30) return launch_nv<30, 64>(h, a, st);
@@ -130,7 +133,7 @@ hipError_t dmalloc(T** p, size_t count) {
 }
 
 void free_all(Handle* h) {
-  void* ptrs[] = {h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
+  void* ptrs[] = {h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used};
   for (void* p : ptrs)
@@ -212,6 +215,9 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_consts, 1));
   ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
   ok(dmalloc(&h->d_stats, 4 * I));
+#ifdef HDSM_PROFILE
+  ok(dmalloc(&h->d_prof, 16 * I));
+#endif
   ok(dmalloc(&h->d_agent, I));
   ok(dmalloc(&h->d_npoly, I));
   ok(dmalloc(&h->d_nrows, I * P));
@@ -352,6 +358,25 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
   if (int rc = check_common(h, n_inst, 0)) return rc;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
+#ifdef HDSM_PROFILE
+  {  // development aid: phase cycle counters of the slowest instance and the batch mean
+    std::vector<long long> pr((size_t)n_inst * 16);
+    HIP_TRY(hipMemcpy(pr.data(), h->d_prof, pr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    int worst = 0;
+    double mean[16] = {0};
+    for (int k = 0; k < n_inst; ++k) {
+      if (pr[(size_t)k * 16 + 11] > pr[(size_t)worst * 16 + 11]) worst = k;
+      for (int j = 0; j < 16; ++j) mean[j] += (double)pr[(size_t)k * 16 + j] / n_inst;
+    }
+    static const char* nm[16] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
+                                 "leaf", "TOTAL", "iters", "sweeps", "nodes", "ncand"};
+    std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);
+    for (int j = 0; j < 16; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 16 + j]);
+    std::fprintf(stderr, "\nHDSM_PROFILE mean:");
+    for (int j = 0; j < 16; ++j) std::fprintf(stderr, " %s=%.0f", nm[j], mean[j]);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   int32_t* dst[4] = {qp_iters, nodes, sweeps, cand};
   for (int k = 0; k < 4; ++k)
     if (dst[k])

@@ -73,10 +73,14 @@ struct Shm {
   double J[NV * LD];
   double R[NV * LD];
 #else
-  alignas(16) double T[NV * LDT];       // transposition / row-shift buffer of the register-resident factors
+  alignas(16) double T[NV * LDT];       // transposition buffer for d = J^T a (J rows live in registers)
+  alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
+  alignas(16) double dz[NV + 2];        // d with the entries of the active columns zeroed
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
   alignas(16) double cs[2 * NV];        // Givens pairs (c_j, s_j)
   double gz[3][3][2 * MAXH];            // zero-padded impulse responses: gz[ax][s][MAXH + lag]
+  long long prof_acc[16];
+  long long prof_last;
 #endif
   double x[NV], lam[NV], d[NV], w[NV], z[NV], r[NV], a[NV], suf[NV + 1], gc[NV], gs[NV], grad[NV];
   double inc_x[NV];
@@ -100,6 +104,7 @@ struct Shm {
   int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
   int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
+  Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
 }  // namespace hdsm
@@ -651,11 +656,19 @@ struct Solver {
   }
 
   // ---- one instance, start to finish ------------------------------------------------------------------------
-  static HD void solve_instance(S& s, const Consts& c, const Args& a, int inst) {
+  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst) {
+    if (IS_T0) s.args = a_in;
+    SYNC();
+    const Args& a = s.args;
     const int N = c.N, n = c.n, P = c.P, RS = c.RS;
     const int self = a.agent_id[inst];
     double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
 
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+    const long long t_begin_ = clock64();
+    long long t_sweep_ = 0, t_leaf_ = 0;
+    if (threadIdx.x < 16) s.prof_acc[threadIdx.x] = 0;
+#endif
     // ---- stage the instance in LDS
     PAR_FOR(k, 9) s.state0[k] = a.state[(int64_t)inst * 9 + k];
     PAR_FOR(k, 6 * N) s.ref[k / 6][k % 6] = a.ref[(int64_t)inst * 6 * N + k];
@@ -721,11 +734,11 @@ struct Solver {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         R.Jr[j] = (lane < n && j < n) ? c.J0[lane * n + j] : ((lane == j) ? 1.0 : 0.0);
-        R.Ur[j] = 0.0;
       }
-      R.lami = 0.0;
-      R.acti = -1;
     }
+    W::init_lane(R, c, (int)threadIdx.x);
+    PAR_FOR(k, NV * S::LDT) s.U[k] = 0.0;
+    PAR_FOR(k, NV) s.lam[k] = 0.0, s.act[k] = -1;
     PAR_FOR(k, 9 * 2 * MAXH) {
       const int ax = k / (6 * MAXH), comp = (k / (2 * MAXH)) % 3, e = k % (2 * MAXH), lag = e - MAXH;
       s.gz[ax][comp][e] = (lag >= 0 && lag < N) ? c.g[ax][comp][lag] : 0.0;
@@ -752,6 +765,9 @@ struct Solver {
     }
     SYNC();
 
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+    const long long t_setup_ = clock64() - t_begin_;
+#endif
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
     bool limit = false;
@@ -763,14 +779,26 @@ struct Solver {
         break;
       }
       if (rc == GI_OK) {
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+        const long long tl_ = clock64();
+#endif
         const int bstep = leaf_check(s, c);
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+        t_leaf_ += clock64() - tl_;
+#endif
         if (bstep < 0) {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
           double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
           for (;;) {
             SYNC();
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+            const long long ts_ = clock64();
+#endif
             sweep(s, c, a, self, thresh, sweeps == 0);
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+            t_sweep_ += clock64() - ts_;
+#endif
             ++sweeps;
             if (!s.overflow || thresh <= -c.tol) break;
             // dense neighbourhood: more rows within the staging radius than LDS slots -> tighten it
@@ -812,6 +840,14 @@ struct Solver {
       run = select_child(s, c, R, snap, nodes, limit);
     }
 
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+    if (IS_T0 && a.prof) {
+      long long* pr = a.prof + (int64_t)inst * 16;
+      for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k];
+      pr[8] = t_setup_, pr[9] = t_sweep_, pr[10] = t_leaf_, pr[11] = clock64() - t_begin_;
+      pr[12] = iters, pr[13] = sweeps, pr[14] = nodes, pr[15] = s.ncand;
+    }
+#endif
     // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective
     const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
     if (s.have_inc) {

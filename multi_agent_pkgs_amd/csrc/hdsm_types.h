@@ -53,6 +53,7 @@ struct Args {
   int32_t* st_cand;
   double* scratch;        // n_inst * scratch_stride doubles
   int64_t scratch_stride;
+  long long* prof;        // HDSM_PROFILE builds: 16 cycle counters per instance (else null)
 };
 
 }  // namespace hdsm

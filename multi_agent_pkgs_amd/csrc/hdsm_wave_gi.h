@@ -43,6 +43,36 @@ __device__ __forceinline__ double wave_max64(double v) {
   v = fmax(v, dpp64<0x128>(v));  // row_ror:8  -> every lane holds the max of its 16-lane row
   return fmax(fmax(bcast64(v, 0), bcast64(v, 16)), fmax(bcast64(v, 32), bcast64(v, 48)));
 }
+// DPP move with zero fill for lanes shifted in from outside the 16-lane row
+template <int CTRL>
+__device__ __forceinline__ double dpp64z(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// suffix sum over the wave: out[i] = sum_{k >= i} v[k]   (row_shl scans + row totals through v_readlane)
+__device__ __forceinline__ double wave_suffix_sum(double v, int lane) {
+  v += dpp64z<0x101>(v);
+  v += dpp64z<0x102>(v);
+  v += dpp64z<0x104>(v);
+  v += dpp64z<0x108>(v);
+  const double t1 = bcast64(v, 16), t2 = bcast64(v, 32), t3 = bcast64(v, 48);
+  const int row = lane >> 4;
+  return v + (row == 0 ? (t1 + t2) + t3 : (row == 1 ? t2 + t3 : (row == 2 ? t3 : 0.0)));
+}
+// prefix sum over the wave: out[i] = sum_{k <= i} v[k]
+__device__ __forceinline__ double wave_prefix_sum(double v, int lane) {
+  v += dpp64z<0x111>(v);
+  v += dpp64z<0x112>(v);
+  v += dpp64z<0x114>(v);
+  v += dpp64z<0x118>(v);
+  const double t0 = bcast64(v, 15), t1 = bcast64(v, 31), t2 = bcast64(v, 47);
+  const int row = lane >> 4;
+  return v + (row == 3 ? (t0 + t1) + t2 : (row == 2 ? t0 + t1 : (row == 1 ? t0 : 0.0)));
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 #ifdef HDSM_WSYNC_STRONG
 __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -58,6 +88,15 @@ struct alignas(16) D2 {
   double x, y;
 };
 
+#ifdef HDSM_PROFILE
+// cycle counters accumulated in LDS by lane 0 (keeps them out of the SGPR file)
+#define PROF_DECL if (threadIdx.x == 0) s.prof_last = clock64();
+#define PROF(k) if (threadIdx.x == 0) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last; s.prof_last = now_; }
+#else
+#define PROF_DECL
+#define PROF(k)
+#endif
+
 template <int NV, int CMAX>
 struct WaveGI {
   using S = Shm<NV, CMAX>;
@@ -65,11 +104,36 @@ struct WaveGI {
   static constexpr int HT = NV / 3;  // horizon capacity of this instantiation
 
   struct Regs {
-    double Jr[NV];
-    double Ur[NV];
-    double xi, lami;
-    int acti;
+    double Jr[NV];  // row `lane` of J
+    double xi;      // u[lane]
+    // per-lane constants of the violation scan (bounds with "absent" mapped to +-DINF), set by init_lane()
+    double ub_own, lb_own;      // box of this lane's input
+    double sb_ub[2], sb_lb[2];  // boxes of the (up to two) state-bound items scanned by this lane
+    int sb_off[2], sb_id[2];    // their offset in st[][] (as a flat index) and id base; -1 = no item
   };
+
+  static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane) {
+    const int N = c.N, n = c.n;
+    R.ub_own = DINF, R.lb_own = -DINF;
+    if (lane < n) {
+      const int ax = lane / N;
+      if (fabs(c.ubu[ax]) < ABSENT) R.ub_own = c.ubu[ax];
+      if (fabs(c.lbu[ax]) < ABSENT) R.lb_own = c.lbu[ax];
+    }
+    const int n_sb = 6 * (N - 1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int idx = lane + 64 * e;
+      R.sb_off[e] = -1, R.sb_id[e] = 0, R.sb_ub[e] = DINF, R.sb_lb[e] = -DINF;
+      if (idx < n_sb) {
+        const int i = idx / 6 + 1, k = idx % 6, comp = 1 + k / 3, ax = k % 3;
+        R.sb_off[e] = i * 9 + 3 * comp + ax;
+        R.sb_id[e] = (i << 5) | (comp << 3) | (ax << 1);
+        if (fabs(c.ubs[comp][ax]) < ABSENT) R.sb_ub[e] = c.ubs[comp][ax];
+        if (fabs(c.lbs[comp][ax]) < ABSENT) R.sb_lb[e] = c.lbs[comp][ax];
+      }
+    }
+  }
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
   static __device__ __forceinline__ void states(S& s, const Consts& c, int lane) {
@@ -96,29 +160,27 @@ struct WaveGI {
   }
 
   // most violated row of the current node -> (v, id), id < 0 if none exceeds tol
-  static __device__ __forceinline__ void select(S& s, const Consts& c, int lane, double xi, double& vbest, int& ibest) {
-    const int N = c.N, n = c.n, RS = c.RS;
-    double v = c.tol;
+  static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
+                                                double& vbest, int& ibest) {
+    double v = tol;
     int id = -1;
-    if (lane < n) {
-      const int ax = lane / N;
-      const double vu = (fabs(c.ubu[ax]) < ABSENT) ? xi - c.ubu[ax] : -DINF;
-      const double vl = (fabs(c.lbu[ax]) < ABSENT) ? c.lbu[ax] - xi : -DINF;
+    {  // this lane's input bound
+      const double vu = R.xi - R.ub_own, vl = R.lb_own - R.xi;
       if (vu > v) v = vu, id = mk_id(K_U, lane << 1);
       if (vl > v) v = vl, id = mk_id(K_U, (lane << 1) | 1);
     }
-    const int n_sb = 6 * (N - 1);
-    for (int idx = lane; idx < n_sb; idx += 64) {
-      const int i = idx / 6 + 1, k = idx % 6, comp = 1 + k / 3, ax = k % 3;
-      const double sv = s.st[i][3 * comp + ax];
-      const double vu = (fabs(c.ubs[comp][ax]) < ABSENT) ? sv - c.ubs[comp][ax] : -DINF;
-      const double vl = (fabs(c.lbs[comp][ax]) < ABSENT) ? c.lbs[comp][ax] - sv : -DINF;
-      const int base = (i << 5) | (comp << 3) | (ax << 1);
-      if (vu > v) v = vu, id = mk_id(K_S, base);
-      if (vl > v) v = vl, id = mk_id(K_S, base | 1);
+    const double* stf = &s.st[0][0];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {  // velocity / acceleration boxes on x_1 .. x_{N-1}
+      if (R.sb_off[e] >= 0) {
+        const double sv = stf[R.sb_off[e]];
+        const double vu = sv - R.sb_ub[e], vl = R.sb_lb[e] - sv;
+        if (vu > v) v = vu, id = mk_id(K_S, R.sb_id[e]);
+        if (vl > v) v = vl, id = mk_id(K_S, R.sb_id[e] | 1);
+      }
     }
-    if (s.level > 0) {  // rows of the polyhedra assigned on the current branch
-      const int n_sp = N * 2 * RS;
+    if (uni(s.level) > 0) {  // rows of the polyhedra assigned on the current branch
+      const int RS = c.RS, n_sp = N * 2 * RS;
       for (int idx = lane; idx < n_sp; idx += 64) {
         const int i = idx / (2 * RS), rem = idx % (2 * RS), e = rem / RS, r = rem % RS;
         const int j = s.assign[i];
@@ -129,17 +191,35 @@ struct WaveGI {
         if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
       }
     }
-    const int nc = s.ncand;
-    for (int idx = lane; idx < nc; idx += 64) {
-      const double* row = s.cand[idx];
-      const double* pm = s.st[s.cand_m[idx]];
-      const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-      if (vv > v) v = vv, id = mk_id(K_C, idx);
+    // staged neighbour rows, four per trip with all loads issued before the first use
+    const int nc = uni(s.ncand);
+    for (int base = 0; base < nc; base += 256) {
+      int idx[4], mm[4];
+      D2 r01[4], r23[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        idx[u] = base + 64 * u + lane;
+        const int ii = idx[u] < nc ? idx[u] : 0;
+        mm[u] = s.cand_m[ii];
+        r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
+        r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
+      }
+      double px[4], py[4], pz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* pm = s.st[mm[u]];
+        px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
+        if (idx[u] < nc && vv > v) v = vv, id = mk_id(K_C, idx[u]);
+      }
     }
     const double m = wave_max64(v);
     vbest = m;
     ibest = -1;
-    if (m > c.tol) {
+    if (m > tol) {
       const unsigned long long mask = __ballot(v == m && id >= 0);
       const int src = __ffsll((long long)mask) - 1;
       ibest = __builtin_amdgcn_readlane(id, src);
@@ -199,8 +279,8 @@ struct WaveGI {
     return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
   }
 
-  // d = J^T (-a) -> s.dvec (LDS, read back by every lane as broadcast b128 loads)
-  static __device__ __forceinline__ void compute_d(S& s, const Regs& R, int id, double ai, int lane) {
+  // d = J^T (-a) -> s.dvec[0..NV) in LDS; returns this lane's own entry d_lane (0 beyond NV)
+  static __device__ __forceinline__ double compute_d(S& s, const Regs& R, int id, double ai, int lane) {
     if (id_kind(id) == K_U) {  // a = sg e_k: d = -sg * (row k of J)
       const int var = id_payload(id) >> 1;
       const double msg = (id_payload(id) & 1) ? 1.0 : -1.0;
@@ -209,35 +289,36 @@ struct WaveGI {
         for (int j = 0; j < NV; j += 2) *reinterpret_cast<D2*>(&s.dvec[j]) = D2{msg * R.Jr[j], msg * R.Jr[j + 1]};
       }
       wsync();
-    } else {
-      if (lane < NV) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) s.T[j * LDT + lane] = R.Jr[j] * ai;
-      }
-      wsync();
-      if (lane < NV) {
-        double a0 = 0, a1 = 0;
-        const D2* row = reinterpret_cast<const D2*>(&s.T[lane * LDT]);
-#pragma unroll
-        for (int i = 0; i < NV / 2; ++i) {
-          const D2 t = row[i];
-          a0 += t.x;
-          a1 += t.y;
-        }
-        s.dvec[lane] = -(a0 + a1);
-      }
-      wsync();
+      return (lane < NV) ? s.dvec[lane] : 0.0;
     }
+    if (lane < NV) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) s.T[j * LDT + lane] = R.Jr[j] * ai;
+    }
+    wsync();
+    double dj = 0.0;
+    if (lane < NV) {
+      double a0 = 0, a1 = 0;
+      const D2* row = reinterpret_cast<const D2*>(&s.T[lane * LDT]);
+#pragma unroll
+      for (int i = 0; i < NV / 2; ++i) {
+        const D2 t = row[i];
+        a0 += t.x;
+        a1 += t.y;
+      }
+      dj = -(a0 + a1);
+      s.dvec[lane] = dj;
+    }
+    return dj;  // the caller synchronises before anybody reads dvec
   }
 
-  // working set += id (full step taken). dv = current d, zz = sum_{k>=q} d_k^2, ri = r of this lane.
-  static __device__ __forceinline__ void add(S& s, Regs& R, int id, double lam_p, int q, int lane, double sufj, double zz,
-                                             double ri) {
-    // own Givens pair (column j = lane, j > q): zero d_j into d_{j-1}
-    {
+  // working set += id at position q (full step taken)
+  static __device__ __forceinline__ void add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dj, double sufj,
+                                             double zz, double ri) {
+    {  // own Givens pair (column j = lane, j > q): zero d_j into d_{j-1}; identity for j <= q
       double cc = 1.0, ss = 0.0;
       if (lane > q && lane < NV) {
-        const double dj = s.dvec[lane], dm1 = s.dvec[lane - 1];
+        const double dm1 = s.dvec[lane - 1];
         const double h = sqrt(sufj + dm1 * dm1);
         if (h > 0) {
           cc = dm1 / h;
@@ -247,10 +328,16 @@ struct WaveGI {
       if (lane < NV) *reinterpret_cast<D2*>(&s.cs[2 * lane]) = D2{cc, ss};
     }
     const double rho = (q == NV - 1) ? s.dvec[NV - 1] : sqrt(zz);
+    // new column q of U = R^{-1}: (-r / rho ; 1 / rho ; 0)
+    if (lane < NV) s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
+    if (lane == q) {
+      s.lam[q] = lam_p;
+      s.act[q] = id;
+    }
     wsync();
     if (lane < NV) {
-      // branch-free sweep from the last column down: pairs for j <= q are the identity (1, 0), which makes
-      // the recurrence copy every column back onto itself and leaves the rotated tail in column q
+      // branch-free sweep from the last column down: the identity pairs (1, 0) for j <= q make the
+      // recurrence copy those columns back onto themselves and leave the rotated tail in column q
       double carry = R.Jr[NV - 1];
 #pragma unroll
       for (int j = NV - 1; j >= 1; --j) {
@@ -261,79 +348,68 @@ struct WaveGI {
       }
       R.Jr[0] = carry;
     }
-    // new column q of U = R^{-1}: (-r / rho ; 1 / rho)
-    const double ucol = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) R.Ur[j] = (j == q) ? ucol : R.Ur[j];
-    if (lane == q) {
-      R.lami = lam_p;
-      R.acti = id;
-    }
   }
 
-  // working set -= entry at position l
+  // working set -= entry at position l: U' = E^T U G^T with G rotating row l of U onto the last axis
   static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
-    if (lane == l) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 2) *reinterpret_cast<D2*>(&s.dvec[j]) = D2{R.Ur[j], R.Ur[j + 1]};
-    }
-    wsync();
-    {  // own rotation pair for column j = lane in [l, q-2]: (a_j, u_{j+1}) -> (0, sigma_{j+1})
+    {  // own pair for column j = lane in [l, q-2]: (a_j, u_{j+1}) -> (0, sigma_{j+1}); identity elsewhere
+      const double ul = (lane >= l && lane < q) ? s.U[l * LDT + lane] : 0.0;  // row l of U, own entry
+      const double pre = wave_prefix_sum(ul * ul, lane);                        // sum_{k=l..lane} u_k^2
       double cd = 1.0, sd = 0.0;
       if (lane >= l && lane <= q - 2) {
-        double pre = 0;  // sum_{k=l..lane} u_k^2
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const double uk = s.dvec[k];
-          if (k >= l && k <= lane) pre += uk * uk;
-        }
-        const double aj = (lane == l) ? s.dvec[l] : sqrt(pre);
-        const double bj = s.dvec[lane + 1];
+        const double aj = (lane == l) ? ul : sqrt(pre);
+        const double bj = s.U[l * LDT + lane + 1];
         const double sg = sqrt(pre + bj * bj);
         cd = bj / sg;
         sd = aj / sg;
       }
       if (lane < NV) *reinterpret_cast<D2*>(&s.cs[2 * lane]) = D2{cd, sd};
     }
+    double lam_next = 0.0;
+    int act_next = -1;
+    if (lane >= l && lane < q - 1) lam_next = s.lam[lane + 1], act_next = s.act[lane + 1];
+    double ur[NV];
+    if (lane < NV) {
+      const D2* row = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+#pragma unroll
+      for (int j = 0; j < NV; j += 2) {
+        const D2 t = row[j / 2];
+        ur[j] = t.x;
+        ur[j + 1] = t.y;
+      }
+    }
     wsync();
     if (lane < NV) {
-      // branch-free forward sweep: identity pairs outside [l, q-2] copy the columns through unchanged; the
-      // freed direction ends up in column q-1 (kept in J as a free column, stale in U until the next add)
-      double cu = R.Ur[0], cj = R.Jr[0];
+      // branch-free forward sweep on this lane's row of U and of J: identity pairs outside [l, q-2]
+      double cu = ur[0], cj = R.Jr[0];
 #pragma unroll
       for (int j = 0; j < NV - 1; ++j) {
         const D2 g = *reinterpret_cast<const D2*>(&s.cs[2 * j]);
-        const double tu = R.Ur[j + 1], tj = R.Jr[j + 1];
-        R.Ur[j] = g.x * cu - g.y * tu;
+        const double tu = ur[j + 1], tj = R.Jr[j + 1];
+        ur[j] = g.x * cu - g.y * tu;
         cu = g.y * cu + g.x * tu;
         R.Jr[j] = g.x * cj - g.y * tj;
         cj = g.y * cj + g.x * tj;
       }
-      R.Ur[NV - 1] = cu;
+      ur[NV - 1] = cu;
       R.Jr[NV - 1] = cj;
-    }
-    // rows l+1 .. q-1 of U (and their multipliers / ids) move up one lane
-    if (lane > l && lane < q) {
+      // rows above l stay, rows l+1..q-1 move up one slot, row l (the dropped entry) disappears
+      if (lane != l && lane < q) {
+        D2* dst = reinterpret_cast<D2*>(&s.U[(lane > l ? lane - 1 : lane) * LDT]);
 #pragma unroll
-      for (int j = 0; j < NV; j += 2) *reinterpret_cast<D2*>(&s.T[(lane - 1) * LDT + j]) = D2{R.Ur[j], R.Ur[j + 1]};
-      s.w[lane - 1] = R.lami;
-      s.red_i[lane - 1] = R.acti;
-    }
-    wsync();
-    if (lane >= l && lane < q - 1) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 2) {
-        const D2 t = *reinterpret_cast<const D2*>(&s.T[lane * LDT + j]);
-        R.Ur[j] = t.x;
-        R.Ur[j + 1] = t.y;
+        for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
       }
-      R.lami = s.w[lane];
-      R.acti = s.red_i[lane];
-    } else if (lane == q - 1) {
+    }
+    if (lane >= l && lane < q - 1) s.lam[lane] = lam_next, s.act[lane] = act_next;
+    wsync();
+    // structural zeros: slot q-1 is free again, column q-1 of every row belongs to the freed direction
+    if (lane < NV) {
+      s.U[lane * LDT + (q - 1)] = 0.0;
+      if (lane == q - 1) {
+        D2* dst = reinterpret_cast<D2*>(&s.U[lane * LDT]);
 #pragma unroll
-      for (int j = 0; j < NV; ++j) R.Ur[j] = 0.0;
-      R.lami = 0.0;
-      R.acti = -1;
+        for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{0.0, 0.0};
+      }
     }
     wsync();
   }
@@ -341,19 +417,24 @@ struct WaveGI {
   // Continues from the current (dual feasible) state until no row of the current node is violated.
   static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
     const int lane = (int)threadIdx.x;
-    const int n = c.n;
+    const int n = c.n, N = c.N, max_iters = c.max_iters;
+    const double tol = c.tol;
     double f = s.f;
-    int q = s.q, neq = s.neq_done;
+    int q = uni(s.q), neq = uni(s.neq_done);
     int rc = GI_OK;
+    PROF_DECL
     for (;;) {
       states(s, c, lane);
+      PROF(0)
       int ip;
       double vip;
       if (neq < 6) {
         ip = mk_id(K_E, neq);
         vip = resid(s, c, ip);
       } else {
-        select(s, c, lane, R.xi, vip, ip);
+        select(s, c, R, lane, tol, N, vip, ip);
+        ip = uni(ip);
+        PROF(1)
         if (ip < 0) break;
       }
       const bool is_eq = id_kind(ip) == K_E;
@@ -361,59 +442,62 @@ struct WaveGI {
       double lam_p = 0;
       bool stop = false;
       for (;;) {
-        if (iters >= c.max_iters) {
+        if (iters >= max_iters) {
           rc = GI_ITERLIM;
           stop = true;
           break;
         }
         ++iters;
-        compute_d(s, R, ip, ai, lane);
-        double dd = 0, zz = 0, zi = 0, ri = 0, sufj = 0;
+        PROF(2)
+        const double dj = compute_d(s, R, ip, ai, lane);
+        PROF(3)
+        const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
+        const double dd = bcast64(sufj, 0);
+        const double zz = (q < NV) ? bcast64(sufj, q) : 0.0;
+        if (lane < NV) s.dz[lane] = (lane >= q) ? dj : 0.0;  // d2 padded with zeros: no predicate in the dot products
+        wsync();
+        double zi = 0, ri = 0;
+        if (lane < NV) {
+          const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+          double z0 = 0, z1 = 0, r0 = 0, r1 = 0;  // independent accumulators: no 60-deep dependent FMA chain
 #pragma unroll
-        for (int k2 = 0; k2 < NV; k2 += 2) {
-          const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k2]);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int k = k2 + h;
-            const double dval = h ? dk.y : dk.x;
-            const double d2 = dval * dval;
-            dd += d2;
-            if (k >= q) {
-              zz += d2;
-              zi += R.Jr[k] * dval;
-            } else if (k >= lane) {
-              ri += R.Ur[k] * dval;
-            }
-            if (k >= lane) sufj += d2;
+          for (int k = 0; k < NV; k += 2) {
+            const D2 dzk = *reinterpret_cast<const D2*>(&s.dz[k]);
+            const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+            const D2 uk = urow[k / 2];
+            z0 += R.Jr[k] * dzk.x;
+            z1 += R.Jr[k + 1] * dzk.y;
+            r0 += uk.x * dk.x;  // U is upper triangular with zero columns >= q: r = U d1 needs no mask
+            r1 += uk.y * dk.y;
           }
+          zi = z0 + z1;
+          ri = r0 + r1;
         }
         const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
-#ifdef HDSM_DEBUG
-        if (blockIdx.x == 2 && lane < 4)
-          printf("it %d lane %d ip %x q %d vip %.6e dd %.6e zz %.6e zi %.6e ri %.6e ai %.6e d[lane] %.6e J0 %.4e J1 %.4e\n", iters, lane, ip, q,
-                 vip, dd, zz, zi, ri, ai, s.dvec[lane], R.Jr[0], R.Jr[1]);
-#endif
         double t1 = DINF;
         int l = -1;
         if (!is_eq) {  // ratio test over the active inequalities (position k lives in lane k)
-          const bool okk = lane < q && id_kind(R.acti) != K_E && ri > 0;
-          const double ratio = okk ? R.lami / ri : DINF;
+          const bool okk = lane < q && id_kind(s.act[lane]) != K_E && ri > 0;
+          const double ratio = okk ? s.lam[lane] / ri : DINF;
           const double m = -wave_max64(-ratio);
           if (m < DINF) {
             t1 = m;
-            l = __ffsll((long long)__ballot(okk && ratio == m)) - 1;
+            l = uni(__ffsll((long long)__ballot(okk && ratio == m)) - 1);
           }
         }
+        PROF(4)
         if (dependent && l < 0) {
           rc = GI_INFEASIBLE;
           stop = true;
           break;
         }
         if (dependent) {  // dual step only; constraint l leaves
-          if (lane < q) R.lami -= t1 * ri;
+          if (lane < q) s.lam[lane] -= t1 * ri;
           lam_p += t1;
+          wsync();
           drop(s, R, l, q, lane);
           --q;
+          PROF(7)
           continue;
         }
         const double t2 = vip / zz;
@@ -423,16 +507,20 @@ struct WaveGI {
           R.xi += t * zi;
           s.x[lane] = R.xi;
         }
-        if (lane < q) R.lami -= t * ri;
+        if (lane < q) s.lam[lane] -= t * ri;
         f += t * zz * (0.5 * t + lam_p);
         lam_p += t;
+        PROF(5)
         if (full) {
-          add(s, R, ip, lam_p, q, lane, sufj, zz, ri);
+          add(s, R, ip, lam_p, q, lane, dj, sufj, zz, ri);
+          PROF(6)
           ++q;
           if (is_eq) ++neq;
           break;
         }
+        wsync();
         drop(s, R, l, q, lane);
+        PROF(7)
         --q;
         states(s, c, lane);
         vip = resid(s, c, ip);
@@ -454,22 +542,22 @@ struct WaveGI {
     return rc;
   }
 
-  // snapshots of the register state, layout [row j][lane] (coalesced), then x, lam, act, (f, q)
+  // snapshots: J rows from registers, U rows / multipliers / ids / x from LDS; layout [row j][lane]
   static constexpr int SNAP_DOUBLES = (2 * NV + 3) * NV + 2;
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
     if (lane < NV) {
       if (save) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) buf[j * NV + lane] = R.Jr[j], buf[(NV + j) * NV + lane] = R.Ur[j];
+        for (int j = 0; j < NV; ++j) buf[j * NV + lane] = R.Jr[j], buf[(NV + j) * NV + lane] = s.U[lane * LDT + j];
         buf[2 * NV * NV + lane] = R.xi;
-        buf[(2 * NV + 1) * NV + lane] = R.lami;
-        buf[(2 * NV + 2) * NV + lane] = (double)R.acti;
+        buf[(2 * NV + 1) * NV + lane] = s.lam[lane];
+        buf[(2 * NV + 2) * NV + lane] = (double)s.act[lane];
       } else {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) R.Jr[j] = buf[j * NV + lane], R.Ur[j] = buf[(NV + j) * NV + lane];
+        for (int j = 0; j < NV; ++j) R.Jr[j] = buf[j * NV + lane], s.U[lane * LDT + j] = buf[(NV + j) * NV + lane];
         R.xi = buf[2 * NV * NV + lane];
-        R.lami = buf[(2 * NV + 1) * NV + lane];
-        R.acti = (int)buf[(2 * NV + 2) * NV + lane];
+        s.lam[lane] = buf[(2 * NV + 1) * NV + lane];
+        s.act[lane] = (int)buf[(2 * NV + 2) * NV + lane];
         s.x[lane] = R.xi;
       }
     }
