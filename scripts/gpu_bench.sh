@@ -1,12 +1,10 @@
-# usage (on the GPU box, via gpurun): bash scripts/gpu_bench.sh
-set -x
+# usage (on the GPU box, via gpurun): bash scripts/gpu_bench.sh <tag>
+TAG=${1:-r01}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python bench.py > gpurun_out/bench_t64.json 2> gpurun_out/bench_t64.err; tail -3 gpurun_out/bench_t64.err; cat gpurun_out/bench_t64.json
-HDSM_THREADS=128 python bench.py --no-cpu-baseline > gpurun_out/bench_t128.json 2>> gpurun_out/bench_t64.err; cat gpurun_out/bench_t128.json
-HDSM_THREADS=256 python bench.py --no-cpu-baseline > gpurun_out/bench_t256.json 2>> gpurun_out/bench_t64.err; cat gpurun_out/bench_t256.json
+python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; tail -2 gpurun_out/bench_$TAG.err; cat gpurun_out/bench_$TAG.json
 export TMPDIR=/tmp
-cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG.err
 cd $GRAFT_REPO_ROOT
-ls -R gpurun_out/prof | head -20
-find gpurun_out/prof -name "*kernel_stats*" | head -1 | xargs -r head -12
+find gpurun_out/prof_$TAG -name "*kernel_stats*" | head -1 | xargs -r head -8
+ls gpurun_out/prof_$TAG/* | head

@@ -82,7 +82,7 @@ def swarm_snapshot(prm, n_rob, seed, spacing=2.0, speed=(0.0, 6.0), box_half=2.2
         path_vel = rng.uniform(4.5, 9.0)
         r = ref_from_path(p0, dirv, path_vel, dt, N)
         if turn:  # L-shaped path: after a few samples continue at 90 degrees
-            kturn = int(rng.integers(2, N - 2))
+            kturn = int(rng.integers(1, max(2, N - 2)))
             perp = np.array([-dirv[1], dirv[0], 0.0])
             pts = [p0 + dirv * path_vel * dt * i for i in range(kturn + 1)]
             for i in range(kturn + 1, N + 1):

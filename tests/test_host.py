@@ -1,0 +1,141 @@
+"""CPU tests of the host side: the C ABI surface, parameter plumbing, scenario geometry, the swarm host code
+(corridor / reference / fallback logic of include/hdsm_swarm.h) and its closed loop driven by the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from multi_agent_pkgs_amd import lib, swarm
+from multi_agent_pkgs_amd.params import HdsmParams, agile_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(hdsm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    names = declared_functions("hdsm.h") + declared_functions("hdsm_swarm.h")
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(lib.EXPORTS) <= set(names)
+    assert L.hdsm_version() >> 16 == 1
+
+
+def test_default_params_match_python_mirror():
+    L = lib.load()
+    p = HdsmParams()
+    L.hdsm_default_params(C.byref(p), 10)
+    q = agile_params(10)
+    for name, _ in HdsmParams._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        if hasattr(a, "__len__"):
+            assert list(a) == list(b), name
+        else:
+            assert a == b, name
+
+
+def test_no_device_means_error_not_fallback():
+    """There is no GPU in the build container: creating a solver must FAIL (HDSM_ERR_NO_DEVICE), not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lib.HdsmError) as e:
+        lib.Solver(agile_params(10), 4, 4)
+    assert e.value.code == lib.HDSM_ERR_NO_DEVICE
+
+
+def test_circle_scenario_known_answers():
+    g = np.load(os.path.join(GOLD, "circle.npz"))
+    starts, goals = swarm.circle_scenario(10, radius=22.0)
+    assert np.abs(starts - g["starts"]).max() < 1e-12 and np.abs(goals - g["goals"]).max() < 1e-12
+    # start_0 = (40, 15, 1.5), start_1 = (35.7984, 27.9313, 1.5), goal_0 = start_5 = (-4, 15, 1.5)
+    assert np.allclose(starts[0], [40, 15, 1.5]) and np.allclose(goals[0], [-4, 15, 1.5])
+    assert np.allclose(starts[1], [35.7984, 27.9313, 1.5], atol=1e-4)
+    assert swarm.shard_range(1024, 3, 8) == (384, 128) and swarm.shard_range(10, 3, 4) == (9, 1)
+
+
+def _first_round(n=1, **cfgkw):
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+    for k, v in cfgkw.items():
+        setattr(cfg, k, v)
+    starts = np.array([[9.95, 9.95, 3.15]] * n)
+    goals = starts + [30.0, 0, 0]
+    sh = swarm.SwarmShard(prm, cfg, n, 0, starts, goals)
+    inp = sh.prepare(np.zeros((n, 11, 9)), np.zeros(n, np.uint8))
+    return prm, sh, inp
+
+
+def test_free_space_polyhedron_matches_reference_golden():
+    """SURVEY.md 8c-5 (obtained by running the reference's convex_decomp.cpp): free 66x66x20 grid @0.3 m, origin 0,
+    seed voxel (33,33,10), n_it = 42 -> box x,y in [7.8, 12.3], z in [0.9, 5.4]; row order -y,+x,+y,-x,+z,-z."""
+    prm, sh, inp = _first_round(grid_z_min=-100.0)
+    # agent at (9.95, 9.95, 3.15): local grid origin = floor((p - range/2)/0.3)*0.3 = (-0.3+..): use the first box
+    A, b = inp["A"][0, 0, :6], inp["b"][0, 0, :6]
+    assert inp["n_rows"][0, 0] == 6
+    assert np.array_equal(A, [[0, -1, 0], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1]])
+    lo = np.array([-b[3], -b[0], -b[5]])
+    hi = np.array([b[1], b[2], b[4]])
+    assert np.allclose(hi - lo, [4.5, 4.5, 4.5])           # 15 voxels per axis = 7 layers per face
+    assert np.all(lo <= [9.95, 9.95, 3.15]) and np.all(hi >= [9.95, 9.95, 3.15])
+    assert np.allclose((lo / 0.3).round() * 0.3, lo)       # faces sit on the voxel lattice
+    # ground clipping: with the grid floor at z = 0 a seed at z = 1.5 cannot grow below the ground
+    prm2, sh2, inp2 = _first_round(grid_z_min=0.0)
+    assert -inp2["b"][0, 0, 5] >= 0.0
+
+
+def test_first_round_inputs_follow_the_reference_conventions():
+    prm, sh, inp = _first_round()
+    ref = inp["ref"][0]
+    assert np.allclose(ref[0, :3], [9.95, 9.95, 3.15])               # ref_0 is the sampling start (AC:1625)
+    assert np.allclose(np.diff(ref[:, 0]), 9.0 * prm.dt)             # nobody around: path_vel_max * dt spacing
+    assert np.allclose(ref[:, 3], -9.0) and np.allclose(ref[:, 4:], 0)  # backward velocity reference (AC:1533)
+    assert 2 <= inp["n_poly"][0] <= 4                                  # chain of boxes along the path
+
+
+def test_closed_loop_with_oracle_swaps_eight_agents_without_collision(oracle):
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+
+    def solve(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"],
+                             inp["A"], inp["b"], plans, has, n_threads=8)
+
+    loop = swarm.SwarmLoop(prm, cfg, 8, solve=solve)
+    min_sep = 1e9
+    for r in range(100):
+        loop.step()
+        pos, dist, nfail = loop.shard.state()
+        D = np.linalg.norm(pos[:, None] - pos[None], axis=2) + np.eye(8) * 1e9
+        min_sep = min(min_sep, D.min())
+    assert nfail.sum() == 0
+    assert dist.max() < 0.2            # everybody arrived at the antipodal point
+    assert min_sep > 2 * prm.drone_radius
+
+
+def test_fallback_shifts_previous_plan():
+    """AC:1000-1019: on failure the previous plan loses its first state and the last one is duplicated."""
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+    sh = swarm.SwarmShard(prm, cfg, 1, 0, np.array([[0, 0, 1.5]]), np.array([[30, 0, 1.5]]))
+    sh.prepare(np.zeros((1, 11, 9)), np.zeros(1, np.uint8))
+    traj = np.arange(99, dtype=float).reshape(1, 11, 9)
+    ok = dict(traj=traj, ctrl=np.arange(30, dtype=float).reshape(1, 10, 3), used=np.array([[1, 0, 0, 0]], np.uint8),
+              status=np.array([0], np.int32))
+    plans, has = sh.commit(ok)
+    assert has[0] == 1 and np.array_equal(plans[0], traj[0])
+    sh.prepare(plans, has)
+    bad = dict(ok, status=np.array([2], np.int32), traj=np.zeros_like(traj))
+    plans2, has2 = sh.commit(bad)
+    assert has2[0] == 1
+    assert np.array_equal(plans2[0, :10], traj[0, 1:]) and np.array_equal(plans2[0, 10], traj[0, 10])
+    assert sh.state()[2][0] == 1
