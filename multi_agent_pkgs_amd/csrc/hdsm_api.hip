@@ -14,6 +14,7 @@
 #include "../../include/hdsm.h"
 #include "hdsm_consts.h"
 #include "hdsm_core.h"
+#include "hdsm_level1.h"
 
 namespace {
 
@@ -388,9 +389,64 @@ int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_
                const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows, const double* A,
                const double* b, double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status,
                double* obj) {
-  (void)handle, (void)n_inst, (void)r_max, (void)state_curr, (void)traj_ref, (void)n_poly, (void)n_rows;
-  (void)A, (void)b, (void)traj_out, (void)ctrl_out, (void)poly_used, (void)status, (void)obj;
-  return set_err(HDSM_ERR_BAD_ARG, "hdsm_solve (level 1) is not available in this build");
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, 0)) return rc;
+  if (n_inst == 0) return HDSM_OK;
+  if (!state_curr || !traj_ref || !n_poly || !n_rows || !A || !b || !traj_out || !ctrl_out || !poly_used || !status || !obj)
+    return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  hdsm::Level1Split sp;
+  const char* msg = nullptr;
+  if (int rc = hdsm::level1_split(h->prm, n_inst, r_max, n_poly, n_rows, A, b, &sp, &msg))
+    return set_err(rc, msg ? msg : "bad level-1 input");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t I = (size_t)n_inst, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
+  hipStream_t st = h->stream;
+  double* d_common = nullptr;
+  int32_t* d_ncommon = nullptr;
+  uint8_t* d_zero = nullptr;
+  HIP_TRY(dmalloc(&d_common, sp.common.size()));
+  hipError_t e = dmalloc(&d_ncommon, sp.n_common.size());
+  if (e == hipSuccess) e = dmalloc(&d_zero, 1);
+  const auto H2D = hipMemcpyHostToDevice;
+  const auto D2H = hipMemcpyDeviceToHost;
+  std::vector<int32_t> ids(I, -1);
+  auto cp = [&](void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  };
+  cp(d_common, sp.common.data(), sp.common.size() * 8, H2D);
+  cp(d_ncommon, sp.n_common.data(), sp.n_common.size() * 4, H2D);
+  cp(h->d_agent, ids.data(), I * 4, H2D);
+  cp(h->d_state, state_curr, I * 9 * 8, H2D);
+  cp(h->d_ref, traj_ref, I * N * 6 * 8, H2D);
+  cp(h->d_npoly, sp.n_poly.data(), I * 4, H2D);
+  cp(h->d_nrows, sp.n_rows_static.data(), I * P * 4, H2D);
+  cp(h->d_A, sp.A_static.data(), I * P * RS * 3 * 8, H2D);
+  cp(h->d_b, sp.b_static.data(), I * P * RS * 8, H2D);
+  cp(h->d_traj, traj_out, I * (N + 1) * 9 * 8, H2D);
+  cp(h->d_ctrl, ctrl_out, I * N * 3 * 8, H2D);
+  cp(h->d_used, poly_used, I * P, H2D);
+  cp(h->d_obj, obj, I * 8, H2D);
+  int rc = HDSM_OK;
+  if (e == hipSuccess) {
+    hdsm::Args a{};
+    a.n_inst = n_inst, a.n_rob = 0, a.agent_id = h->d_agent, a.state = h->d_state, a.ref = h->d_ref;
+    a.n_poly = h->d_npoly, a.n_rows = h->d_nrows, a.A = h->d_A, a.b = h->d_b, a.plans = h->d_plans;
+    a.has_plan = d_zero, a.traj = h->d_traj, a.ctrl = h->d_ctrl, a.used = h->d_used, a.status = h->d_status;
+    a.obj = h->d_obj, a.l1_rows = d_common, a.l1_nrows = d_ncommon, a.l1_rmax = sp.rc_max;
+    rc = launch(h, a, st);
+  }
+  cp(traj_out, h->d_traj, I * (N + 1) * 9 * 8, D2H);
+  cp(ctrl_out, h->d_ctrl, I * N * 3 * 8, D2H);
+  cp(poly_used, h->d_used, I * P, D2H);
+  cp(status, h->d_status, I * 4, D2H);
+  cp(obj, h->d_obj, I * 8, D2H);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d_common);
+  (void)hipFree(d_ncommon);
+  (void)hipFree(d_zero);
+  if (rc) return rc;
+  if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_solve: ") + hipGetErrorString(e));
+  return HDSM_OK;
 }
 
 }  // extern "C"

@@ -504,14 +504,26 @@ struct Solver {
     return true;
   }
 
-  static HD void sweep(S& s, const Consts& c, const Args& a, int self, double thresh, bool check_fixed) {
-    const int N = c.N, total = a.n_rob * N;
+  static HD void sweep(S& s, const Consts& c, const Args& a, int inst, int self, double thresh, bool check_fixed) {
+    const int N = c.N;
+    const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
+    const int total = explicit_rows ? N * a.l1_rmax : a.n_rob * N;
     PAR_FOR(idx, total) {
-      const int k = idx / N, i = idx % N;
-      if (k == self || !a.has_plan[k]) continue;
-      const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
       double row[4];
-      if (!tasc_plane(c, s.cprev[i], op, row)) continue;
+      int i;
+      if (explicit_rows) {
+        i = idx / a.l1_rmax;
+        const int r = idx % a.l1_rmax;
+        if (r >= a.l1_nrows[(int64_t)inst * N + i]) continue;
+        const double* src = a.l1_rows + (((int64_t)inst * N + i) * a.l1_rmax + r) * 4;
+        row[0] = src[0], row[1] = src[1], row[2] = src[2], row[3] = src[3];
+      } else {
+        const int k = idx / N;
+        i = idx % N;
+        if (k == self || !a.has_plan[k]) continue;
+        const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+        if (!tasc_plane(c, s.cprev[i], op, row)) continue;
+      }
       for (int e = 0; e < 2; ++e) {
         const int m = i + e;
         const double* pm = s.st[m];
@@ -795,7 +807,7 @@ struct Solver {
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
             const long long ts_ = clock64();
 #endif
-            sweep(s, c, a, self, thresh, sweeps == 0);
+            sweep(s, c, a, inst, self, thresh, sweeps == 0);
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
             t_sweep_ += clock64() - ts_;
 #endif

@@ -53,6 +53,10 @@ struct Args {
   int32_t* st_cand;
   double* scratch;        // n_inst * scratch_stride doubles
   int64_t scratch_stride;
+  // level 1 (hdsm_solve): explicit rows common to every polyhedron of a step, instead of the plans buffer
+  const double* l1_rows;   // [n_inst][N][l1_rmax][4] or null
+  const int32_t* l1_nrows; // [n_inst][N]
+  int32_t l1_rmax;
   long long* prof;        // HDSM_PROFILE builds: 16 cycle counters per instance (else null)
 };
 

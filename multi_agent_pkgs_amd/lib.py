@@ -116,6 +116,22 @@ class Solver:
                                            vp(n_rows), vp(A), vp(b), vp(plans), vp(has_plan), vp(traj),
                                            vp(ctrl), vp(used), vp(status), vp(obj), sp))
 
+    def solve(self, state, ref, n_poly, n_rows, A, b, out=None):
+        """Level 1 (hdsm_solve): fully formed per-step polyhedra poly_const_final_vec_[N][<=P]."""
+        N, P = self.prm.n_hor, self.prm.poly_hor
+        state, ref, A, b = _f64(state), _f64(ref), _f64(A), _f64(b)
+        n_poly, n_rows = _i32(n_poly), _i32(n_rows)
+        n_inst, r_max = state.shape[0], A.shape[3]
+        if out is None:
+            out = dict(traj=np.zeros((n_inst, N + 1, 9)), ctrl=np.zeros((n_inst, N, 3)),
+                       used=np.zeros((n_inst, P), dtype=np.uint8), status=np.zeros(n_inst, dtype=np.int32),
+                       obj=np.zeros(n_inst))
+        d, i, u = C.c_double, C.c_int32, C.c_uint8
+        _check(self.lib.hdsm_solve(self.h, n_inst, r_max, _p(state, d), _p(ref, d), _p(n_poly, i), _p(n_rows, i),
+                                   _p(A, d), _p(b, d), _p(out["traj"], d), _p(out["ctrl"], d), _p(out["used"], u),
+                                   _p(out["status"], i), _p(out["obj"], d)))
+        return out
+
     def tasc_planes(self, agent_id, state, plans, has_plan):
         N = self.prm.n_hor
         agent_id, state, plans, has_plan = _i32(agent_id), _f64(state), _f64(plans), _u8(has_plan)

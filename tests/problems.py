@@ -129,3 +129,28 @@ def circle_states(n, R=22.0, cx=18.0, cy=15.0, z=1.5):
     for k in range(n):
         goals.append(starts[(k + n // 2) % n])
     return np.array(starts), np.array(goals)
+
+
+def level1_from_snapshot(prm, sn, planes_fn):
+    """Fully formed per-step polyhedra poly_const_final_vec_[N][<=P] of a swarm snapshot: the static rows followed
+    by the neighbour planes, appended to EVERY polyhedron (AddHyperplane, agent_class.cpp:1217-1234).
+    planes_fn(agent) -> (planes[N][n_rob][4], valid[N][n_rob])."""
+    N, P = prm.n_hor, prm.poly_hor
+    n_inst = sn["state"].shape[0]
+    n_rob = sn["plans"].shape[0]
+    r_max = prm.max_rows_static + n_rob
+    n_poly = np.zeros((n_inst, N), np.int32)
+    n_rows = np.zeros((n_inst, N, P), np.int32)
+    A = np.zeros((n_inst, N, P, r_max, 3))
+    b = np.zeros((n_inst, N, P, r_max))
+    for a in range(n_inst):
+        planes, valid = planes_fn(a)
+        for i in range(N):
+            rows = planes[i][valid[i] > 0]
+            n_poly[a, i] = min(P, len(sn["polys"][a]))
+            for j, (Aj, bj) in enumerate(sn["polys"][a][:P]):
+                r = len(bj) + len(rows)
+                n_rows[a, i, j] = r
+                A[a, i, j, :r] = np.vstack([Aj, rows[:, :3]])
+                b[a, i, j, :r] = np.concatenate([bj, rows[:, 3]])
+    return n_poly, n_rows, A, b

@@ -70,3 +70,32 @@ def test_lazy_rows_are_verified(emu):
     sn = problems.swarm_snapshot(prm, 16, seed=2, turn=True)
     e = emu.replan(prm, *[sn[k] for k in ARG_KEYS])
     assert (e["sweeps"][e["status"] == 0] >= 1).all()
+
+
+@pytest.mark.parametrize("kw", [dict(seed=41, narrow=True, turn=True, spacing=1.6), dict(seed=42, spacing=1.2), dict(seed=43, chamfer=True, turn=True)])
+def test_level1_split_and_solve_match_literal_oracle(emu, oracle, kw):
+    """hdsm_solve's host-side split (common suffix = the planes AddHyperplane appended) + kernel logic vs the
+    oracle's LITERAL level-1 semantics (every row is a choice row)."""
+    prm = make_params(n_hor=6, poly_hor=3, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 8, **kw)
+    n_poly, n_rows, A, b = problems.level1_from_snapshot(
+        prm, sn, lambda a: oracle.tasc_planes(prm, a, sn["state"][a], sn["plans"], sn["has_plan"]))
+    e = emu.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b)
+    assert e["rc"] == 0
+    o = oracle.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b, n_threads=8)
+    compare(e, o, tol=1e-7)
+
+
+def test_level1_rejects_step_dependent_static_polyhedra(emu):
+    prm = make_params(n_hor=6, poly_hor=3, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 2, seed=1)
+    n_poly = np.full((2, 6), 2, np.int32)
+    n_rows = np.full((2, 6, 3), 6, np.int32)
+    A = np.zeros((2, 6, 3, 8, 3))
+    b = np.zeros((2, 6, 3, 8))
+    for i in range(6):
+        for j in range(2):
+            Aj, bj = problems.box_rows(np.array([-1.0 - j, -1, 0]), np.array([1.0 + i, 1 + j, 3]))  # grows with the step
+            A[:, i, j, :6], b[:, i, j, :6] = Aj, bj
+    e = emu.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b)
+    assert e["rc"] == -1  # HDSM_ERR_BAD_ARG

@@ -120,3 +120,36 @@ def test_capacity_and_argument_errors(hdsm):
     with pytest.raises(hdsm.HdsmError) as e:
         hdsm.Solver(bad, 4, 4)
     assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("kw", [dict(seed=41, narrow=True, turn=True, spacing=1.6), dict(seed=42, spacing=1.2)])
+def test_level1_solve_matches_literal_oracle(hdsm, oracle, kw):
+    """hdsm_solve (exact stand-in for the Gurobi call alone, AC:870-1019) on fully formed per-step polyhedra."""
+    from multi_agent_pkgs_amd.params import make_params
+    prm = make_params(n_hor=6, poly_hor=3, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 8, **kw)
+    n_poly, n_rows, A, b = problems.level1_from_snapshot(
+        prm, sn, lambda a: oracle.tasc_planes(prm, a, sn["state"][a], sn["plans"], sn["has_plan"]))
+    g = hdsm.Solver(prm, 8, 8).solve(sn["state"], sn["ref"], n_poly, n_rows, A, b)
+    o = oracle.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b, n_threads=8)
+    compare(g, o)
+
+
+def test_closed_loop_on_device_matches_oracle_loop(hdsm, oracle):
+    """20 closed-loop rounds of an 8-agent circle exchange: device solver vs oracle solver, same host code."""
+    from multi_agent_pkgs_amd import swarm
+    prm = agile_params(10, max_rows_static=18)
+    sol = hdsm.Solver(prm, 8, 8)
+
+    def dev(inp, plans, has):
+        return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    la = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 8, solve=dev)
+    lb = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 8, solve=cpu)
+    for r in range(45):
+        la.step()
+        lb.step()
+    assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6
