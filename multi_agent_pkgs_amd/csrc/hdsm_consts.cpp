@@ -62,6 +62,9 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
   c->cand_tau = 1.5;  // [m] rows whose slack at the first converged iterate is below this are staged
   if (const char* e = std::getenv("HDSM_CAND_TAU")) c->cand_tau = std::atof(e);
+  c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
+                      // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.
+  if (const char* e = std::getenv("HDSM_HOT_TAU")) c->hot_tau = std::atof(e);
   c->r_u = prm->r_u;
   for (int k = 0; k < 6; ++k) c->wx[k] = prm->r_x[k], c->wn[k] = prm->r_n[k];
   for (int ax = 0; ax < 3; ++ax) {
@@ -151,6 +154,60 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
       for (int k = 0; k < n; ++k) s += c->J0[i * n + k] * c->J0[j * n + k];
       c->Hinv[i * n + j] = s;
     }
+  // ---- state after the six terminal equalities: row e = (ax = e % 3, comp = 1 + e / 3), normal in u-space
+  //      a_e[ax*N + k] = g[ax][comp][N-1-k]; added one after the other with Householder reflections (same update
+  //      the device uses), in plain dense fp64.
+  {
+    std::vector<double> J(c->J0, c->J0 + (size_t)n * n), Rm(36, 0.0), E(6 * n, 0.0);
+    for (int e = 0; e < 6; ++e) {
+      const int ax = e % 3, comp = 1 + e / 3;
+      for (int k = 0; k < N; ++k) E[(size_t)e * n + ax * N + k] = c->g[ax][comp][N - 1 - k];
+    }
+    for (int q = 0; q < 6; ++q) {
+      std::vector<double> d(n, 0.0);
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) d[j] += J[(size_t)i * n + j] * E[(size_t)q * n + i];  // d = J^T a (sign is irrelevant here)
+      double zz = 0;
+      for (int j = q; j < n; ++j) zz += d[j] * d[j];
+      if (!(zz > 0)) return fail(err, "terminal equalities are linearly dependent");
+      const double rho = (d[q] > 0 ? -1.0 : 1.0) * std::sqrt(zz);
+      const double beta = 1.0 / (rho * (rho - d[q]));
+      for (int i = 0; i < n; ++i) {  // J2 -= (J2 v) beta v^T, v = d2 - rho e_q
+        double w = -rho * J[(size_t)i * n + q];
+        for (int j = q; j < n; ++j) w += J[(size_t)i * n + j] * d[j];
+        w *= beta;
+        for (int j = q; j < n; ++j) J[(size_t)i * n + j] -= w * (d[j] - (j == q ? rho : 0.0));
+      }
+      for (int i = 0; i < q; ++i) Rm[i * 6 + q] = d[i];
+      Rm[q * 6 + q] = rho;
+    }
+    std::memcpy(c->Jeq, J.data(), sizeof(double) * n * n);
+    std::memcpy(c->Req, Rm.data(), sizeof(double) * 36);
+    // Ueq = Req^{-1} (upper triangular back substitution per column)
+    for (int col = 0; col < 6; ++col)
+      for (int i = 5; i >= 0; --i) {
+        double sacc = (i == col) ? 1.0 : 0.0;
+        for (int k = i + 1; k < 6; ++k) sacc -= Rm[i * 6 + k] * c->Ueq[k * 6 + col];
+        c->Ueq[i * 6 + col] = sacc / Rm[i * 6 + i];
+      }
+    // Seq = (E H^{-1} E^T)^{-1} = Ueq Ueq^T ;  Meq = H^{-1} E^T Seq
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        double sacc = 0;
+        for (int k = 0; k < 6; ++k) sacc += c->Ueq[i * 6 + k] * c->Ueq[j * 6 + k];
+        c->Seq[i * 6 + j] = sacc;
+      }
+    std::vector<double> HE((size_t)n * 6, 0.0);  // H^{-1} E^T
+    for (int i = 0; i < n; ++i)
+      for (int e = 0; e < 6; ++e)
+        for (int k = 0; k < n; ++k) HE[(size_t)i * 6 + e] += c->Hinv[(size_t)i * n + k] * E[(size_t)e * n + k];
+    for (int i = 0; i < n; ++i)
+      for (int e = 0; e < 6; ++e) {
+        double sacc = 0;
+        for (int k = 0; k < 6; ++k) sacc += HE[(size_t)i * 6 + k] * c->Seq[k * 6 + e];
+        c->Meq[(size_t)i * 6 + e] = sacc;
+      }
+  }
   return HDSM_OK;
 }
 

@@ -75,9 +75,7 @@ struct Shm {
 #else
   alignas(16) double T[NV * LDT];       // transposition buffer for d = J^T a (J rows live in registers)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
-  alignas(16) double dz[NV + 2];        // d with the entries of the active columns zeroed
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
-  alignas(16) double cs[2 * NV];        // Givens pairs (c_j, s_j)
   double gz[3][3][2 * MAXH];            // zero-padded impulse responses: gz[ax][s][MAXH + lag]
   long long prof_acc[16];
   long long prof_last;
@@ -104,6 +102,7 @@ struct Shm {
   int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
   int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
+  int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
@@ -533,8 +532,17 @@ struct Solver {
           continue;
         }
         if (-v < thresh) {
+#ifdef HDSM_EMU
           const int slot = atomic_inc_i32(&s.ncand);
-          if (slot < CMAX) {
+          const bool fits = slot < CMAX;
+#else
+          // violated (or almost) -> hot list, scanned every iteration; merely close -> cold list at the top of
+          // the staging area, scanned only when the hot rows are all satisfied
+          const bool hot = -v < c.hot_tau;
+          const int slot = hot ? atomic_inc_i32(&s.ncand) : CMAX - 1 - atomic_inc_i32(&s.ncold);
+          const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
+#endif
+          if (fits && slot >= 0 && slot < CMAX) {
             s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
             s.cand[slot][3] = row[3];
             s.cand_m[slot] = m;
@@ -545,7 +553,13 @@ struct Solver {
       }
     }
     SYNC();
-    if (IS_T0 && s.ncand > CMAX) s.ncand = CMAX;
+    if (IS_T0) {
+#ifdef HDSM_EMU
+      if (s.ncand > CMAX) s.ncand = CMAX;
+#else
+      if (s.ncand + s.ncold > CMAX) s.overflow = 1;  // the two lists met: whatever was written may be clobbered
+#endif
+    }
     SYNC();
   }
 
@@ -701,8 +715,8 @@ struct Solver {
     }
     PAR_FOR(k, MAXH) s.assign[k] = -1;
     if (IS_T0) {
-      s.n_poly = np, s.q = 0, s.neq_done = 0, s.ncand = 0, s.level = 0, s.have_inc = 0;
-      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF;
+      s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
+      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0;
     }
     SYNC();
     // free response + st[0]
@@ -728,29 +742,58 @@ struct Solver {
       s.grad[k] = gsum;
     }
     SYNC();
-    PAR_FOR(k, n) {  // x0 = -H^{-1} grad
+    PAR_FOR(k, n) {  // x0 = -H^{-1} grad (unconstrained minimiser)
       double t = 0;
       for (int j = 0; j < n; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
+      s.w[k] = t;
+    }
+    SYNC();
+    // residual of the six terminal equalities at x0: resid_e = v/a component of x_N
+    PAR_FOR(e, 6) {
+      const int ax = e % 3, comp = 1 + e / 3;
+      double t = s.fr[ax][N][comp];
+      for (int k = 0; k < N; ++k) t += c.g[ax][comp][N - 1 - k] * s.w[ax * N + k];
+      s.red_v[e] = t;
+    }
+    SYNC();
+    PAR_FOR(k, n) {  // x_eq = x0 - Meq resid: minimiser subject to v_N = a_N = 0
+      double t = s.w[k];
+      for (int e = 0; e < 6; ++e) t -= c.Meq[k * 6 + e] * s.red_v[e];
       s.x[k] = t;
     }
     GIState R;
 #ifdef HDSM_EMU
     PAR_FOR(k, n * n) {
       const int i = k / n, j = k % n;
-      s.J[i * LD + j] = c.J0[k];
-      s.R[i * LD + j] = 0;
+      s.J[i * LD + j] = c.Jeq[k];
+      s.R[i * LD + j] = (i < 6 && j < 6) ? c.Req[i * 6 + j] : 0.0;
+    }
+    PAR_FOR(e, 6) {
+      double nu = 0;
+      for (int k = 0; k < 6; ++k) nu += c.Seq[e * 6 + k] * s.red_v[k];
+      s.lam[e] = nu;
+      s.act[e] = mk_id(K_E, e);
     }
 #else
     {  // lane i holds row i of J = L^{-T} (identity beyond n) and of U = R^{-1} (empty)
       const int lane = (int)threadIdx.x;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        R.Jr[j] = (lane < n && j < n) ? c.J0[lane * n + j] : ((lane == j) ? 1.0 : 0.0);
+        R.Jr[j] = (lane < n && j < n) ? c.Jeq[lane * n + j] : ((lane == j) ? 1.0 : 0.0);
       }
     }
     W::init_lane(R, c, (int)threadIdx.x);
-    PAR_FOR(k, NV * S::LDT) s.U[k] = 0.0;
-    PAR_FOR(k, NV) s.lam[k] = 0.0, s.act[k] = -1;
+    PAR_FOR(k, NV * S::LDT) {
+      const int i = k / S::LDT, j = k % S::LDT;
+      s.U[k] = (i < 6 && j < 6) ? c.Ueq[i * 6 + j] : 0.0;
+    }
+    PAR_FOR(k, NV) {
+      double nu = 0;
+      if (k < 6)
+        for (int e = 0; e < 6; ++e) nu += c.Seq[k * 6 + e] * s.red_v[e];
+      s.lam[k] = nu;
+      s.act[k] = (k < 6) ? mk_id(K_E, k) : -1;
+    }
     PAR_FOR(k, 9 * 2 * MAXH) {
       const int ax = k / (6 * MAXH), comp = (k / (2 * MAXH)) % 3, e = k % (2 * MAXH), lag = e - MAXH;
       s.gz[ax][comp][e] = (lag >= 0 && lag < N) ? c.g[ax][comp][lag] : 0.0;
@@ -771,7 +814,9 @@ struct Solver {
         }
       }
       double f = f0;
-      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.x[k];
+      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.w[k];  // J(x0)
+      for (int e = 0; e < 6; ++e)                                  // + 1/2 resid' (E H^{-1} E')^{-1} resid
+        for (int k = 0; k < 6; ++k) f += 0.5 * s.red_v[e] * c.Seq[e * 6 + k] * s.red_v[k];
       s.f0 = f0;
       s.f = f;
     }
@@ -801,6 +846,7 @@ struct Solver {
         if (bstep < 0) {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
+          const int before_cold = s.ncold;
           double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
           for (;;) {
             SYNC();
@@ -816,7 +862,7 @@ struct Solver {
             // dense neighbourhood: more rows within the staging radius than LDS slots -> tighten it
             // (the radius only decides what is pre-staged; exactness comes from the verification sweeps)
             SYNC();
-            if (IS_T0) s.ncand = before, s.overflow = 0;
+            if (IS_T0) s.ncand = before, s.ncold = before_cold, s.overflow = 0;
             thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
           }
           if (s.fixed_bad) break;  // a common row is violated at the pinned point: infeasible whatever j
@@ -904,7 +950,7 @@ struct Solver {
       if (a.st_iters) a.st_iters[inst] = iters;
       if (a.st_nodes) a.st_nodes[inst] = nodes;
       if (a.st_sweeps) a.st_sweeps[inst] = sweeps;
-      if (a.st_cand) a.st_cand[inst] = s.ncand;
+      if (a.st_cand) a.st_cand[inst] = s.ncand + s.ncold;
     }
     SYNC();
   }

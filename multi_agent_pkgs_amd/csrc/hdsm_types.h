@@ -18,7 +18,7 @@ constexpr double DINF = 1e300;
 struct Consts {
   int32_t N, n, P, RS;
   int32_t max_nodes, max_iters, pad0, pad1;
-  double tol, ftol_fixed, cand_tau;
+  double tol, ftol_fixed, cand_tau, hot_tau;
   double r_u, wx[6], wn[6];
   double lbu[3], ubu[3];       // input box (absent if |.| >= ABSENT)
   double lbs[3][3], ubs[3][3]; // state box [comp][ax], comp 1 = v, 2 = a
@@ -28,6 +28,12 @@ struct Consts {
   double phi[3][MAXH + 1][3][3]; // Ad^i
   double Hinv[MAXNV * MAXNV];    // inverse Hessian, dense n x n, row-major with stride n
   double J0[MAXNV * MAXNV];      // L^{-T}, H = L L^T
+  // State of the active-set method AFTER the six terminal equalities v_N = a_N = 0 (AC:2078-2081) have been
+  // added (they are in every working set and their normals are config constants):
+  double Jeq[MAXNV * MAXNV];     // J with J^T E^T = [Req; 0], stride n
+  double Req[36], Ueq[36];       // Req upper triangular 6x6, Ueq = Req^{-1}
+  double Meq[MAXNV * 6];         // x_eq = x0 - Meq * resid,  resid_e = (E x0 - e)_e;  Meq = H^{-1}E^T (E H^{-1} E^T)^{-1}
+  double Seq[36];                // (E H^{-1} E^T)^{-1}: multipliers nu = Seq * resid, f_eq = f(x0) + 1/2 resid' Seq resid
 };
 
 // Per-launch arguments (device pointers), layouts of include/hdsm.h.

@@ -8,11 +8,14 @@
 //   * r = U d1 is a lane-local dot product: no back-substitution chain;
 //   * d = J^T a is a transposition through LDS (T[j][i] = J[i][j] a_i, conflict-free strides), or a single
 //     row broadcast when the incoming row is an input bound (a = +-e_k, the common case in bang-bang plans);
-//   * "add": the Givens sweep on columns q..NV-1 of J is lane-local; its coefficients come from suffix sums
-//     of d^2 (each lane computes its own pair, one LDS exchange) — no sequential sqrt chain;
-//     U gets the new column (-r/rho ; 1/rho);
-//   * "drop l": U' = E^T U G^T where G rotates row l of U onto the last axis: coefficients from PREFIX sums
-//     of that row, sweep lane-local on U and J, then the rows >= l of U move up one lane;
+//   * "add" is ONE Householder reflection of the free columns q..NV-1 of J that maps d2 onto rho e_q: a
+//     rank-1 update J2 -= (J2 v) beta v^T with v = d2 - rho e_q. J2 v = z - rho J[:,q] reuses the primal
+//     direction z that the step needs anyway, so the update costs one FMA per free column, one sqrt and
+//     one division per ITERATION (not per lane) and no coefficient exchange; U gets the column (-r/rho; 1/rho).
+//     R = U^{-1} stays a general invertible matrix (it need not be triangular for the method);
+//   * "drop l": any orthogonal G with G u_l^T = sigma e_{q-1} (u_l = row l of U) gives
+//     U' = (E^T U G^T)[:, :q-1]; G is again one Householder reflection: rank-1 updates of the rows of U (LDS)
+//     and of the columns 0..q-1 of J (registers), then the rows > l of U are written one slot up;
 //   * cross-lane reductions use DPP row rotations + v_readlane, not LDS trees.
 // Dimension handling: the factors are padded to NV (identity beyond n = 3N), so every loop has a
 // compile-time trip count and unrolls; a padded direction never receives a step (d_k = 0 there).
@@ -135,9 +138,20 @@ struct WaveGI {
     }
   }
 
+  // register array access with a wave-uniform dynamic index (select chain on an SGPR compare)
+  static __device__ __forceinline__ double reg_get(const double (&a)[NV], int q) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v = (k == q) ? a[k] : v;
+    return v;
+  }
+  static __device__ __forceinline__ void reg_set(double (&a)[NV], int q, double v) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = (k == q) ? v : a[k];
+  }
+
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
-  static __device__ __forceinline__ void states(S& s, const Consts& c, int lane) {
-    const int N = c.N;
+  static __device__ __forceinline__ void states(S& s, const Consts& c, int lane, int N) {
     if (lane < 3 * N) {
       const int ax = lane / N, m = lane % N + 1;
       double acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
@@ -159,19 +173,46 @@ struct WaveGI {
     wsync();
   }
 
-  // most violated row of the current node -> (v, id), id < 0 if none exceeds tol
+  // violation of staged rows [lo, hi) -> running (v, id); four rows per trip, loads issued before first use
+  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double& v, int& id) {
+    for (int base = lo; base < hi; base += 256) {
+      int idx[4], mm[4];
+      D2 r01[4], r23[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        idx[u] = base + 64 * u + lane;
+        const int ii = idx[u] < hi ? idx[u] : lo;
+        mm[u] = s.cand_m[ii];
+        r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
+        r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
+      }
+      double px[4], py[4], pz[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* pm = s.st[mm[u]];
+        px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
+        if (idx[u] < hi && vv > v) v = vv, id = mk_id(K_C, idx[u]);
+      }
+    }
+  }
+
+  // most violated row among: input / state boxes, rows of assigned polyhedra, HOT staged rows
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
                                                 double& vbest, int& ibest) {
     double v = tol;
     int id = -1;
-    {  // this lane's input bound
+    {
       const double vu = R.xi - R.ub_own, vl = R.lb_own - R.xi;
       if (vu > v) v = vu, id = mk_id(K_U, lane << 1);
       if (vl > v) v = vl, id = mk_id(K_U, (lane << 1) | 1);
     }
     const double* stf = &s.st[0][0];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {  // velocity / acceleration boxes on x_1 .. x_{N-1}
+    for (int e = 0; e < 2; ++e) {
       if (R.sb_off[e] >= 0) {
         const double sv = stf[R.sb_off[e]];
         const double vu = sv - R.sb_ub[e], vl = R.sb_lb[e] - sv;
@@ -191,44 +232,46 @@ struct WaveGI {
         if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
       }
     }
-    // staged neighbour rows, four per trip with all loads issued before the first use
-    const int nc = uni(s.ncand);
-    for (int base = 0; base < nc; base += 256) {
-      int idx[4], mm[4];
-      D2 r01[4], r23[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        idx[u] = base + 64 * u + lane;
-        const int ii = idx[u] < nc ? idx[u] : 0;
-        mm[u] = s.cand_m[ii];
-        r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
-        r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
-      }
-      double px[4], py[4], pz[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double* pm = s.st[mm[u]];
-        px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
-        if (idx[u] < nc && vv > v) v = vv, id = mk_id(K_C, idx[u]);
-      }
-    }
+    scan_rows(s, 0, uni(s.ncand), lane, v, id);
     const double m = wave_max64(v);
     vbest = m;
     ibest = -1;
     if (m > tol) {
       const unsigned long long mask = __ballot(v == m && id >= 0);
-      const int src = __ffsll((long long)mask) - 1;
-      ibest = __builtin_amdgcn_readlane(id, src);
+      ibest = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
     }
   }
 
+  // No hot row is violated: check the COLD staged rows (kept at the top of the staging area, scanned only
+  // here) and promote the violated ones into the hot list. Returns the number promoted.
+  static __device__ __forceinline__ int promote_cold(S& s, int lane, double tol) {
+    const int ncold = uni(s.ncold);
+    if (ncold == 0) return 0;
+    const int before = uni(s.ncand);
+    for (int idx = CMAX - ncold + lane; idx < CMAX; idx += 64) {
+      const double* row = s.cand[idx];
+      const double* pm = s.st[s.cand_m[idx]];
+      const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+      if (vv > tol) {
+        const int slot = atomicAdd(&s.ncand, 1);
+        if (slot < CMAX - ncold) {
+          s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2], s.cand[slot][3] = row[3];
+          s.cand_m[slot] = s.cand_m[idx];
+          s.cand[idx][3] = DINF;  // neutralise the cold copy: it can never be violated again
+        } else {
+          s.overflow = 1;
+        }
+      }
+    }
+    wsync();
+    if (lane == 0 && s.ncand > CMAX - ncold) s.ncand = CMAX - ncold;
+    wsync();
+    return uni(s.ncand) - before;
+  }
+
   // entry `lane` of the dense normal a of constraint id (a . u <= rhs form)
-  static __device__ __forceinline__ double normal_entry(const S& s, const Consts& c, int id, int lane) {
-    const int N = c.N, n = c.n, kind = id_kind(id), p = id_payload(id);
+  static __device__ __forceinline__ double normal_entry(const S& s, const Consts& c, int id, int lane, int N, int n) {
+    const int kind = id_kind(id), p = id_payload(id);
     if (lane >= n) return 0.0;
     const int ax = lane / N, kk = lane % N;
     if (kind == K_U) return (lane == (p >> 1)) ? ((p & 1) ? -1.0 : 1.0) : 0.0;
@@ -254,8 +297,8 @@ struct WaveGI {
     return (kk < m) ? row[ax] * s.gz[ax][0][MAXH + m - 1 - kk] : 0.0;
   }
 
-  static __device__ __forceinline__ double resid(const S& s, const Consts& c, int id) {
-    const int N = c.N, kind = id_kind(id), p = id_payload(id);
+  static __device__ __forceinline__ double resid(const S& s, const Consts& c, int id, int N) {
+    const int kind = id_kind(id), p = id_payload(id);
     if (kind == K_U) {
       const int var = p >> 1, ax = var / N;
       return (p & 1) ? (c.lbu[ax] - s.x[var]) : (s.x[var] - c.ubu[ax]);
@@ -309,103 +352,71 @@ struct WaveGI {
       dj = -(a0 + a1);
       s.dvec[lane] = dj;
     }
-    return dj;  // the caller synchronises before anybody reads dvec
-  }
-
-  // working set += id at position q (full step taken)
-  static __device__ __forceinline__ void add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dj, double sufj,
-                                             double zz, double ri) {
-    {  // own Givens pair (column j = lane, j > q): zero d_j into d_{j-1}; identity for j <= q
-      double cc = 1.0, ss = 0.0;
-      if (lane > q && lane < NV) {
-        const double dm1 = s.dvec[lane - 1];
-        const double h = sqrt(sufj + dm1 * dm1);
-        if (h > 0) {
-          cc = dm1 / h;
-          ss = ((lane == NV - 1) ? dj : sqrt(sufj)) / h;
-        }
-      }
-      if (lane < NV) *reinterpret_cast<D2*>(&s.cs[2 * lane]) = D2{cc, ss};
-    }
-    const double rho = (q == NV - 1) ? s.dvec[NV - 1] : sqrt(zz);
-    // new column q of U = R^{-1}: (-r / rho ; 1 / rho ; 0)
-    if (lane < NV) s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
-    if (lane == q) {
-      s.lam[q] = lam_p;
-      s.act[q] = id;
-    }
     wsync();
-    if (lane < NV) {
-      // branch-free sweep from the last column down: the identity pairs (1, 0) for j <= q make the
-      // recurrence copy those columns back onto themselves and leave the rotated tail in column q
-      double carry = R.Jr[NV - 1];
-#pragma unroll
-      for (int j = NV - 1; j >= 1; --j) {
-        const D2 g = *reinterpret_cast<const D2*>(&s.cs[2 * j]);
-        const double t1 = R.Jr[j - 1];
-        R.Jr[j] = g.x * carry - g.y * t1;
-        carry = g.x * t1 + g.y * carry;
-      }
-      R.Jr[0] = carry;
-    }
+    return dj;
   }
 
-  // working set -= entry at position l: U' = E^T U G^T with G rotating row l of U onto the last axis
+  // working set -= entry at position l (one Householder reflection, see the header comment)
   static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
-    {  // own pair for column j = lane in [l, q-2]: (a_j, u_{j+1}) -> (0, sigma_{j+1}); identity elsewhere
-      const double ul = (lane >= l && lane < q) ? s.U[l * LDT + lane] : 0.0;  // row l of U, own entry
-      const double pre = wave_prefix_sum(ul * ul, lane);                        // sum_{k=l..lane} u_k^2
-      double cd = 1.0, sd = 0.0;
-      if (lane >= l && lane <= q - 2) {
-        const double aj = (lane == l) ? ul : sqrt(pre);
-        const double bj = s.U[l * LDT + lane + 1];
-        const double sg = sqrt(pre + bj * bj);
-        cd = bj / sg;
-        sd = aj / sg;
-      }
-      if (lane < NV) *reinterpret_cast<D2*>(&s.cs[2 * lane]) = D2{cd, sd};
-    }
-    double lam_next = 0.0;
-    int act_next = -1;
-    if (lane >= l && lane < q - 1) lam_next = s.lam[lane + 1], act_next = s.act[lane + 1];
-    double ur[NV];
-    if (lane < NV) {
-      const D2* row = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+    const int t = q - 1;
+    double uv[NV];  // row l of U, broadcast to every lane
+    {
+      const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT]);
 #pragma unroll
       for (int j = 0; j < NV; j += 2) {
-        const D2 t = row[j / 2];
-        ur[j] = t.x;
-        ur[j + 1] = t.y;
+        const D2 v2 = rl[j / 2];
+        uv[j] = v2.x, uv[j + 1] = v2.y;
       }
     }
-    wsync();
-    if (lane < NV) {
-      // branch-free forward sweep on this lane's row of U and of J: identity pairs outside [l, q-2]
-      double cu = ur[0], cj = R.Jr[0];
+    const double ut = s.U[l * LDT + t];
+    double s0 = 0, s1 = 0;
 #pragma unroll
-      for (int j = 0; j < NV - 1; ++j) {
-        const D2 g = *reinterpret_cast<const D2*>(&s.cs[2 * j]);
-        const double tu = ur[j + 1], tj = R.Jr[j + 1];
-        ur[j] = g.x * cu - g.y * tu;
-        cu = g.y * cu + g.x * tu;
-        R.Jr[j] = g.x * cj - g.y * tj;
-        cj = g.y * cj + g.x * tj;
+    for (int j = 0; j < NV; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
+    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(s0 + s1);
+    const double beta = 1.0 / (sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
+    double lam_next = 0.0;
+    int act_next = -1;
+    if (lane >= l && lane < t) lam_next = s.lam[lane + 1], act_next = s.act[lane + 1];
+    if (lane < NV) {
+      // own row of U (LDS) and of J (registers): x -= (x . v) beta v
+      double ur[NV];
+      const D2* ro = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+#pragma unroll
+      for (int j = 0; j < NV; j += 2) {
+        const D2 v2 = ro[j / 2];
+        ur[j] = v2.x, ur[j + 1] = v2.y;
       }
-      ur[NV - 1] = cu;
-      R.Jr[NV - 1] = cj;
+      const double urt = s.U[lane * LDT + t];
+      const double jt = reg_get(R.Jr, t);
+      double wu0 = 0, wu1 = 0, wj0 = 0, wj1 = 0;
+#pragma unroll
+      for (int j = 0; j < NV; j += 2) {
+        wu0 += ur[j] * uv[j], wu1 += ur[j + 1] * uv[j + 1];
+        wj0 += R.Jr[j] * uv[j], wj1 += R.Jr[j + 1] * uv[j + 1];  // uv is zero beyond column t
+      }
+      const double cu = ((wu0 + wu1) - sigma * urt) * beta, cj = ((wj0 + wj1) - sigma * jt) * beta;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        ur[j] -= cu * uv[j];
+        R.Jr[j] -= cj * uv[j];
+      }
+      reg_set(R.Jr, t, jt - cj * (ut - sigma));  // the freed direction stays in J as a free column
+      wsync();                                   // every lane has read its row before anybody rewrites a slot
       // rows above l stay, rows l+1..q-1 move up one slot, row l (the dropped entry) disappears
       if (lane != l && lane < q) {
         D2* dst = reinterpret_cast<D2*>(&s.U[(lane > l ? lane - 1 : lane) * LDT]);
 #pragma unroll
         for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
       }
+    } else {
+      wsync();
     }
-    if (lane >= l && lane < q - 1) s.lam[lane] = lam_next, s.act[lane] = act_next;
+    if (lane >= l && lane < t) s.lam[lane] = lam_next, s.act[lane] = act_next;
     wsync();
-    // structural zeros: slot q-1 is free again, column q-1 of every row belongs to the freed direction
+    // structural zeros: column t of every row belongs to the freed direction, slot t is empty again
     if (lane < NV) {
-      s.U[lane * LDT + (q - 1)] = 0.0;
-      if (lane == q - 1) {
+      s.U[lane * LDT + t] = 0.0;
+      if (lane == t) {
         D2* dst = reinterpret_cast<D2*>(&s.U[lane * LDT]);
 #pragma unroll
         for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{0.0, 0.0};
@@ -424,21 +435,25 @@ struct WaveGI {
     int rc = GI_OK;
     PROF_DECL
     for (;;) {
-      states(s, c, lane);
+      states(s, c, lane, N);
       PROF(0)
       int ip;
       double vip;
       if (neq < 6) {
         ip = mk_id(K_E, neq);
-        vip = resid(s, c, ip);
+        vip = resid(s, c, ip, N);
       } else {
         select(s, c, R, lane, tol, N, vip, ip);
         ip = uni(ip);
+        if (ip < 0) {
+          if (promote_cold(s, lane, tol) > 0) continue;
+          PROF(1)
+          break;
+        }
         PROF(1)
-        if (ip < 0) break;
       }
       const bool is_eq = id_kind(ip) == K_E;
-      const double ai = normal_entry(s, c, ip, lane);
+      const double ai = normal_entry(s, c, ip, lane, N, n);
       double lam_p = 0;
       bool stop = false;
       for (;;) {
@@ -454,21 +469,29 @@ struct WaveGI {
         const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
         const double dd = bcast64(sufj, 0);
         const double zz = (q < NV) ? bcast64(sufj, q) : 0.0;
-        if (lane < NV) s.dz[lane] = (lane >= q) ? dj : 0.0;  // d2 padded with zeros: no predicate in the dot products
-        wsync();
+        const double dq = (q < NV) ? bcast64(dj, q) : 0.0;
+        double dv[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k += 2) {
+          const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+          dv[k] = dk.x, dv[k + 1] = dk.y;
+        }
         double zi = 0, ri = 0;
         if (lane < NV) {
           const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
-          double z0 = 0, z1 = 0, r0 = 0, r1 = 0;  // independent accumulators: no 60-deep dependent FMA chain
+          double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
 #pragma unroll
-          for (int k = 0; k < NV; k += 2) {
-            const D2 dzk = *reinterpret_cast<const D2*>(&s.dz[k]);
-            const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+          for (int k = 0; k < NV; k += 2) {  // U has zero columns >= q: r = U d1 needs no mask
             const D2 uk = urow[k / 2];
-            z0 += R.Jr[k] * dzk.x;
-            z1 += R.Jr[k + 1] * dzk.y;
-            r0 += uk.x * dk.x;  // U is upper triangular with zero columns >= q: r = U d1 needs no mask
-            r1 += uk.y * dk.y;
+            r0 += uk.x * dv[k];
+            r1 += uk.y * dv[k + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {  // z = J2 d2: free columns only (wave-uniform predicate)
+            if (k >= q) {
+              if (k & 1) z1 += R.Jr[k] * dv[k];
+              else z0 += R.Jr[k] * dv[k];
+            }
           }
           zi = z0 + z1;
           ri = r0 + r1;
@@ -512,7 +535,23 @@ struct WaveGI {
         lam_p += t;
         PROF(5)
         if (full) {
-          add(s, R, ip, lam_p, q, lane, dj, sufj, zz, ri);
+          // ---- add at position q: Householder on the free columns, d2 -> rho e_q
+          const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
+          const double beta = 1.0 / (rho * (rho - dq));
+          if (lane < NV) {
+            const double jq = reg_get(R.Jr, q);
+            const double coef = (zi - rho * jq) * beta;  // (J2 v) beta, v = d2 - rho e_q
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+              if (k >= q) R.Jr[k] -= coef * dv[k];
+            reg_set(R.Jr, q, jq - coef * (dq - rho));
+            s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
+          }
+          if (lane == q) {
+            s.lam[q] = lam_p;
+            s.act[q] = ip;
+          }
+          wsync();
           PROF(6)
           ++q;
           if (is_eq) ++neq;
@@ -522,8 +561,8 @@ struct WaveGI {
         drop(s, R, l, q, lane);
         PROF(7)
         --q;
-        states(s, c, lane);
-        vip = resid(s, c, ip);
+        states(s, c, lane, N);
+        vip = resid(s, c, ip, N);
         if (f >= f_cut) {
           rc = GI_CUTOFF;
           stop = true;
