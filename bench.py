@@ -46,6 +46,16 @@ def main():
     ap.add_argument("--first-round", type=int, default=25, help="first recorded closed-loop round")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall-clock budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default="", help="npz file with the recorded rounds: written after the closed-loop "
+                    "set-up if missing, loaded instead of flying the swarm if present (profiling runs: only the "
+                    "timed launches remain in the process)")
+    ap.add_argument("--no-event-pass", action="store_true", help="skip the second (HIP-event) pass")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the product path) or gloo "
+                    "(testing the multi-rank flow on a box with fewer GPUs than ranks: ranks share devices and the "
+                    "all-gather is staged through the host)")
+    ap.add_argument("--round-offset", type=int, default=-1, help="index of the first TIMED recorded round "
+                    "(default = warmup). A profiling run uses --warmup 0 --round-offset 10 to launch exactly the "
+                    "rounds the default run times")
     args = ap.parse_args()
 
     import torch
@@ -57,12 +67,25 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank = local_rank % max(1, torch.cuda.device_count()) if args.dist_backend == "gloo" else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    host_staged = world > 1 and args.dist_backend != "nccl"
+
+    def all_gather_dev(full, shard):
+        """one all-gather of the shard into the full buffer (RCCL on device memory; host-staged under gloo)"""
+        if not host_staged:
+            dist.all_gather_into_tensor(full, shard)
+        else:
+            f = torch.empty(full.shape, dtype=full.dtype)
+            dist.all_gather_into_tensor(f, shard.cpu())
+            full.copy_(f)
 
     from multi_agent_pkgs_amd import lib, swarm
     from multi_agent_pkgs_amd.params import agile_params
@@ -74,7 +97,8 @@ def main():
     first, n_local = swarm.shard_range(n_rob, rank, world)
     per = (n_rob + world - 1) // world
     K, W = args.steps, args.warmup
-    n_rec = K + W
+    off = args.round_offset if args.round_offset >= 0 else W
+    n_rec = max(K + W, off + K)
 
     solver = lib.Solver(prm, max(n_local, 1), n_rob, device=dev.index)
     stream = torch.cuda.current_stream()
@@ -83,7 +107,7 @@ def main():
     def allgather_np(local):
         t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
         full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        dist.all_gather_into_tensor(full, t)
+        all_gather_dev(full, t)
         return full.cpu().numpy()
 
     def solve_np(inp, plans, has):
@@ -91,13 +115,23 @@ def main():
                              inp["A"], inp["b"], plans, has)
 
     cfg = swarm.default_swarm_config()
-    loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
-                           allgather=allgather_np if world > 1 else None)
     rec, fails, total_rounds = [], 0, args.first_round + n_rec
-    for r in range(total_rounds):
-        out = loop.step(record=rec if r >= args.first_round else None)
-        if r >= args.first_round:
-            fails += int((out["status"] == 2).sum())
+    cache = (args.cache + f".rank{rank}" if world > 1 else args.cache) if args.cache else ""
+    keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        assert int(z["n_rob"]) == n_rob and int(z["N"]) == N and z["state"].shape[0] >= n_rec
+        rec = [{k: z[k][r] for k in keys} for r in range(n_rec)]
+        fails = int(z["fails"])
+    else:
+        loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
+                               allgather=allgather_np if world > 1 else None)
+        for r in range(total_rounds):
+            out = loop.step(record=rec if r >= args.first_round else None)
+            if r >= args.first_round:
+                fails += int((out["status"] == 2).sum())
+        if cache:
+            np.savez(cache, n_rob=n_rob, N=N, fails=fails, **{k: np.stack([x[k] for x in rec]) for k in keys})
 
     def stack(key, dtype):
         return torch.from_numpy(np.ascontiguousarray(np.stack([x[key] for x in rec]), dtype=dtype)).to(dev)
@@ -121,7 +155,7 @@ def main():
                              d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
                              d_status[:n_local], d_obj[:n_local], stream=stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_next, d_traj)
+            all_gather_dev(d_next, d_traj)
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,29 +164,30 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- timed region (the contract)
-    for r in range(W):
+    for r in range(off - W, off):
         step(r)
     barrier()
     t0 = time.perf_counter()
-    for r in range(W, W + K):
+    for r in range(off, off + K):
         step(r)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not host_staged else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---------------------------------------------------------------- second pass: per-launch kernel time
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for k, r in enumerate(range(W, W + K)):
+    for k, r in enumerate(range(off, off + K) if not args.no_event_pass else []):
         ev[k][0].record(stream)
         solver.replan_device(d_agent[r], d_state[r], d_ref[r], d_npoly[r], d_nrows[r], d_A[r], d_b[r],
                              d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
                              d_status[:n_local], d_obj[:n_local], stream=stream)
         ev[k][1].record(stream)
     torch.cuda.synchronize()
-    kern_ms = np.array([a.elapsed_time(b) for a, b in ev])
+    kern_ms = (np.array([a.elapsed_time(b) for a, b in ev]) if not args.no_event_pass
+               else np.full(K, elapsed / K * 1e3))
     stats = solver.last_stats(n_local)
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
@@ -171,7 +206,7 @@ def main():
                        x["plans"], x["has_plan"], n_threads=1)
             return n_local
 
-        sample = rec[W:W + K]
+        sample = rec[off:off + K]
         t1 = time.perf_counter()
         one(sample[0])
         per_task = max(time.perf_counter() - t1, 1e-4)
