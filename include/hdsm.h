@@ -85,6 +85,13 @@ typedef struct hdsm_params {
   int32_t max_qp_iters;     /* active-set iteration budget per instance (summed over nodes)                */
   double feas_tol_fixed;    /* tolerance for rows on the pinned point p_0 (Gurobi FeasibilityTol 1e-6)     */
   double solver_tol;        /* primal feasibility tolerance of the exact active-set solver (default 1e-9)  */
+  /* The reference keeps ONE GRBModel per agent across replans (AC:32), so Gurobi restarts from the previous
+   * solution. 1 = do the same: the optimal working set of the previous hdsm_replan / hdsm_replan_device call is
+   * kept per instance INDEX on the handle and seeds the next solve (the answer does not depend on it, only
+   * the work). The caller must then keep the agent <-> instance index mapping stable between calls, or call
+   * hdsm_reset_warm_start() when it changes.                                                              */
+  int32_t warm_start;
+  int32_t reserved0;
 } hdsm_params;
 
 /* Fills `p` with the agile configuration shipped by the reference
@@ -155,6 +162,9 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
  * Synchronises the handle's stream.                                                                       */
 int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
                     int32_t* cand);
+
+/* Forget the working sets kept for warm_start (e.g. after re-assigning agents to instance indices).      */
+int hdsm_reset_warm_start(void* handle);
 
 /* Text of the last error on this thread (HIP error string or argument check that failed).                 */
 const char* hdsm_last_error(void);

@@ -83,6 +83,7 @@ struct Handle {
   int64_t scratch_stride = 0;
   int32_t* d_stats = nullptr;  // 4 * max_inst
   long long* d_prof = nullptr; // 16 * max_inst (HDSM_PROFILE builds)
+  int32_t* d_warm = nullptr;   // (MAXNV + 2) * max_inst: previous optimal working sets (params.warm_start)
   // staging for the host-pointer entry points
   int32_t *d_agent = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr;
   double *d_state = nullptr, *d_ref = nullptr, *d_A = nullptr, *d_b = nullptr, *d_plans = nullptr;
@@ -117,6 +118,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.st_sweeps = h->d_stats + 2 * h->max_inst;
   a.st_cand = h->d_stats + 3 * h->max_inst;
   a.prof = h->d_prof;
+  a.warm = (h->prm.warm_start && a.l1_rows == nullptr) ? h->d_warm : nullptr;
   h->last_stream = st;
   // one 64-lane wavefront per agent-replan: the factorisation lives in that wave's registers
   if (h->n <= 30) return launch_nv<30, 64>(h, a, st);
@@ -134,7 +136,7 @@ hipError_t dmalloc(T** p, size_t count) {
 }
 
 void free_all(Handle* h) {
-  void* ptrs[] = {h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
+  void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used};
   for (void* p : ptrs)
@@ -175,6 +177,7 @@ void hdsm_default_params(hdsm_params* p, int32_t n_hor) {
   }
   p->drone_radius = 0.25, p->drone_z_offset = 0.25, p->plane_perturb = 0.1;
   p->max_nodes = 0, p->max_qp_iters = 0, p->feas_tol_fixed = 1e-6, p->solver_tol = 1e-9;
+  p->warm_start = 1;
 }
 
 int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_max, int32_t device,
@@ -216,6 +219,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_consts, 1));
   ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
   ok(dmalloc(&h->d_stats, 4 * I));
+  ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
 #ifdef HDSM_PROFILE
   ok(dmalloc(&h->d_prof, 16 * I));
 #endif
@@ -236,6 +240,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 4 * I * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(h->d_warm, 0, (hdsm::MAXNV + 2) * I * sizeof(int32_t));
   delete hc;
   if (e != hipSuccess) {
     free_all(h);
@@ -350,6 +355,15 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d_planes);
   if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_tasc_planes: ") + hipGetErrorString(e));
+  return HDSM_OK;
+}
+
+int hdsm_reset_warm_start(void* handle) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return set_err(HDSM_ERR_BAD_ARG, "null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(h->d_warm, 0, (size_t)(hdsm::MAXNV + 2) * h->max_inst * sizeof(int32_t)));
   return HDSM_OK;
 }
 

@@ -166,7 +166,7 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
     for (int q = 0; q < 6; ++q) {
       std::vector<double> d(n, 0.0);
       for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) d[j] += J[(size_t)i * n + j] * E[(size_t)q * n + i];  // d = J^T a (sign is irrelevant here)
+        for (int i = 0; i < n; ++i) d[j] -= J[(size_t)i * n + j] * E[(size_t)q * n + i];  // d = J^T np, np = -a (device convention)
       double zz = 0;
       for (int j = q; j < n; ++j) zz += d[j] * d[j];
       if (!(zz > 0)) return fail(err, "terminal equalities are linearly dependent");

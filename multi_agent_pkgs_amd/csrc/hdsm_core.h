@@ -77,6 +77,10 @@ struct Shm {
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
   double gz[3][3][2 * MAXH];            // zero-padded impulse responses: gz[ax][s][MAXH + lag]
+  double x0[NV];                        // unconstrained minimiser (base point of the warm start)
+  double fx0;                           // J(x0)
+  int32_t cand_src[CMAX];               // origin of a staged row: (neighbour << 6) | (step << 1) | endpoint, -1 = explicit
+  int32_t inc_act[NV], inc_nact;        // working set of the incumbent (portable ids) -> next replan's guess
   long long prof_acc[16];
   long long prof_last;
 #endif
@@ -105,6 +109,30 @@ struct Shm {
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
+
+// One separating plane (AC:1100-1205) from own position cp and neighbour position op: out = (n_f, n_f . q).
+HD bool tasc_plane_eval(const Consts& c, const double* cp, const double* op, double* out) {
+  const double dx = op[0] - cp[0], dy = op[1] - cp[1], dz = op[2] - cp[2];
+  const double n2 = dx * dx + dy * dy + dz * dz;
+  if (!(n2 > 0)) return false;  // Eigen normalized() keeps a zero vector: the row is 0.p <= 0
+  const double nrm = sqrt(n2), inv = 1.0 / nrm;
+  const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
+  // ellipsoid support distance: hypot(r cos t, h sin t), t = atan((r/h) tan(pi/2 - |acos hz|))
+  //   == r / sqrt(1 + ((r/h)^2 - 1) hz^2)
+  const double sd = c.radius / sqrt(1.0 + c.k2m1 * hz * hz);
+  const double back = 0.5 * fmin(2.0 * sd, nrm);
+  const double qx = 0.5 * (cp[0] + op[0]) - back * hx;
+  const double qy = 0.5 * (cp[1] + op[1]) - back * hy;
+  const double qz = 0.5 * (cp[2] + op[2]) - back * hz;
+  // n x (0,0,1) = (hy,-hx,0);  n x (0,1,0) = (-hz,0,hx);  n_f = n + pert*(c1+c2) + pert*c2
+  const double fx = hx + c.pert * (hy - hz) - c.pert * hz;
+  const double fy = hy - c.pert * hx;
+  const double fz = hz + c.pert * hx + c.pert * hx;
+  out[0] = fx, out[1] = fy, out[2] = fz;
+  out[3] = fx * qx + fy * qy + fz * qz;
+  return true;
+}
+
 
 }  // namespace hdsm
 #include "hdsm_wave_gi.h"
@@ -482,25 +510,7 @@ struct Solver {
 
   // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
   static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
-    const double dx = op[0] - cp[0], dy = op[1] - cp[1], dz = op[2] - cp[2];
-    const double n2 = dx * dx + dy * dy + dz * dz;
-    if (!(n2 > 0)) return false;  // Eigen normalized() keeps a zero vector: the row is 0.p <= 0
-    const double nrm = sqrt(n2), inv = 1.0 / nrm;
-    const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
-    // ellipsoid support distance: hypot(r cos t, h sin t), t = atan((r/h) tan(pi/2 - |acos hz|))
-    //   == r / sqrt(1 + ((r/h)^2 - 1) hz^2)
-    const double sd = c.radius / sqrt(1.0 + c.k2m1 * hz * hz);
-    const double back = 0.5 * fmin(2.0 * sd, nrm);
-    const double qx = 0.5 * (cp[0] + op[0]) - back * hx;
-    const double qy = 0.5 * (cp[1] + op[1]) - back * hy;
-    const double qz = 0.5 * (cp[2] + op[2]) - back * hz;
-    // n x (0,0,1) = (hy,-hx,0);  n x (0,1,0) = (-hz,0,hx);  n_f = n + pert*(c1+c2) + pert*c2
-    const double fx = hx + c.pert * (hy - hz) - c.pert * hz;
-    const double fy = hy - c.pert * hx;
-    const double fz = hz + c.pert * hx + c.pert * hx;
-    out[0] = fx, out[1] = fy, out[2] = fz;
-    out[3] = fx * qx + fy * qy + fz * qz;
-    return true;
+    return tasc_plane_eval(c, cp, op, out);
   }
 
   static HD void sweep(S& s, const Consts& c, const Args& a, int inst, int self, double thresh, bool check_fixed) {
@@ -546,6 +556,9 @@ struct Solver {
             s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
             s.cand[slot][3] = row[3];
             s.cand_m[slot] = m;
+#ifndef HDSM_EMU
+            s.cand_src[slot] = explicit_rows ? -1 : (((idx / N) << 6) | (i << 1) | e);
+#endif
           } else {
             s.overflow = 1;
           }
@@ -803,6 +816,8 @@ struct Solver {
     SYNC();
 #ifndef HDSM_EMU
     R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
+    PAR_FOR(k, NV) s.x0[k] = (k < n) ? s.w[k] : 0.0;
+    if (IS_T0) s.inc_nact = 0;
 #endif
     if (IS_T0) {
       double f0 = 0;
@@ -815,6 +830,9 @@ struct Solver {
       }
       double f = f0;
       for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.w[k];  // J(x0)
+#ifndef HDSM_EMU
+      s.fx0 = f;
+#endif
       for (int e = 0; e < 6; ++e)                                  // + 1/2 resid' (E H^{-1} E')^{-1} resid
         for (int k = 0; k < 6; ++k) f += 0.5 * s.red_v[e] * c.Seq[e * 6 + k] * s.red_v[k];
       s.f0 = f0;
@@ -827,6 +845,9 @@ struct Solver {
 #endif
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
+#ifndef HDSM_EMU
+    if (a.warm != nullptr && np > 0) W::warm_start(s, c, a, R, inst, self, iters);
+#endif
     bool limit = false;
     bool run = np > 0;
     while (run) {
@@ -873,6 +894,20 @@ struct Solver {
           }
           PAR_FOR(k, n) s.inc_x[k] = s.x[k];
           PAR_FOR(i, N) s.inc_assign[i] = s.contain[i];
+#ifndef HDSM_EMU
+          PAR_FOR(k, NV) {
+            int code = 0;
+            if (k < s.q) {
+              code = s.act[k];
+              if (id_kind(code) == K_C) {
+                const int src = s.cand_src[id_payload(code)];
+                code = src >= 0 ? mk_id(K_C, src) : mk_id(K_E, 0);  // explicit rows carry no portable identity
+              }
+            }
+            s.inc_act[k] = code;
+          }
+          if (IS_T0) s.inc_nact = s.q;
+#endif
           if (IS_T0) s.inc_f = s.f, s.have_inc = 1;
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
@@ -945,6 +980,14 @@ struct Solver {
           if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
       }
     }
+#ifndef HDSM_EMU
+    if (a.warm != nullptr) {  // next replan's guess (empty when there is no solution)
+      int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
+      const int cnt = s.have_inc ? s.inc_nact : 0;
+      PAR_FOR(k, NV) if (k < cnt) wp[1 + k] = s.inc_act[k];
+      if (IS_T0) wp[0] = cnt;
+    }
+#endif
     if (IS_T0) {
       a.status[inst] = status;
       if (a.st_iters) a.st_iters[inst] = iters;

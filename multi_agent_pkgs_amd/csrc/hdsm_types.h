@@ -63,6 +63,7 @@ struct Args {
   const double* l1_rows;   // [n_inst][N][l1_rmax][4] or null
   const int32_t* l1_nrows; // [n_inst][N]
   int32_t l1_rmax;
+  int32_t* warm;          // [n_inst][MAXNV + 2]: count + portable ids of the previous optimal working set (in/out), or null
   long long* prof;        // HDSM_PROFILE builds: 16 cycle counters per instance (else null)
 };
 

@@ -356,6 +356,172 @@ struct WaveGI {
     return dj;
   }
 
+  // d = J^T(-a), ||d||^2, ||d2||^2, d_q, z_i = (J2 d2)_i, r_i = (U d1)_i for the incoming constraint
+  static __device__ __forceinline__ void direction(S& s, const Regs& R, int id, double ai, int q, int lane, double (&dv)[NV],
+                                                   double& dd, double& zz, double& dq, double& zi, double& ri) {
+    const double dj = compute_d(s, R, id, ai, lane);
+    const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
+    dd = bcast64(sufj, 0);
+    zz = (q < NV) ? bcast64(sufj, q) : 0.0;
+    dq = (q < NV) ? bcast64(dj, q) : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+      const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+      dv[k] = dk.x, dv[k + 1] = dk.y;
+    }
+    zi = 0, ri = 0;
+    if (lane < NV) {
+      const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+      double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
+#pragma unroll
+      for (int k = 0; k < NV; k += 2) {  // U has zero columns >= q: r = U d1 needs no mask
+        const D2 uk = urow[k / 2];
+        r0 += uk.x * dv[k];
+        r1 += uk.y * dv[k + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {  // z = J2 d2: free columns only (wave-uniform predicate)
+        if (k >= q) {
+          if (k & 1) z1 += R.Jr[k] * dv[k];
+          else z0 += R.Jr[k] * dv[k];
+        }
+      }
+      zi = z0 + z1;
+      ri = r0 + r1;
+    }
+  }
+
+  // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q
+  static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane,
+                                                         const double (&dv)[NV], double zz, double dq, double zi, double ri) {
+    const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
+    const double beta = 1.0 / (rho * (rho - dq));
+    if (lane < NV) {
+      const double jq = reg_get(R.Jr, q);
+      const double coef = (zi - rho * jq) * beta;  // (J2 v) beta, v = d2 - rho e_q
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        if (k >= q) R.Jr[k] -= coef * dv[k];
+      reg_set(R.Jr, q, jq - coef * (dq - rho));
+      s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
+    }
+    if (lane == q) {
+      s.lam[q] = lam_p;
+      s.act[q] = id;
+    }
+    wsync();
+  }
+
+  // ---- warm start ---------------------------------------------------------------------------------------
+  // The optimal working set of the previous replan of this instance (a.warm, portable ids), moved one step
+  // towards the present, seeds the dual method: its rows are put into the factorisation WITHOUT taking steps,
+  // the minimiser x_W on them and its multipliers follow in closed form
+  //      t = U^T v,   lambda = U t,   x_W = x0 + J1 t,   f_W = f(x0) + |t|^2 / 2        (v = violations at x0)
+  // and entries with a negative multiplier are dropped until (x_W, W) is a valid S-pair. The regular loop then
+  // continues from there; the result is the same optimum, reached in fewer iterations.
+  static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self,
+                                                    int& iters) {
+    const int lane = (int)threadIdx.x;
+    const int N = c.N, n = c.n;
+    const int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
+    int nw = uni(wp[0]);
+    if (nw <= 0) return;
+    if (nw > NV) nw = NV;
+    int q = uni(s.q);
+    for (int g = 0; g < nw && q < n; ++g) {
+      const int code = uni(wp[1 + g]);
+      const int kind = id_kind(code), p = id_payload(code);
+      int id = -1;
+      if (kind == K_U) {
+        const int var = p >> 1;
+        if (var % N >= 1) id = mk_id(K_U, ((var - 1) << 1) | (p & 1));
+      } else if (kind == K_S) {
+        const int i = p >> 5;
+        if (i - 1 >= 1) id = mk_id(K_S, ((i - 1) << 5) | (p & 31));
+      } else if (kind == K_C && a.l1_rows == nullptr) {
+        const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
+        if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
+          double row[4];
+          const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+          const int slot = uni(s.ncand);
+          if (slot < CMAX - uni(s.ncold) && tasc_plane_eval(c, s.cprev[i], op, row)) {
+            if (lane == 0) {
+              s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2], s.cand[slot][3] = row[3];
+              s.cand_m[slot] = i + e;
+              s.cand_src[slot] = (k << 6) | (i << 1) | e;
+              s.ncand = slot + 1;
+            }
+            wsync();
+            id = mk_id(K_C, slot);
+          }
+        }
+      }
+      if (id < 0) continue;
+      const double ai = normal_entry(s, c, id, lane, N, n);
+      double dv[NV], dd, zz, dq, zi, ri;
+      direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
+      ++iters;
+      if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
+      householder_add(s, R, id, 0.0, q, lane, dv, zz, dq, zi, ri);
+      ++q;
+    }
+    if (q == uni(s.q)) return;  // nothing usable
+    // violations of the working-set rows at the unconstrained minimiser x0
+    if (lane < NV) s.x[lane] = s.x0[lane];
+    wsync();
+    states(s, c, lane, N);
+    for (;;) {
+      const double vk = (lane < q) ? resid(s, c, s.act[lane], N) : 0.0;
+      if (lane < NV) s.dvec[lane] = vk;
+      wsync();
+      double tj = 0.0;  // t = U^T v
+      if (lane < NV) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) tj += s.U[k * LDT + lane] * s.dvec[k];  // rows >= q of U are zero
+      }
+      wsync();
+      if (lane < NV) s.dvec[lane] = tj;
+      wsync();
+      double lk = 0.0, xw = 0.0;
+      if (lane < NV) {
+        const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+        double l0 = 0, l1 = 0, x0 = 0, x1 = 0;
+#pragma unroll
+        for (int k = 0; k < NV; k += 2) {
+          const D2 tk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+          const D2 uk = urow[k / 2];
+          l0 += uk.x * tk.x, l1 += uk.y * tk.y;               // lambda = U t
+          x0 += R.Jr[k] * tk.x, x1 += R.Jr[k + 1] * tk.y;     // J1 t  (t is zero beyond q)
+        }
+        lk = l0 + l1;
+        xw = s.x0[lane] + (x0 + x1);
+      }
+      // most negative multiplier among the inequalities
+      const bool ineq = lane < q && id_kind(s.act[lane]) != K_E;
+      const double worst = -wave_max64(ineq ? -lk : -DINF);
+      if (!(worst < -1e-12) || q <= 6) {
+        const double tt = wave_suffix_sum(tj * tj, lane);
+        if (lane < NV) {
+          s.lam[lane] = (lane < q) ? lk : 0.0;
+          if (lane < n) R.xi = xw, s.x[lane] = xw;
+        }
+        if (lane == 0) s.f = s.fx0 + 0.5 * bcast64(tt, 0), s.q = q;
+        wsync();
+#ifdef HDSM_DEBUG
+        states(s, c, lane, N);
+        if (blockIdx.x == 2 && lane < q)
+          printf("WS lane %d q %d nw %d act %x lam %.4e resid@xW %.3e f %.6e fx0 %.6e\n", lane, q, nw, s.act[lane], lk,
+                 resid(s, c, s.act[lane], N), s.f, s.fx0);
+#endif
+        return;
+      }
+      const int l = uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1);
+      drop(s, R, l, q, lane);
+      --q;
+      ++iters;
+    }
+  }
+
   // working set -= entry at position l (one Householder reflection, see the header comment)
   static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
     const int t = q - 1;
@@ -464,38 +630,9 @@ struct WaveGI {
         }
         ++iters;
         PROF(2)
-        const double dj = compute_d(s, R, ip, ai, lane);
+        double dv[NV], dd, zz, dq, zi, ri;
+        direction(s, R, ip, ai, q, lane, dv, dd, zz, dq, zi, ri);
         PROF(3)
-        const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
-        const double dd = bcast64(sufj, 0);
-        const double zz = (q < NV) ? bcast64(sufj, q) : 0.0;
-        const double dq = (q < NV) ? bcast64(dj, q) : 0.0;
-        double dv[NV];
-#pragma unroll
-        for (int k = 0; k < NV; k += 2) {
-          const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
-          dv[k] = dk.x, dv[k + 1] = dk.y;
-        }
-        double zi = 0, ri = 0;
-        if (lane < NV) {
-          const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
-          double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
-#pragma unroll
-          for (int k = 0; k < NV; k += 2) {  // U has zero columns >= q: r = U d1 needs no mask
-            const D2 uk = urow[k / 2];
-            r0 += uk.x * dv[k];
-            r1 += uk.y * dv[k + 1];
-          }
-#pragma unroll
-          for (int k = 0; k < NV; ++k) {  // z = J2 d2: free columns only (wave-uniform predicate)
-            if (k >= q) {
-              if (k & 1) z1 += R.Jr[k] * dv[k];
-              else z0 += R.Jr[k] * dv[k];
-            }
-          }
-          zi = z0 + z1;
-          ri = r0 + r1;
-        }
         const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
         double t1 = DINF;
         int l = -1;
@@ -536,22 +673,7 @@ struct WaveGI {
         PROF(5)
         if (full) {
           // ---- add at position q: Householder on the free columns, d2 -> rho e_q
-          const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
-          const double beta = 1.0 / (rho * (rho - dq));
-          if (lane < NV) {
-            const double jq = reg_get(R.Jr, q);
-            const double coef = (zi - rho * jq) * beta;  // (J2 v) beta, v = d2 - rho e_q
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-              if (k >= q) R.Jr[k] -= coef * dv[k];
-            reg_set(R.Jr, q, jq - coef * (dq - rho));
-            s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
-          }
-          if (lane == q) {
-            s.lam[q] = lam_p;
-            s.act[q] = ip;
-          }
-          wsync();
+          householder_add(s, R, ip, lam_p, q, lane, dv, zz, dq, zi, ri);
           PROF(6)
           ++q;
           if (is_eq) ++neq;

@@ -17,7 +17,8 @@ SO_PATH = os.path.join(_HERE, "libhdsm.so")
 HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACITY = 0, -1, -2, -3, -4
 
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
-           "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats")
+           "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
+           "hdsm_reset_warm_start")
 
 
 class HdsmError(RuntimeError):
@@ -141,6 +142,9 @@ class Solver:
                                          _p(plans, C.c_double), _p(has_plan, C.c_uint8),
                                          _p(planes, C.c_double)))
         return planes
+
+    def reset_warm_start(self):
+        _check(self.lib.hdsm_reset_warm_start(self.h))
 
     def last_stats(self, n_inst):
         st = {k: np.zeros(n_inst, dtype=np.int32) for k in ("qp_iters", "nodes", "sweeps", "cand")}

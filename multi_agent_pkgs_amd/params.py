@@ -36,6 +36,8 @@ class HdsmParams(C.Structure):
         ("max_qp_iters", C.c_int32),
         ("feas_tol_fixed", C.c_double),
         ("solver_tol", C.c_double),
+        ("warm_start", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def copy(self):
@@ -49,7 +51,8 @@ def make_params(n_hor=10, poly_hor=4, rk4=False, dt=0.1, drag=(0.0, 0.0, 0.0), r
                 r_n=(100.0, 100.0, 100.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0),
                 max_vel=20.0, max_acc_xy=15.0, min_acc_xy=-15.0, max_acc_z=15.0, min_acc_z=-15.0,
                 max_jerk=60.0, drone_radius=0.25, drone_z_offset=0.25, plane_perturb=0.1,
-                max_rows_static=18, max_nodes=0, max_qp_iters=0, feas_tol_fixed=1e-6, solver_tol=1e-9):
+                max_rows_static=18, max_nodes=0, max_qp_iters=0, feas_tol_fixed=1e-6, solver_tol=1e-9,
+                warm_start=True):
     """Build an HdsmParams the way InitializePlannerParameters builds x_lb_/x_ub_/u_lb_/u_ub_ (n_x = 9)."""
     p = HdsmParams()
     p.n_hor, p.poly_hor, p.rk4, p.max_rows_static = n_hor, poly_hor, int(bool(rk4)), max_rows_static
@@ -67,6 +70,7 @@ def make_params(n_hor=10, poly_hor=4, rk4=False, dt=0.1, drag=(0.0, 0.0, 0.0), r
     p.drone_radius, p.drone_z_offset, p.plane_perturb = drone_radius, drone_z_offset, plane_perturb
     p.max_nodes, p.max_qp_iters = max_nodes, max_qp_iters
     p.feas_tol_fixed, p.solver_tol = feas_tol_fixed, solver_tol
+    p.warm_start = int(bool(warm_start))
     return p
 
 
