@@ -384,7 +384,7 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
       for (int j = 0; j < 16; ++j) mean[j] += (double)pr[(size_t)k * 16 + j] / n_inst;
     }
     static const char* nm[16] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
-                                 "leaf", "TOTAL", "iters", "sweeps", "nodes", "ncand"};
+                                 "leaf", "TOTAL", "iters", "sweeps", "warm_ops", "warm_cycles"};
     std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);
     for (int j = 0; j < 16; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 16 + j]);
     std::fprintf(stderr, "\nHDSM_PROFILE mean:");

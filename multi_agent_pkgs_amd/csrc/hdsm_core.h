@@ -107,6 +107,7 @@ struct Shm {
   int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
+  int32_t nviol;  // rows found violated (> tol) by the last sweep
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
@@ -516,6 +517,12 @@ struct Solver {
   static HD void sweep(S& s, const Consts& c, const Args& a, int inst, int self, double thresh, bool check_fixed) {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
+#ifndef HDSM_EMU
+    if (!explicit_rows) {  // device build: lane-per-neighbour sweep (hdsm_wave_gi.h)
+      WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, (int)threadIdx.x);
+      return;
+    }
+#endif
     const int total = explicit_rows ? N * a.l1_rmax : a.n_rob * N;
     PAR_FOR(idx, total) {
       double row[4];
@@ -541,6 +548,7 @@ struct Solver {
           if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
           continue;
         }
+        if (v > c.tol) s.nviol = 1;  // benign race: every writer stores the same value
         if (-v < thresh) {
 #ifdef HDSM_EMU
           const int slot = atomic_inc_i32(&s.ncand);
@@ -600,8 +608,7 @@ struct Solver {
       s.keys[i][j] = vmax;
     }
     SYNC();
-    int first = -1;
-    for (int i = 0; i < N; ++i) {  // uniform scan (N*P <= 128 LDS reads)
+    PAR_FOR(i, N) {  // one thread per step: lowest-index polyhedron containing the segment
       int cont = -1;
       if (s.assign[i] >= 0) {
         cont = s.assign[i];
@@ -612,10 +619,12 @@ struct Solver {
             break;
           }
       }
-      if (IS_T0) s.contain[i] = cont;
-      if (cont < 0 && first < 0) first = i;
+      s.contain[i] = cont;
     }
     SYNC();
+    int first = -1;
+    for (int i = N - 1; i >= 0; --i)
+      if (s.contain[i] < 0) first = i;
     return first;
   }
 
@@ -755,9 +764,10 @@ struct Solver {
       s.grad[k] = gsum;
     }
     SYNC();
-    PAR_FOR(k, n) {  // x0 = -H^{-1} grad (unconstrained minimiser)
+    PAR_FOR(k, n) {  // x0 = -H^{-1} grad (unconstrained minimiser); H is block diagonal per axis
       double t = 0;
-      for (int j = 0; j < n; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
+      const int j0 = (k / N) * N;
+      for (int j = j0; j < j0 + N; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
       s.w[k] = t;
     }
     SYNC();
@@ -788,12 +798,13 @@ struct Solver {
       s.act[e] = mk_id(K_E, e);
     }
 #else
-    {  // lane i holds row i of J = L^{-T} (identity beyond n) and of U = R^{-1} (empty)
+    {  // lane i holds row i of J (identity beyond n): coalesced global reads, staged through the T buffer
       const int lane = (int)threadIdx.x;
+      PAR_FOR(k, n * n) s.T[(k / n) * S::LDT + (k % n)] = c.Jeq[k];
+      SYNC();
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        R.Jr[j] = (lane < n && j < n) ? c.Jeq[lane * n + j] : ((lane == j) ? 1.0 : 0.0);
-      }
+      for (int j = 0; j < NV; ++j)
+        R.Jr[j] = (lane < n && j < n) ? s.T[lane * S::LDT + j] : ((lane == j) ? 1.0 : 0.0);
     }
     W::init_lane(R, c, (int)threadIdx.x);
     PAR_FOR(k, NV * S::LDT) {
@@ -846,7 +857,15 @@ struct Solver {
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
 #ifndef HDSM_EMU
+#ifdef HDSM_PROFILE
+    const long long tw_ = clock64();
+#endif
     if (a.warm != nullptr && np > 0) W::warm_start(s, c, a, R, inst, self, iters);
+#ifdef HDSM_PROFILE
+    t_leaf_ -= 0;
+    const long long t_warm_ = clock64() - tw_;
+    const int it_warm_ = iters;
+#endif
 #endif
     bool limit = false;
     bool run = np > 0;
@@ -871,6 +890,8 @@ struct Solver {
           double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
           for (;;) {
             SYNC();
+            if (IS_T0) s.nviol = 0;
+            SYNC();
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
             const long long ts_ = clock64();
 #endif
@@ -887,7 +908,9 @@ struct Solver {
             thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
           }
           if (s.fixed_bad) break;  // a common row is violated at the pinned point: infeasible whatever j
-          if (s.ncand > before) continue;  // rows were staged: the dual method continues on this node
+          // rows were staged AND at least one of them is violated: the dual method continues on this node.
+          // (Rows staged merely because they are close do not move the iterate: the point is verified.)
+          if (s.ncand > before && s.nviol) continue;
           if (s.overflow) {  // staging capacity exhausted, a violated row could not be staged
             limit = true;
             break;
@@ -938,7 +961,7 @@ struct Solver {
       long long* pr = a.prof + (int64_t)inst * 16;
       for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k];
       pr[8] = t_setup_, pr[9] = t_sweep_, pr[10] = t_leaf_, pr[11] = clock64() - t_begin_;
-      pr[12] = iters, pr[13] = sweeps, pr[14] = nodes, pr[15] = s.ncand;
+      pr[12] = iters, pr[13] = sweeps, pr[14] = it_warm_, pr[15] = t_warm_;
     }
 #endif
     // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective

@@ -412,6 +412,80 @@ struct WaveGI {
     wsync();
   }
 
+  // ---- neighbour sweep, device version -----------------------------------------------------------------------
+  // 1 / sqrt(x) to double precision: v_rsq_f64 seed + two Newton steps (no v_sqrt / v_rcp expansion per plane)
+  static __device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+  }
+
+  // Same planes as tasc_plane_eval (AC:1100-1205), organised for the wave: lane <-> neighbour k, the N future
+  // positions of that neighbour are loaded up-front (one 792-B record per lane, every byte of the position part
+  // used), then the N planes are evaluated back to back with independent instruction streams.
+  static __device__ __forceinline__ void sweep_planes(S& s, const Consts& c, const Args& a, int self, double thresh,
+                                                      bool check_fixed, int lane) {
+    const int N = c.N, n_rob = a.n_rob;
+    const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
+    for (int k0 = 0; k0 < n_rob; k0 += 64) {
+      const int k = k0 + lane;
+      const bool on = k < n_rob && k != self && a.has_plan[k < n_rob ? k : 0];
+      const double* rec = a.plans + ((int64_t)(on ? k : 0) * (N + 1) + 1) * 9;
+      double ox[HT], oy[HT], oz[HT];
+#pragma unroll
+      for (int i = 0; i < HT; ++i) {
+        if (i < N) {
+          ox[i] = rec[9 * i], oy[i] = rec[9 * i + 1], oz[i] = rec[9 * i + 2];
+        } else {
+          ox[i] = oy[i] = oz[i] = 0.0;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HT; ++i) {
+        if (i >= N) continue;
+        const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
+        const double dx = ox[i] - cx, dy = oy[i] - cy, dz = oz[i] - cz;
+        const double n2 = dx * dx + dy * dy + dz * dz;
+        if (!on || !(n2 > 0)) continue;  // coincident agents: the row is 0 . p <= 0
+        const double inv = rsqrt_nr(n2), nrm = n2 * inv;
+        const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
+        const double sd = radius * rsqrt_nr(1.0 + k2m1 * hz * hz);  // ellipsoid support distance
+        const double back = 0.5 * fmin(2.0 * sd, nrm);
+        const double qx = 0.5 * (cx + ox[i]) - back * hx, qy = 0.5 * (cy + oy[i]) - back * hy,
+                     qz = 0.5 * (cz + oz[i]) - back * hz;
+        const double fx = hx + pert * (hy - hz) - pert * hz, fy = hy - pert * hx, fz = hz + 2.0 * pert * hx;
+        const double rhs = fx * qx + fy * qy + fz * qz;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int m = i + e;
+          const double* pm = s.st[m];
+          const double v = fx * pm[0] + fy * pm[1] + fz * pm[2] - rhs;
+          if (m == 0) {
+            if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
+            continue;
+          }
+          if (v > tol) s.nviol = 1;
+          if (-v < thresh) {
+            const bool hot = -v < hot_tau;
+            const int slot = hot ? atomicAdd(&s.ncand, 1) : CMAX - 1 - atomicAdd(&s.ncold, 1);
+            const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
+            if (fits && slot >= 0 && slot < CMAX) {
+              s.cand[slot][0] = fx, s.cand[slot][1] = fy, s.cand[slot][2] = fz, s.cand[slot][3] = rhs;
+              s.cand_m[slot] = m;
+              s.cand_src[slot] = (k << 6) | (i << 1) | e;
+            } else {
+              s.overflow = 1;
+            }
+          }
+        }
+      }
+    }
+    wsync();
+    if (lane == 0 && s.ncand + s.ncold > CMAX) s.overflow = 1;
+    wsync();
+  }
+
   // ---- warm start ---------------------------------------------------------------------------------------
   // The optimal working set of the previous replan of this instance (a.warm, portable ids), moved one step
   // towards the present, seeds the dual method: its rows are put into the factorisation WITHOUT taking steps,
