@@ -76,7 +76,7 @@ struct Handle {
   int device = 0;
   int max_inst = 0, n_rob_max = 0;
   int N = 0, P = 0, RS = 0, n = 0;
-  int threads = 64;
+  int threads = 256;
   hdsm_params prm{};
   hdsm::Consts* d_consts = nullptr;
   double* d_scratch = nullptr;
@@ -120,9 +120,10 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.prof = h->d_prof;
   a.warm = (h->prm.warm_start && a.l1_rows == nullptr) ? h->d_warm : nullptr;
   h->last_stream = st;
-  // one 64-lane wavefront per agent-replan: the factorisation lives in that wave's registers
-  if (h->n <= 30) return launch_nv<30, 64>(h, a, st);
-  return launch_nv<48, 64>(h, a, st);
+  // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
+  // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
+  if (h->n <= 30) return h->threads == 64 ? launch_nv<30, 64>(h, a, st) : launch_nv<30, 256>(h, a, st);
+  return h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
 }
 
 int64_t scratch_stride_for(int n) {
@@ -208,7 +209,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   h->N = hc->N, h->P = hc->P, h->RS = hc->RS, h->n = hc->n;
   if (const char* e = std::getenv("HDSM_THREADS")) {
     const int t = std::atoi(e);
-    if (t == 64 || t == 128 || t == 256) h->threads = t;
+    if (t == 64 || t == 256) h->threads = t;
   }
   h->scratch_stride = scratch_stride_for(h->n);
   const size_t I = (size_t)max_instances, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;

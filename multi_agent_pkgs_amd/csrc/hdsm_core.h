@@ -108,6 +108,7 @@ struct Shm {
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   int32_t nviol;  // rows found violated (> tol) by the last sweep
+  int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
@@ -633,11 +634,20 @@ struct Solver {
   using W = WaveGI<NV, CMAX>;
   using GIState = typename W::Regs;
   static constexpr int SNAP_STRIDE = W::SNAP_DOUBLES + 2;  // doubles per level
+  // The factorisation lives in the registers of wave 0; the other waves of the workgroup (they take part in the
+  // sweeps, the set-up and the leaf test) wait at the barrier and pick the outcome up from LDS.
   static HD void snapshot_io(S& s, const Consts& c, GIState& R, double* buf, bool save) {
-    W::snapshot(s, R, buf, save, (int)threadIdx.x);
+    if (threadIdx.x < 64) W::snapshot(s, R, buf, save, (int)threadIdx.x);
+    SYNC();
   }
   static HD int gi_run(S& s, const Consts& c, GIState& R, double f_cut, int& iters) {
-    return W::run(s, c, R, f_cut, iters);
+    if (threadIdx.x < 64) {
+      const int rc = W::run(s, c, R, f_cut, iters);
+      if (threadIdx.x == 0) s.rc = rc, s.iters_sh = iters;
+    }
+    SYNC();
+    iters = s.iters_sh;
+    return s.rc;
   }
 #else
   struct GIState {};
@@ -738,7 +748,7 @@ struct Solver {
     PAR_FOR(k, MAXH) s.assign[k] = -1;
     if (IS_T0) {
       s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
-      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0;
+      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
     }
     SYNC();
     // free response + st[0]
@@ -860,7 +870,14 @@ struct Solver {
 #ifdef HDSM_PROFILE
     const long long tw_ = clock64();
 #endif
-    if (a.warm != nullptr && np > 0) W::warm_start(s, c, a, R, inst, self, iters);
+    if (a.warm != nullptr && np > 0) {
+      if (threadIdx.x < 64) {
+        W::warm_start(s, c, a, R, inst, self, iters);
+        if (threadIdx.x == 0) s.iters_sh = iters;
+      }
+      SYNC();
+      iters = s.iters_sh;
+    }
 #ifdef HDSM_PROFILE
     t_leaf_ -= 0;
     const long long t_warm_ = clock64() - tw_;

@@ -76,16 +76,14 @@ __device__ __forceinline__ double wave_prefix_sum(double v, int lane) {
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-#ifdef HDSM_WSYNC_STRONG
+// Ordering point INSIDE the one wavefront that runs the active-set iteration. LDS operations of a wave execute in
+// program order, so no s_barrier is needed (and none may be used: the other waves of the workgroup are parked at a
+// real barrier while wave 0 iterates) — only the compiler must not move LDS accesses across it.
 __device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-#else
-__device__ __forceinline__ void wsync() { __syncthreads(); }  // single-wave workgroup: lowers to a waitcnt
-#endif
 
 struct alignas(16) D2 {
   double x, y;
@@ -426,9 +424,9 @@ struct WaveGI {
   // used), then the N planes are evaluated back to back with independent instruction streams.
   static __device__ __forceinline__ void sweep_planes(S& s, const Consts& c, const Args& a, int self, double thresh,
                                                       bool check_fixed, int lane) {
-    const int N = c.N, n_rob = a.n_rob;
+    const int N = c.N, n_rob = a.n_rob, nt = (int)blockDim.x;  // lane = thread of the WORKGROUP here (all waves sweep)
     const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
-    for (int k0 = 0; k0 < n_rob; k0 += 64) {
+    for (int k0 = 0; k0 < n_rob; k0 += nt) {
       const int k = k0 + lane;
       const bool on = k < n_rob && k != self && a.has_plan[k < n_rob ? k : 0];
       const double* rec = a.plans + ((int64_t)(on ? k : 0) * (N + 1) + 1) * 9;
@@ -481,9 +479,9 @@ struct WaveGI {
         }
       }
     }
-    wsync();
+    __syncthreads();
     if (lane == 0 && s.ncand + s.ncold > CMAX) s.overflow = 1;
-    wsync();
+    __syncthreads();
   }
 
   // ---- warm start ---------------------------------------------------------------------------------------
