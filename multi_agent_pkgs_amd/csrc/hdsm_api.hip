@@ -32,8 +32,10 @@ int set_err(int code, const std::string& msg) {
       return set_err(HDSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
   } while (0)
 
-constexpr int CMAX30 = 1536;  // staged neighbour rows (LDS) for n <= 30
-constexpr int CMAX48 = 1024;  // ... for n <= 48
+// staged neighbour rows (LDS). One workgroup per CU is resident anyway (the iteration wave needs > 256 registers,
+// a 256-register budget spills 644 B/lane), so LDS capacity is spent on fewer staging-radius retries.
+constexpr int CMAX30 = 1536;  // n <= 30
+constexpr int CMAX48 = 1024;  // n <= 48
 
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {

@@ -60,7 +60,7 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->max_iters = prm->max_qp_iters > 0 ? prm->max_qp_iters : 100000;
   c->tol = prm->solver_tol > 0 ? prm->solver_tol : 1e-9;
   c->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
-  c->cand_tau = 1.5;  // [m] rows whose slack at the first converged iterate is below this are staged
+  c->cand_tau = 0.6;  // [m] rows whose slack at the first converged iterate is below this are staged
   if (const char* e = std::getenv("HDSM_CAND_TAU")) c->cand_tau = std::atof(e);
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
                       // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.

@@ -426,6 +426,20 @@ struct WaveGI {
                                                       bool check_fixed, int lane) {
     const int N = c.N, n_rob = a.n_rob, nt = (int)blockDim.x;  // lane = thread of the WORKGROUP here (all waves sweep)
     const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
+    // Rigorous cull. With p = c + delta:  slack(p) = n_f.(q - p) = |d|/2 - back - n_f.delta  and n_f.n = 1,
+    // back <= s_max = max(r, h), |n_f| <= sqrt(1 + (3 pert)^2)  ==>  slack >= |d|/2 - s_max - |n_f| |delta|.
+    // A neighbour with |d| >= 2 (max(thresh, tol) + s_max + |n_f| delta_max) can be neither staged nor violated.
+    double dmax2 = 0.0;  // max over (step i, endpoint e) of |p_{i+e} - c_i|^2 (uniform: every thread scans 2N points)
+    for (int i = 0; i < N; ++i)
+      for (int e = 0; e < 2; ++e) {
+        const double ux = s.st[i + e][0] - s.cprev[i][0], uy = s.st[i + e][1] - s.cprev[i][1],
+                     uz = s.st[i + e][2] - s.cprev[i][2];
+        dmax2 = fmax(dmax2, ux * ux + uy * uy + uz * uz);
+      }
+    const double smax = radius * fmax(1.0, rsqrt_nr(1.0 + k2m1));  // max(r, h): h = r / sqrt(1 + k2m1)
+    const double nfmax = sqrt(1.0 + 9.0 * pert * pert);
+    const double cull = 2.0 * (fmax(thresh, tol) + smax + nfmax * sqrt(dmax2)) * (1.0 + 1e-9);
+    const double cull2 = cull * cull;
     for (int k0 = 0; k0 < n_rob; k0 += nt) {
       const int k = k0 + lane;
       const bool on = k < n_rob && k != self && a.has_plan[k < n_rob ? k : 0];
@@ -445,7 +459,7 @@ struct WaveGI {
         const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
         const double dx = ox[i] - cx, dy = oy[i] - cy, dz = oz[i] - cz;
         const double n2 = dx * dx + dy * dy + dz * dz;
-        if (!on || !(n2 > 0)) continue;  // coincident agents: the row is 0 . p <= 0
+        if (!on || !(n2 > 0) || n2 >= cull2) continue;  // absent / coincident (row 0.p <= 0) / provably slack
         const double inv = rsqrt_nr(n2), nrm = n2 * inv;
         const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
         const double sd = radius * rsqrt_nr(1.0 + k2m1 * hz * hz);  // ellipsoid support distance
