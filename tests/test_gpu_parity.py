@@ -198,3 +198,43 @@ def test_warm_start_closed_loop_saves_iterations(hdsm):
     assert np.abs(res[True][1] - res[False][1]).max() < 1e-6        # same flight
     print("max-iteration per round, cold vs warm:", res[False][0][20:60].mean(), res[True][0][20:60].mean())
     assert res[True][0][20:60].mean() < res[False][0][20:60].mean()
+
+
+@pytest.mark.parametrize("n_rob,n_hor", [(256, 10), (128, 15)])
+def test_full_size_properties(hdsm, oracle, n_rob, n_hor):
+    """BASELINE-scale batch (256 agents H=10 / 128 agents H=15, every agent sees every other agent's planes):
+    size-independent properties on ALL instances + oracle parity on a random subset.
+      * the trajectory is the literal rollout of the returned controls (dynamics AC:2115-2167),
+      * input / velocity / acceleration boxes and the terminal v_N = a_N = 0 hold (AC:2078-2084, 2179-2186),
+      * every separating plane of every step holds at p_i and p_{i+1} (AC:909-941 + AC:1086-1215),
+      * every segment lies in a polyhedron flagged in poly_used (AC:979-985),
+      * obj is the literal objective (AC:870-883)."""
+    prm = agile_params(n_hor, max_rows_static=18)
+    N = n_hor
+    sn = problems.swarm_snapshot(prm, n_rob, seed=500 + n_rob, spacing=1.8, turn=True)
+    args = [sn[k] for k in ARG_KEYS]
+    sol = hdsm.Solver(prm, n_rob, n_rob)
+    g = sol.replan(*args)
+    ok = np.where(g["status"] == 0)[0]
+    assert len(ok) > n_rob // 2
+    planes = sol.tasc_planes(sn["agent_id"], sn["state"], sn["plans"], sn["has_plan"])  # [inst][N][n_rob][4]
+    for a in ok:
+        traj, ctrl = g["traj"][a], g["ctrl"][a]
+        assert np.abs(oracle.rollout(prm, sn["state"][a], ctrl) - traj).max() < 1e-10
+        assert np.abs(ctrl).max() <= 60 + 1e-8
+        assert np.abs(traj[1:N, 3:6]).max() <= 20 + 1e-8 and np.abs(traj[1:N, 6:9]).max() <= 15 + 1e-8
+        assert np.abs(traj[N, 3:9]).max() < 1e-8
+        assert abs(oracle.objective(prm, traj, ctrl, sn["ref"][a]) - g["obj"][a]) < 1e-7 * max(1, abs(g["obj"][a]))
+        for i in range(N):
+            rows = planes[a, i]
+            for m in (i, i + 1):
+                viol = (rows[:, :3] @ traj[m, :3] - rows[:, 3]).max()
+                assert viol < (1e-6 if m == 0 else 1e-7), (a, i, m, viol)
+            inside = [j for j, (A, b) in enumerate(sn["polys"][a][: prm.poly_hor]) if g["used"][a, j]
+                      and (A @ traj[i, :3] - b).max() < 1e-6 and (A @ traj[i + 1, :3] - b).max() < 1e-7]
+            assert inside, (a, i)
+    rng = np.random.default_rng(0)
+    sub = rng.choice(n_rob, 24, replace=False)
+    o = oracle.replan(prm, sn["agent_id"][sub], sn["state"][sub], sn["ref"][sub], sn["n_poly"][sub], sn["n_rows"][sub],
+                      sn["A"][sub], sn["b"][sub], sn["plans"], sn["has_plan"], n_threads=8)
+    compare({k: g[k][sub] for k in ("status", "traj", "ctrl", "obj")}, o)
