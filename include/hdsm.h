@@ -149,6 +149,35 @@ int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_
                const double* b, double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status,
                double* obj);
 
+/* ---- next row f1: reference-trajectory generation (Agent::GenerateReferenceTrajectory AC:1449-1553) ----------
+ * Mirrors the ROS parameters the reference reads for it (AC:2190-2248).                                    */
+typedef struct hdsm_ref_config {
+  double path_vel_min, path_vel_max; /* path_vel_min_/max_  (agile config: 4.5 / 9.0)                        */
+  double sens_dist, sens_pot;        /* GetVelocityLimit sensitivities (0.05 / 0.18)                         */
+  double sens_other_agents;          /* default 1.0 (AC:2213)                                                */
+  double path_vel_dec;               /* deceleration of the sampling distance (0.0)                          */
+} hdsm_ref_config;
+
+/* For every instance: path_vel = min(vel_cap, neighbour term of Agent::ComputePathVelocity AC:1769-1801 with
+ * GetVelocityLimit AC:1805-1817) over all steps of the agent's own previous plan (plans_all[agent_id], skipped
+ * while it has none) and all other agents that have a plan; then Agent::SamplePath (AC:1591-1663) along the
+ * polyline path[n_path] (first point = sampling start) and the velocity references of AC:1527-1547.
+ *   path     [n_inst][pmax][3], n_path [n_inst] (>= 1)
+ *   vel_cap  [n_inst] or NULL: the voxel/potential-field part of ComputePathVelocity (AC:1709-1766), which stays
+ *            on the host with the map; NULL = path_vel_max (obstacle-free world)
+ *   ref_full [n_inst][N+1][6]  traj_ref_curr_ (all N+1 rows: the increment check AC:569-585 needs them)
+ *   ref      [n_inst][N][6]    rows 0..N-1, the layout hdsm_replan* reads (may be NULL)
+ *   path_vel [n_inst]          path_vel_
+ * Host pointers / device pointers + stream, like hdsm_replan / hdsm_replan_device.                          */
+int hdsm_reference(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
+                   const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
+                   const double* vel_cap, const double* plans_all, const uint8_t* has_plan,
+                   double* ref_full, double* ref, double* path_vel);
+int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
+                          const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
+                          const double* vel_cap, const double* plans_all, const uint8_t* has_plan,
+                          double* ref_full, double* ref, double* path_vel, void* hip_stream);
+
 /* Stand-alone plane generator = Agent::GenerateTimeAwareSafeCorridor's inner maths (AC:1100-1205) for one
  * batch: planes[n_inst][N][n_rob][4] = (n_f.x, n_f.y, n_f.z, n_f . q), rows of absent/self agents are
  * filled with zeros. Host pointers. Used by tests and by callers that want the level-1 input.             */

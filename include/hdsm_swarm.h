@@ -58,6 +58,14 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
 int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_out, const uint8_t* poly_used,
                       const int32_t* status, double* plans_local, uint8_t* has_plan_local);
 
+/* f1 on the device: (1) hdsm_swarm_reference_inputs() exports, for every local agent, the polyline
+ * GenerateReferenceTrajectory would sample this round (AC:1459-1496: the starting point taken from the previous
+ * reference, then the rest of the global path): path[n_local][3][3], n_path[n_local]; (2) the caller runs
+ * hdsm_reference / hdsm_reference_device; (3) hdsm_swarm_set_reference() hands the result back — the next
+ * hdsm_swarm_prepare() then uses it instead of generating the reference on the host.                        */
+int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path);
+int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel);
+
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);
 

@@ -6,4 +6,4 @@ This package holds its sources (csrc/), the build recipe, and a thin ctypes bind
 the benchmark and the multi-GPU harness. There is no CPU fallback: importing :mod:`.lib` without the built
 ``libhdsm.so`` raises.
 """
-from .params import HdsmParams, make_params, agile_params, default_params  # noqa: F401
+from .params import HdsmParams, RefConfig, make_params, agile_params, default_params, agile_ref_config  # noqa: F401

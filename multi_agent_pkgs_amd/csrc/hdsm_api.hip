@@ -74,6 +74,121 @@ __global__ __launch_bounds__(256) void k_tasc_planes(const hdsm::Consts* __restr
   }
 }
 
+// ---- next row f1: reference trajectory (AC:1449-1553). One workgroup per agent: the neighbour term of
+// ComputePathVelocity is a min-reduction over (step, neighbour) streamed from the all-gathered plans buffer
+// (thread <-> neighbour, all N+1 positions of that neighbour read back to back), SamplePath is a short sequential
+// walk done by one thread, the velocity references are elementwise.
+struct RefArgs {
+  int32_t n_inst, n_rob, pmax, N;
+  double dt;
+  hdsm_ref_config cfg;
+  const int32_t* agent_id;
+  const double* path;
+  const int32_t* n_path;
+  const double* vel_cap;
+  const double* plans;
+  const uint8_t* has_plan;
+  double* ref_full;
+  double* ref;
+  double* path_vel;
+};
+
+__global__ __launch_bounds__(256) void k_reference(RefArgs a) {
+  __shared__ double own[hdsm::MAXH + 1][3];
+  __shared__ double wocc[hdsm::MAXH + 1];
+  __shared__ double red[256];
+  __shared__ double pts[hdsm::MAXH + 1][3];
+  __shared__ int cnt_s;
+  const int inst = blockIdx.x, tid = threadIdx.x, N = a.N;
+  const int self = a.agent_id[inst];
+  const int np = a.n_path[inst];
+  const bool own_has = self >= 0 && self < a.n_rob && a.has_plan[self];
+  const double* pth = a.path + (int64_t)inst * a.pmax * 3;
+  if (tid <= N) {
+    for (int c = 0; c < 3; ++c) own[tid][c] = own_has ? a.plans[((int64_t)self * (N + 1) + tid) * 9 + c] : 0.0;
+    double occ = 100 * pow(a.cfg.sens_other_agents, (double)tid);  // AC:1791-1795
+    occ = occ < 0 ? 0 : (occ > 100 ? 100 : occ);
+    wocc[tid] = pow(occ / 100, a.cfg.sens_pot);  // GetVelocityLimit AC:1805-1817
+  }
+  __syncthreads();
+  double pv = a.vel_cap ? a.vel_cap[inst] : a.cfg.path_vel_max;
+  if (pv > a.cfg.path_vel_max) pv = a.cfg.path_vel_max;
+  if (own_has && np >= 2) {
+    for (int j = tid; j < a.n_rob; j += 256) {
+      if (j == self || !a.has_plan[j]) continue;
+      const double* rec = a.plans + (int64_t)j * (N + 1) * 9;
+      for (int i = 0; i <= N; ++i) {
+        const double dx = own[i][0] - rec[9 * i], dy = own[i][1] - rec[9 * i + 1], dz = own[i][2] - rec[9 * i + 2];
+        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+        const double alpha = (1 - wocc[i] * (1 / exp(a.cfg.sens_dist * d)));
+        const double v = a.cfg.path_vel_min + (a.cfg.path_vel_max - a.cfg.path_vel_min) * alpha;
+        if (v < pv) pv = v;
+      }
+    }
+  }
+  red[tid] = pv;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] = fmin(red[tid], red[tid + off]);
+    __syncthreads();
+  }
+  pv = (np < 2) ? 0.0 : red[0];
+  if (tid == 0) {  // SamplePath, AC:1591-1663
+    int cnt = 0;
+    if (np < 2) {
+      for (int i = 0; i < N; ++i, ++cnt)
+        for (int c = 0; c < 3; ++c) pts[cnt][c] = pth[c];
+    } else {
+      const double samp = pv * a.dt;
+      int path_idx = 1, ref_idx = 0;
+      double cur[3] = {pth[0], pth[1], pth[2]};
+      for (int c = 0; c < 3; ++c) pts[0][c] = cur[c];
+      cnt = 1;
+      double limit = samp;
+      while (ref_idx < N) {
+        const double* nx = pth + 3 * path_idx;
+        const double d0 = nx[0] - cur[0], d1 = nx[1] - cur[1], d2 = nx[2] - cur[2];
+        const double dist_next = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if (dist_next > limit) {
+          cur[0] = cur[0] + limit * d0 / dist_next, cur[1] = cur[1] + limit * d1 / dist_next;
+          cur[2] = cur[2] + limit * d2 / dist_next;
+          for (int c = 0; c < 3; ++c) pts[cnt][c] = cur[c];
+          ++cnt, ++ref_idx;
+          limit = fmax(0.0, samp - a.cfg.path_vel_dec * a.dt);
+        } else {
+          cur[0] = nx[0], cur[1] = nx[1], cur[2] = nx[2];
+          if (++path_idx == np) {
+            for (int i = ref_idx; i < N; ++i, ++cnt)
+              for (int c = 0; c < 3; ++c) pts[cnt][c] = pth[3 * (np - 1) + c];
+            break;
+          }
+          limit -= dist_next;
+        }
+      }
+    }
+    cnt_s = cnt;
+    a.path_vel[inst] = pv;
+  }
+  __syncthreads();
+  const int cnt = cnt_s;
+  if (tid <= N) {  // velocity reference AC:1527-1547: row i looks back from i+1; the last row copies the previous one
+    const int i = tid < cnt ? tid : cnt - 1;
+    const int ii = (i + 1 < cnt) ? i : (cnt >= 2 ? cnt - 2 : 0);  // pair used by row i
+    double v[3] = {0, 0, 0};
+    if (cnt > 1) {
+      const double d0 = pts[ii][0] - pts[ii + 1][0], d1 = pts[ii][1] - pts[ii + 1][1], d2 = pts[ii][2] - pts[ii + 1][2];
+      const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+      if (dist > 1e-2) v[0] = pv * d0 / dist, v[1] = pv * d1 / dist, v[2] = pv * d2 / dist;
+    }
+    double* out = a.ref_full + ((int64_t)inst * (N + 1) + tid) * 6;
+    for (int c = 0; c < 3; ++c) out[c] = pts[i][c], out[3 + c] = v[c];
+    if (a.ref && tid < N) {
+      double* o2 = a.ref + ((int64_t)inst * N + tid) * 6;
+      for (int c = 0; c < 6; ++c) o2[c] = out[c];
+    }
+  }
+}
+
 struct Handle {
   int device = 0;
   int max_inst = 0, n_rob_max = 0;
@@ -358,6 +473,66 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d_planes);
   if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_tasc_planes: ") + hipGetErrorString(e));
+  return HDSM_OK;
+}
+
+int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
+                          const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
+                          const double* vel_cap, const double* plans_all, const uint8_t* has_plan,
+                          double* ref_full, double* ref, double* path_vel, void* hip_stream) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, n_rob)) return rc;
+  if (n_inst == 0) return HDSM_OK;
+  if (!cfg || !agent_id || !path || !n_path || !plans_all || !has_plan || !ref_full || !path_vel || pmax < 1)
+    return set_err(HDSM_ERR_BAD_ARG, "null or empty argument");
+  RefArgs a{};
+  a.n_inst = n_inst, a.n_rob = n_rob, a.pmax = pmax, a.N = h->N, a.dt = h->prm.dt, a.cfg = *cfg;
+  a.agent_id = agent_id, a.path = path, a.n_path = n_path, a.vel_cap = vel_cap, a.plans = plans_all;
+  a.has_plan = has_plan, a.ref_full = ref_full, a.ref = ref, a.path_vel = path_vel;
+  hipLaunchKernelGGL(k_reference, dim3(n_inst), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
+int hdsm_reference(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                   const double* path, const int32_t* n_path, int32_t pmax, const double* vel_cap,
+                   const double* plans_all, const uint8_t* has_plan, double* ref_full, double* ref, double* path_vel) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, n_rob)) return rc;
+  if (n_inst == 0) return HDSM_OK;
+  if (!cfg || !agent_id || !path || !n_path || !plans_all || !has_plan || !ref_full || !path_vel || pmax < 1)
+    return set_err(HDSM_ERR_BAD_ARG, "null or empty argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t I = (size_t)n_inst, N = (size_t)h->N;
+  hipStream_t st = h->stream;
+  double *d_path = nullptr, *d_cap = nullptr, *d_full = nullptr, *d_pv = nullptr;
+  int32_t* d_np = nullptr;
+  hipError_t e = dmalloc(&d_path, I * pmax * 3);
+  if (e == hipSuccess) e = dmalloc(&d_cap, I);
+  if (e == hipSuccess) e = dmalloc(&d_full, I * (N + 1) * 6);
+  if (e == hipSuccess) e = dmalloc(&d_pv, I);
+  if (e == hipSuccess) e = dmalloc(&d_np, I);
+  auto cp = [&](void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  };
+  cp(d_path, path, I * pmax * 3 * 8, hipMemcpyHostToDevice);
+  cp(d_np, n_path, I * 4, hipMemcpyHostToDevice);
+  if (vel_cap) cp(d_cap, vel_cap, I * 8, hipMemcpyHostToDevice);
+  cp(h->d_agent, agent_id, I * 4, hipMemcpyHostToDevice);
+  cp(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, hipMemcpyHostToDevice);
+  cp(h->d_has, has_plan, (size_t)n_rob, hipMemcpyHostToDevice);
+  int rc = HDSM_OK;
+  if (e == hipSuccess)
+    rc = hdsm_reference_device(handle, cfg, n_inst, n_rob, h->d_agent, d_path, d_np, pmax, vel_cap ? d_cap : nullptr,
+                               h->d_plans, h->d_has, d_full, ref ? h->d_ref : nullptr, d_pv, st);
+  cp(ref_full, d_full, I * (N + 1) * 6 * 8, hipMemcpyDeviceToHost);
+  if (ref) cp(ref, h->d_ref, I * N * 6 * 8, hipMemcpyDeviceToHost);
+  cp(path_vel, d_pv, I * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  for (void* p : {(void*)d_path, (void*)d_cap, (void*)d_full, (void*)d_pv, (void*)d_np})
+    if (p) (void)hipFree(p);
+  if (rc) return rc;
+  if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_reference: ") + hipGetErrorString(e));
   return HDSM_OK;
 }
 

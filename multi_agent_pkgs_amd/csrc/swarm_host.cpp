@@ -40,6 +40,7 @@ struct Agent {
   std::vector<Poly> polys;                         // poly_const_vec_ / poly_seeds_
   std::vector<uint8_t> poly_used;                  // poly_used_idx_
   bool increment_traj_ref = false;
+  bool external_ref = false;  // traj_ref was supplied by hdsm_swarm_set_reference() for the coming prepare()
   double path_vel = 0;
   int n_fail = 0;
 };
@@ -223,6 +224,28 @@ bool on_segment(const V3& p, const V3& a, const V3& b) {
   return false;
 }
 
+// The polyline SamplePath walks this round (AC:1459-1496): starting point from the previous reference, then the
+// global path from the segment that contains it.
+std::vector<V3> reference_polyline(const Agent& ag) {
+  const std::vector<V3> path_curr = {ag.start, ag.goal};
+  V3 starting;
+  if (!ag.traj_ref.empty()) {
+    const auto& r = ag.increment_traj_ref ? ag.traj_ref[1] : ag.traj_ref[0];
+    starting = {r[0], r[1], r[2]};
+  } else {
+    starting = path_curr[0];
+  }
+  size_t start_idx = 0;
+  for (size_t i = 0; i + 1 < path_curr.size(); ++i)
+    if (on_segment(starting, path_curr[i], path_curr[i + 1])) {
+      start_idx = i + 1;
+      break;
+    }
+  std::vector<V3> path_samp = {starting};
+  for (size_t i = start_idx; i < path_curr.size(); ++i) path_samp.push_back(path_curr[i]);
+  return path_samp;
+}
+
 // GenerateReferenceTrajectory, AC:1449-1553
 void generate_reference(const Swarm& sw, Agent& ag, const double* plans_all, const uint8_t* has_plan) {
   const std::vector<V3> path_curr = {ag.start, ag.goal};
@@ -334,7 +357,8 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
   for (int k = 0; k < sw->n_local; ++k) {
     Agent& ag = sw->agents[k];
     generate_safe_corridor(*sw, ag);                     // AC:165
-    generate_reference(*sw, ag, plans_all, has_plan);    // AC:171
+    if (!ag.external_ref) generate_reference(*sw, ag, plans_all, has_plan);  // AC:171 (or done on the device, f1)
+    ag.external_ref = false;
     agent_id[k] = ag.id;
     for (int c = 0; c < 9; ++c) state_curr[9 * k + c] = ag.state_curr[c];
     for (int i = 0; i < N; ++i)
@@ -388,6 +412,33 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
     for (int i = 0; i <= N; ++i)
       for (int c = 0; c < 9; ++c)
         plans_local[((size_t)k * (N + 1) + i) * 9 + c] = have_plan ? ag.traj_curr[i][c] : 0.0;
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !path || !n_path) return HDSM_ERR_BAD_ARG;
+  for (int k = 0; k < sw->n_local; ++k) {
+    const std::vector<V3> pl = reference_polyline(sw->agents[k]);
+    n_path[k] = (int32_t)pl.size();
+    for (int i = 0; i < 3; ++i)
+      for (int c = 0; c < 3; ++c) path[((size_t)k * 3 + i) * 3 + c] = i < (int)pl.size() ? pl[i][c] : pl.back()[c];
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !ref_full || !path_vel) return HDSM_ERR_BAD_ARG;
+  const int N = sw->prm.n_hor;
+  for (int k = 0; k < sw->n_local; ++k) {
+    Agent& ag = sw->agents[k];
+    ag.traj_ref.assign(N + 1, {});
+    for (int i = 0; i <= N; ++i)
+      for (int c = 0; c < 6; ++c) ag.traj_ref[i][c] = ref_full[((size_t)k * (N + 1) + i) * 6 + c];
+    ag.path_vel = path_vel[k];
+    ag.external_ref = true;
   }
   return HDSM_OK;
 }

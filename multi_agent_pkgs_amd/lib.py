@@ -18,7 +18,7 @@ HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACIT
 
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
-           "hdsm_reset_warm_start")
+           "hdsm_reset_warm_start", "hdsm_reference", "hdsm_reference_device")
 
 
 class HdsmError(RuntimeError):
@@ -132,6 +132,20 @@ class Solver:
                                    _p(A, d), _p(b, d), _p(out["traj"], d), _p(out["ctrl"], d), _p(out["used"], u),
                                    _p(out["status"], i), _p(out["obj"], d)))
         return out
+
+    def reference(self, cfg, agent_id, path, n_path, plans, has_plan, vel_cap=None):
+        """Next row f1 (hdsm_reference): path_vel + sampled reference for every instance. path [n_inst][pmax][3]."""
+        N = self.prm.n_hor
+        agent_id, n_path = _i32(agent_id), _i32(n_path)
+        path, plans, has_plan = _f64(path), _f64(plans), _u8(has_plan)
+        n_inst, pmax, n_rob = path.shape[0], path.shape[1], plans.shape[0]
+        ref_full, ref, pv = np.zeros((n_inst, N + 1, 6)), np.zeros((n_inst, N, 6)), np.zeros(n_inst)
+        cap = _f64(vel_cap) if vel_cap is not None else None
+        d, i, u = C.c_double, C.c_int32, C.c_uint8
+        _check(self.lib.hdsm_reference(self.h, C.byref(cfg), n_inst, n_rob, _p(agent_id, i), _p(path, d), _p(n_path, i),
+                                       pmax, _p(cap, d) if cap is not None else None, _p(plans, d), _p(has_plan, u),
+                                       _p(ref_full, d), _p(ref, d), _p(pv, d)))
+        return ref_full, ref, pv
 
     def tasc_planes(self, agent_id, state, plans, has_plan):
         N = self.prm.n_hor

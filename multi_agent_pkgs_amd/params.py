@@ -85,3 +85,19 @@ def default_params(n_hor=9, **over):
               max_jerk=30.0, drone_radius=0.125, drone_z_offset=0.125)
     kw.update(over)
     return make_params(n_hor=n_hor, **kw)
+
+
+class RefConfig(C.Structure):
+    """ctypes mirror of hdsm_ref_config (reference-trajectory parameters, agent_class.cpp:2190-2248)."""
+    _fields_ = [("path_vel_min", C.c_double), ("path_vel_max", C.c_double), ("sens_dist", C.c_double),
+                ("sens_pot", C.c_double), ("sens_other_agents", C.c_double), ("path_vel_dec", C.c_double)]
+
+
+def agile_ref_config(**over):
+    """agent_agile_config.yaml: path_vel 4.5..9.0, sens_dist 0.05, sens_pot 0.18; sens_other_agents default 1.0."""
+    kw = dict(path_vel_min=4.5, path_vel_max=9.0, sens_dist=0.05, sens_pot=0.18, sens_other_agents=1.0, path_vel_dec=0.0)
+    kw.update(over)
+    c = RefConfig()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c

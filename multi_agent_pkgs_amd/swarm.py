@@ -93,6 +93,22 @@ class SwarmShard:
             raise _lib.HdsmError(rc, "hdsm_swarm_prepare")
         return i
 
+    def reference_inputs(self):
+        """Polyline each agent's reference will be sampled along this round (for hdsm_reference, f1)."""
+        path = np.zeros((self.n_local, 3, 3))
+        n_path = np.zeros(self.n_local, np.int32)
+        rc = self.lib.hdsm_swarm_reference_inputs(self.h, _p(path, C.c_double), _p(n_path, C.c_int32))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_reference_inputs")
+        return path, n_path
+
+    def set_reference(self, ref_full, path_vel):
+        ref_full = np.ascontiguousarray(ref_full, dtype=np.float64)
+        path_vel = np.ascontiguousarray(path_vel, dtype=np.float64)
+        rc = self.lib.hdsm_swarm_set_reference(self.h, _p(ref_full, C.c_double), _p(path_vel, C.c_double))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_set_reference")
+
     def commit(self, out):
         N = self.prm.n_hor
         plans_local = np.zeros((self.n_local, N + 1, 9))
@@ -120,8 +136,11 @@ class SwarmLoop:
     """One rank of the lock-step loop. `solve(inputs, plans_all, has_plan) -> out dict` is the device solver
     (or, in CPU tests, the oracle); `allgather(local_array) -> full array` exchanges the shards."""
 
-    def __init__(self, prm, cfg, n_rob, rank=0, world=1, solve=None, allgather=None, radius=None):
+    def __init__(self, prm, cfg, n_rob, rank=0, world=1, solve=None, allgather=None, radius=None, reference=None):
+        """reference(agent_id, path, n_path, plans_all, has_plan) -> (ref_full, path_vel): when given, the reference
+        trajectory comes from it (the device kernel of row f1, or the oracle) instead of the host code."""
         self.prm, self.n_rob, self.rank, self.world = prm, n_rob, rank, world
+        self.reference = reference
         starts, goals = circle_scenario(n_rob, radius)
         self.first, self.n_local = shard_range(n_rob, rank, world)
         sl = slice(self.first, self.first + self.n_local)
@@ -133,6 +152,11 @@ class SwarmLoop:
         self.round_idx = 0
 
     def step(self, record=None):
+        if self.reference is not None:
+            path, n_path = self.shard.reference_inputs()
+            ids = np.arange(self.first, self.first + self.n_local, dtype=np.int32)
+            ref_full, pv = self.reference(ids, path, n_path, self.plans_all, self.has_plan)
+            self.shard.set_reference(ref_full, pv)
         inputs = self.shard.prepare(self.plans_all, self.has_plan)
         if record is not None:
             record.append(dict({k: v.copy() for k, v in inputs.items()}, plans=self.plans_all.copy(),

@@ -959,3 +959,91 @@ int orc_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const doubl
   B.traj = traj_out, B.ctrl = ctrl_out, B.obj = obj, B.used = poly_used, B.status = status;
   return run_batch(&B, n_threads);
 }
+
+/* ===================================================================== f1: reference trajectory (restatement) */
+
+/* GetVelocityLimit, AC:1805-1817 */
+static double velocity_limit(const hdsm_ref_config* c, double occ_val, double dist_start) {
+  if (occ_val < 0) occ_val = 0;
+  if (occ_val > 100) occ_val = 100;
+  double alpha = (1 - pow(occ_val / 100, c->sens_pot) * (1 / exp(c->sens_dist * dist_start)));
+  return c->path_vel_min + (c->path_vel_max - c->path_vel_min) * alpha;
+}
+
+int orc_reference(const hdsm_params* prm, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
+                  const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
+                  const double* vel_cap, const double* plans_all, const uint8_t* has_plan, double* ref_full,
+                  double* ref, double* path_vel) {
+  const int N = prm->n_hor;
+  for (int k = 0; k < n_inst; k++) {
+    const int self = agent_id[k];
+    const double* pth = path + (size_t)k * pmax * 3;
+    const int np = n_path[k];
+    double* out = ref_full + (size_t)k * (N + 1) * 6;
+    /* ComputePathVelocity: start from the cap (voxel part, host) and apply the neighbour term AC:1769-1801 */
+    double pv = vel_cap ? vel_cap[k] : cfg->path_vel_max;
+    if (pv > cfg->path_vel_max) pv = cfg->path_vel_max;
+    const int own = self >= 0 && self < n_rob && has_plan[self];
+    if (own && np >= 2) { /* SamplePath only calls ComputePathVelocity for paths with >= 2 points (AC:1595-1612) */
+      for (int i = 0; i <= N; i++) { /* traj_curr_.size() = N + 1 */
+        const double* s0 = plans_all + ((size_t)self * (N + 1) + i) * 9;
+        double occ = 100 * pow(cfg->sens_other_agents, i);
+        for (int j = 0; j < n_rob; j++) {
+          if (j == self || !has_plan[j]) continue;
+          const double* so = plans_all + ((size_t)j * (N + 1) + i) * 9;
+          double d = sqrt((s0[0] - so[0]) * (s0[0] - so[0]) + (s0[1] - so[1]) * (s0[1] - so[1]) +
+                          (s0[2] - so[2]) * (s0[2] - so[2]));
+          double v = velocity_limit(cfg, occ, d);
+          if (v < pv) pv = v;
+        }
+      }
+    }
+    if (np < 2) pv = 0; /* path_vel_ is not updated in that branch; report 0 */
+    path_vel[k] = pv;
+    /* SamplePath, AC:1591-1663 */
+    double pts[HDSM_MAX_HOR + 1][3];
+    int cnt = 0;
+    if (np < 2) {
+      for (int i = 0; i < N; i++) memcpy(pts[cnt++], pth, 24); /* N copies of the single point */
+    } else {
+      const double samp_dist = pv * prm->dt;
+      int path_idx = 1, ref_idx = 0;
+      double cur[3] = {pth[0], pth[1], pth[2]};
+      memcpy(pts[cnt++], pth, 24);
+      double limit = samp_dist;
+      while (ref_idx < N) {
+        const double* nx = pth + 3 * path_idx;
+        double df[3] = {nx[0] - cur[0], nx[1] - cur[1], nx[2] - cur[2]};
+        double dist_next = sqrt(df[0] * df[0] + df[1] * df[1] + df[2] * df[2]);
+        if (dist_next > limit) {
+          for (int c = 0; c < 3; c++) cur[c] = cur[c] + limit * df[c] / dist_next;
+          memcpy(pts[cnt++], cur, 24);
+          ref_idx++;
+          limit = fmax(0.0, samp_dist - cfg->path_vel_dec * prm->dt);
+        } else {
+          memcpy(cur, nx, 24);
+          path_idx++;
+          if (path_idx == np) {
+            for (int i = ref_idx; i < N; i++) memcpy(pts[cnt++], pth + 3 * (np - 1), 24);
+            break;
+          }
+          limit -= dist_next;
+        }
+      }
+    }
+    /* velocity reference, AC:1527-1547 (points backwards along the path; the last row copies the previous one) */
+    double v[3] = {0, 0, 0};
+    for (int i = 0; i < cnt; i++) {
+      if (i + 1 < cnt) {
+        double dd[3] = {pts[i][0] - pts[i + 1][0], pts[i][1] - pts[i + 1][1], pts[i][2] - pts[i + 1][2]};
+        double dist = sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+        for (int c = 0; c < 3; c++) v[c] = dist > 1e-2 ? pv * dd[c] / dist : 0.0;
+      }
+      for (int c = 0; c < 3; c++) out[6 * i + c] = pts[i][c], out[6 * i + 3 + c] = (cnt > 1) ? v[c] : 0.0;
+    }
+    for (int i = cnt; i <= N; i++) /* single-point case yields N rows: pad the (N+1)-th with the last one */
+      for (int c = 0; c < 6; c++) out[6 * i + c] = out[6 * (cnt - 1) + c];
+    if (ref) memcpy(ref + (size_t)k * N * 6, out, sizeof(double) * N * 6);
+  }
+  return 0;
+}

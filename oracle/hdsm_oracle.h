@@ -70,6 +70,12 @@ int orc_qp_fixed(const hdsm_params* prm, const double state_curr[9], const doubl
                  const orc_corridor* cor, const int32_t* assign, double* traj, double* ctrl,
                  orc_result* res);
 
+/* ---- next row f1: reference trajectory (AC:1449-1553, 1591-1663, 1769-1817), same layouts as hdsm_reference -- */
+int orc_reference(const hdsm_params* prm, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
+                  const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
+                  const double* vel_cap, const double* plans_all, const uint8_t* has_plan, double* ref_full,
+                  double* ref, double* path_vel);
+
 /* ---- batch entry points with the SAME array layouts as include/hdsm.h -------------------------------- */
 /* Level 2 (fused planes + solve): restates hdsm_replan. n_threads > 1 farms instances over pthreads.     */
 int orc_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,

@@ -195,3 +195,18 @@ def solve(prm, state, ref, n_poly, n_rows, A, b, n_threads=1):
                          _ip(out["status"]), _dp(out["obj"]), int(n_threads))
     assert rc == 0
     return out
+
+
+def reference(prm, cfg, agent_id, path, n_path, plans_all, has_plan, vel_cap=None):
+    """f1 restatement (orc_reference), layouts of hdsm_reference."""
+    N = prm.n_hor
+    agent_id, n_path = i32(agent_id), i32(n_path)
+    path, plans_all, has_plan = f64(path), f64(plans_all), u8(has_plan)
+    n_inst, pmax, n_rob = path.shape[0], path.shape[1], plans_all.shape[0]
+    ref_full, ref, pv = np.zeros((n_inst, N + 1, 6)), np.zeros((n_inst, N, 6)), np.zeros(n_inst)
+    cap = f64(vel_cap) if vel_cap is not None else None
+    rc = lib().orc_reference(C.byref(prm), C.byref(cfg), n_inst, n_rob, _ip(agent_id), _dp(path), _ip(n_path), pmax,
+                             _dp(cap) if cap is not None else None, _dp(plans_all), _bp(has_plan), _dp(ref_full),
+                             _dp(ref), _dp(pv))
+    assert rc == 0
+    return ref_full, ref, pv

@@ -238,3 +238,55 @@ def test_full_size_properties(hdsm, oracle, n_rob, n_hor):
     o = oracle.replan(prm, sn["agent_id"][sub], sn["state"][sub], sn["ref"][sub], sn["n_poly"][sub], sn["n_rows"][sub],
                       sn["A"][sub], sn["b"][sub], sn["plans"], sn["has_plan"], n_threads=8)
     compare({k: g[k][sub] for k in ("status", "traj", "ctrl", "obj")}, o)
+
+
+def test_reference_kernel_matches_oracle(hdsm, oracle):
+    """Row f1 on the device vs its oracle: exp/pow differ from glibc by an ulp or two -> 1e-10 relative."""
+    from multi_agent_pkgs_amd.params import agile_ref_config
+    rng = np.random.default_rng(5)
+    for n_hor, n_rob, sens_other in [(10, 64, 1.0), (15, 200, 0.8), (7, 9, 1.0)]:
+        prm = agile_params(n_hor, max_rows_static=18)
+        rcfg = agile_ref_config(sens_other_agents=sens_other, path_vel_dec=0.5 if n_hor == 7 else 0.0)
+        sn = problems.swarm_snapshot(prm, n_rob, seed=70 + n_hor, spacing=1.5)
+        sn["has_plan"][rng.random(n_rob) < 0.1] = 0
+        path = np.zeros((n_rob, 3, 3))
+        n_path = np.full(n_rob, 3, np.int32)
+        for k in range(n_rob):
+            p0 = sn["state"][k, :3]
+            path[k] = [p0, p0 + rng.normal(size=3) * [2, 2, 0.2], p0 + rng.normal(size=3) * [6, 6, 0.3]]
+        n_path[::7] = 2
+        n_path[3] = 1
+        cap = rng.uniform(5.0, 12.0, n_rob)
+        sol = hdsm.Solver(prm, n_rob, n_rob)
+        for vc in (None, cap):
+            g = sol.reference(rcfg, sn["agent_id"], path, n_path, sn["plans"], sn["has_plan"], vel_cap=vc)
+            o = oracle.reference(prm, rcfg, sn["agent_id"], path, n_path, sn["plans"], sn["has_plan"], vel_cap=vc)
+            for x, y in zip(g, o):
+                assert np.abs(x - y).max() < 1e-10 * max(1.0, np.abs(y).max())
+        assert (o[2][n_path >= 2] <= 9.0 + 1e-12).all() and o[2][3] == 0.0
+
+
+def test_closed_loop_with_device_reference(hdsm, oracle):
+    """Solver AND reference generation on the device vs the all-host/oracle loop."""
+    from multi_agent_pkgs_amd import swarm
+    from multi_agent_pkgs_amd.params import agile_ref_config
+    prm = agile_params(10, max_rows_static=18)
+    rcfg = agile_ref_config()
+    sol = hdsm.Solver(prm, 12, 12)
+
+    def dev(inp, plans, has):
+        return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+    def dev_ref(ids, path, n_path, plans, has):
+        full, ref, pv = sol.reference(rcfg, ids, path, n_path, plans, has)
+        return full, pv
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    la = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=dev, reference=dev_ref)
+    lb = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=cpu)
+    for r in range(40):
+        la.step()
+        lb.step()
+    assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6

@@ -139,3 +139,35 @@ def test_fallback_shifts_previous_plan():
     assert has2[0] == 1
     assert np.array_equal(plans2[0, :10], traj[0, 1:]) and np.array_equal(plans2[0, 10], traj[0, 10])
     assert sh.state()[2][0] == 1
+
+
+def test_reference_oracle_equals_host_restatement_in_closed_loop(oracle):
+    """Row f1: the oracle's restatement of GenerateReferenceTrajectory (oracle/hdsm_oracle.c, orc_reference) and
+    the host code in csrc/swarm_host.cpp are two independent restatements of AC:1449-1553 / 1591-1663 / 1769-1817:
+    flying the same swarm with either must give the same references, round after round."""
+    from multi_agent_pkgs_amd.params import agile_ref_config
+    prm = agile_params(10, max_rows_static=18)
+    rcfg = agile_ref_config()
+
+    def solve(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"],
+                             inp["b"], plans, has, n_threads=8)
+
+    seen = []
+
+    def ref_fn(ids, path, n_path, plans, has):
+        full, ref, pv = oracle.reference(prm, rcfg, ids, path, n_path, plans, has)
+        seen.append((full.copy(), pv.copy()))
+        return full, pv
+
+    a = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=solve)
+    b = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=solve, reference=ref_fn)
+    slowed = False
+    for r in range(40):
+        a.step()
+        b.step()
+        assert np.abs(a.shard.inp["ref"] - b.shard.inp["ref"]).max() < 1e-9, r
+        slowed |= bool((seen[-1][1] < 8.99).any())
+    assert np.abs(a.plans_all - b.plans_all).max() < 1e-7
+    assert slowed                                   # the neighbour speed modulation was active at some point
+    assert np.allclose(seen[0][1], 9.0)             # first round: nobody has a plan -> path_vel_max
