@@ -147,6 +147,15 @@ class Solver:
                                        _p(ref_full, d), _p(ref, d), _p(pv, d)))
         return ref_full, ref, pv
 
+    def reference_device(self, cfg, agent_id, path, n_path, plans, has_plan, ref_full, ref, path_vel, vel_cap=None,
+                         stream=None):
+        """hdsm_reference_device on CUDA/HIP torch tensors (asynchronous on `stream`)."""
+        n_inst, pmax, n_rob = path.shape[0], path.shape[1], plans.shape[0]
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
+        _check(self.lib.hdsm_reference_device(self.h, C.byref(cfg), n_inst, n_rob, vp(agent_id), vp(path), vp(n_path), pmax,
+                                              vp(vel_cap), vp(plans), vp(has_plan), vp(ref_full), vp(ref), vp(path_vel), sp))
+
     def tasc_planes(self, agent_id, state, plans, has_plan):
         N = self.prm.n_hor
         agent_id, state, plans, has_plan = _i32(agent_id), _f64(state), _f64(plans), _u8(has_plan)
