@@ -109,6 +109,9 @@ struct Shm {
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
+  int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
+  double part_v[4];      // per-wave partial maxima of the staged-row scan
+  int32_t part_id[4];
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
@@ -644,6 +647,8 @@ struct Solver {
     if (threadIdx.x < 64) {
       const int rc = W::run(s, c, R, f_cut, iters);
       if (threadIdx.x == 0) s.rc = rc, s.iters_sh = iters;
+    } else {
+      W::helper_loop(s);  // waves 1..3: share the staged-row scans of wave 0's iteration
     }
     SYNC();
     iters = s.iters_sh;

@@ -172,8 +172,9 @@ struct WaveGI {
   }
 
   // violation of staged rows [lo, hi) -> running (v, id); four rows per trip, loads issued before first use
-  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double& v, int& id) {
-    for (int base = lo; base < hi; base += 256) {
+  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double& v, int& id,
+                                                   int stride = 256) {
+    for (int base = lo; base < hi; base += stride) {
       int idx[4], mm[4];
       D2 r01[4], r23[4];
 #pragma unroll
@@ -230,13 +231,50 @@ struct WaveGI {
         if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
       }
     }
-    scan_rows(s, 0, uni(s.ncand), lane, v, id);
-    const double m = wave_max64(v);
-    vbest = m;
-    ibest = -1;
+    const int nc = uni(s.ncand);
+    const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
+    if (mw) {
+      if (lane == 0) s.cmd = 1;
+      __syncthreads();                             // helpers start on their share: rows [256 (w), ...) stride 1024
+      scan_rows(s, 0, nc, lane, v, id, 1024);
+    } else {
+      scan_rows(s, 0, nc, lane, v, id);
+    }
+    double m = wave_max64(v);
+    int best = -1;
     if (m > tol) {
       const unsigned long long mask = __ballot(v == m && id >= 0);
-      ibest = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+      best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+    }
+    if (mw) {
+      __syncthreads();                             // partial results of waves 1..3 are in LDS
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const double pv = s.part_v[w];
+        if (pv > m) m = pv, best = s.part_id[w];
+      }
+    }
+    vbest = m;
+    ibest = (m > tol) ? best : -1;
+  }
+
+  // Waves 1..3 while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
+  static __device__ __forceinline__ void helper_loop(S& s) {
+    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+    for (;;) {
+      __syncthreads();
+      if (uni(s.cmd) == 0) return;
+      double v = -DINF;
+      int id = -1;
+      scan_rows(s, 256 * w, uni(s.ncand), lane, v, id, 1024);
+      const double m = wave_max64(v);
+      int best = -1;
+      if (m > -DINF) {
+        const unsigned long long mask = __ballot(v == m && id >= 0);
+        best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+      }
+      if (lane == 0) s.part_v[w] = m, s.part_id[w] = best;
+      __syncthreads();
     }
   }
 
@@ -784,8 +822,9 @@ struct WaveGI {
       }
     }
     wsync();
-    if (lane == 0) s.f = f, s.q = q, s.neq_done = neq;
-    wsync();
+    if (lane == 0) s.f = f, s.q = q, s.neq_done = neq, s.cmd = 0;
+    if (blockDim.x > 64) __syncthreads();  // releases the helper waves (they leave on cmd == 0)
+    else wsync();
     return rc;
   }
 
