@@ -50,6 +50,8 @@ def main():
                     "set-up if missing, loaded instead of flying the swarm if present (profiling runs: only the "
                     "timed launches remain in the process)")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the second (HIP-event) pass")
+    ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
+                    "flight on the host (csrc/swarm_host.cpp) instead of with the f1 device kernel (hdsm_reference)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the product path) or gloo "
                     "(testing the multi-rank flow on a box with fewer GPUs than ranks: ranks share devices and the "
                     "all-gather is staged through the host)")
@@ -124,8 +126,16 @@ def main():
         rec = [{k: z[k][r] for k in keys} for r in range(n_rec)]
         fails = int(z["fails"])
     else:
+        from multi_agent_pkgs_amd.params import agile_ref_config
+        rcfg = agile_ref_config()
+
+        def ref_dev(ids, path, n_path, plans, has):  # row f1 on the device: removes the host's O(n_rob^2 N) step
+            full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has)
+            return full, pv
+
         loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
-                               allgather=allgather_np if world > 1 else None)
+                               allgather=allgather_np if world > 1 else None,
+                               reference=None if args.host_reference else ref_dev)
         for r in range(total_rounds):
             out = loop.step(record=rec if r >= args.first_round else None)
             if r >= args.first_round:
