@@ -45,6 +45,32 @@ __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ 
   Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
 }
 
+// bounds[n_rob][4]: centre of the bounding box of steps 1..N of each published plan and the radius of the sphere
+// around it that holds them (radius -1 = no plan). One thread per agent; the replan kernel's sweeps use it to skip
+// whole neighbours (hdsm_wave_gi.h, sweep_planes). Only launched for swarms of at least bounds_min agents.
+__global__ __launch_bounds__(256) void k_plan_bounds(int N, int n_rob, const double* __restrict__ plans,
+                                                     const uint8_t* __restrict__ has_plan,
+                                                     double* __restrict__ bounds) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n_rob) return;
+  double4 out = {0.0, 0.0, 0.0, -1.0};
+  if (has_plan[k]) {
+    const double* rec = plans + ((int64_t)k * (N + 1) + 1) * 9;
+    double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[0], rec[1], rec[2]};
+    for (int i = 1; i < N; ++i)
+      for (int ax = 0; ax < 3; ++ax) lo[ax] = fmin(lo[ax], rec[9 * i + ax]), hi[ax] = fmax(hi[ax], rec[9 * i + ax]);
+    out.x = 0.5 * (lo[0] + hi[0]), out.y = 0.5 * (lo[1] + hi[1]), out.z = 0.5 * (lo[2] + hi[2]);
+    double r2 = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const double ux = rec[9 * i] - out.x, uy = rec[9 * i + 1] - out.y, uz = rec[9 * i + 2] - out.z;
+      r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
+    }
+    out.w = sqrt(r2) * (1.0 + 1e-9);
+    if (!(out.w >= 0.0)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
+  }
+  *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+}
+
 // planes[n_inst][N][n_rob][4] for tests / level-1 callers (AC:1100-1205)
 __global__ __launch_bounds__(256) void k_tasc_planes(const hdsm::Consts* __restrict__ cp, int n_inst, int n_rob,
                                                      const int32_t* agent_id, const double* state,
@@ -194,12 +220,14 @@ struct Handle {
   int max_inst = 0, n_rob_max = 0;
   int N = 0, P = 0, RS = 0, n = 0;
   int threads = 256;
+  int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
+  double* d_bounds = nullptr; // [n_rob_max][4]
   hdsm_params prm{};
   hdsm::Consts* d_consts = nullptr;
   double* d_scratch = nullptr;
   int64_t scratch_stride = 0;
   int32_t* d_stats = nullptr;  // 4 * max_inst
-  long long* d_prof = nullptr; // 16 * max_inst (HDSM_PROFILE builds)
+  long long* d_prof = nullptr; // 24 * max_inst (HDSM_PROFILE builds)
   int32_t* d_warm = nullptr;   // (MAXNV + 2) * max_inst: previous optimal working sets (params.warm_start)
   // staging for the host-pointer entry points
   int32_t *d_agent = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr;
@@ -237,6 +265,13 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.prof = h->d_prof;
   a.warm = (h->prm.warm_start && a.l1_rows == nullptr) ? h->d_warm : nullptr;
   h->last_stream = st;
+  a.bounds = nullptr;
+  if (a.l1_rows == nullptr && a.n_rob >= h->bounds_min) {
+    hipLaunchKernelGGL(k_plan_bounds, dim3((a.n_rob + 255) / 256), dim3(256), 0, st, h->N, a.n_rob, a.plans,
+                       a.has_plan, h->d_bounds);
+    HIP_TRY(hipGetLastError());
+    a.bounds = h->d_bounds;
+  }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
   if (h->n <= 30) return h->threads == 64 ? launch_nv<30, 64>(h, a, st) : launch_nv<30, 256>(h, a, st);
@@ -255,7 +290,7 @@ hipError_t dmalloc(T** p, size_t count) {
 
 void free_all(Handle* h) {
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
-                  h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_traj,  h->d_ctrl,
+                  h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -328,6 +363,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     const int t = std::atoi(e);
     if (t == 64 || t == 256) h->threads = t;
   }
+  if (const char* e = std::getenv("HDSM_BOUNDS_MIN")) h->bounds_min = std::atoi(e) > 0 ? std::atoi(e) : 1;
   h->scratch_stride = scratch_stride_for(h->n);
   const size_t I = (size_t)max_instances, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
   hipError_t e = hipSuccess;
@@ -339,7 +375,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_stats, 4 * I));
   ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
 #ifdef HDSM_PROFILE
-  ok(dmalloc(&h->d_prof, 16 * I));
+  ok(dmalloc(&h->d_prof, 24 * I));
 #endif
   ok(dmalloc(&h->d_agent, I));
   ok(dmalloc(&h->d_npoly, I));
@@ -350,6 +386,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_A, I * P * RS * 3));
   ok(dmalloc(&h->d_b, I * P * RS));
   ok(dmalloc(&h->d_plans, (size_t)n_rob_max * (N + 1) * 9));
+  ok(dmalloc(&h->d_bounds, (size_t)n_rob_max * 4));
   ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
   ok(dmalloc(&h->d_ctrl, I * N * 3));
   ok(dmalloc(&h->d_obj, I));
@@ -553,20 +590,21 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
   HIP_TRY(hipStreamSynchronize(h->last_stream));
 #ifdef HDSM_PROFILE
   {  // development aid: phase cycle counters of the slowest instance and the batch mean
-    std::vector<long long> pr((size_t)n_inst * 16);
+    std::vector<long long> pr((size_t)n_inst * 24);
     HIP_TRY(hipMemcpy(pr.data(), h->d_prof, pr.size() * sizeof(long long), hipMemcpyDeviceToHost));
     int worst = 0;
-    double mean[16] = {0};
+    double mean[24] = {0};
     for (int k = 0; k < n_inst; ++k) {
-      if (pr[(size_t)k * 16 + 11] > pr[(size_t)worst * 16 + 11]) worst = k;
-      for (int j = 0; j < 16; ++j) mean[j] += (double)pr[(size_t)k * 16 + j] / n_inst;
+      if (pr[(size_t)k * 24 + 11] > pr[(size_t)worst * 24 + 11]) worst = k;
+      for (int j = 0; j < 24; ++j) mean[j] += (double)pr[(size_t)k * 24 + j] / n_inst;
     }
-    static const char* nm[16] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
-                                 "leaf", "TOTAL", "iters", "sweeps", "warm_ops", "warm_cycles"};
+    static const char* nm[24] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
+                                 "leaf", "TOTAL", "iters", "sweeps", "warm_ops", "warm_cycles", "sw_cull", "sw_filter",
+                                 "sw_load", "sw_body", "sw_tail", "su_stage", "su_grad", "su_fact"};
     std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);
-    for (int j = 0; j < 16; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 16 + j]);
+    for (int j = 0; j < 24; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 24 + j]);
     std::fprintf(stderr, "\nHDSM_PROFILE mean:");
-    for (int j = 0; j < 16; ++j) std::fprintf(stderr, " %s=%.0f", nm[j], mean[j]);
+    for (int j = 0; j < 24; ++j) std::fprintf(stderr, " %s=%.0f", nm[j], mean[j]);
     std::fprintf(stderr, "\n");
   }
 #endif

@@ -63,6 +63,8 @@ HD int mk_id(int kind, int payload) { return (kind << 28) | payload; }
 HD int id_kind(int id) { return (id >> 28) & 7; }
 HD int id_payload(int id) { return id & 0x0fffffff; }
 
+constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered sweep
+
 // ---------------------------------------------------------------------------------------------------------
 // All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
 template <int NV, int CMAX>
@@ -110,6 +112,9 @@ struct Shm {
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
+  int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
+  int32_t list[LISTCAP];
+  double sw[5];          // sweep scalars: cull radius, own sphere (centre, radius)
   double part_v[4];      // per-wave partial maxima of the staged-row scan
   int32_t part_id[4];
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
@@ -731,6 +736,11 @@ struct Solver {
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
     if (threadIdx.x < 16) s.prof_acc[threadIdx.x] = 0;
+    SYNC();
+    PROF_DECL
+#define SU_PROF(k) PROF(k)
+#else
+#define SU_PROF(k)
 #endif
     // ---- stage the instance in LDS
     PAR_FOR(k, 9) s.state0[k] = a.state[(int64_t)inst * 9 + k];
@@ -756,6 +766,7 @@ struct Solver {
       s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
     }
     SYNC();
+    SU_PROF(13)
     // free response + st[0]
     PAR_FOR(k, 9 * (N + 1)) {
       const int i = k / 9, comp = (k % 9) / 3, ax = k % 3;
@@ -799,6 +810,7 @@ struct Solver {
       for (int e = 0; e < 6; ++e) t -= c.Meq[k * 6 + e] * s.red_v[e];
       s.x[k] = t;
     }
+    SU_PROF(14)
     GIState R;
 #ifdef HDSM_EMU
     PAR_FOR(k, n * n) {
@@ -865,6 +877,7 @@ struct Solver {
       s.f = f;
     }
     SYNC();
+    SU_PROF(15)
 
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     const long long t_setup_ = clock64() - t_begin_;
@@ -980,8 +993,8 @@ struct Solver {
 
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     if (IS_T0 && a.prof) {
-      long long* pr = a.prof + (int64_t)inst * 16;
-      for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k];
+      long long* pr = a.prof + (int64_t)inst * 24;
+      for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k], pr[16 + k] = s.prof_acc[8 + k];  // 16..23: inside the sweeps
       pr[8] = t_setup_, pr[9] = t_sweep_, pr[10] = t_leaf_, pr[11] = clock64() - t_begin_;
       pr[12] = iters, pr[13] = sweeps, pr[14] = it_warm_, pr[15] = t_warm_;
     }

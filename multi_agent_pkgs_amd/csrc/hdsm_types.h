@@ -65,6 +65,9 @@ struct Args {
   int32_t l1_rmax;
   int32_t* warm;          // [n_inst][MAXNV + 2]: count + portable ids of the previous optimal working set (in/out), or null
   long long* prof;        // HDSM_PROFILE builds: 16 cycle counters per instance (else null)
+  // [n_rob][4] = (centre, radius) of a sphere around steps 1..N of every published plan, radius < 0 = no plan;
+  // written by k_plan_bounds before the launch for large swarms, null = sweeps test every neighbour step by step
+  const double* bounds;
 };
 
 }  // namespace hdsm

@@ -457,83 +457,127 @@ struct WaveGI {
     return y;
   }
 
-  // Same planes as tasc_plane_eval (AC:1100-1205), organised for the wave: lane <-> neighbour k, the N future
-  // positions of that neighbour are loaded up-front (one 792-B record per lane, every byte of the position part
-  // used), then the N planes are evaluated back to back with independent instruction streams.
+  // Same planes as tasc_plane_eval (AC:1100-1205), organised for the workgroup: thread <-> (neighbour, step) pair, so
+  // the dependent f64 chain of one plane (two reciprocal square roots) is walked once per thread and not N times.
+  // For large swarms (a.bounds) the neighbours first pass a sphere test and only the survivors form pairs.
   static __device__ __forceinline__ void sweep_planes(S& s, const Consts& c, const Args& a, int self, double thresh,
                                                       bool check_fixed, int lane) {
     const int N = c.N, n_rob = a.n_rob, nt = (int)blockDim.x;  // lane = thread of the WORKGROUP here (all waves sweep)
+    PROF_DECL
     const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
+    const bool pre = a.bounds != nullptr;
     // Rigorous cull. With p = c + delta:  slack(p) = n_f.(q - p) = |d|/2 - back - n_f.delta  and n_f.n = 1,
     // back <= s_max = max(r, h), |n_f| <= sqrt(1 + (3 pert)^2)  ==>  slack >= |d|/2 - s_max - |n_f| |delta|.
     // A neighbour with |d| >= 2 (max(thresh, tol) + s_max + |n_f| delta_max) can be neither staged nor violated.
-    double dmax2 = 0.0;  // max over (step i, endpoint e) of |p_{i+e} - c_i|^2 (uniform: every thread scans 2N points)
-    for (int i = 0; i < N; ++i)
-      for (int e = 0; e < 2; ++e) {
-        const double ux = s.st[i + e][0] - s.cprev[i][0], uy = s.st[i + e][1] - s.cprev[i][1],
-                     uz = s.st[i + e][2] - s.cprev[i][2];
-        dmax2 = fmax(dmax2, ux * ux + uy * uy + uz * uz);
+    // Sphere prefilter: |o_i - c_i| >= |C_k - C_self| - rho_k - rho_self for every step i, so a neighbour whose
+    // sphere is further than cull + rho_k + rho_self from ours is skipped without touching its plan.
+    if (lane < 64) {  // wave 0: delta_max^2 over the 2N (step, endpoint) pairs and the own sphere, lane-parallel
+      double d2 = 0.0, r2 = 0.0;
+      const double mx = 0.5 * (s.cprev[0][0] + s.cprev[N - 1][0]), my = 0.5 * (s.cprev[0][1] + s.cprev[N - 1][1]),
+                   mz = 0.5 * (s.cprev[0][2] + s.cprev[N - 1][2]);
+      if (lane < 2 * N) {
+        const int i = lane >> 1, m = i + (lane & 1);
+        const double ux = s.st[m][0] - s.cprev[i][0], uy = s.st[m][1] - s.cprev[i][1], uz = s.st[m][2] - s.cprev[i][2];
+        d2 = ux * ux + uy * uy + uz * uz;
+        const double wx = s.cprev[i][0] - mx, wy = s.cprev[i][1] - my, wz = s.cprev[i][2] - mz;
+        r2 = wx * wx + wy * wy + wz * wz;
       }
-    const double smax = radius * fmax(1.0, rsqrt_nr(1.0 + k2m1));  // max(r, h): h = r / sqrt(1 + k2m1)
-    const double nfmax = sqrt(1.0 + 9.0 * pert * pert);
-    const double cull = 2.0 * (fmax(thresh, tol) + smax + nfmax * sqrt(dmax2)) * (1.0 + 1e-9);
-    const double cull2 = cull * cull;
-    for (int k0 = 0; k0 < n_rob; k0 += nt) {
-      const int k = k0 + lane;
-      const bool on = k < n_rob && k != self && a.has_plan[k < n_rob ? k : 0];
-      const double* rec = a.plans + ((int64_t)(on ? k : 0) * (N + 1) + 1) * 9;
-      double ox[HT], oy[HT], oz[HT];
-#pragma unroll
-      for (int i = 0; i < HT; ++i) {
-        if (i < N) {
-          ox[i] = rec[9 * i], oy[i] = rec[9 * i + 1], oz[i] = rec[9 * i + 2];
-        } else {
-          ox[i] = oy[i] = oz[i] = 0.0;
-        }
+      d2 = wave_max64(d2), r2 = wave_max64(r2);
+      if (lane == 0) {
+        const double smax = radius * fmax(1.0, rsqrt_nr(1.0 + k2m1));  // max(r, h): h = r / sqrt(1 + k2m1)
+        const double nfmax = sqrt(1.0 + 9.0 * pert * pert);
+        s.sw[0] = 2.0 * (fmax(thresh, tol) + smax + nfmax * sqrt(d2)) * (1.0 + 1e-9);
+        s.sw[1] = mx, s.sw[2] = my, s.sw[3] = mz, s.sw[4] = sqrt(r2) * (1.0 + 1e-9);
+        s.nlist = 0;
       }
+    }
+    __syncthreads();
+    const double cull = s.sw[0], cull2 = cull * cull;
+    PROF(8)
+    const int chunk = pre ? LISTCAP : n_rob;
+    for (int base = 0; base < n_rob; base += chunk) {
+      const int end = (base + chunk < n_rob) ? base + chunk : n_rob;
+      int cnt = end - base;
+      if (pre) {
+        const double sx = s.sw[1], sy = s.sw[2], sz = s.sw[3], reach0 = cull + s.sw[4];
+        constexpr int FB = 4;  // sphere records in flight per thread
+        for (int k0 = base + lane; k0 < end; k0 += FB * nt) {
+          double4 bk[FB];
 #pragma unroll
-      for (int i = 0; i < HT; ++i) {
-        if (i >= N) continue;
-        const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
-        const double dx = ox[i] - cx, dy = oy[i] - cy, dz = oz[i] - cz;
-        const double n2 = dx * dx + dy * dy + dz * dz;
-        if (!on || !(n2 > 0) || n2 >= cull2) continue;  // absent / coincident (row 0.p <= 0) / provably slack
-        const double inv = rsqrt_nr(n2), nrm = n2 * inv;
-        const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
-        const double sd = radius * rsqrt_nr(1.0 + k2m1 * hz * hz);  // ellipsoid support distance
-        const double back = 0.5 * fmin(2.0 * sd, nrm);
-        const double qx = 0.5 * (cx + ox[i]) - back * hx, qy = 0.5 * (cy + oy[i]) - back * hy,
-                     qz = 0.5 * (cz + oz[i]) - back * hz;
-        const double fx = hx + pert * (hy - hz) - pert * hz, fy = hy - pert * hx, fz = hz + 2.0 * pert * hx;
-        const double rhs = fx * qx + fy * qy + fz * qz;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int m = i + e;
-          const double* pm = s.st[m];
-          const double v = fx * pm[0] + fy * pm[1] + fz * pm[2] - rhs;
-          if (m == 0) {
-            if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
-            continue;
+          for (int f = 0; f < FB; ++f) {
+            const int k = k0 + f * nt;
+            bk[f] = *reinterpret_cast<const double4*>(a.bounds + 4 * (int64_t)(k < end ? k : base));
           }
-          if (v > tol) s.nviol = 1;
-          if (-v < thresh) {
-            const bool hot = -v < hot_tau;
-            const int slot = hot ? atomicAdd(&s.ncand, 1) : CMAX - 1 - atomicAdd(&s.ncold, 1);
-            const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
-            if (fits && slot >= 0 && slot < CMAX) {
-              s.cand[slot][0] = fx, s.cand[slot][1] = fy, s.cand[slot][2] = fz, s.cand[slot][3] = rhs;
-              s.cand_m[slot] = m;
-              s.cand_src[slot] = (k << 6) | (i << 1) | e;
-            } else {
-              s.overflow = 1;
+#pragma unroll
+          for (int f = 0; f < FB; ++f) {
+            const int k = k0 + f * nt;
+            const double ux = bk[f].x - sx, uy = bk[f].y - sy, uz = bk[f].z - sz, reach = reach0 + bk[f].w;
+            if (k < end && k != self && bk[f].w >= 0 && ux * ux + uy * uy + uz * uz < reach * reach)
+              s.list[atomicAdd(&s.nlist, 1)] = k;
+          }
+        }
+        __syncthreads();
+        cnt = s.nlist;
+        PROF(9)
+      }
+      const int total = cnt * N;
+      for (int idx0 = 0; idx0 < total; idx0 += nt) {
+        const int idx = idx0 + lane;
+        const bool in = idx < total;
+        const int j = in ? idx / N : 0, i = in ? idx - j * N : 0;
+        const int k = in ? (pre ? s.list[j] : base + j) : 0;  // idle threads read agent 0's record (always there)
+        const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+        const double ox = op[0], oy = op[1], oz = op[2];
+        const bool on = in && k != self && (pre || a.has_plan[k]);
+        PROF(10)
+        const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
+        const double dx = ox - cx, dy = oy - cy, dz = oz - cz;
+        const double n2 = dx * dx + dy * dy + dz * dz;
+        if (on && n2 > 0 && n2 < cull2) {  // else absent / coincident (row 0.p <= 0) / provably slack
+          const double inv = rsqrt_nr(n2), nrm = n2 * inv;
+          const double hx = dx * inv, hy = dy * inv, hz = dz * inv;
+          const double sd = radius * rsqrt_nr(1.0 + k2m1 * hz * hz);  // ellipsoid support distance
+          const double back = 0.5 * fmin(2.0 * sd, nrm);
+          const double qx = 0.5 * (cx + ox) - back * hx, qy = 0.5 * (cy + oy) - back * hy,
+                       qz = 0.5 * (cz + oz) - back * hz;
+          const double fx = hx + pert * (hy - hz) - pert * hz, fy = hy - pert * hx, fz = hz + 2.0 * pert * hx;
+          const double rhs = fx * qx + fy * qy + fz * qz;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int m = i + e;
+            const double* pm = s.st[m];
+            const double v = fx * pm[0] + fy * pm[1] + fz * pm[2] - rhs;
+            if (m == 0) {
+              if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
+              continue;
+            }
+            if (v > tol) s.nviol = 1;
+            if (-v < thresh) {
+              const bool hot = -v < hot_tau;
+              const int slot = hot ? atomicAdd(&s.ncand, 1) : CMAX - 1 - atomicAdd(&s.ncold, 1);
+              const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
+              if (fits && slot >= 0 && slot < CMAX) {
+                s.cand[slot][0] = fx, s.cand[slot][1] = fy, s.cand[slot][2] = fz, s.cand[slot][3] = rhs;
+                s.cand_m[slot] = m;
+                s.cand_src[slot] = (k << 6) | (i << 1) | e;
+              } else {
+                s.overflow = 1;
+              }
             }
           }
         }
+        PROF(11)
+      }
+      if (pre && end < n_rob) {  // next chunk reuses the list
+        __syncthreads();
+        if (lane == 0) s.nlist = 0;
+        __syncthreads();
       }
     }
     __syncthreads();
     if (lane == 0 && s.ncand + s.ncold > CMAX) s.overflow = 1;
     __syncthreads();
+    PROF(12)
   }
 
   // ---- warm start ---------------------------------------------------------------------------------------

@@ -290,3 +290,38 @@ def test_closed_loop_with_device_reference(hdsm, oracle):
         la.step()
         lb.step()
     assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", [dict(n_rob=64, seed=7, spacing=1.5, turn=True), dict(n_rob=64, seed=8, absent_frac=0.3),
+                                  dict(n_rob=16, seed=6, first_round=True), dict(n_rob=100, seed=11, spacing=6.0)],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_sphere_prefilter_never_changes_the_answer(hdsm, oracle, case, monkeypatch):
+    """Sweeps that first skip whole neighbours by bounding spheres (k_plan_bounds, default for >= 256 agents; forced
+    here by HDSM_BOUNDS_MIN=1) stage exactly the rows the step-by-step test would: same result as without it and
+    as the oracle, which generates every plane (AC:1100-1205)."""
+    prm = agile_params(10, max_rows_static=18)
+    case = dict(case)
+    n_rob, seed = case.pop("n_rob"), case.pop("seed")
+    sn = problems.swarm_snapshot(prm, n_rob, seed, **case)
+    args = [sn[k] for k in ARG_KEYS]
+    monkeypatch.setenv("HDSM_BOUNDS_MIN", "1")
+    g_pre = hdsm.Solver(prm, n_rob, n_rob).replan(*args)
+    monkeypatch.setenv("HDSM_BOUNDS_MIN", "1000000")
+    g_all = hdsm.Solver(prm, n_rob, n_rob).replan(*args)
+    assert (g_pre["status"] == g_all["status"]).all()
+    ok = g_all["status"] != 2
+    assert np.abs(g_pre["traj"] - g_all["traj"])[ok].max() < 1e-9
+    compare(g_pre, oracle.replan(prm, *args, n_threads=8))
+
+
+def test_sphere_prefilter_chunks_beyond_list_capacity(hdsm, oracle):
+    """1300 agents (> one chunk of 1024 neighbours): instances from both ends of the id range against the oracle."""
+    prm = agile_params(10, max_rows_static=18)
+    n_rob = 1300
+    sn = problems.swarm_snapshot(prm, n_rob, seed=77, spacing=1.7, turn=True)
+    sub = np.concatenate([np.arange(0, 20), np.arange(1010, 1040), np.arange(1280, 1300)]).astype(np.int32)
+    sel = [sn[k][sub] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")] + [sn["plans"], sn["has_plan"]]
+    g = hdsm.Solver(prm, len(sub), n_rob).replan(*sel)
+    o = oracle.replan(prm, *sel, n_threads=8)
+    assert (o["status"] == 0).sum() > len(sub) // 2
+    compare(g, o)
