@@ -207,6 +207,76 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
         for (int k = 0; k < 6; ++k) sacc += HE[(size_t)i * 6 + k] * c->Seq[k * 6 + e];
         c->Meq[(size_t)i * 6 + e] = sacc;
       }
+    for (int j = 0; j < MAXNV; ++j)
+      for (int lane = 0; lane < 64; ++lane)
+        c->JeqP[(size_t)j * 64 + lane] = (lane < n && j < n) ? c->Jeq[(size_t)lane * n + j] : (lane == j ? 1.0 : 0.0);
+    // Set-up map: free response -> gradient at u = 0 -> x0 = -H^{-1} grad -> equality residual -> x_eq, nu, applied
+    // to the unit vectors of v = (state_curr, traj_ref). The tracking cost pairs x_i with ref_{i-1} (AC:870-883).
+    const int nv = 9 + 6 * N;
+    std::vector<double> v(nv), fr((size_t)3 * (N + 1) * 3), grad(n), x0(n), res(6);
+    for (int col = 0; col < nv; ++col) {
+      std::fill(v.begin(), v.end(), 0.0);
+      v[col] = 1.0;
+      const double* st0 = v.data();
+      const double* ref = v.data() + 9;  // [N][6]
+      for (int ax = 0; ax < 3; ++ax)
+        for (int i = 0; i <= N; ++i)
+          for (int comp = 0; comp < 3; ++comp) {
+            double t = 0;
+            for (int cc = 0; cc < 3; ++cc) t += c->phi[ax][i][comp][cc] * st0[3 * cc + ax];
+            fr[((size_t)ax * (N + 1) + i) * 3 + comp] = t;
+          }
+      for (int k = 0; k < n; ++k) {
+        const int ax = k / N, kk = k % N;
+        double gsum = 0;
+        for (int i = kk + 1; i <= N; ++i) {
+          const double* w = (i == N) ? c->wn : c->wx;
+          for (int comp = 0; comp < 2; ++comp)
+            gsum += 2.0 * w[3 * comp + ax] * c->g[ax][comp][i - 1 - kk] *
+                    (fr[((size_t)ax * (N + 1) + i) * 3 + comp] - ref[(i - 1) * 6 + 3 * comp + ax]);
+        }
+        grad[k] = gsum;
+      }
+      for (int k = 0; k < n; ++k) {
+        double t = 0;
+        const int j0 = (k / N) * N;
+        for (int j = j0; j < j0 + N; ++j) t -= c->Hinv[(size_t)k * n + j] * grad[j];
+        x0[k] = t;
+      }
+      for (int e = 0; e < 6; ++e) {
+        const int ax = e % 3, comp = 1 + e / 3;
+        double t = fr[((size_t)ax * (N + 1) + N) * 3 + comp];
+        for (int k = 0; k < N; ++k) t += c->g[ax][comp][N - 1 - k] * x0[ax * N + k];
+        res[e] = t;
+      }
+      double* out = c->KT + (size_t)col * KROWS;
+      for (int k = 0; k < n; ++k) {
+        double t = x0[k];
+        for (int e = 0; e < 6; ++e) t -= c->Meq[(size_t)k * 6 + e] * res[e];
+        out[k] = t, out[n + k] = x0[k], out[2 * n + k] = grad[k];
+      }
+      for (int e = 0; e < 6; ++e) {
+        double nu = 0;
+        for (int k = 0; k < 6; ++k) nu += c->Seq[e * 6 + k] * res[k];
+        out[3 * n + e] = res[e], out[3 * n + 6 + e] = nu;
+      }
+    }
+    const int nk = 3 * n + 12;
+    double off_axis = 0.0, on_axis = 0.0;
+    for (int row = 0; row < nk; ++row) {
+      const int ax = (row < 3 * n) ? (row % n) / N : (row - 3 * n) % 3;
+      c->kax[row] = ax;
+      for (int u = 0; u < 3 + 2 * N; ++u) c->KTC[(size_t)u * KROWS + row] = c->KT[(size_t)(ax + 3 * u) * KROWS + row];
+      for (int col = 0; col < nv; ++col) {
+        const double v = std::fabs(c->KT[(size_t)col * KROWS + row]);
+        if (col % 3 == ax) on_axis = std::fmax(on_axis, v);
+        else off_axis = std::fmax(off_axis, v);
+      }
+    }
+    if (!(off_axis <= 1e-9 * on_axis)) {  // cannot happen for per-axis dynamics and weights; guards the compact form
+      if (err) *err = "internal: set-up map is not axis-separable";
+      return HDSM_ERR_BAD_ARG;
+    }
   }
   return HDSM_OK;
 }

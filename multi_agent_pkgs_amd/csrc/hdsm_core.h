@@ -32,6 +32,7 @@
 #define HD inline
 #define HDN inline
 #define PAR_FOR(i, cnt) for (int i = 0; i < (cnt); ++i)
+#define HDSM_UNROLL
 #define SYNC() ((void)0)
 #define IS_T0 (true)
 #define HDSM_NT 1
@@ -43,6 +44,7 @@ static inline int atomic_inc_i32(int* p) { return (*p)++; }
 #define HD __device__ __forceinline__
 #define HDN __device__ __noinline__
 #define PAR_FOR(i, cnt) for (int i = (int)threadIdx.x; i < (cnt); i += (int)blockDim.x)
+#define HDSM_UNROLL _Pragma("unroll")
 #define SYNC() __syncthreads()
 #define IS_T0 (threadIdx.x == 0)
 namespace hdsm {
@@ -115,6 +117,7 @@ struct Shm {
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
   int32_t list[LISTCAP];
   double sw[5];          // sweep scalars: cull radius, own sphere (centre, radius)
+  double vin[KCOLS + 8];  // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded
   double part_v[4];      // per-wave partial maxima of the staged-row scan
   int32_t part_id[4];
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
@@ -742,6 +745,7 @@ struct Solver {
 #else
 #define SU_PROF(k)
 #endif
+#ifdef HDSM_EMU
     // ---- stage the instance in LDS
     PAR_FOR(k, 9) s.state0[k] = a.state[(int64_t)inst * 9 + k];
     PAR_FOR(k, 6 * N) s.ref[k / 6][k % 6] = a.ref[(int64_t)inst * 6 * N + k];
@@ -754,11 +758,13 @@ struct Solver {
       s.sp[j][r][0] = Ar[0], s.sp[j][r][1] = Ar[1], s.sp[j][r][2] = Ar[2];
       s.sp[j][r][3] = a.b[((int64_t)inst * P + j) * RS + r];
     }
-    const bool own_plan = self >= 0 && self < a.n_rob && a.has_plan[self];
-    PAR_FOR(k, 3 * N) {
+    PAR_FOR(k, 9 + 6 * N) s.vin[k] = (k < 9) ? a.state[(int64_t)inst * 9 + k] : a.ref[(int64_t)inst * 6 * N + (k - 9)];
+    const bool self_ok = self >= 0 && self < a.n_rob;
+    PAR_FOR(k, 3 * N) {  // both candidates are requested before has_plan[self] is known: one memory latency, not two
       const int i = k / 3, ax = k % 3;
-      s.cprev[i][ax] = own_plan ? a.plans[((int64_t)self * (N + 1) + (i + 1)) * 9 + ax]
-                                : a.state[(int64_t)inst * 9 + ax];
+      const double from_plan = a.plans[((int64_t)(self_ok ? self : 0) * (N + 1) + (i + 1)) * 9 + ax];
+      const double from_state = a.state[(int64_t)inst * 9 + ax];
+      s.cprev[i][ax] = (self_ok && a.has_plan[self_ok ? self : 0]) ? from_plan : from_state;
     }
     PAR_FOR(k, MAXH) s.assign[k] = -1;
     if (IS_T0) {
@@ -766,97 +772,203 @@ struct Solver {
       s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
     }
     SYNC();
-    SU_PROF(13)
-    // free response + st[0]
-    PAR_FOR(k, 9 * (N + 1)) {
-      const int i = k / 9, comp = (k % 9) / 3, ax = k % 3;
-      double v = 0;
-      for (int cc = 0; cc < 3; ++cc) v += c.phi[ax][i][comp][cc] * s.state0[3 * cc + ax];
-      s.fr[ax][i][comp] = v;
-      if (i == 0) s.st[0][3 * comp + ax] = s.state0[3 * comp + ax];
+    // x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at u = 0, the residual
+    // of the six terminal equalities at x0 and their multipliers: one dot product each with the precomputed map KT
+    // (hdsm_consts.cpp). The remaining threads build the free response and st[0].
+    const int nk = 3 * n + 12, nvt = 9 + 6 * N;
+    PAR_FOR(idx, nk + 9 * (N + 1)) {
+      if (idx < nk) {
+        double acc = 0;
+        for (int j = 0; j < nvt; ++j) acc += c.KT[j * KROWS + idx] * s.vin[j];
+        if (idx < n) s.x[idx] = acc;
+        else if (idx < 2 * n) s.w[idx - n] = acc;
+        else if (idx < 3 * n) s.grad[idx - 2 * n] = acc;
+        else if (idx < 3 * n + 6) s.red_v[idx - 3 * n] = acc;
+        else s.lam[idx - 3 * n - 6] = acc;
+      } else {
+        const int k = idx - nk;
+        const int i = k / 9, comp = (k % 9) / 3, ax = k % 3;
+        double v = 0;
+        for (int cc = 0; cc < 3; ++cc) v += c.phi[ax][i][comp][cc] * s.state0[3 * cc + ax];
+        s.fr[ax][i][comp] = v;
+        if (i == 0) s.st[0][3 * comp + ax] = s.state0[3 * comp + ax];
+      }
     }
-    SYNC();
-    // gradient of J at u = 0 and the constant term
-    PAR_FOR(k, n) {
-      const int ax = k / N, kk = k % N;
-      double gsum = 0;
-      for (int i = kk + 1; i <= N; ++i) {
-        const double* w = (i == N) ? c.wn : c.wx;
-        for (int comp = 0; comp < 2; ++comp) {
-          const double e = s.fr[ax][i][comp] - s.ref[i - 1][3 * comp + ax];
-          gsum += 2.0 * w[3 * comp + ax] * s.g[ax][comp][i - 1 - kk] * e;
+#else
+    // ---- stage the instance in LDS and apply the set-up map. Every global read of the set-up is REQUESTED before
+    // the first one is consumed (memory latency is paid once, or twice for the own plan, whose address needs
+    // agent_id[inst]); the generic loops of the CPU build above do the same thing one array at a time.
+    GIState R;
+    const int nk = 3 * n + 12, nvt = 9 + 6 * N;
+    double fw0, fw1;  // weights of the (at most two) tracking residuals this lane of wave 0 squares for the constant term
+    const int np = min_i(a.n_poly[inst], P);
+    {
+      const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+      constexpr int KH = 3 + 2 * (NV / 3);  // inputs one output of the set-up map depends on (compact form, KTC)
+      // one output of the set-up map per thread: its coefficients
+      double kv[KH];
+      const bool k_on = tid < nk;
+      const int krow = k_on ? tid : 0, kbase = c.kax[krow];
+      if (tid < ((nk + 63) & ~63)) {  // whole wavefronts only
+        HDSM_UNROLL
+        for (int u = 0; u < KH; ++u) kv[u] = c.KTC[u * KROWS + krow];
+      }
+      // lane i of wave 0 takes row i of Jeq, identity beyond n. With n <= 30 the registers hold this next to the
+      // coefficients; the larger kernel asks for it once those are consumed.
+      if constexpr (NV <= 30) {
+        if (tid < 64) {
+          HDSM_UNROLL
+          for (int j = 0; j < NV; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
         }
       }
-      s.grad[k] = gsum;
+      W::init_lane(R, c, tid);
+      const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
+      fw0 = (tid < 64) ? ((fi0 == N) ? c.wn[fk0] : c.wx[fk0]) : 0.0;
+      fw1 = (tid < 64) ? ((fi1 == N) ? c.wn[fk1] : c.wx[fk1]) : 0.0;
+      // Everything else is staged in "virtual thread" slots: slot vt takes item vt of every array. Round 0 (vt = tid)
+      // is split into requests and LDS writes so that the two reads that need agent_id[inst] (the own plan) go out
+      // while all the others are already in flight; the kernel arguments are used straight from the SGPRs here.
+      const Args& g = a_in;
+      struct Req {
+        double v_in, v_g, a0, a1, a2, a3, p0, p1, p2, q0, q1, q2, v_u;
+        int nr, sj, sr, fi, fcomp, fax;
+      };
+      auto request = [&](int vt) {
+        Req r;
+        r.v_in = (vt < nvt) ? (vt < 9 ? g.state[(int64_t)inst * 9 + vt] : g.ref[(int64_t)inst * 6 * N + (vt - 9)]) : 0.0;
+        r.v_g = (vt < 9 * MAXH) ? (&c.g[0][0][0])[vt] : 0.0;
+        r.sj = (vt < P * RS) ? vt / RS : 0, r.sr = (vt < P * RS) ? vt % RS : 0;
+        const double* Ar = g.A + (((int64_t)inst * P + r.sj) * RS + r.sr) * 3;
+        r.a0 = Ar[0], r.a1 = Ar[1], r.a2 = Ar[2], r.a3 = g.b[((int64_t)inst * P + r.sj) * RS + r.sr];
+        r.nr = g.n_rows[(int64_t)inst * P + (vt < P ? vt : 0)];
+        r.fi = (vt < 9 * (N + 1)) ? vt / 9 : 0, r.fcomp = (vt % 9) / 3, r.fax = vt % 3;
+        r.p0 = c.phi[r.fax][r.fi][r.fcomp][0], r.p1 = c.phi[r.fax][r.fi][r.fcomp][1], r.p2 = c.phi[r.fax][r.fi][r.fcomp][2];
+        r.q0 = g.state[(int64_t)inst * 9 + r.fax], r.q1 = g.state[(int64_t)inst * 9 + 3 + r.fax],
+        r.q2 = g.state[(int64_t)inst * 9 + 6 + r.fax];
+        const int ui = vt / S::LDT, uj = vt % S::LDT;
+        r.v_u = (ui < 6 && uj < 6) ? c.Ueq[ui * 6 + uj] : 0.0;
+        return r;
+      };
+      auto commit = [&](int vt, const Req& r) {
+        if (vt < KCOLS + 8) s.vin[vt] = r.v_in;  // zero beyond 9 + 6N: padded coefficients (N < NV / 3) meet finite numbers
+        if (vt < nvt) {
+          if (vt < 9) s.state0[vt] = r.v_in;
+          else (&s.ref[0][0])[vt - 9] = r.v_in;
+        }
+        if (vt < 9 * MAXH) {
+          (&s.g[0][0][0])[vt] = r.v_g;
+          const int ax = vt / (3 * MAXH), comp = (vt / MAXH) % 3, lag = vt % MAXH;
+          s.gz[ax][comp][lag] = 0.0;
+          s.gz[ax][comp][MAXH + lag] = (lag < N) ? r.v_g : 0.0;
+        }
+        if (vt < P * RS) s.sp[r.sj][r.sr][0] = r.a0, s.sp[r.sj][r.sr][1] = r.a1, s.sp[r.sj][r.sr][2] = r.a2, s.sp[r.sj][r.sr][3] = r.a3;
+        if (vt < P) s.sp_rows[vt] = (vt < np) ? min_i(r.nr, RS) : 0;
+        if (vt < 9 * (N + 1)) {
+          s.fr[r.fax][r.fi][r.fcomp] = r.p0 * r.q0 + r.p1 * r.q1 + r.p2 * r.q2;
+          if (r.fi == 0) s.st[0][3 * r.fcomp + r.fax] = (r.fcomp == 0) ? r.q0 : (r.fcomp == 1 ? r.q1 : r.q2);
+        }
+        if (vt < 6 * S::LDT) s.U[vt] = r.v_u;  // rows 0..5 of U = Ueq, zero-padded
+        if (vt < NV) {
+          if (vt >= 6) s.lam[vt] = 0.0;
+          s.act[vt] = (vt < 6) ? mk_id(K_E, vt) : -1;
+          if (vt >= n) s.x[vt] = 0.0;
+        }
+        if (vt < MAXH) s.assign[vt] = -1;
+      };
+      ST_PROF(8)
+      const Req r0 = request(tid);
+      ST_PROF(9)
+      // the own plan (or, before the first plan exists, the current position at every step)
+      const bool self_ok = self >= 0 && self < g.n_rob;
+      const int sidx = self_ok ? self : 0;
+      const uint8_t has_own = g.has_plan[sidx];
+      for (int k = tid; k < 3 * N; k += nt) {
+        const int ci = k / 3, cax = k % 3;
+        const double from_plan = g.plans[((int64_t)sidx * (N + 1) + (ci + 1)) * 9 + cax];
+        const double from_state = g.state[(int64_t)inst * 9 + cax];
+        s.cprev[ci][cax] = (self_ok && has_own) ? from_plan : from_state;
+      }
+      ST_PROF(10)
+      commit(tid, r0);
+      ST_PROF(11)
+      const int items = max_i(max_i(P * RS, 6 * S::LDT), max_i(9 * MAXH, 9 * (N + 1)));
+      for (int vt = tid + nt; vt < items; vt += nt) commit(vt, request(vt));
+      for (int k = 6 * S::LDT + tid; k < NV * S::LDT; k += nt) s.U[k] = 0.0;
+      if (tid == 0) {
+        s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
+        s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
+      }
+      ST_PROF(12)
+      SYNC();
+      SU_PROF(13)
+      // the set-up map: x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at
+      // u = 0, the residual of the six terminal equalities at x0 and their multipliers
+      auto store = [&](int row, double acc) {
+        if (row < n) s.x[row] = acc;
+        else if (row < 2 * n) s.w[row - n] = acc;
+        else if (row < 3 * n) s.grad[row - 2 * n] = acc;
+        else if (row < 3 * n + 6) s.red_v[row - 3 * n] = acc;
+        else s.lam[row - 3 * n - 6] = acc;
+      };
+      if (tid < ((nk + 63) & ~63)) {
+        double acc = 0;
+        HDSM_UNROLL
+        for (int u = 0; u < KH; ++u) acc += kv[u] * s.vin[kbase + 3 * u];
+        if (k_on) store(tid, acc);
+      }
+      for (int row = tid + nt; row < nk; row += nt) {  // 64-thread launches
+        const int base = c.kax[row];
+        double acc = 0;
+        for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * s.vin[base + 3 * u];
+        store(row, acc);
+      }
+      if constexpr (NV > 30) {
+        if (tid < 64) {
+          HDSM_UNROLL
+          for (int j = 0; j < NV; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
+        }
+      }
     }
-    SYNC();
-    PAR_FOR(k, n) {  // x0 = -H^{-1} grad (unconstrained minimiser); H is block diagonal per axis
-      double t = 0;
-      const int j0 = (k / N) * N;
-      for (int j = j0; j < j0 + N; ++j) t -= c.Hinv[k * n + j] * s.grad[j];
-      s.w[k] = t;
-    }
-    SYNC();
-    // residual of the six terminal equalities at x0: resid_e = v/a component of x_N
-    PAR_FOR(e, 6) {
-      const int ax = e % 3, comp = 1 + e / 3;
-      double t = s.fr[ax][N][comp];
-      for (int k = 0; k < N; ++k) t += c.g[ax][comp][N - 1 - k] * s.w[ax * N + k];
-      s.red_v[e] = t;
-    }
-    SYNC();
-    PAR_FOR(k, n) {  // x_eq = x0 - Meq resid: minimiser subject to v_N = a_N = 0
-      double t = s.w[k];
-      for (int e = 0; e < 6; ++e) t -= c.Meq[k * 6 + e] * s.red_v[e];
-      s.x[k] = t;
-    }
+#endif
     SU_PROF(14)
-    GIState R;
 #ifdef HDSM_EMU
+    GIState R;
     PAR_FOR(k, n * n) {
       const int i = k / n, j = k % n;
       s.J[i * LD + j] = c.Jeq[k];
       s.R[i * LD + j] = (i < 6 && j < 6) ? c.Req[i * 6 + j] : 0.0;
     }
-    PAR_FOR(e, 6) {
-      double nu = 0;
-      for (int k = 0; k < 6; ++k) nu += c.Seq[e * 6 + k] * s.red_v[k];
-      s.lam[e] = nu;
-      s.act[e] = mk_id(K_E, e);
-    }
-#else
-    {  // lane i holds row i of J (identity beyond n): coalesced global reads, staged through the T buffer
-      const int lane = (int)threadIdx.x;
-      PAR_FOR(k, n * n) s.T[(k / n) * S::LDT + (k % n)] = c.Jeq[k];
-      SYNC();
-#pragma unroll
-      for (int j = 0; j < NV; ++j)
-        R.Jr[j] = (lane < n && j < n) ? s.T[lane * S::LDT + j] : ((lane == j) ? 1.0 : 0.0);
-    }
-    W::init_lane(R, c, (int)threadIdx.x);
-    PAR_FOR(k, NV * S::LDT) {
-      const int i = k / S::LDT, j = k % S::LDT;
-      s.U[k] = (i < 6 && j < 6) ? c.Ueq[i * 6 + j] : 0.0;
-    }
-    PAR_FOR(k, NV) {
-      double nu = 0;
-      if (k < 6)
-        for (int e = 0; e < 6; ++e) nu += c.Seq[k * 6 + e] * s.red_v[e];
-      s.lam[k] = nu;
-      s.act[k] = (k < 6) ? mk_id(K_E, k) : -1;
-    }
-    PAR_FOR(k, 9 * 2 * MAXH) {
-      const int ax = k / (6 * MAXH), comp = (k / (2 * MAXH)) % 3, e = k % (2 * MAXH), lag = e - MAXH;
-      s.gz[ax][comp][e] = (lag >= 0 && lag < N) ? c.g[ax][comp][lag] : 0.0;
-    }
-    PAR_FOR(k, NV) if (k >= n) s.x[k] = 0.0;
+    PAR_FOR(e, 6) s.act[e] = mk_id(K_E, e);
 #endif
     SYNC();
+    // constant term f0, J(x0) = f0 + grad.x0 / 2 and J(x_eq) = J(x0) + resid.nu / 2
 #ifndef HDSM_EMU
     R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
     PAR_FOR(k, NV) s.x0[k] = (k < n) ? s.w[k] : 0.0;
-    if (IS_T0) s.inc_nact = 0;
-#endif
+    if (threadIdx.x < 64) {
+      const int lane = (int)threadIdx.x;
+      double t0 = 0.0;
+      if (lane < 6 * N) {
+        const int i = lane / 6 + 1, k = lane % 6;
+        const double e = s.fr[k % 3][i][k / 3] - s.ref[i - 1][k];
+        t0 = fw0 * e * e;
+      }
+      if (lane + 64 < 6 * N) {
+        const int i = (lane + 64) / 6 + 1, k = (lane + 64) % 6;
+        const double e = s.fr[k % 3][i][k / 3] - s.ref[i - 1][k];
+        t0 += fw1 * e * e;
+      }
+      t0 = wave_sum64(t0);
+      const double t1 = wave_sum64(lane < n ? s.grad[lane] * s.w[lane] : 0.0);
+      const double t2 = wave_sum64(lane < 6 ? s.red_v[lane] * s.lam[lane] : 0.0);
+      if (lane == 0) {
+        s.f0 = t0;
+        s.fx0 = t0 + 0.5 * t1;
+        s.f = s.fx0 + 0.5 * t2;
+        s.inc_nact = 0;
+      }
+    }
+#else
     if (IS_T0) {
       double f0 = 0;
       for (int i = 1; i <= N; ++i) {
@@ -867,15 +979,12 @@ struct Solver {
         }
       }
       double f = f0;
-      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.w[k];  // J(x0)
-#ifndef HDSM_EMU
-      s.fx0 = f;
-#endif
-      for (int e = 0; e < 6; ++e)                                  // + 1/2 resid' (E H^{-1} E')^{-1} resid
-        for (int k = 0; k < 6; ++k) f += 0.5 * s.red_v[e] * c.Seq[e * 6 + k] * s.red_v[k];
+      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.w[k];
+      for (int e = 0; e < 6; ++e) f += 0.5 * s.red_v[e] * s.lam[e];
       s.f0 = f0;
       s.f = f;
     }
+#endif
     SYNC();
     SU_PROF(15)
 
@@ -1057,6 +1166,7 @@ struct Solver {
   }
 
   static HD int min_i(int x, int y) { return x < y ? x : y; }
+  static HD int max_i(int x, int y) { return x > y ? x : y; }
 };
 
 }  // namespace hdsm

@@ -9,6 +9,9 @@ constexpr int MAXP = 8;    // HDSM_MAX_POLY
 constexpr int MAXRS = 32;  // HDSM_MAX_ROWS_STATIC
 constexpr int MAXNV = 3 * MAXH;
 constexpr int MAXT = 256;  // largest workgroup
+constexpr int KCOLS = 9 + 6 * MAXH;     // inputs of the set-up map: state_curr, traj_ref
+constexpr int KROWS = 3 * MAXNV + 12;   // outputs: x_eq, x0, gradient, equality residuals and multipliers
+constexpr int KCH = 3 + 2 * MAXH;       // inputs one output of the set-up map really depends on (its own axis)
 constexpr double ABSENT = 1e20;
 constexpr double DINF = 1e300;
 
@@ -34,6 +37,16 @@ struct Consts {
   double Req[36], Ueq[36];       // Req upper triangular 6x6, Ueq = Req^{-1}
   double Meq[MAXNV * 6];         // x_eq = x0 - Meq * resid,  resid_e = (E x0 - e)_e;  Meq = H^{-1}E^T (E H^{-1} E^T)^{-1}
   double Seq[36];                // (E H^{-1} E^T)^{-1}: multipliers nu = Seq * resid, f_eq = f(x0) + 1/2 resid' Seq resid
+  // Everything an instance needs before its first iteration is LINEAR in v = (state_curr[9], traj_ref[N][6]):
+  //   rows [0,n) x_eq, [n,2n) x0, [2n,3n) gradient at u = 0, [3n,3n+6) resid, [3n+6,3n+12) nu.
+  // KT[j * KROWS + row] is the coefficient of v[j] (input-major, so a wavefront reads consecutive rows coalesced).
+  double KT[KCOLS * KROWS];
+  // The axes are decoupled (dynamics, cost and terminal equalities are per axis), so a row that belongs to axis ax has
+  // non-zeros only at state_curr[3 cc + ax] and traj_ref[i][3 comp + ax] — flat positions ax + 3 u, u < 3 + 2N. The
+  // device set-up uses this compact form: KTC[u * KROWS + row] = KT[(kax[row] + 3 u) * KROWS + row].
+  double KTC[KCH * KROWS];
+  int32_t kax[KROWS];
+  double JeqP[MAXNV * 64];       // JeqP[j * 64 + lane] = Jeq[lane][j], identity beyond n: lane i takes row i of Jeq
 };
 
 // Per-launch arguments (device pointers), layouts of include/hdsm.h.

@@ -46,6 +46,13 @@ __device__ __forceinline__ double wave_max64(double v) {
   v = fmax(v, dpp64<0x128>(v));  // row_ror:8  -> every lane holds the max of its 16-lane row
   return fmax(fmax(bcast64(v, 0), bcast64(v, 16)), fmax(bcast64(v, 32), bcast64(v, 48)));
 }
+__device__ __forceinline__ double wave_sum64(double v) {  // every lane gets the sum over the wave
+  v += dpp64<0x121>(v);
+  v += dpp64<0x122>(v);
+  v += dpp64<0x124>(v);
+  v += dpp64<0x128>(v);
+  return (bcast64(v, 0) + bcast64(v, 16)) + (bcast64(v, 32) + bcast64(v, 48));
+}
 // DPP move with zero fill for lanes shifted in from outside the 16-lane row
 template <int CTRL>
 __device__ __forceinline__ double dpp64z(double v) {
@@ -97,6 +104,14 @@ struct alignas(16) D2 {
 #define PROF_DECL
 #define PROF(k)
 #endif
+// -DHDSM_PROF_STAGE (with -DHDSM_PROFILE): slots 16..20 time the steps of the staging phase instead of the sweeps
+#if defined(HDSM_PROFILE) && defined(HDSM_PROF_STAGE)
+#define SW_PROF(k)
+#define ST_PROF(k) PROF(k)
+#else
+#define SW_PROF(k) PROF(k)
+#define ST_PROF(k)
+#endif
 
 template <int NV, int CMAX>
 struct WaveGI {
@@ -115,24 +130,27 @@ struct WaveGI {
 
   static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane) {
     const int N = c.N, n = c.n;
-    R.ub_own = DINF, R.lb_own = -DINF;
-    if (lane < n) {
-      const int ax = lane / N;
-      if (fabs(c.ubu[ax]) < ABSENT) R.ub_own = c.ubu[ax];
-      if (fabs(c.lbu[ax]) < ABSENT) R.lb_own = c.lbu[ax];
-    }
     const int n_sb = 6 * (N - 1);
+    // all bounds are requested first and selected afterwards (no wait between the loads)
+    const int ax0 = (lane < n) ? lane / N : 0;
+    const double ubu = c.ubu[ax0], lbu = c.lbu[ax0];
+    double ubs[2], lbs[2];
+    int comp[2], axs[2], ii[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int idx = lane + 64 * e;
-      R.sb_off[e] = -1, R.sb_id[e] = 0, R.sb_ub[e] = DINF, R.sb_lb[e] = -DINF;
-      if (idx < n_sb) {
-        const int i = idx / 6 + 1, k = idx % 6, comp = 1 + k / 3, ax = k % 3;
-        R.sb_off[e] = i * 9 + 3 * comp + ax;
-        R.sb_id[e] = (i << 5) | (comp << 3) | (ax << 1);
-        if (fabs(c.ubs[comp][ax]) < ABSENT) R.sb_ub[e] = c.ubs[comp][ax];
-        if (fabs(c.lbs[comp][ax]) < ABSENT) R.sb_lb[e] = c.lbs[comp][ax];
-      }
+      const int idx = lane + 64 * e, k = idx % 6;
+      ii[e] = idx / 6 + 1, comp[e] = 1 + k / 3, axs[e] = k % 3;
+      ubs[e] = c.ubs[comp[e]][axs[e]], lbs[e] = c.lbs[comp[e]][axs[e]];
+    }
+    R.ub_own = (lane < n && fabs(ubu) < ABSENT) ? ubu : DINF;
+    R.lb_own = (lane < n && fabs(lbu) < ABSENT) ? lbu : -DINF;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool on = lane + 64 * e < n_sb;
+      R.sb_off[e] = on ? ii[e] * 9 + 3 * comp[e] + axs[e] : -1;
+      R.sb_id[e] = on ? ((ii[e] << 5) | (comp[e] << 3) | (axs[e] << 1)) : 0;
+      R.sb_ub[e] = (on && fabs(ubs[e]) < ABSENT) ? ubs[e] : DINF;
+      R.sb_lb[e] = (on && fabs(lbs[e]) < ABSENT) ? lbs[e] : -DINF;
     }
   }
 
@@ -493,7 +511,7 @@ struct WaveGI {
     }
     __syncthreads();
     const double cull = s.sw[0], cull2 = cull * cull;
-    PROF(8)
+    SW_PROF(8)
     const int chunk = pre ? LISTCAP : n_rob;
     for (int base = 0; base < n_rob; base += chunk) {
       const int end = (base + chunk < n_rob) ? base + chunk : n_rob;
@@ -518,7 +536,7 @@ struct WaveGI {
         }
         __syncthreads();
         cnt = s.nlist;
-        PROF(9)
+        SW_PROF(9)
       }
       const int total = cnt * N;
       for (int idx0 = 0; idx0 < total; idx0 += nt) {
@@ -529,7 +547,7 @@ struct WaveGI {
         const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
         const double ox = op[0], oy = op[1], oz = op[2];
         const bool on = in && k != self && (pre || a.has_plan[k]);
-        PROF(10)
+        SW_PROF(10)
         const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
         const double dx = ox - cx, dy = oy - cy, dz = oz - cz;
         const double n2 = dx * dx + dy * dy + dz * dz;
@@ -566,7 +584,7 @@ struct WaveGI {
             }
           }
         }
-        PROF(11)
+        SW_PROF(11)
       }
       if (pre && end < n_rob) {  // next chunk reuses the list
         __syncthreads();
@@ -577,7 +595,7 @@ struct WaveGI {
     __syncthreads();
     if (lane == 0 && s.ncand + s.ncold > CMAX) s.overflow = 1;
     __syncthreads();
-    PROF(12)
+    SW_PROF(12)
   }
 
   // ---- warm start ---------------------------------------------------------------------------------------
