@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_tasc_planes(const hdsm::Consts* __restr
       for (int ax = 0; ax < 3; ++ax)
         cp3[ax] = own ? plans[((int64_t)self * (N + 1) + (i + 1)) * 9 + ax] : state[(int64_t)inst * 9 + ax];
       double tmp[4];
-      if (hdsm::Solver<30, 16>::tasc_plane(c, cp3, plans + ((int64_t)k * (N + 1) + (i + 1)) * 9, tmp))
+      if (hdsm::Solver<32, 16>::tasc_plane(c, cp3, plans + ((int64_t)k * (N + 1) + (i + 1)) * 9, tmp))
         row[0] = tmp[0], row[1] = tmp[1], row[2] = tmp[2], row[3] = tmp[3];
     }
     double* out = planes + idx * 4;
@@ -240,7 +240,7 @@ struct Handle {
 
 template <int NV, int NT>
 int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
-  constexpr int CM = (NV <= 30) ? CMAX30 : CMAX48;
+  constexpr int CM = (NV <= 32) ? CMAX30 : CMAX48;
   using Sol = hdsm::Solver<NV, CM>;
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan<NV, CM, NT>;
@@ -274,12 +274,12 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
-  if (h->n <= 30) return h->threads == 64 ? launch_nv<30, 64>(h, a, st) : launch_nv<30, 256>(h, a, st);
+  if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
   return h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
 }
 
 int64_t scratch_stride_for(int n) {
-  return n <= 30 ? (int64_t)hdsm::Solver<30, CMAX30>::SNAP_STRIDE * hdsm::MAXH
+  return n <= hdsm::SPLIT_N_MAX ? (int64_t)hdsm::Solver<32, CMAX30>::SNAP_STRIDE * hdsm::MAXH
                  : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
 }
 

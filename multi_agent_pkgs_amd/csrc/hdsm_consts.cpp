@@ -208,8 +208,12 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
         c->Meq[(size_t)i * 6 + e] = sacc;
       }
     for (int j = 0; j < MAXNV; ++j)
-      for (int lane = 0; lane < 64; ++lane)
-        c->JeqP[(size_t)j * 64 + lane] = (lane < n && j < n) ? c->Jeq[(size_t)lane * n + j] : (lane == j ? 1.0 : 0.0);
+      for (int lane = 0; lane < 64; ++lane) {
+        const bool split = n <= SPLIT_N_MAX;
+        if (split && j >= 16) continue;
+        const int row = split ? (lane & 31) : lane, col = split ? 16 * (lane >> 5) + j : j;
+        c->JeqP[(size_t)j * 64 + lane] = (row < n && col < n) ? c->Jeq[(size_t)row * n + col] : (row == col ? 1.0 : 0.0);
+      }
     // Set-up map: free response -> gradient at u = 0 -> x0 = -H^{-1} grad -> equality residual -> x_eq, nu, applied
     // to the unit vectors of v = (state_curr, traj_ref). The tracking cost pairs x_i with ref_{i-1} (AC:870-883).
     const int nv = 9 + 6 * N;

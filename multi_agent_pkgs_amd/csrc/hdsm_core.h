@@ -72,7 +72,7 @@ constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered s
 template <int NV, int CMAX>
 struct Shm {
   static constexpr int LD = NV + 1;  // odd leading dimension: row- and column-walks are bank-conflict free
-  static constexpr int LDT = (NV == 30) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
+  static constexpr int LDT = (NV <= 32) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
 #ifdef HDSM_EMU
   double J[NV * LD];
   double R[NV * LD];
@@ -80,6 +80,7 @@ struct Shm {
   alignas(16) double T[NV * LDT];       // transposition buffer for d = J^T a (J rows live in registers)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
+  alignas(16) double dvz[NV + 2];       // d with the working-set columns (j < q) zeroed
   double gz[3][3][2 * MAXH];            // zero-padded impulse responses: gz[ax][s][MAXH + lag]
   double x0[NV];                        // unconstrained minimiser (base point of the warm start)
   double fx0;                           // J(x0)
@@ -813,12 +814,12 @@ struct Solver {
         HDSM_UNROLL
         for (int u = 0; u < KH; ++u) kv[u] = c.KTC[u * KROWS + krow];
       }
-      // lane i of wave 0 takes row i of Jeq, identity beyond n. With n <= 30 the registers hold this next to the
-      // coefficients; the larger kernel asks for it once those are consumed.
-      if constexpr (NV <= 30) {
+      // wave 0 takes Jeq (identity beyond n) in the lane layout of its kernel (JeqP, see hdsm_wave_gi.h). With n <= 30
+      // the registers hold this next to the coefficients; the larger kernel asks for it once those are consumed.
+      if constexpr (NV <= 32) {
         if (tid < 64) {
           HDSM_UNROLL
-          for (int j = 0; j < NV; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
+          for (int j = 0; j < W::NC; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
         }
       }
       W::init_lane(R, c, tid);
@@ -922,10 +923,10 @@ struct Solver {
         for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * s.vin[base + 3 * u];
         store(row, acc);
       }
-      if constexpr (NV > 30) {
+      if constexpr (NV > 32) {
         if (tid < 64) {
           HDSM_UNROLL
-          for (int j = 0; j < NV; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
+          for (int j = 0; j < W::NC; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
         }
       }
     }

@@ -11,6 +11,7 @@ constexpr int MAXNV = 3 * MAXH;
 constexpr int MAXT = 256;  // largest workgroup
 constexpr int KCOLS = 9 + 6 * MAXH;     // inputs of the set-up map: state_curr, traj_ref
 constexpr int KROWS = 3 * MAXNV + 12;   // outputs: x_eq, x0, gradient, equality residuals and multipliers
+constexpr int SPLIT_N_MAX = 30;         // n <= 30 runs on the split kernel (NV = 32), larger n on NV = 48
 constexpr int KCH = 3 + 2 * MAXH;       // inputs one output of the set-up map really depends on (its own axis)
 constexpr double ABSENT = 1e20;
 constexpr double DINF = 1e300;
@@ -46,7 +47,10 @@ struct Consts {
   // device set-up uses this compact form: KTC[u * KROWS + row] = KT[(kax[row] + 3 u) * KROWS + row].
   double KTC[KCH * KROWS];
   int32_t kax[KROWS];
-  double JeqP[MAXNV * 64];       // JeqP[j * 64 + lane] = Jeq[lane][j], identity beyond n: lane i takes row i of Jeq
+  // Jeq (identity beyond n) in the register layout of the kernel that serves this n (hdsm_wave_gi.h):
+  //   n <= 30 (split kernel, NV = 32): JeqP[c * 64 + lane] = Jeq[lane & 31][16 (lane >> 5) + c], c < 16
+  //   n  > 30 (NV = 48):               JeqP[j * 64 + lane] = Jeq[lane][j], j < 48
+  double JeqP[MAXNV * 64];
 };
 
 // Per-launch arguments (device pointers), layouts of include/hdsm.h.

@@ -82,6 +82,14 @@ __device__ __forceinline__ double wave_prefix_sum(double v, int lane) {
   return v + (row == 3 ? (t0 + t1) + t2 : (row == 2 ? t0 + t1 : (row == 1 ? t0 : 0.0)));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// v[lane & 31] + v[32 + (lane & 31)] in every lane (v_permlane32_swap: no LDS round trip). The split kernel keeps the
+// two halves of a row of J in lanes L and L + 32; this is how their partial dot products meet.
+__device__ __forceinline__ double half_sum64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 
 // Ordering point INSIDE the one wavefront that runs the active-set iteration. LDS operations of a wave execute in
 // program order, so no s_barrier is needed (and none may be used: the other waves of the workgroup are parked at a
@@ -118,9 +126,22 @@ struct WaveGI {
   using S = Shm<NV, CMAX>;
   static constexpr int LDT = S::LDT;
   static constexpr int HT = NV / 3;  // horizon capacity of this instantiation
+  // NV = 32 (n <= 30): every row of J is SPLIT over two lanes, lane L holds columns [16 h, 16 h + 16) of row L & 31,
+  // h = L >> 5, so the unrolled per-lane loops are 16 long and all 64 lanes work; partial dot products meet through
+  // half_sum64. NV = 48: one lane per row, 48 columns. Per-row scalars (x, z, r, multipliers) always live in lane =
+  // row index (< NV); in the split kernel lanes 32.. carry copies.
+  static constexpr bool SPLIT = (NV == 32);
+  static constexpr int NC = SPLIT ? NV / 2 : NV;
+  static __device__ __forceinline__ int row_of(int lane) { return SPLIT ? (lane & 31) : lane; }
+  static __device__ __forceinline__ int col0_of(int lane) { return SPLIT ? (lane >> 5) * NC : 0; }
+  static __device__ __forceinline__ bool row_ok(int lane) { return SPLIT || lane < NV; }
+  static __device__ __forceinline__ double hsum(double v) {
+    if constexpr (SPLIT) return half_sum64(v);
+    else return v;
+  }
 
   struct Regs {
-    double Jr[NV];  // row `lane` of J
+    double Jr[NC];  // columns [col0, col0 + NC) of row row_of(lane) of J
     double xi;      // u[lane]
     // per-lane constants of the violation scan (bounds with "absent" mapped to +-DINF), set by init_lane()
     double ub_own, lb_own;      // box of this lane's input
@@ -154,16 +175,16 @@ struct WaveGI {
     }
   }
 
-  // register array access with a wave-uniform dynamic index (select chain on an SGPR compare)
-  static __device__ __forceinline__ double reg_get(const double (&a)[NV], int q) {
+  // register array access with a dynamic index (select chain); an index outside [0, NC) reads 0 / writes nothing
+  static __device__ __forceinline__ double reg_get(const double (&a)[NC], int q) {
     double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v = (k == q) ? a[k] : v;
+    for (int k = 0; k < NC; ++k) v = (k == q) ? a[k] : v;
     return v;
   }
-  static __device__ __forceinline__ void reg_set(double (&a)[NV], int q, double v) {
+  static __device__ __forceinline__ void reg_set(double (&a)[NC], int q, double v) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) a[k] = (k == q) ? v : a[k];
+    for (int k = 0; k < NC; ++k) a[k] = (k == q) ? v : a[k];
   }
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
@@ -376,89 +397,111 @@ struct WaveGI {
     return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
   }
 
-  // d = J^T (-a) -> s.dvec[0..NV) in LDS; returns this lane's own entry d_lane (0 beyond NV)
-  static __device__ __forceinline__ double compute_d(S& s, const Regs& R, int id, double ai, int lane) {
+  // d = J^T (-a) -> s.dvec (all of d) and s.dvz (d with the entries of the working-set columns, j < q, zeroed);
+  // returns d_lane for lane < NV, 0 beyond. `ai` is entry row_of(lane) of the normal.
+  static __device__ __forceinline__ double compute_d(S& s, const Regs& R, int id, double ai, int q, int lane) {
+    const int row = row_of(lane), c0 = col0_of(lane);
+    double dj = 0.0;
     if (id_kind(id) == K_U) {  // a = sg e_k: d = -sg * (row k of J)
       const int var = id_payload(id) >> 1;
       const double msg = (id_payload(id) & 1) ? 1.0 : -1.0;
-      if (lane == var) {
+      if (row_ok(lane) && row == var) {
 #pragma unroll
-        for (int j = 0; j < NV; j += 2) *reinterpret_cast<D2*>(&s.dvec[j]) = D2{msg * R.Jr[j], msg * R.Jr[j + 1]};
+        for (int j = 0; j < NC; j += 2) *reinterpret_cast<D2*>(&s.dvec[c0 + j]) = D2{msg * R.Jr[j], msg * R.Jr[j + 1]};
       }
       wsync();
-      return (lane < NV) ? s.dvec[lane] : 0.0;
+      if (lane < NV) dj = s.dvec[lane], s.dvz[lane] = (lane >= q) ? dj : 0.0;
+      wsync();
+      return dj;
     }
-    if (lane < NV) {
+    if (row_ok(lane)) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) s.T[j * LDT + lane] = R.Jr[j] * ai;
+      for (int j = 0; j < NC; ++j) s.T[(c0 + j) * LDT + row] = R.Jr[j] * ai;
     }
     wsync();
-    double dj = 0.0;
-    if (lane < NV) {
+    {
       double a0 = 0, a1 = 0;
-      const D2* row = reinterpret_cast<const D2*>(&s.T[lane * LDT]);
+      if (row_ok(lane)) {  // entries [c0, c0 + NC) of row `row` of T
+        const D2* tr = reinterpret_cast<const D2*>(&s.T[row * LDT + c0]);
 #pragma unroll
-      for (int i = 0; i < NV / 2; ++i) {
-        const D2 t = row[i];
-        a0 += t.x;
-        a1 += t.y;
+        for (int i = 0; i < NC / 2; ++i) {
+          const D2 t = tr[i];
+          a0 += t.x;
+          a1 += t.y;
+        }
       }
-      dj = -(a0 + a1);
-      s.dvec[lane] = dj;
+      dj = -hsum(a0 + a1);
     }
+    if (lane < NV) s.dvec[lane] = dj, s.dvz[lane] = (lane >= q) ? dj : 0.0;
+    else dj = 0.0;
     wsync();
     return dj;
   }
 
-  // d = J^T(-a), ||d||^2, ||d2||^2, d_q, z_i = (J2 d2)_i, r_i = (U d1)_i for the incoming constraint
-  static __device__ __forceinline__ void direction(S& s, const Regs& R, int id, double ai, int q, int lane, double (&dv)[NV],
+  // d = J^T(-a), ||d||^2, ||d2||^2, d_q, z_i = (J2 d2)_i, r_i = (U d1)_i for the incoming constraint. dv = this lane's
+  // columns of d (split kernel: with the working-set part zeroed — what the Householder update multiplies).
+  static __device__ __forceinline__ void direction(S& s, const Regs& R, int id, double ai, int q, int lane, double (&dv)[NC],
                                                    double& dd, double& zz, double& dq, double& zi, double& ri) {
-    const double dj = compute_d(s, R, id, ai, lane);
+    const double dj = compute_d(s, R, id, ai, q, lane);
     const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
     dd = bcast64(sufj, 0);
     zz = (q < NV) ? bcast64(sufj, q) : 0.0;
     dq = (q < NV) ? bcast64(dj, q) : 0.0;
+    const int row = row_of(lane), c0 = col0_of(lane);
+    double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
+    if constexpr (SPLIT) {
+      const D2* urow = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
 #pragma unroll
-    for (int k = 0; k < NV; k += 2) {
-      const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
-      dv[k] = dk.x, dv[k + 1] = dk.y;
-    }
-    zi = 0, ri = 0;
-    if (lane < NV) {
-      const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
-      double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
-#pragma unroll
-      for (int k = 0; k < NV; k += 2) {  // U has zero columns >= q: r = U d1 needs no mask
+      for (int k = 0; k < NC; k += 2) {
+        const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
+        const D2 zk = *reinterpret_cast<const D2*>(&s.dvz[c0 + k]);
         const D2 uk = urow[k / 2];
-        r0 += uk.x * dv[k];
-        r1 += uk.y * dv[k + 1];
+        dv[k] = zk.x, dv[k + 1] = zk.y;
+        r0 += uk.x * dk.x, r1 += uk.y * dk.y;                  // r = U d1: U has zero columns >= q, no mask needed
+        z0 += R.Jr[k] * zk.x, z1 += R.Jr[k + 1] * zk.y;        // z = J2 d2: dvz is zero on the other columns
       }
+    } else {  // one lane per row: q is wave-uniform against the column index, the free columns are picked by predicate
 #pragma unroll
-      for (int k = 0; k < NV; ++k) {  // z = J2 d2: free columns only (wave-uniform predicate)
-        if (k >= q) {
-          if (k & 1) z1 += R.Jr[k] * dv[k];
-          else z0 += R.Jr[k] * dv[k];
+      for (int k = 0; k < NC; k += 2) {
+        const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
+        dv[k] = dk.x, dv[k + 1] = dk.y;
+      }
+      if (lane < NV) {
+        const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+#pragma unroll
+        for (int k = 0; k < NC; k += 2) {
+          const D2 uk = urow[k / 2];
+          r0 += uk.x * dv[k];
+          r1 += uk.y * dv[k + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          if (k >= q) {
+            if (k & 1) z1 += R.Jr[k] * dv[k];
+            else z0 += R.Jr[k] * dv[k];
+          }
         }
       }
-      zi = z0 + z1;
-      ri = r0 + r1;
     }
+    ri = hsum(r0 + r1);
+    zi = hsum(z0 + z1);
   }
 
   // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q
   static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane,
-                                                         const double (&dv)[NV], double zz, double dq, double zi, double ri) {
+                                                         const double (&dv)[NC], double zz, double dq, double zi, double ri) {
     const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
     const double beta = 1.0 / (rho * (rho - dq));
-    if (lane < NV) {
-      const double jq = reg_get(R.Jr, q);
+    const int c0 = col0_of(lane);
+    const double jq = hsum(row_ok(lane) ? reg_get(R.Jr, q - c0) : 0.0);  // J[row][q]: held by one of the halves
+    if (row_ok(lane)) {
       const double coef = (zi - rho * jq) * beta;  // (J2 v) beta, v = d2 - rho e_q
 #pragma unroll
-      for (int k = 0; k < NV; ++k)
-        if (k >= q) R.Jr[k] -= coef * dv[k];
-      reg_set(R.Jr, q, jq - coef * (dq - rho));
-      s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
+      for (int k = 0; k < NC; ++k)
+        if (SPLIT || k >= q) R.Jr[k] -= coef * dv[k];  // (split kernel: dv is already zero on the working-set columns)
+      reg_set(R.Jr, q - c0, jq - coef * (dq - rho));
     }
+    if (lane < NV) s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
     if (lane == q) {
       s.lam[q] = lam_p;
       s.act[q] = id;
@@ -643,8 +686,8 @@ struct WaveGI {
         }
       }
       if (id < 0) continue;
-      const double ai = normal_entry(s, c, id, lane, N, n);
-      double dv[NV], dd, zz, dq, zi, ri;
+      const double ai = normal_entry(s, c, id, row_of(lane), N, n);
+      double dv[NC], dd, zz, dq, zi, ri;
       direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
       ++iters;
       if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
@@ -660,27 +703,39 @@ struct WaveGI {
       const double vk = (lane < q) ? resid(s, c, s.act[lane], N) : 0.0;
       if (lane < NV) s.dvec[lane] = vk;
       wsync();
-      double tj = 0.0;  // t = U^T v
-      if (lane < NV) {
+      const int row = row_of(lane), c0 = col0_of(lane);
+      double tj;  // t = U^T v: column `row` of U, this lane's share of the rows (rows >= q of U are zero)
+      {
+        double p0 = 0, p1 = 0;
+        if (row_ok(lane)) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) tj += s.U[k * LDT + lane] * s.dvec[k];  // rows >= q of U are zero
+          for (int k = 0; k < NC; k += 2) {
+            const D2 vk2 = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
+            p0 += s.U[(c0 + k) * LDT + row] * vk2.x, p1 += s.U[(c0 + k + 1) * LDT + row] * vk2.y;
+          }
+        }
+        tj = hsum(p0 + p1);
       }
       wsync();
       if (lane < NV) s.dvec[lane] = tj;
+      else tj = 0.0;
       wsync();
-      double lk = 0.0, xw = 0.0;
-      if (lane < NV) {
-        const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+      double lk, xw = 0.0;
+      {
         double l0 = 0, l1 = 0, x0 = 0, x1 = 0;
+        if (row_ok(lane)) {
+          const D2* urow = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
 #pragma unroll
-        for (int k = 0; k < NV; k += 2) {
-          const D2 tk = *reinterpret_cast<const D2*>(&s.dvec[k]);
-          const D2 uk = urow[k / 2];
-          l0 += uk.x * tk.x, l1 += uk.y * tk.y;               // lambda = U t
-          x0 += R.Jr[k] * tk.x, x1 += R.Jr[k + 1] * tk.y;     // J1 t  (t is zero beyond q)
+          for (int k = 0; k < NC; k += 2) {
+            const D2 tk = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
+            const D2 uk = urow[k / 2];
+            l0 += uk.x * tk.x, l1 += uk.y * tk.y;               // lambda = U t
+            x0 += R.Jr[k] * tk.x, x1 += R.Jr[k + 1] * tk.y;     // J1 t  (t is zero beyond q)
+          }
         }
-        lk = l0 + l1;
-        xw = s.x0[lane] + (x0 + x1);
+        lk = hsum(l0 + l1);
+        const double xs = hsum(x0 + x1);
+        if (lane < NV) xw = s.x0[lane] + xs;
       }
       // most negative multiplier among the inequalities
       const bool ineq = lane < q && id_kind(s.act[lane]) != K_E;
@@ -711,11 +766,13 @@ struct WaveGI {
   // working set -= entry at position l (one Householder reflection, see the header comment)
   static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
     const int t = q - 1;
-    double uv[NV];  // row l of U, broadcast to every lane
+    const int row = row_of(lane), c0 = col0_of(lane);
+    const bool on = row_ok(lane);
+    double uv[NC];  // this lane's columns of row l of U
     {
-      const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT]);
+      const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT + c0]);
 #pragma unroll
-      for (int j = 0; j < NV; j += 2) {
+      for (int j = 0; j < NC; j += 2) {
         const D2 v2 = rl[j / 2];
         uv[j] = v2.x, uv[j + 1] = v2.y;
       }
@@ -723,42 +780,42 @@ struct WaveGI {
     const double ut = s.U[l * LDT + t];
     double s0 = 0, s1 = 0;
 #pragma unroll
-    for (int j = 0; j < NV; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
-    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(s0 + s1);
+    for (int j = 0; j < NC; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
+    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(hsum(s0 + s1));
     const double beta = 1.0 / (sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
     double lam_next = 0.0;
     int act_next = -1;
     if (lane >= l && lane < t) lam_next = s.lam[lane + 1], act_next = s.act[lane + 1];
-    if (lane < NV) {
+    if (on) {  // (always true in the split kernel, so the cross-half sums below are executed by every lane)
       // own row of U (LDS) and of J (registers): x -= (x . v) beta v
-      double ur[NV];
-      const D2* ro = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
+      double ur[NC];
+      const D2* ro = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
 #pragma unroll
-      for (int j = 0; j < NV; j += 2) {
+      for (int j = 0; j < NC; j += 2) {
         const D2 v2 = ro[j / 2];
         ur[j] = v2.x, ur[j + 1] = v2.y;
       }
-      const double urt = s.U[lane * LDT + t];
-      const double jt = reg_get(R.Jr, t);
+      const double urt = s.U[row * LDT + t];
+      const double jt = hsum(reg_get(R.Jr, t - c0));
       double wu0 = 0, wu1 = 0, wj0 = 0, wj1 = 0;
 #pragma unroll
-      for (int j = 0; j < NV; j += 2) {
+      for (int j = 0; j < NC; j += 2) {
         wu0 += ur[j] * uv[j], wu1 += ur[j + 1] * uv[j + 1];
         wj0 += R.Jr[j] * uv[j], wj1 += R.Jr[j + 1] * uv[j + 1];  // uv is zero beyond column t
       }
-      const double cu = ((wu0 + wu1) - sigma * urt) * beta, cj = ((wj0 + wj1) - sigma * jt) * beta;
+      const double cu = (hsum(wu0 + wu1) - sigma * urt) * beta, cj = (hsum(wj0 + wj1) - sigma * jt) * beta;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
+      for (int j = 0; j < NC; ++j) {
         ur[j] -= cu * uv[j];
         R.Jr[j] -= cj * uv[j];
       }
-      reg_set(R.Jr, t, jt - cj * (ut - sigma));  // the freed direction stays in J as a free column
-      wsync();                                   // every lane has read its row before anybody rewrites a slot
+      reg_set(R.Jr, t - c0, jt - cj * (ut - sigma));  // the freed direction stays in J as a free column
+      wsync();                                        // every lane has read its row before anybody rewrites a slot
       // rows above l stay, rows l+1..q-1 move up one slot, row l (the dropped entry) disappears
-      if (lane != l && lane < q) {
-        D2* dst = reinterpret_cast<D2*>(&s.U[(lane > l ? lane - 1 : lane) * LDT]);
+      if (row != l && row < q) {
+        D2* dst = reinterpret_cast<D2*>(&s.U[(row > l ? row - 1 : row) * LDT + c0]);
 #pragma unroll
-        for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
+        for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
       }
     } else {
       wsync();
@@ -766,13 +823,11 @@ struct WaveGI {
     if (lane >= l && lane < t) s.lam[lane] = lam_next, s.act[lane] = act_next;
     wsync();
     // structural zeros: column t of every row belongs to the freed direction, slot t is empty again
-    if (lane < NV) {
-      s.U[lane * LDT + t] = 0.0;
-      if (lane == t) {
-        D2* dst = reinterpret_cast<D2*>(&s.U[lane * LDT]);
+    if (lane < NV) s.U[lane * LDT + t] = 0.0;
+    if (on && row == t) {
+      D2* dst = reinterpret_cast<D2*>(&s.U[row * LDT + c0]);
 #pragma unroll
-        for (int j = 0; j < NV; j += 2) dst[j / 2] = D2{0.0, 0.0};
-      }
+      for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{0.0, 0.0};
     }
     wsync();
   }
@@ -805,7 +860,7 @@ struct WaveGI {
         PROF(1)
       }
       const bool is_eq = id_kind(ip) == K_E;
-      const double ai = normal_entry(s, c, ip, lane, N, n);
+      const double ai = normal_entry(s, c, ip, row_of(lane), N, n);
       double lam_p = 0;
       bool stop = false;
       for (;;) {
@@ -816,7 +871,7 @@ struct WaveGI {
         }
         ++iters;
         PROF(2)
-        double dv[NV], dd, zz, dq, zi, ri;
+        double dv[NC], dd, zz, dq, zi, ri;
         direction(s, R, ip, ai, q, lane, dv, dd, zz, dq, zi, ri);
         PROF(3)
         const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
@@ -893,16 +948,24 @@ struct WaveGI {
   // snapshots: J rows from registers, U rows / multipliers / ids / x from LDS; layout [row j][lane]
   static constexpr int SNAP_DOUBLES = (2 * NV + 3) * NV + 2;
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
-    if (lane < NV) {
+    const int row = row_of(lane), c0 = col0_of(lane);
+    if (row_ok(lane)) {
       if (save) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) buf[j * NV + lane] = R.Jr[j], buf[(NV + j) * NV + lane] = s.U[lane * LDT + j];
+        for (int j = 0; j < NC; ++j)
+          buf[(c0 + j) * NV + row] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          R.Jr[j] = buf[(c0 + j) * NV + row], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+      }
+    }
+    if (lane < NV) {
+      if (save) {
         buf[2 * NV * NV + lane] = R.xi;
         buf[(2 * NV + 1) * NV + lane] = s.lam[lane];
         buf[(2 * NV + 2) * NV + lane] = (double)s.act[lane];
       } else {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) R.Jr[j] = buf[j * NV + lane], s.U[lane * LDT + j] = buf[(NV + j) * NV + lane];
         R.xi = buf[2 * NV * NV + lane];
         s.lam[lane] = buf[(2 * NV + 1) * NV + lane];
         s.act[lane] = (int)buf[(2 * NV + 2) * NV + lane];
