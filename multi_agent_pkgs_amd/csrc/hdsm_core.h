@@ -118,6 +118,7 @@ struct Shm {
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
   int32_t list[LISTCAP];
   double sw[5];          // sweep scalars: cull radius, own sphere (centre, radius)
+  double bnd[24];        // device build: lbu[3], ubu[3], lbs[3][3], ubs[3][3] (read by resid() inside the iteration)
   double vin[KCOLS + 8];  // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded
   double part_v[4];      // per-wave partial maxima of the staged-row scan
   int32_t part_id[4];
@@ -831,7 +832,7 @@ struct Solver {
       // while all the others are already in flight; the kernel arguments are used straight from the SGPRs here.
       const Args& g = a_in;
       struct Req {
-        double v_in, v_g, a0, a1, a2, a3, p0, p1, p2, q0, q1, q2, v_u;
+        double v_in, v_g, a0, a1, a2, a3, p0, p1, p2, q0, q1, q2, v_u, v_b;
         int nr, sj, sr, fi, fcomp, fax;
       };
       auto request = [&](int vt) {
@@ -848,6 +849,8 @@ struct Solver {
         r.q2 = g.state[(int64_t)inst * 9 + 6 + r.fax];
         const int ui = vt / S::LDT, uj = vt % S::LDT;
         r.v_u = (ui < 6 && uj < 6) ? c.Ueq[ui * 6 + uj] : 0.0;
+        r.v_b = (vt < 3) ? c.lbu[vt] : (vt < 6) ? c.ubu[vt - 3] : (vt < 15) ? (&c.lbs[0][0])[vt - 6]
+                                                                : (&c.ubs[0][0])[vt < 24 ? vt - 15 : 0];
         return r;
       };
       auto commit = [&](int vt, const Req& r) {
@@ -875,6 +878,7 @@ struct Solver {
           if (vt >= n) s.x[vt] = 0.0;
         }
         if (vt < MAXH) s.assign[vt] = -1;
+        if (vt < 24) s.bnd[vt] = r.v_b;
       };
       ST_PROF(8)
       const Req r0 = request(tid);

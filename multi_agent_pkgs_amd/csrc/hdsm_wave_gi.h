@@ -376,12 +376,12 @@ struct WaveGI {
     const int kind = id_kind(id), p = id_payload(id);
     if (kind == K_U) {
       const int var = p >> 1, ax = var / N;
-      return (p & 1) ? (c.lbu[ax] - s.x[var]) : (s.x[var] - c.ubu[ax]);
+      return (p & 1) ? (s.bnd[ax] - s.x[var]) : (s.x[var] - s.bnd[3 + ax]);
     }
     if (kind == K_S) {
       const int sg = p & 1, ax = (p >> 1) & 3, comp = (p >> 3) & 3, i = p >> 5;
       const double v = s.st[i][3 * comp + ax];
-      return sg ? (c.lbs[comp][ax] - v) : (v - c.ubs[comp][ax]);
+      return sg ? (s.bnd[6 + 3 * comp + ax] - v) : (v - s.bnd[15 + 3 * comp + ax]);
     }
     if (kind == K_E) return s.st[N][3 * (1 + p / 3) + p % 3];
     const double* row;
@@ -656,33 +656,45 @@ struct WaveGI {
     int nw = uni(wp[0]);
     if (nw <= 0) return;
     if (nw > NV) nw = NV;
-    int q = uni(s.q);
-    for (int g = 0; g < nw && q < n; ++g) {
-      const int code = uni(wp[1 + g]);
+    // Lane g prepares entry g of the guess — translation of the id to this replan's indices and, for a neighbour row,
+    // the global reads and the plane itself — so the sequential loop below only broadcasts (v_readlane) what it needs.
+    int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
+    double my_row[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lane < nw) {
+      const int code = wp[1 + lane];
       const int kind = id_kind(code), p = id_payload(code);
-      int id = -1;
       if (kind == K_U) {
         const int var = p >> 1;
-        if (var % N >= 1) id = mk_id(K_U, ((var - 1) << 1) | (p & 1));
+        if (var % N >= 1) pre = mk_id(K_U, ((var - 1) << 1) | (p & 1));
       } else if (kind == K_S) {
         const int i = p >> 5;
-        if (i - 1 >= 1) id = mk_id(K_S, ((i - 1) << 5) | (p & 31));
+        if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
       } else if (kind == K_C && a.l1_rows == nullptr) {
         const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
         if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
-          double row[4];
           const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
-          const int slot = uni(s.ncand);
-          if (slot < CMAX - uni(s.ncold) && tasc_plane_eval(c, s.cprev[i], op, row)) {
-            if (lane == 0) {
-              s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2], s.cand[slot][3] = row[3];
-              s.cand_m[slot] = i + e;
-              s.cand_src[slot] = (k << 6) | (i << 1) | e;
-              s.ncand = slot + 1;
-            }
-            wsync();
-            id = mk_id(K_C, slot);
+          if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
+        }
+      }
+    }
+    int q = uni(s.q);
+    for (int g = 0; g < nw && q < n; ++g) {
+      int id = __builtin_amdgcn_readlane(pre, g);
+      if (id == -2) {
+        id = -1;
+        const int slot = uni(s.ncand);
+        if (slot < CMAX - uni(s.ncold)) {
+          const double r0 = bcast64(my_row[0], g), r1 = bcast64(my_row[1], g), r2 = bcast64(my_row[2], g),
+                       r3 = bcast64(my_row[3], g);
+          const int m = __builtin_amdgcn_readlane(my_m, g), src = __builtin_amdgcn_readlane(my_src, g);
+          if (lane == 0) {
+            s.cand[slot][0] = r0, s.cand[slot][1] = r1, s.cand[slot][2] = r2, s.cand[slot][3] = r3;
+            s.cand_m[slot] = m;
+            s.cand_src[slot] = src;
+            s.ncand = slot + 1;
           }
+          wsync();
+          id = mk_id(K_C, slot);
         }
       }
       if (id < 0) continue;
