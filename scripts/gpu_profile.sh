@@ -22,3 +22,7 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INS
 done
 python scripts/summarize_pmc.py $TAG
 cp gpurun_out/${TAG}_trace/bench_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
+# 4. the bench line once more, now that profiles/pmc_latest.json (written by summarize_pmc.py above) holds this
+#    kernel's HBM traffic: this is the line to keep
+python bench.py --cache $CACHE > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+cut -c1-260 gpurun_out/${TAG}_bench.json
