@@ -325,3 +325,37 @@ def test_sphere_prefilter_chunks_beyond_list_capacity(hdsm, oracle):
     o = oracle.replan(prm, *sel, n_threads=8)
     assert (o["status"] == 0).sum() > len(sub) // 2
     compare(g, o)
+
+
+def test_maximum_dimensions(hdsm, oracle):
+    """The largest shapes the ABI admits (HDSM_MAX_HOR = 16, HDSM_MAX_POLY = 8, HDSM_MAX_ROWS_STATIC = 32): ragged
+    n_poly (2..4 of 8 slots used), static polyhedra padded to 30 rows with positive multiples of their own rows
+    (same feasible set, linearly dependent normals), absent neighbours."""
+    prm = agile_params(16, poly_hor=8, max_rows_static=32)
+    sn = problems.swarm_snapshot(prm, 16, seed=906, spacing=1.5, box_half=5.0, absent_frac=0.2)
+    polys = []
+    for plist in sn["polys"]:
+        out = []
+        for A, b in plist:
+            rows_A, rows_b, k = [A], [b], 2.0
+            while sum(len(x) for x in rows_b) + len(b) <= 30:
+                rows_A.append(k * A), rows_b.append(k * b)
+                k += 1.0
+            out.append((np.vstack(rows_A), np.concatenate(rows_b)))
+        polys.append(out)
+    n_poly, n_rows, A, b = problems.pack_static(polys, prm.poly_hor, prm.max_rows_static)
+    assert n_rows.max() == 30 and n_poly.min() < n_poly.max() <= 8
+    args = [sn["agent_id"], sn["state"], sn["ref"], n_poly, n_rows, A, b, sn["plans"], sn["has_plan"]]
+    g = hdsm.Solver(prm, 16, 16).replan(*args)
+    o = oracle.replan(prm, *args, n_threads=8)
+    assert (o["status"] == 0).sum() >= 6
+    compare(g, o)
+
+
+def test_empty_batch_is_a_no_op(hdsm):
+    prm = agile_params(10)
+    sol = hdsm.Solver(prm, 4, 8)
+    sn = problems.swarm_snapshot(prm, 8, seed=3)
+    sel = [sn[k][:0] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")] + [sn["plans"], sn["has_plan"]]
+    g = sol.replan(*sel)
+    assert g["traj"].shape[0] == 0 and g["status"].shape[0] == 0
