@@ -118,6 +118,9 @@ struct Shm {
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
   int32_t list[LISTCAP];
   double sw[5];          // sweep scalars: cull radius, own sphere (centre, radius)
+  double sw_ref[MAXH + 1][3];  // positions at the last STAGING sweep and its radius (0 = none): every row not staged then
+  double sw_tau;               // had slack >= sw_tau there, so it cannot be violated while |p - sw_ref| |n_f| <= sw_tau
+  double sw_d2;                // max_m |st[m] - sw_ref[m]|^2 (scratch of the displacement test)
   double bnd[24];        // device build: lbu[3], ubu[3], lbs[3][3], ubs[3][3] (read by resid() inside the iteration)
   double vin[KCOLS + 8];  // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded
   double part_v[4];      // per-wave partial maxima of the staged-row scan
@@ -1018,6 +1021,81 @@ struct Solver {
 #endif
     bool limit = false;
     bool run = np > 0;
+    if (IS_T0) s.sw_tau = 0.0;
+    SYNC();
+    // all neighbour rows near (first call) or violated at (later calls) the current point -> staging area; a staging
+    // radius that overflows the LDS slots is tightened (it only decides what is pre-staged: exactness comes from the
+    // verification sweeps)
+    auto sweep_all = [&](int before, int before_cold) {
+      double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
+      if (sweeps > 0 && a.l1_rows == nullptr && s.sw_tau > 0) {
+        // Verification: rows left unstaged by the staging sweep had slack >= sw_tau at sw_ref; a row's slack moves by
+        // at most |n_f| |dp| with |n_f| <= sqrt(1 + (3 pert)^2) (the planes themselves are fixed during an instance).
+        // If no trajectory point has moved further than that allows, nothing unstaged can be violated: no sweep.
+#ifdef HDSM_EMU
+        double d2 = 0;
+        for (int m = 0; m <= N; ++m) {
+          const double ux = s.st[m][0] - s.sw_ref[m][0], uy = s.st[m][1] - s.sw_ref[m][1], uz = s.st[m][2] - s.sw_ref[m][2];
+          d2 = d2 > ux * ux + uy * uy + uz * uz ? d2 : ux * ux + uy * uy + uz * uz;
+        }
+        s.sw_d2 = d2;
+#else
+        if (threadIdx.x < 64) {
+          const int m = (int)threadIdx.x;
+          double d2 = 0;
+          if (m <= N) {
+            const double ux = s.st[m][0] - s.sw_ref[m][0], uy = s.st[m][1] - s.sw_ref[m][1], uz = s.st[m][2] - s.sw_ref[m][2];
+            d2 = ux * ux + uy * uy + uz * uz;
+          }
+          d2 = wave_max64(d2);
+          if (m == 0) s.sw_d2 = d2;
+        }
+#endif
+        SYNC();
+        const double nf2 = 1.0 + 9.0 * c.pert * c.pert;
+        if (nf2 * s.sw_d2 * (1.0 + 1e-9) <= s.sw_tau * s.sw_tau) {
+          if (IS_T0) s.nviol = 0;
+          SYNC();
+          return;
+        }
+      }
+      for (;;) {
+        SYNC();
+        if (IS_T0) s.nviol = 0;
+        SYNC();
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+        const long long ts_ = clock64();
+#endif
+        sweep(s, c, a, inst, self, thresh, sweeps == 0);
+#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+        t_sweep_ += clock64() - ts_;
+#endif
+        ++sweeps;
+        if (!s.overflow || thresh <= -c.tol) break;
+        SYNC();
+        if (IS_T0) s.ncand = before, s.ncold = before_cold, s.overflow = 0;
+        thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
+      }
+      if (thresh > 0 && !s.overflow) {  // a staging sweep went through: remember where, and with what radius
+        SYNC();
+        PAR_FOR(k, 3 * (N + 1)) s.sw_ref[k / 3][k % 3] = s.st[k / 3][k % 3];
+        if (IS_T0) s.sw_tau = thresh;
+        SYNC();
+      }
+    };
+    if (run && (c.presweep == 1 || (c.presweep == 2 && (a.bounds != nullptr ? s.ncand > 0 : N > 10)))) {
+      // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: large
+      // (prefiltered) swarms when the warm start already holds neighbour rows, i.e. a dense neighbourhood; small
+      // swarms with long horizons
+#ifdef HDSM_EMU
+      compute_states(s, c);
+#else
+      if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
+#endif
+      SYNC();
+      sweep_all(s.ncand, s.ncold);
+      if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
+    }
     while (run) {
       const int rc = gi_run(s, c, R, cutoff(s), iters);
       if (rc == GI_ITERLIM) {
@@ -1036,26 +1114,7 @@ struct Solver {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
           const int before_cold = s.ncold;
-          double thresh = (sweeps == 0) ? c.cand_tau : -c.tol;
-          for (;;) {
-            SYNC();
-            if (IS_T0) s.nviol = 0;
-            SYNC();
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
-            const long long ts_ = clock64();
-#endif
-            sweep(s, c, a, inst, self, thresh, sweeps == 0);
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
-            t_sweep_ += clock64() - ts_;
-#endif
-            ++sweeps;
-            if (!s.overflow || thresh <= -c.tol) break;
-            // dense neighbourhood: more rows within the staging radius than LDS slots -> tighten it
-            // (the radius only decides what is pre-staged; exactness comes from the verification sweeps)
-            SYNC();
-            if (IS_T0) s.ncand = before, s.ncold = before_cold, s.overflow = 0;
-            thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
-          }
+          sweep_all(before, before_cold);
           if (s.fixed_bad) break;  // a common row is violated at the pinned point: infeasible whatever j
           // rows were staged AND at least one of them is violated: the dual method continues on this node.
           // (Rows staged merely because they are close do not move the iterate: the point is verified.)

@@ -147,6 +147,7 @@ struct WaveGI {
     double ub_own, lb_own;      // box of this lane's input
     double sb_ub[2], sb_lb[2];  // boxes of the (up to two) state-bound items scanned by this lane
     int sb_off[2], sb_id[2];    // their offset in st[][] (as a flat index) and id base; -1 = no item
+    int ax, kk;                 // variable row_of(lane) = jerk of axis ax at step kk (runtime divisions done once)
   };
 
   static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane) {
@@ -163,6 +164,7 @@ struct WaveGI {
       ii[e] = idx / 6 + 1, comp[e] = 1 + k / 3, axs[e] = k % 3;
       ubs[e] = c.ubs[comp[e]][axs[e]], lbs[e] = c.lbs[comp[e]][axs[e]];
     }
+    R.ax = row_of(lane) / N, R.kk = row_of(lane) % N;
     R.ub_own = (lane < n && fabs(ubu) < ABSENT) ? ubu : DINF;
     R.lb_own = (lane < n && fabs(lbu) < ABSENT) ? lbu : -DINF;
 #pragma unroll
@@ -188,9 +190,9 @@ struct WaveGI {
   }
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
-  static __device__ __forceinline__ void states(S& s, const Consts& c, int lane, int N) {
+  static __device__ __forceinline__ void states(S& s, const Regs& R, int lane, int N) {
     if (lane < 3 * N) {
-      const int ax = lane / N, m = lane % N + 1;
+      const int ax = R.ax, m = R.kk + 1;
       double acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
       const double* xx = s.x + ax * N;
       const double* g0 = &s.gz[ax][0][MAXH + m - 1];
@@ -345,10 +347,11 @@ struct WaveGI {
   }
 
   // entry `lane` of the dense normal a of constraint id (a . u <= rhs form)
-  static __device__ __forceinline__ double normal_entry(const S& s, const Consts& c, int id, int lane, int N, int n) {
+  // (`var` = row_of(lane); its axis and step come from the registers)
+  static __device__ __forceinline__ double normal_entry(const S& s, const Regs& R, int id, int var, int N, int n) {
     const int kind = id_kind(id), p = id_payload(id);
-    if (lane >= n) return 0.0;
-    const int ax = lane / N, kk = lane % N;
+    if (var >= n) return 0.0;
+    const int lane = var, ax = R.ax, kk = R.kk;
     if (kind == K_U) return (lane == (p >> 1)) ? ((p & 1) ? -1.0 : 1.0) : 0.0;
     if (kind == K_S) {
       const int cax = (p >> 1) & 3, comp = (p >> 3) & 3, m = p >> 5;
@@ -698,7 +701,7 @@ struct WaveGI {
         }
       }
       if (id < 0) continue;
-      const double ai = normal_entry(s, c, id, row_of(lane), N, n);
+      const double ai = normal_entry(s, R, id, row_of(lane), N, n);
       double dv[NC], dd, zz, dq, zi, ri;
       direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
       ++iters;
@@ -710,7 +713,7 @@ struct WaveGI {
     // violations of the working-set rows at the unconstrained minimiser x0
     if (lane < NV) s.x[lane] = s.x0[lane];
     wsync();
-    states(s, c, lane, N);
+    states(s, R, lane, N);
     for (;;) {
       const double vk = (lane < q) ? resid(s, c, s.act[lane], N) : 0.0;
       if (lane < NV) s.dvec[lane] = vk;
@@ -761,7 +764,7 @@ struct WaveGI {
         if (lane == 0) s.f = s.fx0 + 0.5 * bcast64(tt, 0), s.q = q;
         wsync();
 #ifdef HDSM_DEBUG
-        states(s, c, lane, N);
+        states(s, R, lane, N);
         if (blockIdx.x == 2 && lane < q)
           printf("WS lane %d q %d nw %d act %x lam %.4e resid@xW %.3e f %.6e fx0 %.6e\n", lane, q, nw, s.act[lane], lk,
                  resid(s, c, s.act[lane], N), s.f, s.fx0);
@@ -854,7 +857,7 @@ struct WaveGI {
     int rc = GI_OK;
     PROF_DECL
     for (;;) {
-      states(s, c, lane, N);
+      states(s, R, lane, N);
       PROF(0)
       int ip;
       double vip;
@@ -872,7 +875,7 @@ struct WaveGI {
         PROF(1)
       }
       const bool is_eq = id_kind(ip) == K_E;
-      const double ai = normal_entry(s, c, ip, row_of(lane), N, n);
+      const double ai = normal_entry(s, R, ip, row_of(lane), N, n);
       double lam_p = 0;
       bool stop = false;
       for (;;) {
@@ -936,7 +939,7 @@ struct WaveGI {
         drop(s, R, l, q, lane);
         PROF(7)
         --q;
-        states(s, c, lane, N);
+        states(s, R, lane, N);
         vip = resid(s, c, ip, N);
         if (f >= f_cut) {
           rc = GI_CUTOFF;
