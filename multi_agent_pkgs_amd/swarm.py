@@ -136,12 +136,16 @@ class SwarmLoop:
     """One rank of the lock-step loop. `solve(inputs, plans_all, has_plan) -> out dict` is the device solver
     (or, in CPU tests, the oracle); `allgather(local_array) -> full array` exchanges the shards."""
 
-    def __init__(self, prm, cfg, n_rob, rank=0, world=1, solve=None, allgather=None, radius=None, reference=None):
+    def __init__(self, prm, cfg, n_rob, rank=0, world=1, solve=None, allgather=None, radius=None, reference=None,
+                 starts=None, goals=None):
         """reference(agent_id, path, n_path, plans_all, has_plan) -> (ref_full, path_vel): when given, the reference
-        trajectory comes from it (the device kernel of row f1, or the oracle) instead of the host code."""
+        trajectory comes from it (the device kernel of row f1, or the oracle) instead of the host code.
+        starts / goals [n_rob][3]: explicit scenario (default: the circular exchange)."""
         self.prm, self.n_rob, self.rank, self.world = prm, n_rob, rank, world
         self.reference = reference
-        starts, goals = circle_scenario(n_rob, radius)
+        if starts is None:
+            starts, goals = circle_scenario(n_rob, radius)
+        starts, goals = np.asarray(starts, dtype=np.float64), np.asarray(goals, dtype=np.float64)
         self.first, self.n_local = shard_range(n_rob, rank, world)
         sl = slice(self.first, self.first + self.n_local)
         self.shard = SwarmShard(prm, cfg, n_rob, self.first, starts[sl], goals[sl])

@@ -359,3 +359,32 @@ def test_empty_batch_is_a_no_op(hdsm):
     sel = [sn[k][:0] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")] + [sn["plans"], sn["has_plan"]]
     g = sol.replan(*sel)
     assert g["traj"].shape[0] == 0 and g["status"].shape[0] == 0
+
+
+def test_baseline_config_1_single_agent(hdsm, oracle):
+    """BASELINE configs[0]: ONE agent, start (0, 0, 1.5), goal (42.15, 42.15, 1.5) (agent_agile_config.yaml:42-43),
+    empty world, H = 10: a chain of up to four overlapping free-space boxes, so the problem is a genuine MIQP although
+    there are no neighbours. Closed loop on the device against the same loop on the oracle."""
+    from multi_agent_pkgs_amd import swarm
+    prm = agile_params(10, max_rows_static=18)
+    sol = hdsm.Solver(prm, 1, 1)
+    start, goal = [[0.0, 0.0, 1.5]], [[42.15, 42.15, 1.5]]
+    used_max = [0]
+
+    def dev(inp, plans, has):
+        out = sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+        used_max[0] = max(used_max[0], int(out["used"].sum()))
+        return out
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+    la = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 1, solve=dev, starts=start, goals=goal)
+    lb = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 1, solve=cpu, starts=start, goals=goal)
+    for r in range(60):
+        oa, ob = la.step(), lb.step()
+        assert oa["status"][0] == ob["status"][0] == 0, r
+    assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6
+    pos, dist, nfail = la.shard.state()
+    assert nfail[0] == 0 and dist[0] < 35.0  # 59.6 m to go at the start; moving at 4.5..9 m/s for 6 s
+    assert used_max[0] >= 2                   # several polyhedra in use on one horizon: the binaries matter
