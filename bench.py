@@ -50,6 +50,9 @@ def main():
                     "set-up if missing, loaded instead of flying the swarm if present (profiling runs: only the "
                     "timed launches remain in the process)")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the second (HIP-event) pass")
+    ap.add_argument("--radius", type=float, default=0.0, help="circle radius [m]. Default: 22 m x number of GPUs when the "
+                    "swarm is the default 64 agents per GPU (the ring density of BASELINE configs[1] at every N); with "
+                    "--agents, max(22, agents / 2 pi) (chord >= 1 m, SURVEY.md section 8d)")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
                     "flight on the host (csrc/swarm_host.cpp) instead of with the f1 device kernel (hdsm_reference)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the product path) or gloo "
@@ -96,6 +99,7 @@ def main():
     prm = agile_params(N, max_rows_static=18)
     P, RS = prm.poly_hor, prm.max_rows_static
     n_rob = args.agents if args.agents > 0 else 64 * world
+    radius = args.radius if args.radius > 0 else (22.0 * world if args.agents <= 0 else max(22.0, n_rob / (2 * np.pi)))
     first, n_local = swarm.shard_range(n_rob, rank, world)
     per = (n_rob + world - 1) // world
     K, W = args.steps, args.warmup
@@ -123,6 +127,7 @@ def main():
     if cache and os.path.exists(cache):
         z = np.load(cache)
         assert int(z["n_rob"]) == n_rob and int(z["N"]) == N and z["state"].shape[0] >= n_rec
+        assert "radius" not in z or abs(float(z["radius"]) - radius) < 1e-9
         rec = [{k: z[k][r] for k in keys} for r in range(n_rec)]
         fails = int(z["fails"])
     else:
@@ -134,14 +139,15 @@ def main():
             return full, pv
 
         loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
-                               allgather=allgather_np if world > 1 else None,
+                               allgather=allgather_np if world > 1 else None, radius=radius,
                                reference=None if args.host_reference else ref_dev)
         for r in range(total_rounds):
             out = loop.step(record=rec if r >= args.first_round else None)
             if r >= args.first_round:
                 fails += int((out["status"] == 2).sum())
         if cache:
-            np.savez(cache, n_rob=n_rob, N=N, fails=fails, **{k: np.stack([x[k] for x in rec]) for k in keys})
+            np.savez(cache, n_rob=n_rob, N=N, fails=fails, radius=radius,
+                     **{k: np.stack([x[k] for x in rec]) for k in keys})
 
     def stack(key, dtype):
         return torch.from_numpy(np.ascontiguousarray(np.stack([x[key] for x in rec]), dtype=dtype)).to(dev)
@@ -258,7 +264,7 @@ def main():
             "metric": "agent QP-replans/sec", "value": value, "unit": "agent-replans/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_rob} agents circular exchange, empty env, H={N}, "
+            "config": {"workload": f"{n_rob} agents circular exchange (R = {radius:g} m), empty env, H={N}, "
                                    f"poly_hor={P}, closed-loop rounds {args.first_round}..{total_rounds - 1} replayed",
                        "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
                        "parallelism": f"agents sharded over {world} GPU(s), one all-gather per round"},
