@@ -66,6 +66,17 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
 int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path);
 int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel);
 
+/* Next row f2, first piece — the convex voxel decomposition GenerateSafeCorridor calls for every seed
+ * (convex_decomp_lib::GetPolyOcta3D, convex_decomp_util/src/convex_decomp.cpp:5-376): a cuboid of free voxels grown
+ * from `seed` face by face (n_it face turns, order -y +x +y -x +z -z), chamfered with integer slopes where obstacles
+ * cut an edge.
+ *   grid  [dim[2]][dim[1]][dim[0]] int8, x fastest: < 100 free, >= 100 occupied (CVX_DCMP_OCC); voxels taken by the
+ *         polyhedron are overwritten with `mark` (the reference's CONV: a negative value, one per polyhedron)
+ *   rows  [max_rows][4] = (n, n . p): n . x <= n . p; chamfers first, then the six faces; at most 18 rows
+ * Returns HDSM_ERR_CAPACITY (and the needed count in n_rows) if max_rows is too small.                        */
+int hdsm_poly_octa3d(const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
+                     int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows);
+
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);
 

@@ -1,0 +1,290 @@
+// corridor_host.cpp — next row f2, first piece: the convex voxel decomposition the reference's corridor generator
+// calls for every seed (GenerateSafeCorridor, agent_class.cpp:1236-1447 -> convex_decomp_lib::GetPolyOcta3D,
+// convex_decomp_util/src/convex_decomp.cpp:5-376, "CD" below). Host code, plain C ABI (include/hdsm_swarm.h).
+//
+// What the algorithm does (restated; the tables below are DERIVED from the cube's geometry, only the numbering of
+// faces and edges is taken over because it fixes the order of the output rows):
+//   * a cuboid of voxels grows from the seed, one face per iteration, round robin over (-y, +x, +y, -x, +z, -z)
+//     (CD:17-18, 54-55); a face advances by one voxel layer;
+//   * the new layer is itself grown in the face's plane from a 2-D seed, side by side (+u, +v, -u, -v round robin),
+//     over free voxels that sit on top of voxels already in the polyhedron; voxels next to the polyhedron but not on
+//     top of it are carried along as "virtual" cells so that the sides keep their shape (CD:112-200);
+//   * where a new layer comes out SHORTER than the previous one on some side, the edge shared with the neighbouring
+//     face becomes a chamfer with an integer slope; a small state machine per edge (slope, steps taken on the current
+//     stair, which of the two faces is the long direction, whether the slope is final) decides whether later layers
+//     are still consistent with ONE plane through that edge — if not, the face stops growing (CD:209-283);
+//   * a layer that reaches the full extent of the previous one on a side also extends the neighbouring face's
+//     outermost layer (CD:291-301);
+//   * the result: one half-space per chamfered edge (normal = slope * long-face normal + other-face normal) and one
+//     per face (CD:322-373). Rows are n . x <= n . p (decomp_geometry/polyhedron.h:98-147).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "../../include/hdsm_swarm.h"
+
+namespace {
+
+struct Cell {
+  int x, y, z;
+  bool operator==(const Cell& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+inline Cell operator+(Cell a, Cell b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Cell operator-(Cell a, Cell b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Cell neg(Cell a) { return {-a.x, -a.y, -a.z}; }
+inline int dot(Cell a, Cell b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+constexpr int kOccupied = 100;  // CVX_DCMP_OCC (convex_decomp.hpp:11): values below it are free
+
+// outward normals in the order of the output rows (CD:17-18)
+const Cell kNormal[6] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
+// the two faces meeting in edge e (numbering of CD:28-31: it fixes the order of the chamfer rows)
+const int kEdgeFaces[12][2] = {{0, 1}, {0, 4}, {0, 3}, {0, 5}, {1, 5}, {1, 4}, {3, 4}, {3, 5}, {1, 2}, {2, 4}, {2, 3}, {2, 5}};
+
+struct Frame {      // in-plane frame of a face and what lies across each of its four sides
+  Cell side[4];     // +u, +v, -u, -v
+  int face[4];      // neighbouring face across that side
+  int edge[4];      // edge shared with that neighbour
+  int back[4];      // index, among the NEIGHBOUR's sides, of the direction this face grows in
+};
+
+int face_with_normal(Cell n) {
+  for (int f = 0; f < 6; ++f)
+    if (kNormal[f] == n) return f;
+  return -1;
+}
+
+// u = normal of the next lateral face and v = +z for the four lateral faces; (-y, +x) / (-y, -x) for top / bottom
+// (CD:33-41). Everything else follows from that.
+void build_frames(Frame fr[6]) {
+  for (int f = 0; f < 6; ++f) {
+    Cell u, v;
+    if (f < 4) u = kNormal[(f + 1) % 4], v = Cell{0, 0, 1};
+    else u = kNormal[0], v = (f == 4) ? kNormal[1] : kNormal[3];
+    fr[f].side[0] = u, fr[f].side[1] = v, fr[f].side[2] = neg(u), fr[f].side[3] = neg(v);
+  }
+  for (int f = 0; f < 6; ++f)
+    for (int j = 0; j < 4; ++j) {
+      const int g = face_with_normal(fr[f].side[j]);
+      fr[f].face[j] = g;
+      fr[f].edge[j] = -1;
+      for (int e = 0; e < 12; ++e)
+        if ((kEdgeFaces[e][0] == f && kEdgeFaces[e][1] == g) || (kEdgeFaces[e][0] == g && kEdgeFaces[e][1] == f))
+          fr[f].edge[j] = e;
+      fr[f].back[j] = -1;
+      for (int k = 0; k < 4; ++k)
+        if (fr[g].side[k] == kNormal[f]) fr[f].back[j] = k;
+    }
+}
+
+struct Edge {      // Corner3D (convex_decomp.hpp:21-36)
+  double pos[3] = {0, 0, 0};
+  int slope = 0;   // 0 = square edge
+  int dir = -1;    // face along which the chamfer runs `slope` voxels per voxel of the other face; -1 = undecided
+  bool fixed = false;
+  int steps = 0;   // voxels taken on the current stair
+};
+
+struct Grid {
+  int8_t* data;
+  int nx, ny, nz;
+  bool inside(Cell c) const { return c.x >= 0 && c.y >= 0 && c.z >= 0 && c.x < nx && c.y < ny && c.z < nz; }
+  int8_t& at(Cell c) const { return data[c.x + c.y * nx + c.z * nx * ny]; }
+};
+
+}  // namespace
+
+extern "C" int hdsm_poly_octa3d(const int32_t seed_in[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
+                                int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows) {
+  if (!seed_in || !grid || !dim || !origin || !rows || !n_rows || n_it < 0 || !(res > 0) || mark >= kOccupied)
+    return HDSM_ERR_BAD_ARG;
+  Grid g{grid, dim[0], dim[1], dim[2]};
+  const Cell seed{seed_in[0], seed_in[1], seed_in[2]};
+  if (!g.inside(seed)) return HDSM_ERR_BAD_ARG;
+  static Frame fr[6];
+  static bool frames_ready = false;
+  if (!frames_ready) build_frames(fr), frames_ready = true;
+
+  std::vector<Cell> outer[6];  // outermost layer of every face
+  Cell anchor[6];              // a voxel of that layer (gives the face plane)
+  int reach[6][4];             // extent of the layer along the face's four sides (dot products)
+  Edge edges[12];
+  bool growing[6];
+  for (int f = 0; f < 6; ++f) {
+    outer[f].assign(1, seed);
+    anchor[f] = seed;
+    growing[f] = true;
+    for (int j = 0; j < 4; ++j) reach[f][j] = dot(seed, fr[f].side[j]);
+  }
+  g.at(seed) = (int8_t)mark;
+
+  for (int it = 0; it < n_it; ++it) {
+    const int f = it % 6;
+    if (!growing[f]) continue;
+    const Cell up = kNormal[f];
+    const Cell* sd = fr[f].side;
+
+    // how far the next layer may extend on each side, given the chamfers already started (CD:71-91)
+    int allow[4];
+    Edge trial[4];
+    for (int j = 0; j < 4; ++j) {
+      allow[j] = reach[f][j];
+      const Edge& e = trial[j] = edges[fr[f].edge[j]];
+      if (e.slope > 0) {
+        if (e.dir == f) allow[j] -= e.slope;                         // our layers retreat `slope` voxels each
+        else if (e.fixed && e.steps >= e.slope) allow[j] -= 1;       // the other face's stair is complete: step in
+      }
+    }
+
+    // a free voxel on top of the current layer, inside the interior of the grid and inside the allowance (CD:94-116)
+    bool have_seed = false;
+    Cell s2{0, 0, 0};
+    for (const Cell& c : outer[f]) {
+      const Cell t = c + up;
+      if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx - 1 || t.y >= g.ny - 1 || t.z >= g.nz - 1) continue;
+      if (g.at(t) >= kOccupied) continue;
+      bool in = true;
+      for (int k = 0; k < 4; ++k) in = in && dot(t, sd[k]) <= allow[k];
+      if (in) {
+        s2 = t, have_seed = true;
+        break;
+      }
+    }
+    if (!have_seed) continue;
+
+    // grow the layer in its plane (CD:118-200)
+    std::deque<Cell> rim[4], rim_real[4];  // current outline of the layer per side: all cells / cells of the layer
+    for (int j = 0; j < 4; ++j) rim[j].assign(1, s2), rim_real[j].assign(1, s2);
+    std::vector<Cell> layer(1, s2);
+    Cell far[4] = {s2, s2, s2, s2};
+    bool alive[4] = {true, true, true, true};
+    for (int k = 0; alive[0] || alive[1] || alive[2] || alive[3]; ++k) {
+      const int s = k % 4, prev = (k + 3) % 4, next = (k + 1) % 4;
+      std::deque<Cell> moved, moved_real;
+      bool ok = true;
+      for (const Cell& c : rim[s]) {
+        const Cell t = c + sd[s];
+        if (dot(t, sd[s]) > allow[s]) {
+          ok = false;
+          break;
+        }
+        const Cell below = t - up;
+        if (g.inside(below) && g.at(below) == (int8_t)mark) {  // on top of the polyhedron: must be free
+          if (g.inside(t) && g.at(t) < kOccupied) {
+            moved.push_back(t), moved_real.push_back(t);
+          } else {
+            ok = false;
+            break;
+          }
+        } else {
+          moved.push_back(t);  // beside the polyhedron: carried along, not part of the layer
+        }
+      }
+      if (!ok) {
+        alive[s] = false;  // (a side that failed is still tried again on later turns, as in CD:128-133)
+        continue;
+      }
+      rim[s] = moved;
+      layer.insert(layer.end(), moved_real.begin(), moved_real.end());
+      rim_real[s] = moved_real;
+      rim[prev].push_back(moved.front());
+      rim[next].push_front(moved.back());
+      if (!moved_real.empty()) {
+        if (moved.front() == moved_real.front()) rim_real[prev].push_back(moved.front());
+        if (moved.back() == moved_real.back()) rim_real[next].push_front(moved.back());
+      }
+      for (int j = 0; j < 4; ++j)
+        if (!rim_real[j].empty()) far[j] = rim_real[j].front();
+    }
+
+    // is the layer consistent with ONE plane through every edge? (CD:209-283)
+    bool accept = true;
+    for (int j = 0; j < 4 && accept; ++j) {
+      if (rim_real[j].empty()) continue;
+      Edge e = trial[j];
+      const int gap = reach[f][j] - dot(rim_real[j].front(), sd[j]);  // voxels this layer falls short of the last one
+      if (e.slope == 0) {
+        if (gap > 0) {  // a chamfer starts here: a point of its plane, between this layer and the neighbouring face
+          const Cell c = rim_real[j].front();
+          const Cell nb = kNormal[fr[f].face[j]];
+          e.pos[0] = c.x * res - up.x * res / 2 + nb.x * res / 2 + res / 2;
+          e.pos[1] = c.y * res - up.y * res / 2 + nb.y * res / 2 + res / 2;
+          e.pos[2] = c.z * res - up.z * res / 2 + nb.z * res / 2 + res / 2;
+          e.slope = e.steps = gap;
+          if (gap > 1) e.dir = f;
+        }
+      } else if (e.fixed) {
+        if (e.dir == f || e.dir == -1) {
+          if (gap > e.slope) accept = false;
+        } else if (e.steps >= e.slope) {  // the other face has finished a stair: we may step in by one, once
+          if (gap > 1) accept = false;
+          else e.steps = 1;
+        } else {                          // in the middle of a stair: no step allowed
+          if (gap != 0) accept = false;
+          else e.steps += 1;
+        }
+      } else if (e.dir == -1) {           // slope 1 so far, long direction still open
+        if (gap == 0) e.dir = fr[f].face[j], e.steps += 1, e.slope += 1;
+        else if (gap == 1) e.fixed = true;
+        else accept = false;
+      } else if (e.dir == f) {            // first layer after our own multi-voxel retreat fixes the slope
+        e.slope = gap, e.fixed = true;
+      } else {                            // the other face is the long direction and is still lengthening its stair
+        if (gap == 0) e.slope += 1, e.steps += 1;
+        else if (gap == 1) e.fixed = true, e.steps = 1;
+        else accept = false;
+      }
+      trial[j] = e;
+    }
+    if (!accept) {
+      growing[f] = false;
+      continue;
+    }
+
+    outer[f] = layer;
+    for (int j = 0; j < 4; ++j) {
+      reach[f][j] = dot(far[j], sd[j]);
+      edges[fr[f].edge[j]] = trial[j];
+      // full-width side on a square edge: these voxels are now also the outermost layer of the neighbouring face
+      if (trial[j].slope == 0 && !rim_real[j].empty() && reach[f][j] == dot(rim_real[j].front(), sd[j])) {
+        const int nbf = fr[f].face[j];
+        outer[nbf].insert(outer[nbf].end(), rim_real[j].begin(), rim_real[j].end());
+        reach[nbf][fr[f].back[j]] += 1;
+      }
+    }
+    anchor[f] = layer.front();
+    for (const Cell& c : layer) g.at(c) = (int8_t)mark;
+  }
+
+  // half-spaces: chamfered edges first (edge numbering order), then the six faces (CD:322-373)
+  int n = 0;
+  auto emit = [&](const double nrm[3], const double p[3]) {
+    if (n < max_rows) {
+      double* r = rows + 4 * (size_t)n;
+      r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
+      r[3] = nrm[0] * p[0] + nrm[1] * p[1] + nrm[2] * p[2];
+    }
+    ++n;
+  };
+  for (int e = 0; e < 12; ++e) {
+    if (edges[e].slope <= 0) continue;
+    const int fa = kEdgeFaces[e][0], fb = kEdgeFaces[e][1];
+    const int lng = (edges[e].dir == fa) ? fa : fb, oth = (edges[e].dir == fa) ? fb : fa;
+    const double nrm[3] = {(double)(edges[e].slope * kNormal[lng].x + kNormal[oth].x),
+                           (double)(edges[e].slope * kNormal[lng].y + kNormal[oth].y),
+                           (double)(edges[e].slope * kNormal[lng].z + kNormal[oth].z)};
+    const double p[3] = {edges[e].pos[0] + origin[0], edges[e].pos[1] + origin[1], edges[e].pos[2] + origin[2]};
+    emit(nrm, p);
+  }
+  for (int f = 0; f < 6; ++f) {
+    const double nrm[3] = {(double)kNormal[f].x, (double)kNormal[f].y, (double)kNormal[f].z};
+    const double p[3] = {anchor[f].x * res + kNormal[f].x * res / 2 + res / 2 + origin[0],
+                         anchor[f].y * res + kNormal[f].y * res / 2 + res / 2 + origin[1],
+                         anchor[f].z * res + kNormal[f].z * res / 2 + res / 2 + origin[2]};
+    emit(nrm, p);
+  }
+  *n_rows = n;
+  return n <= max_rows ? HDSM_OK : HDSM_ERR_CAPACITY;
+}

@@ -171,3 +171,73 @@ def test_reference_oracle_equals_host_restatement_in_closed_loop(oracle):
     assert np.abs(a.plans_all - b.plans_all).max() < 1e-7
     assert slowed                                   # the neighbour speed modulation was active at some point
     assert np.allclose(seen[0][1], 9.0)             # first round: nobody has a plan -> path_vel_max
+
+
+# ---- next row f2, first piece: the convex voxel decomposition (hdsm_poly_octa3d) ---------------------------------
+def _free_grid():
+    return np.zeros((20, 66, 66), np.int8)  # [z][y][x]: 66 x 66 x 20 voxels of 0.3 m, the local grid of the reference
+
+
+def test_poly_octa3d_reproduces_the_reference_outputs():
+    """SURVEY.md section 8c-5: outputs of convex_decomp_lib::GetPolyOcta3D itself (grid 66x66x20, res 0.3, origin 0,
+    seed voxel (33,33,10), CONV = -1), rows n.x <= n.p, chamfers first, then -y +x +y -x +z -z."""
+    from multi_agent_pkgs_amd.swarm import poly_octa3d
+    box = lambda lo, hi, zlo, zhi: [[0, -1, 0, -lo], [1, 0, 0, hi], [0, 1, 0, hi], [-1, 0, 0, -lo], [0, 0, 1, zhi], [0, 0, -1, -zlo]]
+    rows, _ = poly_octa3d(_free_grid(), (33, 33, 10), n_it=42)
+    assert np.allclose(rows, box(7.8, 12.3, 0.9, 5.4), atol=1e-12)
+    rows, _ = poly_octa3d(_free_grid(), (33, 33, 10), n_it=60)      # z clipped to voxels 1..18
+    assert np.allclose(rows, box(6.9, 13.2, 0.3, 5.7), atol=1e-12)
+    rows, _ = poly_octa3d(_free_grid(), (33, 33, 3), n_it=42)
+    assert np.allclose(rows, box(7.8, 12.3, 0.3, 3.3), atol=1e-12)
+    g = _free_grid()
+    g[:, 35, 37] = 100                                               # one full-height occupied column at (37, 35)
+    rows, _ = poly_octa3d(g, (33, 33, 10), n_it=42)
+    want = [[3, 1, 0, 43.8]] + box(7.8, 12.3, 0.9, 5.4)
+    want[2][3] = 12.0                                                # the +x face is pulled in
+    assert np.allclose(rows, want, atol=1e-12)
+    assert np.isclose(rows[0, :3] @ [11.1, 10.5, 2.25], 43.8)       # the chamfer passes through p = (11.1, 10.5, 2.25)
+    g = _free_grid()
+    for t in range(12):
+        g[:, 30 + t, 36 + t] = 100                                   # occupied diagonal columns (36+t, 30+t)
+    rows, _ = poly_octa3d(g, (33, 33, 10), n_it=42)
+    assert np.allclose(rows, [[2, -1, 0, 12.3]] + box(7.8, 12.3, 0.9, 5.4), atol=1e-12)
+
+
+def test_poly_octa3d_properties_in_random_forests():
+    """Size-independent properties on pillar forests with walls: the seed lies inside, no occupied voxel centre lies
+    strictly inside, at most 18 rows (what GetPolyOcta3D can emit: 12 edges + 6 faces), only free voxels are taken."""
+    from multi_agent_pkgs_amd.swarm import poly_octa3d
+    rng = np.random.default_rng(5)
+    res = 0.3
+    for case in range(120):
+        g = _free_grid()
+        for _ in range(int(rng.integers(5, 120))):
+            x, y = rng.integers(1, 65, 2)
+            w = int(rng.integers(1, 3))
+            g[:, y:y + w, x:x + w] = 100
+        if rng.random() < 0.3:
+            g[:int(rng.integers(3, 20)), int(rng.integers(5, 60)), 10:50] = 100
+        while True:
+            s = (int(rng.integers(5, 60)), int(rng.integers(5, 60)), int(rng.integers(2, 18)))
+            if g[s[2], s[1], s[0]] == 0:
+                break
+        g0 = g.copy()
+        rows, gm = poly_octa3d(g, s, n_it=int(rng.choice([24, 42, 60])), res=res)
+        A, b = rows[:, :3], rows[:, 3]
+        assert 6 <= len(rows) <= 18
+        assert (A @ ((np.array(s) + 0.5) * res) - b <= 1e-9).all()
+        zz, yy, xx = np.nonzero(g0 >= 100)
+        ctr = (np.stack([xx, yy, zz], 1) + 0.5) * res
+        assert not (ctr @ A.T - b < -1e-9).all(axis=1).any(), case
+        assert ((gm == -1) <= (g0 < 100)).all() and gm[s[2], s[1], s[0]] == -1
+
+
+def test_poly_octa3d_capacity_and_arguments():
+    from multi_agent_pkgs_amd import lib
+    from multi_agent_pkgs_amd.swarm import poly_octa3d
+    with pytest.raises(lib.HdsmError) as e:
+        poly_octa3d(_free_grid(), (33, 33, 10), max_rows=4)
+    assert e.value.code == lib.HDSM_ERR_CAPACITY
+    with pytest.raises(lib.HdsmError) as e:
+        poly_octa3d(_free_grid(), (70, 33, 10))
+    assert e.value.code == lib.HDSM_ERR_BAD_ARG
