@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--radius", type=float, default=0.0, help="circle radius [m]. Default: 22 m x number of GPUs when the "
                     "swarm is the default 64 agents per GPU (the ring density of BASELINE configs[1] at every N); with "
                     "--agents, max(22, agents / 2 pi) (chord >= 1 m, SURVEY.md section 8d)")
+    ap.add_argument("--scenario", choices=("circle", "lanes"), default="circle", help="circle: the antipodal exchange "
+                    "of BASELINE configs[1] (the bench line). lanes: a line formation (32 lanes wide, stacked in z) flying "
+                    "through a pillar forest; corridors come from the voxel decomposition (next row f2). Single GPU.")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
                     "flight on the host (csrc/swarm_host.cpp) instead of with the f1 device kernel (hdsm_reference)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the product path) or gloo "
@@ -138,9 +141,17 @@ def main():
             full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has)
             return full, pv
 
+        starts = goals = None
+        if args.scenario == "lanes":
+            assert world == 1, "--scenario lanes is a single-GPU workload"
+            n_y = min(n_rob, 32)
+            assert n_rob % n_y == 0
+            starts, goals, occ, occ_origin = swarm.lane_forest_scenario(n_y, n_rob // n_y, seed=7)
         loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
                                allgather=allgather_np if world > 1 else None, radius=radius,
-                               reference=None if args.host_reference else ref_dev)
+                               reference=None if args.host_reference else ref_dev, starts=starts, goals=goals)
+        if args.scenario == "lanes":
+            loop.shard.set_world(occ, occ_origin)
         for r in range(total_rounds):
             out = loop.step(record=rec if r >= args.first_round else None)
             if r >= args.first_round:
@@ -264,7 +275,9 @@ def main():
             "metric": "agent QP-replans/sec", "value": value, "unit": "agent-replans/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_rob} agents circular exchange (R = {radius:g} m), empty env, H={N}, "
+            "config": {"workload": (f"{n_rob} agents circular exchange (R = {radius:g} m), empty env" if args.scenario == "circle"
+                                    else f"{n_rob} agents in line formation through a lane forest (corridors by voxel "
+                                         f"decomposition, <= {int(max(x['n_rows'].max() for x in rec))} static rows)") + f", H={N}, "
                                    f"poly_hor={P}, closed-loop rounds {args.first_round}..{total_rounds - 1} replayed",
                        "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
                        "parallelism": f"agents sharded over {world} GPU(s), one all-gather per round"},

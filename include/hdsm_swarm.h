@@ -66,6 +66,15 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
 int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path);
 int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel);
 
+/* Next row f2: an occupied world. occupancy [dim[2]][dim[1]][dim[0]] int8 (x fastest), voxels of cfg.voxel_size,
+ * >= 100 occupied (already inflated by the drone radius — the map builder's job, f4); origin = world position of
+ * voxel (0,0,0), a multiple of the voxel size so that the agents' local grids register with it. From then on
+ * hdsm_swarm_prepare() cuts each agent's local grid (20 x 20 x 6 m around it) out of this world and builds the
+ * corridor polyhedra with hdsm_poly_octa3d instead of the free-space closed form; with an empty world both give
+ * the same polyhedra. NULL occupancy = back to free space. The global path stays the straight segment
+ * start -> goal (f3, JPS + DMP, is not built): the caller is responsible for worlds in which that is collision-free. */
+int hdsm_swarm_set_world(void* swarm, const int8_t* occupancy, const int32_t dim[3], const double origin[3]);
+
 /* Next row f2, first piece — the convex voxel decomposition GenerateSafeCorridor calls for every seed
  * (convex_decomp_lib::GetPolyOcta3D, convex_decomp_util/src/convex_decomp.cpp:5-376): a cuboid of free voxels grown
  * from `seed` face by face (n_it face turns, order -y +x +y -x +z -z), chamfered with integer slopes where obstacles

@@ -50,6 +50,11 @@ struct Swarm {
   hdsm_swarm_config cfg;
   int n_rob = 0, first_id = 0, n_local = 0;
   std::vector<Agent> agents;
+  // optional occupancy of the world (hdsm_swarm_set_world): voxels of cfg.voxel_size, >= 100 occupied
+  bool has_world = false;
+  std::vector<int8_t> world;
+  int wdim[3] = {0, 0, 0};
+  double worigin[3] = {0, 0, 0};
 };
 
 // GetVelocityLimit, AC:1805-1817
@@ -88,6 +93,47 @@ void free_space_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], 
   for (int r = 0; r < 6; ++r) {
     for (int k = 0; k < 3; ++k) out->A[r][k] = n[r][k];
     out->b[r] = rhs[r];
+  }
+}
+
+// Polyhedron around a seed on an occupied world: the agent's local voxel grid (what env_builder hands to the
+// planner, environment_builder.cpp:58-67) is cut out of the world grid and given to the voxel decomposition
+// (AC:1404-1416 -> hdsm_poly_octa3d = GetPolyOcta3D). Voxels below the ground are unknown -> occupied (AC:1302);
+// voxels outside the world grid are free. GetPolyOcta3DNew, which the reference switches to when the seed is squeezed
+// between occupied voxels (AC:1385-1397), is not restated: the original method is used there too.
+void world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int mark, Poly* out) {
+  const hdsm_swarm_config& c = sw.cfg;
+  const double vs = c.voxel_size;
+  int32_t dim[3], off[3];
+  for (int ax = 0; ax < 3; ++ax) {
+    dim[ax] = (int32_t)std::floor(c.grid_range[ax] / vs);
+    off[ax] = (int32_t)std::lround((grid_origin[ax] - sw.worigin[ax]) / vs);  // local voxel 0 in world voxels
+  }
+  std::vector<int8_t> local((size_t)dim[0] * dim[1] * dim[2], 0);
+  const int first_free_z = (int)std::ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
+  for (int k = 0; k < dim[2]; ++k)
+    for (int j = 0; j < dim[1]; ++j)
+      for (int i = 0; i < dim[0]; ++i) {
+        int8_t v = 0;
+        if (k < first_free_z) {
+          v = 100;
+        } else {
+          const int gi = i + off[0], gj = j + off[1], gk = k + off[2];
+          if (gi >= 0 && gj >= 0 && gk >= 0 && gi < sw.wdim[0] && gj < sw.wdim[1] && gk < sw.wdim[2])
+            v = sw.world[(size_t)gi + (size_t)gj * sw.wdim[0] + (size_t)gk * sw.wdim[0] * sw.wdim[1]];
+        }
+        local[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] = v;
+      }
+  const int32_t sd[3] = {seed[0], seed[1], seed[2]};
+  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
+  double rows[HDSM_MAX_ROWS_STATIC * 4];
+  int32_t n = 0;
+  hdsm_poly_octa3d(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, HDSM_MAX_ROWS_STATIC, &n);
+  if (n > HDSM_MAX_ROWS_STATIC) n = HDSM_MAX_ROWS_STATIC;
+  out->rows = n;
+  for (int r = 0; r < n; ++r) {
+    for (int k = 0; k < 3; ++k) out->A[r][k] = rows[4 * r + k];
+    out->b[r] = rows[4 * r + 3];
   }
 }
 
@@ -155,7 +201,8 @@ void generate_safe_corridor(const Swarm& sw, Agent& ag) {
       }
     if (previous_seed) continue;
     Poly np;
-    free_space_poly(sw, origin, seed, &np);
+    if (sw.has_world) world_poly(sw, origin, seed, -(n_poly + 1), &np);
+    else free_space_poly(sw, origin, seed, &np);
     np.seed = seed_world;
     fresh.push_back(np);
     ++n_poly;
@@ -440,6 +487,25 @@ int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* 
     ag.path_vel = path_vel[k];
     ag.external_ref = true;
   }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_set_world(void* swarm, const int8_t* occupancy, const int32_t dim[3], const double origin[3]) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !dim || !origin) return HDSM_ERR_BAD_ARG;
+  if (!occupancy) {
+    sw->has_world = false;
+    sw->world.clear();
+    return HDSM_OK;
+  }
+  if (dim[0] < 1 || dim[1] < 1 || dim[2] < 1) return HDSM_ERR_BAD_ARG;
+  for (int ax = 0; ax < 3; ++ax) {  // local grids must register with the world grid
+    const double q = origin[ax] / sw->cfg.voxel_size;
+    if (std::fabs(q - std::round(q)) > 1e-9) return HDSM_ERR_BAD_ARG;
+    sw->wdim[ax] = dim[ax], sw->worigin[ax] = origin[ax];
+  }
+  sw->world.assign(occupancy, occupancy + (size_t)dim[0] * dim[1] * dim[2]);
+  sw->has_world = true;
   return HDSM_OK;
 }
 

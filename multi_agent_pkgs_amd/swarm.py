@@ -44,6 +44,41 @@ def circle_scenario(n, radius=None, cx=18.0, cy=15.0, z=1.5):
     return starts, goals
 
 
+def lane_forest_scenario(n_y, n_z=1, pitch=2.01, length=96.01, y0=5.0, z0=1.5, voxel=0.3, seed=0,
+                         density=0.1, inflate=0.3, pillar_radius=0.05, jitter=0.3):
+    """A forest the straight paths of a line formation are collision-free in (f3, the path planner, is not built).
+
+    Agents: the line formation of multi_agent_planner_long.launch.py:36-42 generalised to a y-z lattice (SURVEY.md
+    section 8d, cfg 5): start = (0, y0 + pitch i, z0 + pitch j), goal = start + (length, 0, 0). Obstacles: full-height
+    pillars of env_long_config.yaml's kind (radius 0.05 m, inflated by 0.3 m as the map builder does) in the two
+    forest bands x in [3, 33] and [63, 93], `density` pillars per m^2 — but placed within `jitter` of the mid-lines
+    BETWEEN the lanes, so that every lane centre keeps >= 0.2 m to the nearest occupied voxel (the shipped forest is
+    random in y and relies on JPS to route around it). Own seeded PRNG.
+    Returns starts [n][3], goals [n][3], occupancy int8 [nz][ny][nx], origin (3,)."""
+    rng = np.random.default_rng(seed)
+    starts = np.array([[0.0, y0 + pitch * i, z0 + pitch * j] for j in range(n_z) for i in range(n_y)])
+    goals = starts + [length, 0.0, 0.0]
+    origin = np.array([-3.0, 0.0, 0.0])
+    hi = np.array([length + 6.0, y0 + pitch * n_y + 5.0, z0 + pitch * n_z + 3.0])
+    dims = np.ceil((hi - origin) / voxel).astype(int)
+    occ = np.zeros((dims[2], dims[1], dims[0]), np.int8)
+    mids = y0 + pitch * (np.arange(-1, n_y) + 0.5)
+    r = pillar_radius + inflate
+    xc = (np.arange(dims[0]) + 0.5) * voxel + origin[0]
+    yc = (np.arange(dims[1]) + 0.5) * voxel + origin[1]
+    for x_lo, x_hi in ((3.0, 33.0), (63.0, 93.0)):
+        for ym0 in mids:
+            for px in rng.uniform(x_lo, x_hi, rng.poisson(density * (x_hi - x_lo) * pitch)):
+                ym = ym0 + rng.uniform(-jitter, jitter)
+                ix = np.nonzero(np.abs(xc - px) <= r)[0]
+                iy = np.nonzero(np.abs(yc - ym) <= r)[0]
+                for a in ix:
+                    for b in iy:
+                        if (xc[a] - px) ** 2 + (yc[b] - ym) ** 2 <= r * r:
+                            occ[:, b, a] = 100
+    return starts, goals, occ, origin
+
+
 def shard_range(n_rob, rank, world):
     """Contiguous id blocks, n_rob/world per rank."""
     per = (n_rob + world - 1) // world
@@ -80,6 +115,19 @@ class SwarmShard:
         if getattr(self, "h", None):
             self.lib.hdsm_swarm_destroy(self.h)
             self.h = None
+
+    def set_world(self, occupancy, origin=(0.0, 0.0, 0.0)):
+        """occupancy int8 [nz][ny][nx] at cfg.voxel_size (>= 100 occupied, already inflated), or None for free space."""
+        if occupancy is None:
+            rc = self.lib.hdsm_swarm_set_world(self.h, None, _p(np.zeros(3, np.int32), C.c_int32), _p(np.zeros(3), C.c_double))
+        else:
+            occ = np.ascontiguousarray(occupancy, dtype=np.int8)
+            dim = np.asarray(occ.shape[::-1], dtype=np.int32)
+            org = np.asarray(origin, dtype=np.float64)
+            rc = self.lib.hdsm_swarm_set_world(self.h, occ.ctypes.data_as(C.POINTER(C.c_int8)), _p(dim, C.c_int32),
+                                               _p(org, C.c_double))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_set_world")
 
     def prepare(self, plans_all, has_plan):
         i = self.inp

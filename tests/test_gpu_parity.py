@@ -388,3 +388,34 @@ def test_baseline_config_1_single_agent(hdsm, oracle):
     pos, dist, nfail = la.shard.state()
     assert nfail[0] == 0 and dist[0] < 35.0  # 59.6 m to go at the start; moving at 4.5..9 m/s for 6 s
     assert used_max[0] >= 2                   # several polyhedra in use on one horizon: the binaries matter
+
+
+def test_closed_loop_through_a_forest_with_voxel_corridors(hdsm, oracle):
+    """Next row f2 end to end: 12 agents in line formation fly through a pillar forest; every round the host cuts the
+    local voxel grids out of the world, decomposes them (hdsm_poly_octa3d) into chamfered polyhedra, and the device
+    solves. Same loop on the oracle; nobody touches an occupied voxel."""
+    from multi_agent_pkgs_amd import swarm
+    prm = agile_params(10, max_rows_static=18)
+    starts, goals, occ, origin = swarm.lane_forest_scenario(6, 2, seed=1)
+    sol = hdsm.Solver(prm, 12, 12)
+    rows_max = [0]
+
+    def dev(inp, plans, has):
+        rows_max[0] = max(rows_max[0], int(inp["n_rows"].max()))
+        return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    la = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=dev, starts=starts, goals=goals)
+    lb = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 12, solve=cpu, starts=starts, goals=goals)
+    la.shard.set_world(occ, origin), lb.shard.set_world(occ, origin)
+    for r in range(70):
+        oa, ob = la.step(), lb.step()
+        assert (oa["status"] == ob["status"]).all(), r
+        pos, _, _ = la.shard.state()
+        ij = np.floor((pos - origin) / 0.3).astype(int)
+        assert not (occ[ij[:, 2], ij[:, 1], ij[:, 0]] >= 100).any(), r
+    assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6
+    assert rows_max[0] > 6                      # chamfered polyhedra were in play
+    assert la.shard.state()[0][:, 0].min() > 25  # and the formation is through most of the first forest band

@@ -241,3 +241,24 @@ def test_poly_octa3d_capacity_and_arguments():
     with pytest.raises(lib.HdsmError) as e:
         poly_octa3d(_free_grid(), (70, 33, 10))
     assert e.value.code == lib.HDSM_ERR_BAD_ARG
+
+
+def test_empty_world_grid_gives_the_free_space_corridors(oracle):
+    """hdsm_swarm_set_world with an all-free grid: the voxel decomposition on each agent's local grid must produce the
+    polyhedra of the free-space closed form, round after round (8 agents, oracle as the solver)."""
+    prm = agile_params(10, max_rows_static=18)
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"],
+                             inp["b"], plans, has, n_threads=8)
+
+    la = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 8, solve=cpu)
+    lb = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 8, solve=cpu)
+    lb.shard.set_world(np.zeros((30, 200, 200), np.int8), origin=(-12.0, -15.0, 0.0))  # covers the 44 m circle
+    ra, rb = [], []
+    for r in range(30):
+        la.step(record=ra)
+        lb.step(record=rb)
+        for k in ("n_poly", "n_rows", "A", "b"):
+            assert np.array_equal(ra[-1][k], rb[-1][k]) or np.allclose(ra[-1][k], rb[-1][k], atol=1e-12), (r, k)
+    assert np.abs(la.plans_all - lb.plans_all).max() < 1e-9
