@@ -178,6 +178,27 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
                           const double* vel_cap, const double* plans_all, const uint8_t* has_plan,
                           double* ref_full, double* ref, double* path_vel, void* hip_stream);
 
+/* ---- next row f4: map pre-processing ---------------------------------------------------------------------
+ * The three stencil passes mapping_util's MapBuilder runs on every voxel grid before the planner sees it
+ * (map_builder.cpp:209-216): SetUncertainToUnknown (map_builder.cpp:331-362), VoxelGrid::InflateObstacles and
+ * VoxelGrid::CreatePotentialField (voxel_grid_util/src/voxel_grid.cpp:252-297, masks from CreateMask :192-226).
+ * Grids are int8 [nz][ny][nx], x fastest: -1 unknown, 0 free, 100 occupied; the output adds 1..99 = potential.
+ * A batch of n_grids grids of the same dimensions (the local grids of n agents) is processed at once.          */
+typedef struct hdsm_map_config {
+  double voxel_size;      /* 0.3                                  */
+  double inflation_dist;  /* 0.3  (map_builder_default_config.yaml:8) */
+  double potential_dist;  /* 1.5                                  */
+  int32_t potential_pow;  /* 4    (CreatePotentialField takes an int) */
+  int32_t reserved0;
+} hdsm_map_config;
+/* Host pointers: copies in, runs, copies out, synchronises.                                                 */
+int hdsm_map_preprocess(int32_t device, const hdsm_map_config* cfg, int32_t n_grids, const int32_t dim[3],
+                        const int8_t* grids_in, int8_t* grids_out);
+/* Device pointers on `hip_stream`; scratch = 2 * n_grids * nx*ny*nz bytes of device memory.                  */
+int hdsm_map_preprocess_device(int32_t device, const hdsm_map_config* cfg, int32_t n_grids, const int32_t dim[3],
+                               const int8_t* grids_in, int8_t* grids_out, void* scratch, void* hip_stream);
+const char* hdsm_map_last_error(void);
+
 /* Stand-alone plane generator = Agent::GenerateTimeAwareSafeCorridor's inner maths (AC:1100-1205) for one
  * batch: planes[n_inst][N][n_rob][4] = (n_f.x, n_f.y, n_f.z, n_f . q), rows of absent/self agents are
  * filled with zeros. Host pointers. Used by tests and by callers that want the level-1 input.             */

@@ -19,7 +19,7 @@ HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACIT
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
            "hdsm_reset_warm_start", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d",
-           "hdsm_swarm_set_world")
+           "hdsm_swarm_set_world", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")
 
 
 class HdsmError(RuntimeError):
@@ -175,3 +175,35 @@ class Solver:
         _check(self.lib.hdsm_last_stats(self.h, n_inst, _p(st["qp_iters"], C.c_int32), _p(st["nodes"], C.c_int32),
                                         _p(st["sweeps"], C.c_int32), _p(st["cand"], C.c_int32)))
         return st
+
+
+def map_preprocess(cfg, grids, device=0):
+    """hdsm_map_preprocess: grids int8 [n][nz][ny][nx] (-1 unknown, 0 free, 100 occupied) -> same shape, after
+    SetUncertainToUnknown, InflateObstacles and CreatePotentialField (next row f4). Runs on the GPU."""
+    import numpy as np
+    L = load()
+    g = np.ascontiguousarray(grids, dtype=np.int8)
+    assert g.ndim == 4
+    out = np.empty_like(g)
+    dim = np.asarray(g.shape[:0:-1], dtype=np.int32)
+    rc = L.hdsm_map_preprocess(C.c_int32(device), C.byref(cfg), C.c_int32(g.shape[0]), dim.ctypes.data_as(C.POINTER(C.c_int32)),
+                               g.ctypes.data_as(C.POINTER(C.c_int8)), out.ctypes.data_as(C.POINTER(C.c_int8)))
+    if rc:
+        L.hdsm_map_last_error.restype = C.c_char_p
+        raise HdsmError(rc, L.hdsm_map_last_error().decode())
+    return out
+
+
+def map_preprocess_device(cfg, d_in, d_out, d_scratch, stream=None, device=0):
+    """Device-pointer variant on torch tensors: d_in/d_out int8 [n][nz][ny][nx], d_scratch uint8 with >= 2 * d_in.numel()."""
+    import numpy as np
+    L = load()
+    dim = np.asarray(tuple(d_in.shape)[:0:-1], dtype=np.int32)
+    assert d_scratch.numel() >= 2 * d_in.numel() and d_in.is_contiguous() and d_out.is_contiguous()
+    rc = L.hdsm_map_preprocess_device(C.c_int32(device), C.byref(cfg), C.c_int32(d_in.shape[0]),
+                                      dim.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(d_in.data_ptr()),
+                                      C.c_void_p(d_out.data_ptr()), C.c_void_p(d_scratch.data_ptr()),
+                                      C.c_void_p(stream.cuda_stream if stream is not None else 0))
+    if rc:
+        L.hdsm_map_last_error.restype = C.c_char_p
+        raise HdsmError(rc, L.hdsm_map_last_error().decode())

@@ -101,3 +101,13 @@ def agile_ref_config(**over):
     for k, v in kw.items():
         setattr(c, k, v)
     return c
+
+
+class MapConfig(C.Structure):
+    """hdsm_map_config (include/hdsm.h): the map pre-processing parameters of map_builder_default_config.yaml:8-10."""
+    _fields_ = [("voxel_size", C.c_double), ("inflation_dist", C.c_double), ("potential_dist", C.c_double),
+                ("potential_pow", C.c_int32), ("reserved0", C.c_int32)]
+
+
+def default_map_config(voxel_size=0.3, inflation_dist=0.3, potential_dist=1.5, potential_pow=4):
+    return MapConfig(voxel_size, inflation_dist, potential_dist, potential_pow, 0)

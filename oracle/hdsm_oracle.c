@@ -1047,3 +1047,89 @@ int orc_reference(const hdsm_params* prm, const hdsm_ref_config* cfg, int32_t n_
   }
   return 0;
 }
+
+/* ---- next row f4: map pre-processing (mapping_util/src/map_builder.cpp:209-216, "MB"; voxel_grid_util/src/
+ * voxel_grid.cpp, "VG"). LITERAL restatement: the same scatter loops in the same order. -1 unknown, 0 free,
+ * 100 occupied, 1..99 potential (voxel_grid.hpp:12-14). grid [nz][ny][nx], x fastest (VG:68-76).              */
+typedef struct { int dx, dy, dz; int8_t val; } orc_mask_cell;
+
+/* VG:192-226 CreateMask */
+static int orc_create_mask(double mask_dist, double power, double res, orc_mask_cell* mask, int cap) {
+  const double h_max = 100.0;
+  const int rn = (int)ceil(mask_dist / res);
+  int cnt = 0;
+  if (mask_dist > 0)
+    for (int n0 = -rn; n0 <= rn; ++n0)
+      for (int n1 = -rn; n1 <= rn; ++n1)
+        for (int n2 = -rn; n2 <= rn; ++n2) {
+          double dist = hypot(hypot((double)n0, (double)n1), (double)n2);
+          dist = fabs(dist - 1);
+          if (dist * res >= mask_dist) continue;
+          const double h = h_max * pow(1 - hypot(hypot((double)n0, (double)n1), (double)n2) / (rn + 1), power);
+          if (h > 1e-3) {
+            if (cnt < cap) mask[cnt].dx = n0, mask[cnt].dy = n1, mask[cnt].dz = n2, mask[cnt].val = (int8_t)h;
+            ++cnt;
+          }
+        }
+  return cnt;
+}
+
+int orc_map_preprocess(const hdsm_map_config* cfg, int32_t n_grids, const int32_t dim[3], const int8_t* in, int8_t* out) {
+  const int nx = dim[0], ny = dim[1], nz = dim[2];
+  const size_t vox = (size_t)nx * ny * nz;
+  const double res = cfg->voxel_size;
+  const int cap = 40000;
+  orc_mask_cell* m1 = (orc_mask_cell*)malloc(sizeof(orc_mask_cell) * cap);
+  orc_mask_cell* m2 = (orc_mask_cell*)malloc(sizeof(orc_mask_cell) * cap);
+  int32_t* occ = (int32_t*)malloc(sizeof(int32_t) * vox);
+  const int c1 = orc_create_mask(cfg->inflation_dist, 1.0, res, m1, cap);                          /* VG:255-256 */
+  const int c2 = orc_create_mask(cfg->potential_dist, (double)cfg->potential_pow, res, m2, cap);   /* VG:281-282 */
+  if (!m1 || !m2 || !occ || c1 > cap || c2 > cap) return -1;
+#define IDX(x, y, z) ((size_t)(x) + (size_t)(y) * nx + (size_t)(z) * nx * ny)
+#define INSIDE(x, y, z) ((x) >= 0 && (y) >= 0 && (z) >= 0 && (x) < nx && (y) < ny && (z) < nz)
+  for (int g = 0; g < n_grids; ++g) {
+    const int8_t* vg = in + (size_t)g * vox;
+    int8_t* fin = out + (size_t)g * vox;
+    /* MB:331-362 SetUncertainToUnknown: reads vg, writes a copy */
+    memcpy(fin, vg, vox);
+    const int cube = (int)ceil(cfg->inflation_dist / res);
+    for (int i = cube; i < nx - cube; ++i)
+      for (int j = cube; j < ny - cube; ++j)
+        for (int k = cube; k < nz - cube; ++k)
+          if (vg[IDX(i, j, k)] == -1)
+            for (int a = -cube; a <= cube; ++a)
+              for (int b = -cube; b <= cube; ++b)
+                for (int c = -cube; c <= cube; ++c)
+                  if (INSIDE(i + a, j + b, k + c) && vg[IDX(i + a, j + b, k + c)] != 100)  /* !IsOccupied */
+                    fin[IDX(i + a, j + b, k + c)] = -1;
+    /* VG:252-278 InflateObstacles: the occupied voxels are collected first, then the mask is stamped around each */
+    int n_occ = 0;
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y)
+        for (int z = 0; z < nz; ++z)
+          if (fin[IDX(x, y, z)] == 100) occ[n_occ++] = (int32_t)IDX(x, y, z);
+    for (int q = 0; q < n_occ; ++q) {
+      const int z = occ[q] / (nx * ny), y = (occ[q] - z * nx * ny) / nx, x = occ[q] - z * nx * ny - y * nx;
+      for (int t = 0; t < c1; ++t) {
+        const int X = x + m1[t].dx, Y = y + m1[t].dy, Z = z + m1[t].dz;
+        if (INSIDE(X, Y, Z)) fin[IDX(X, Y, Z)] = 100;
+      }
+    }
+    /* VG:280-297 CreatePotentialField: in scan order, on the grid as it evolves */
+    for (int x = 0; x < nx; ++x)
+      for (int y = 0; y < ny; ++y)
+        for (int z = 0; z < nz; ++z)
+          if (fin[IDX(x, y, z)] == 100)
+            for (int t = 0; t < c2; ++t) {
+              const int X = x + m2[t].dx, Y = y + m2[t].dy, Z = z + m2[t].dz;
+              if (INSIDE(X, Y, Z) && fin[IDX(X, Y, Z)] != -1) {
+                const int8_t cur = fin[IDX(X, Y, Z)];
+                fin[IDX(X, Y, Z)] = cur > m2[t].val ? cur : m2[t].val;
+              }
+            }
+  }
+#undef IDX
+#undef INSIDE
+  free(m1), free(m2), free(occ);
+  return 0;
+}

@@ -76,6 +76,11 @@ int orc_reference(const hdsm_params* prm, const hdsm_ref_config* cfg, int32_t n_
                   const double* vel_cap, const double* plans_all, const uint8_t* has_plan, double* ref_full,
                   double* ref, double* path_vel);
 
+/* ---- next row f4: map pre-processing, literal scatter loops (map_builder.cpp:209-216, 331-362; voxel_grid.cpp:
+ * 192-297), same layouts as hdsm_map_preprocess ------------------------------------------------------------- */
+int orc_map_preprocess(const hdsm_map_config* cfg, int32_t n_grids, const int32_t dim[3], const int8_t* in,
+                       int8_t* out);
+
 /* ---- batch entry points with the SAME array layouts as include/hdsm.h -------------------------------- */
 /* Level 2 (fused planes + solve): restates hdsm_replan. n_threads > 1 farms instances over pthreads.     */
 int orc_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,

@@ -210,3 +210,14 @@ def reference(prm, cfg, agent_id, path, n_path, plans_all, has_plan, vel_cap=Non
                              _dp(ref), _dp(pv))
     assert rc == 0
     return ref_full, ref, pv
+
+
+def map_preprocess(cfg, grids):
+    """f4 restatement (orc_map_preprocess): literal scatter loops, layouts of hdsm_map_preprocess."""
+    g = np.ascontiguousarray(grids, dtype=np.int8)
+    out = np.empty_like(g)
+    dim = np.asarray(g.shape[:0:-1], dtype=np.int32)
+    rc = lib().orc_map_preprocess(C.byref(cfg), C.c_int32(g.shape[0]), dim.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  g.ctypes.data_as(C.POINTER(C.c_int8)), out.ctypes.data_as(C.POINTER(C.c_int8)))
+    assert rc == 0
+    return out

@@ -419,3 +419,33 @@ def test_closed_loop_through_a_forest_with_voxel_corridors(hdsm, oracle):
     assert np.abs(la.plans_all - lb.plans_all).max() < 1e-6
     assert rows_max[0] > 6                      # chamfered polyhedra were in play
     assert la.shard.state()[0][:, 0].min() > 25  # and the formation is through most of the first forest band
+
+
+@pytest.mark.parametrize("cfgkw,shape", [
+    (dict(), (3, 20, 66, 66)),                                                   # the local grid of the reference, shipped parameters
+    (dict(inflation_dist=0.6, potential_dist=1.2, potential_pow=2), (2, 17, 33, 41)),
+    (dict(voxel_size=0.2, inflation_dist=0.3, potential_dist=1.0, potential_pow=3), (2, 9, 50, 23)),
+    (dict(inflation_dist=0.0, potential_dist=0.9, potential_pow=1), (1, 8, 30, 30)),
+])
+def test_map_preprocess_matches_the_literal_loops(hdsm, oracle, cfgkw, shape):
+    """Next row f4, bit-exact: the device's distance-transform formulation of SetUncertainToUnknown / InflateObstacles /
+    CreatePotentialField against the oracle's literal scatter loops, on random worlds with pillars, walls, unknown
+    regions and obstacles on the borders."""
+    from multi_agent_pkgs_amd.params import default_map_config
+    cfg = default_map_config(**cfgkw)
+    rng = np.random.default_rng(hash(shape) % 1000)
+    g = np.zeros(shape, np.int8)
+    n, nz, ny, nx = shape
+    for b in range(n):
+        for _ in range(int(rng.integers(3, 40))):
+            x, y = int(rng.integers(0, nx)), int(rng.integers(0, ny))
+            g[b, : int(rng.integers(1, nz + 1)), y, x] = 100
+        g[b, int(rng.integers(0, nz)), :, int(rng.integers(0, nx))] = 100           # a beam
+        unk = rng.random((nz, ny, nx)) < 0.02
+        g[b][unk & (g[b] == 0)] = -1                                                 # scattered unknown voxels
+        g[b, :, : ny // 5, : nx // 4][g[b, :, : ny // 5, : nx // 4] == 0] = -1       # an unexplored corner
+    dev = hdsm.map_preprocess(cfg, g)
+    ref = oracle.map_preprocess(cfg, g)
+    assert dev.dtype == np.int8 and (dev == ref).all(), int((dev != ref).sum())
+    assert ((ref > 0) & (ref < 100)).any() and (ref == -1).any()
+    assert (ref == 100).sum() > (g == 100).sum() or cfg.inflation_dist == 0

@@ -268,3 +268,54 @@ def test_default_config_is_solved(oracle):
     sn = problems.swarm_snapshot(prm, 6, 77, speed=(0, 4))
     o = oracle.replan(prm, *[sn[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")])
     assert (o["status"] == 0).sum() >= 4
+
+
+# ---- next row f4: map pre-processing (orc_map_preprocess) --------------------------------------------------------
+def test_map_preprocess_single_obstacle_matches_the_formulas(oracle):
+    """One occupied voxel in a free grid: after InflateObstacles + CreatePotentialField the value of a voxel depends on
+    its offset n to the NEAREST inflated voxel only; recomputed here from CreateMask's formulas (voxel_grid.cpp:192-226)
+    with numpy: member iff |hypot(n) - 1| * res < dist, value int8(100 (1 - hypot(n) / (rn + 1))^pow)."""
+    from multi_agent_pkgs_amd.params import default_map_config
+    cfg = default_map_config()
+    g = np.zeros((1, 24, 40, 40), np.int8)
+    g[0, 12, 20, 20] = 100
+    out = oracle.map_preprocess(cfg, g)[0]
+    res = cfg.voxel_size
+    zz, yy, xx = np.meshgrid(np.arange(24) - 12, np.arange(40) - 20, np.arange(40) - 20, indexing="ij")
+    hyp = np.hypot(np.hypot(xx, yy), zz)
+    infl = (np.abs(hyp - 1) * res < cfg.inflation_dist) & (hyp > 0) | (hyp == 0)
+    assert ((out == 100) == infl).all() and infl.sum() == 27
+    # potential: max over inflated voxels u of the mask value at (v - u)
+    rn = int(np.ceil(cfg.potential_dist / res))
+    want = np.where(infl, 100, 0).astype(np.int64)
+    occ = np.argwhere(infl)
+    for dz in range(-rn, rn + 1):
+        for dy in range(-rn, rn + 1):
+            for dx in range(-rn, rn + 1):
+                h = np.hypot(np.hypot(dx, dy), dz)
+                if abs(h - 1) * res >= cfg.potential_dist:
+                    continue
+                val = 100.0 * (1 - h / (rn + 1)) ** cfg.potential_pow
+                if not val > 1e-3:
+                    continue
+                v = occ + [dz, dy, dx]
+                ok = (v >= 0).all(1) & (v < [24, 40, 40]).all(1)
+                v = v[ok]
+                want[v[:, 0], v[:, 1], v[:, 2]] = np.maximum(want[v[:, 0], v[:, 1], v[:, 2]], int(val))
+    assert (out == want).all()
+
+
+def test_map_preprocess_unknown_voxels(oracle):
+    """SetUncertainToUnknown (map_builder.cpp:331-362): an interior unknown voxel makes its non-occupied cube
+    neighbours unknown; unknown voxels receive no potential but are overwritten by the inflation."""
+    from multi_agent_pkgs_amd.params import default_map_config
+    cfg = default_map_config()
+    g = np.zeros((1, 12, 16, 16), np.int8)
+    g[0, 6, 8, 8] = -1       # interior unknown voxel
+    g[0, 6, 8, 9] = 100      # an occupied neighbour: stays occupied
+    g[0, 0, 0, 0] = -1       # unknown voxel on the border: does not spread (loop bounds cube .. dim - cube)
+    out = oracle.map_preprocess(cfg, g)[0]
+    assert out[6, 8, 9] == 100 and out[6, 8, 8] == 100      # the unknown voxel itself is within the inflation
+    assert out[5, 7, 7] == -1 and out[7, 9, 7] == -1         # cube neighbours out of the inflation's reach: unknown
+    assert out[0, 0, 0] == -1 and out[1, 1, 1] == 0          # border unknown voxel did not spread
+    assert out[6, 8, 11] > 0 and out[6, 8, 11] < 100         # known voxel near the obstacle: potential
