@@ -5,15 +5,17 @@
 // (AC = multi_agent_planner/src/agent_class.cpp). Design notes: DESIGN.md.
 //
 //   * decision vector u = jerk inputs, condensed (states eliminated), n = 3 N, index ax*N + k;
-//   * exact dual active-set QP (Goldfarb-Idnani) with J = L^{-T} Q and R kept in LDS, parallel over the
-//     lanes of the workgroup: lane j owns column j of J for d = J^T a, lane i owns row i for z = J2 d2 and
-//     for the Givens sweeps; the Givens coefficients of an "add" come from a suffix sum of d^2 so that no
-//     sequential sqrt chain is needed;
+//   * exact dual active-set QP (Goldfarb-Idnani). Device build: the iteration runs on one wavefront with the
+//     factor in registers (hdsm_wave_gi.h). CPU build (HDSM_EMU): the textbook formulation below with J = L^{-T} Q
+//     and R in plain arrays and Givens sweeps — same pivoting rules, so both builds visit the same vertices;
+//   * everything an instance needs before its first iteration is one linear map of (state, reference), precomputed
+//     by hdsm_create (Consts::KT);
 //   * the n_rob-1 neighbour planes per step are NEVER materialised: a sweep over the all-gathered plans
 //     buffer generates each plane on the fly (trig-free closed form of the ellipsoid support distance)
 //     and stages only the rows close to the current iterate in LDS; after convergence a verification sweep
 //     re-checks every row, stages the violated ones and the dual method simply continues (it stays dual
-//     feasible when rows are added), so the result is exact;
+//     feasible when rows are added), so the result is exact; a verification sweep is skipped when a displacement
+//     bound proves that no unstaged row can be violated;
 //   * the one-hot polyhedron choice is handled by a lazy depth-first branch-and-bound: a node branches
 //     only on a step whose segment lies in no polyhedron; children continue the parent's factorisation
 //     (snapshots of the solver state live in a per-instance global scratch, one per depth).
@@ -535,7 +537,7 @@ struct Solver {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
 #ifndef HDSM_EMU
-    if (!explicit_rows) {  // device build: lane-per-neighbour sweep (hdsm_wave_gi.h)
+    if (!explicit_rows) {  // device build: one thread per (neighbour, step) pair, sphere prefilter (hdsm_wave_gi.h)
       WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, (int)threadIdx.x);
       return;
     }

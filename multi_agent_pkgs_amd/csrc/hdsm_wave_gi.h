@@ -3,8 +3,10 @@
 //
 // Same mathematics as Solver::gi_run in hdsm_core.h (Goldfarb-Idnani, J = L^{-T} Q with J^T N = [R; 0]),
 // different data layout, chosen for CDNA4:
-//   * lane i owns row i of J (NV doubles, statically indexed registers) and row i of U = R^{-1};
-//     the multiplier / id of the working-set entry at position k live in lane k;
+//   * the rows of J live in statically indexed registers: with n <= 30 (NV = 32) every row is split over TWO lanes
+//     (lane L: columns [16h, 16h+16) of row L & 31, h = L >> 5; partial sums meet through v_permlane32_swap), with
+//     larger n (NV = 48) lane i owns row i; U = R^{-1} is in LDS by rows; the multiplier / id of the working-set
+//     entry at position k live in lane k;
 //   * r = U d1 is a lane-local dot product: no back-substitution chain;
 //   * d = J^T a is a transposition through LDS (T[j][i] = J[i][j] a_i, conflict-free strides), or a single
 //     row broadcast when the incoming row is an input bound (a = +-e_k, the common case in bang-bang plans);
