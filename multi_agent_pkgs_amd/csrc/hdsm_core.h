@@ -1196,7 +1196,21 @@ struct Solver {
       }
       SYNC();
       PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
+#ifndef HDSM_EMU
+      if (threadIdx.x < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
+        const int lane = (int)threadIdx.x;
+        double part = (lane < n) ? c.r_u * s.inc_x[lane] * s.inc_x[lane] : 0.0;
+        for (int idx = lane; idx < 6 * N; idx += 64) {
+          const int i = idx / 6 + 1, k = idx % 6;
+          const double e = s.st[i][k] - s.ref[i - 1][k];
+          part += ((i == N) ? c.wn[k] : c.wx[k]) * e * e;
+        }
+        part = wave_sum64(part);
+        if (lane == 0) a.obj[inst] = part;
+      }
+#endif
       if (IS_T0) {
+#ifdef HDSM_EMU
         double Jv = 0;
         for (int k = 0; k < n; ++k) Jv += c.r_u * s.inc_x[k] * s.inc_x[k];
         for (int i = 1; i <= N; ++i) {
@@ -1207,6 +1221,7 @@ struct Solver {
           }
         }
         a.obj[inst] = Jv;
+#endif
         uint8_t* us = a.used + (int64_t)inst * P;
         for (int j = 0; j < P; ++j) us[j] = 0;
         for (int i = 0; i < N; ++i)
