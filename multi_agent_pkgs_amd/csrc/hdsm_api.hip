@@ -45,6 +45,19 @@ __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ 
   Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
 }
 
+// The same solver budgeted for TWO workgroups per CU (registers: 2 waves per SIMD; LDS: a staging area of CMAX_DUO
+// rows makes the instance state fit twice into 160 KB). A single instance is bound by the latency of its one iterating
+// wave, so when there are more instances than CUs a second resident workgroup nearly doubles the throughput. Used for
+// n <= 30 only (the NV = 48 factor does not fit the halved register file).
+constexpr int CMAX_DUO = 768;
+template <int NV, int CMAX, int NT>
+__global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sol = hdsm::Solver<NV, CMAX>;
+  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
+  Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
+}
+
 // bounds[n_rob][4]: centre of the bounding box of steps 1..N of each published plan and the radius of the sphere
 // around it that holds them (radius -1 = no plan). One thread per agent; the replan kernel's sweeps use it to skip
 // whole neighbours (hdsm_wave_gi.h, sweep_planes). Only launched for swarms of at least bounds_min agents.
@@ -221,6 +234,7 @@ struct Handle {
   int N = 0, P = 0, RS = 0, n = 0;
   int threads = 256;
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
+  int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   double* d_bounds = nullptr; // [n_rob_max][4]
   hdsm_params prm{};
   hdsm::Consts* d_consts = nullptr;
@@ -255,6 +269,22 @@ int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
   return HDSM_OK;
 }
 
+int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st) {
+  using Sol = hdsm::Solver<32, CMAX_DUO>;
+  static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
+  const size_t shm = sizeof(typename Sol::S);
+  auto kern = k_replan_duo<32, CMAX_DUO, 256>;
+  static thread_local int attr_dev = -1;
+  if (attr_dev != h->device) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    attr_dev = h->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(256), shm, st, h->d_consts, a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
 int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.scratch = h->d_scratch;
   a.scratch_stride = h->scratch_stride;
@@ -274,6 +304,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
+  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) return launch_duo(h, a, st);
   if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
   return h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
 }
@@ -364,6 +395,11 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     if (t == 64 || t == 256) h->threads = t;
   }
   if (const char* e = std::getenv("HDSM_BOUNDS_MIN")) h->bounds_min = std::atoi(e) > 0 ? std::atoi(e) : 1;
+  {
+    hipDeviceProp_t prop;
+    h->duo_min = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount + 1 : 257;
+    if (const char* e = std::getenv("HDSM_DUO_MIN")) h->duo_min = std::atoi(e);  // 0 = never
+  }
   h->scratch_stride = scratch_stride_for(h->n);
   const size_t I = (size_t)max_instances, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
   hipError_t e = hipSuccess;
