@@ -193,6 +193,31 @@ struct WaveGI {
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
   static __device__ __forceinline__ void states(S& s, const Regs& R, int lane, int N) {
+    if constexpr (SPLIT) {  // both halves of the wave work: each sums half of the impulse-response taps
+      const int row = lane & 31, h = lane >> 5;
+      const bool on = row < 3 * N;
+      const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
+      double acc0 = 0, acc1 = 0, acc2 = 0;
+      if (h == 0) acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
+      const double* xx = s.x + ax * N;
+      const double* g0 = &s.gz[ax][0][MAXH + m - 1];
+      const double* g1 = &s.gz[ax][1][MAXH + m - 1];
+      const double* g2 = &s.gz[ax][2][MAXH + m - 1];
+      constexpr int HH = HT / 2;
+      static_assert(HT % 2 == 0, "the split kernel halves the horizon capacity");
+#pragma unroll
+      for (int k = 0; k < HH; ++k) {
+        const int kk = h * HH + k;
+        const double xk = xx[kk];
+        acc0 += g0[-kk] * xk;
+        acc1 += g1[-kk] * xk;
+        acc2 += g2[-kk] * xk;
+      }
+      acc0 = half_sum64(acc0), acc1 = half_sum64(acc1), acc2 = half_sum64(acc2);
+      if (on && h == 0) s.st[m][ax] = acc0, s.st[m][3 + ax] = acc1, s.st[m][6 + ax] = acc2;
+      wsync();
+      return;
+    }
     if (lane < 3 * N) {
       const int ax = R.ax, m = R.kk + 1;
       double acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
