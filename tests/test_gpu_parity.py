@@ -449,3 +449,18 @@ def test_map_preprocess_matches_the_literal_loops(hdsm, oracle, cfgkw, shape):
     assert dev.dtype == np.int8 and (dev == ref).all(), int((dev != ref).sum())
     assert ((ref > 0) & (ref < 100)).any() and (ref == -1).any()
     assert (ref == 100).sum() > (g == 100).sum() or cfg.inflation_dist == 0
+
+
+def test_cpp_example_runs_the_closed_loop_through_the_c_abi():
+    """examples/closed_loop.cpp: the ABI driven from C++ with no Python in between (built by `make -C examples`)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
+    out = subprocess.run([os.path.join(root, "examples", "closed_loop"), "12", "110"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    line = out.stdout.strip()
+    assert "12 agents, 110 rounds" in line
+    sep = float(line.split("closest approach ")[1].split(" m")[0])
+    far = float(line.split("farthest agent ")[1].split(" m")[0])
+    assert sep > 0.45 and far < 2.0, line   # separation planes keep the 0.25 m-radius drones apart; everybody crossed the 44 m circle
