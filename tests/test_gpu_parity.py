@@ -464,3 +464,20 @@ def test_cpp_example_runs_the_closed_loop_through_the_c_abi():
     sep = float(line.split("closest approach ")[1].split(" m")[0])
     far = float(line.split("farthest agent ")[1].split(" m")[0])
     assert sep > 0.45 and far < 2.0, line   # separation planes keep the 0.25 m-radius drones apart; everybody crossed the 44 m circle
+
+
+def test_map_preprocess_edge_cases(hdsm, oracle):
+    """Tiny grids (every voxel next to a border, quads running over the ends of rows and of the buffer), an empty batch,
+    a batch of one-voxel-thick slabs, and the rejection of masks wider than the byte-sized distance field."""
+    from multi_agent_pkgs_amd.params import default_map_config
+    cfg = default_map_config()
+    rng = np.random.default_rng(3)
+    for shape in [(2, 3, 5, 7), (3, 1, 9, 9), (1, 6, 1, 13), (4, 2, 2, 3), (1, 11, 13, 1)]:
+        g = np.zeros(shape, np.int8)
+        g[rng.random(shape) < 0.06] = 100
+        g[(rng.random(shape) < 0.05) & (g == 0)] = -1
+        assert (hdsm.map_preprocess(cfg, g) == oracle.map_preprocess(cfg, g)).all(), shape
+    assert hdsm.map_preprocess(cfg, np.zeros((0, 4, 4, 4), np.int8)).shape == (0, 4, 4, 4)
+    with pytest.raises(hdsm.HdsmError) as e:
+        hdsm.map_preprocess(default_map_config(potential_dist=3.5), np.zeros((1, 4, 4, 4), np.int8))  # rn = 12 > 9
+    assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
