@@ -262,3 +262,14 @@ def test_empty_world_grid_gives_the_free_space_corridors(oracle):
         for k in ("n_poly", "n_rows", "A", "b"):
             assert np.array_equal(ra[-1][k], rb[-1][k]) or np.allclose(ra[-1][k], rb[-1][k], atol=1e-12), (r, k)
     assert np.abs(la.plans_all - lb.plans_all).max() < 1e-9
+
+
+def test_set_world_argument_checks():
+    prm = agile_params(10, max_rows_static=18)
+    starts, goals = swarm.circle_scenario(4)
+    sh = swarm.SwarmShard(prm, swarm.default_swarm_config(), 4, 0, starts, goals)
+    with pytest.raises(lib.HdsmError) as e:   # origin must be a multiple of the voxel size (local grids register with it)
+        sh.set_world(np.zeros((4, 4, 4), np.int8), origin=(0.1, 0.0, 0.0))
+    assert e.value.code == lib.HDSM_ERR_BAD_ARG
+    sh.set_world(np.zeros((4, 4, 4), np.int8), origin=(-0.3, 0.6, 0.0))
+    sh.set_world(None)                         # back to free space
