@@ -62,6 +62,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
   c->cand_tau = 0.6;  // [m] rows whose slack at the first converged iterate is below this are staged
   if (const char* e = std::getenv("HDSM_CAND_TAU")) c->cand_tau = std::atof(e);
+  c->branch_rule = 1;  // most infeasible segment first: measured 4-6x shorter rounds where the search is deep
+  if (const char* e = std::getenv("HDSM_BRANCH_RULE")) c->branch_rule = std::atoi(e) != 0;
   c->presweep = 2;  // 0 never, 1 always, 2 when it was measured to pay: long horizons and large (prefiltered) swarms
   if (const char* e = std::getenv("HDSM_PRESWEEP")) c->presweep = std::atoi(e) != 0;
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at

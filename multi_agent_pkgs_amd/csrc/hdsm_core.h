@@ -641,10 +641,21 @@ struct Solver {
       s.contain[i] = cont;
     }
     SYNC();
-    int first = -1;
-    for (int i = N - 1; i >= 0; --i)
-      if (s.contain[i] < 0) first = i;
-    return first;
+    // the step to branch on among those whose segment lies in no polyhedron: the first in time (rule 0), or the MOST
+    // infeasible one — largest violation of its best polyhedron (rule 1). Any choice is exact; it only shapes the tree.
+    int pick = -1;
+    double worst = -DINF;
+    for (int i = N - 1; i >= 0; --i) {
+      if (s.contain[i] >= 0) continue;
+      if (c.branch_rule == 0) {
+        pick = i;
+        continue;
+      }
+      double best = DINF;
+      for (int j = 0; j < np; ++j) best = s.keys[i][j] < best ? s.keys[i][j] : best;
+      if (best >= worst) worst = best, pick = i;  // ties: the earlier step (the scan runs backwards)
+    }
+    return pick;
   }
 
   // ---- snapshots of the solver state (global scratch), one per branching depth ----------------------------------
