@@ -99,3 +99,25 @@ def test_level1_rejects_step_dependent_static_polyhedra(emu):
             A[:, i, j, :6], b[:, i, j, :6] = Aj, bj
     e = emu.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b)
     assert e["rc"] == -1  # HDSM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("rule", ["0", "1"])
+def test_either_branching_rule_reaches_the_same_optimum(emu, oracle, rule, monkeypatch):
+    """The branching step (first uncontained segment in time / most infeasible one, HDSM_BRANCH_RULE) only shapes the
+    search tree: on corridors that force real branching (narrow boxes, turning paths) both rules must return the
+    oracle's optimum, and the default rule must not need more nodes in total than the other."""
+    monkeypatch.setenv("HDSM_BRANCH_RULE", rule)
+    prm = agile_params(10, max_rows_static=18)
+    nodes = 0
+    for seed in (3, 5, 21, 22):
+        sn = problems.swarm_snapshot(prm, 12, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        args = [sn[k] for k in ARG_KEYS]
+        e = emu.replan(prm, *args)
+        compare(e, oracle.replan(prm, *args, n_threads=8))
+        nodes += int(e["nodes"].sum())
+    assert nodes > 4 * 12                      # the cases do branch
+    test_either_branching_rule_reaches_the_same_optimum.nodes = getattr(test_either_branching_rule_reaches_the_same_optimum, "nodes", {})
+    test_either_branching_rule_reaches_the_same_optimum.nodes[rule] = nodes
+    seen = test_either_branching_rule_reaches_the_same_optimum.nodes
+    if len(seen) == 2:
+        assert seen["1"] <= seen["0"], seen
