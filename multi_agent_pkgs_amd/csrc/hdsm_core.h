@@ -88,6 +88,7 @@ struct Shm {
   double fx0;                           // J(x0)
   int32_t cand_src[CMAX];               // origin of a staged row: (neighbour << 6) | (step << 1) | endpoint, -1 = explicit
   int32_t inc_act[NV], inc_nact;        // working set of the incumbent (portable ids) -> next replan's guess
+  int32_t inf_id;                       // row whose addition proved the last node infeasible (ids as in act[])
   long long prof_acc[16];
   long long prof_last;
 #endif
@@ -1109,8 +1110,10 @@ struct Solver {
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
     }
+    int last_rc = GI_OK;
     while (run) {
       const int rc = gi_run(s, c, R, cutoff(s), iters);
+      last_rc = rc;
       if (rc == GI_ITERLIM) {
         limit = true;
         break;
@@ -1240,9 +1243,27 @@ struct Solver {
       }
     }
 #ifndef HDSM_EMU
-    if (a.warm != nullptr) {  // next replan's guess (empty when there is no solution)
+    if (a.warm != nullptr) {  // next replan's guess
       int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
-      const int cnt = s.have_inc ? s.inc_nact : 0;
+      // No solution because the ROOT relaxation is infeasible (the usual case in a gridlocked neighbourhood, and it
+      // tends to persist for several rounds): hand over the certificate — the working set at the moment of the proof
+      // and the row that could not join it. Seeded with it, the next replan finds the contradiction (or its absence)
+      // after a few operations instead of rebuilding it from the unconstrained optimum.
+      const bool certificate = !s.have_inc && !limit && nodes == 1 && last_rc == GI_INFEASIBLE && s.q < NV;
+      if (certificate) {
+        SYNC();
+        PAR_FOR(k, NV) {
+          const int code = (k < s.q) ? s.act[k] : (k == s.q ? s.inf_id : 0);
+          int portable = code;
+          if (k <= s.q && id_kind(code) == K_C) {
+            const int src = s.cand_src[id_payload(code)];
+            portable = src >= 0 ? mk_id(K_C, src) : mk_id(K_E, 0);
+          }
+          s.inc_act[k] = portable;
+        }
+        SYNC();
+      }
+      const int cnt = s.have_inc ? s.inc_nact : (certificate ? s.q + 1 : 0);
       PAR_FOR(k, NV) if (k < cnt) wp[1 + k] = s.inc_act[k];
       if (IS_T0) wp[0] = cnt;
     }

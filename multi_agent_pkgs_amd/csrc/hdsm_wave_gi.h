@@ -931,6 +931,7 @@ struct WaveGI {
         PROF(4)
         if (dependent && l < 0) {
           rc = GI_INFEASIBLE;
+          if (lane == 0) s.inf_id = ip;  // the row that cannot be satisfied together with the current working set
           stop = true;
           break;
         }
