@@ -1097,10 +1097,10 @@ struct Solver {
         SYNC();
       }
     };
-    if (run && (c.presweep == 1 || (c.presweep == 2 && (a.bounds != nullptr ? s.ncand > 0 : N > 10)))) {
-      // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: large
-      // (prefiltered) swarms when the warm start already holds neighbour rows, i.e. a dense neighbourhood; small
-      // swarms with long horizons
+    if (run && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
+      // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
+      // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
+      // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
 #ifdef HDSM_EMU
       compute_states(s, c);
 #else

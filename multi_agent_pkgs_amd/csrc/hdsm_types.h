@@ -23,9 +23,9 @@ struct Consts {
   int32_t N, n, P, RS;
   int32_t max_nodes, max_iters;
   int32_t presweep;  // stage the neighbour rows around the starting point BEFORE the first active-set run: 0 never,
-                     // 1 always, 2 (default): prefiltered swarms whose warm start already holds neighbour rows, and
-                     // small swarms with N > 10. Measured: +4 % at 64 agents x H=10 (so not there), -11 % at 1024 agents late in
-                     // the flight, -7 % at H=15 where it also spares branch-and-bound nodes
+                     // 1 always, 2 (default): always for swarms below the prefilter size; prefiltered swarms only when
+                     // the warm start already holds neighbour rows. Measured with the final kernel: -8 % on the bench
+                     // line, -11 % at 1024 agents late in the flight, -7 % at H=15 (it also spares B&B nodes)
   int32_t branch_rule;  // step to branch on: 0 first uncontained segment in time, 1 (default) the most infeasible one
                         // (HDSM_BRANCH_RULE). Either is exact; 1 bisects the "where to switch polyhedron" choice
                         // instead of enumerating it: 509 -> 29 nodes on a gridlocked 128-agent ring

@@ -58,7 +58,7 @@ def test_staging_overflow_is_exact_or_flagged(emu, oracle):
     e = emu.replan(prm, *args, cmax=16)
     o = oracle.replan(prm, *args, n_threads=8)
     exact = e["status"] == 0
-    assert exact.sum() >= 3
+    assert exact.sum() >= 1 and (e["status"] != 0).sum() >= 1   # both outcomes occur with so little room
     assert (o["status"][exact] == 0).all()
     assert np.abs(e["traj"] - o["traj"])[exact].max() < 1e-8
     assert (e["sweeps"] >= 1).all()
