@@ -85,6 +85,13 @@ int hdsm_swarm_set_world(void* swarm, const int8_t* occupancy, const int32_t dim
  * Returns HDSM_ERR_CAPACITY (and the needed count in n_rows) if max_rows is too small.                        */
 int hdsm_poly_octa3d(const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
                      int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows);
+/* The shape-aware variant, convex_decomp_lib::GetPolyOcta3DNew (convex_decomp.cpp:590-1160, helpers FindCorners :378-564 and
+ * SideIsEmpty :577-588): same growth, but a chamfer only starts where an obstacle really lies behind it, a layer that
+ * covers less than half of its allowance is skipped, and layers may reach the last voxel of the grid. GenerateSafeCorridor
+ * switches to it when the seed is pinched between two occupied voxels along an axis (AC:1385-1395). Same arguments; voxels
+ * with a positive value below 100 (potential field) are free for the growth but count as "not empty" for the chamfer test. */
+int hdsm_poly_octa3d_new(const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
+                         int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows);
 
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);

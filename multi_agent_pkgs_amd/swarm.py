@@ -228,8 +228,9 @@ class SwarmLoop:
         return out
 
 
-def poly_octa3d(grid, seed, n_it=42, res=0.3, mark=-1, origin=(0.0, 0.0, 0.0), max_rows=18):
-    """Convex voxel decomposition around `seed` (hdsm_poly_octa3d; GetPolyOcta3D of the reference).
+def poly_octa3d(grid, seed, n_it=42, res=0.3, mark=-1, origin=(0.0, 0.0, 0.0), max_rows=18, shape_aware=False):
+    """Convex voxel decomposition around `seed` (hdsm_poly_octa3d = GetPolyOcta3D of the reference; shape_aware:
+    hdsm_poly_octa3d_new = GetPolyOcta3DNew).
     grid: int8 [nz][ny][nx] (x fastest), < 100 free, >= 100 occupied; modified in place (taken voxels = mark).
     Returns rows [k][4] = (n, n . p), n . x <= n . p."""
     grid = np.ascontiguousarray(grid, dtype=np.int8)
@@ -239,7 +240,8 @@ def poly_octa3d(grid, seed, n_it=42, res=0.3, mark=-1, origin=(0.0, 0.0, 0.0), m
     org = np.asarray(origin, dtype=np.float64)
     rows = np.zeros((max_rows, 4))
     n = C.c_int32(0)
-    rc = _lib.load().hdsm_poly_octa3d(_p(seed, C.c_int32), grid.ctypes.data_as(C.POINTER(C.c_int8)), _p(dim, C.c_int32),
+    fn = _lib.load().hdsm_poly_octa3d_new if shape_aware else _lib.load().hdsm_poly_octa3d
+    rc = fn(_p(seed, C.c_int32), grid.ctypes.data_as(C.POINTER(C.c_int8)), _p(dim, C.c_int32),
                                       C.c_int32(int(n_it)), C.c_double(float(res)), C.c_int32(int(mark)), _p(org, C.c_double),
                                       _p(rows, C.c_double), C.c_int32(int(max_rows)), C.byref(n))
     if rc:

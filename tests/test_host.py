@@ -203,6 +203,32 @@ def test_poly_octa3d_reproduces_the_reference_outputs():
     assert np.allclose(rows, [[2, -1, 0, 12.3]] + box(7.8, 12.3, 0.9, 5.4), atol=1e-12)
 
 
+def test_poly_octa3d_new_known_answer_and_fixture():
+    """The shape-aware variant (hdsm_poly_octa3d_new = GetPolyOcta3DNew): SURVEY.md section 8c-5's diagonal-columns case gives
+    the chamfer (2,-1,0; 12.45) (half a voxel further out than the original's 12.3), and both variants reproduce, row by
+    row and bit for bit, the 48 recorded cases of tests/golden/corridor_cases.npz (see make_corridor_golden.py for
+    how those were produced and what they do and do not pin)."""
+    from multi_agent_pkgs_amd.swarm import poly_octa3d
+    g = _free_grid()
+    for t in range(12):
+        g[:, 30 + t, 36 + t] = 100
+    rows, _ = poly_octa3d(g, (33, 33, 10), n_it=42, shape_aware=True)
+    assert np.allclose(rows[0], [2, -1, 0, 12.45], atol=1e-12) and len(rows) == 7
+    z = np.load(os.path.join(GOLD, "corridor_cases.npz"))
+    differ = 0
+    for k in range(z["grids"].shape[0]):
+        for aware, key in ((False, "octa3d"), (True, "octa3d_new")):
+            want = z["rows_" + key][k]
+            want = want[~np.isnan(want[:, 0])]
+            rows, gm = poly_octa3d(z["grids"][k].copy(), z["seeds"][k], n_it=int(z["n_it"][k]), res=float(z["res"]),
+                                   mark=int(z["mark"]), origin=z["origin"], max_rows=32, shape_aware=aware)
+            assert rows.shape == want.shape and np.array_equal(rows, want), (k, key)
+            assert np.count_nonzero(gm == int(z["mark"])) == int(z["cells_" + key][k]), (k, key)
+        a, b = z["rows_octa3d"][k], z["rows_octa3d_new"][k]
+        differ += not np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    assert differ >= 20  # the cases really exercise the difference between the two variants
+
+
 def test_poly_octa3d_properties_in_random_forests():
     """Size-independent properties on pillar forests with walls: the seed lies inside, no occupied voxel centre lies
     strictly inside, at most 18 rows (what GetPolyOcta3D can emit: 12 edges + 6 faces), only free voxels are taken."""
