@@ -40,6 +40,9 @@ typedef struct hdsm_swarm_config {
   double grid_z_min;                 /* z of the local grid origin (ground), 0.0                          */
   int32_t n_it_decomp;               /* 42 -> 7 voxel layers per face                                     */
   int32_t step_plan;                 /* 1                                                                 */
+  int32_t use_cvx_new;               /* use_cvx_new_ (AC:2222, shipped: false): always use the shape-aware decomposition;
+                                        0 = only where the seed is pinched between occupied voxels (AC:1385-1395)      */
+  int32_t reserved0;
 } hdsm_swarm_config;
 
 void hdsm_swarm_default_config(hdsm_swarm_config* cfg);
@@ -92,6 +95,25 @@ int hdsm_poly_octa3d(const int32_t seed[3], int8_t* grid, const int32_t dim[3], 
  * with a positive value below 100 (potential field) are free for the growth but count as "not empty" for the chamfer test. */
 int hdsm_poly_octa3d_new(const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
                          int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows);
+
+/* Global paths (path_curr_ of the reference, produced there by the path thread: JPS + DMP + shortening, AC:261-567 — out of
+ * scope as such). Default: the straight segment start -> goal. hdsm_swarm_set_paths installs caller-supplied polylines
+ * [n_local][pmax][3] with n_path[k] >= 2 points each (first = start, last = goal). hdsm_swarm_route computes them on the
+ * world given to hdsm_swarm_set_world: a minimal collision-free router (3-D A* over free voxels, 26-connected, extra cost next
+ * to obstacles, then greedy line-of-sight shortening) — NOT the reference's JPS3D / distance-map planner, only something
+ * that lets BASELINE's forest configurations fly. hdsm_swarm_get_paths reads the current paths back (n_path > pmax -> CAPACITY).
+ * Both corridor generation (AC:1286-1290) and reference sampling (AC:1459-1496) then walk these polylines. */
+int hdsm_swarm_set_paths(void* swarm, const double* paths, const int32_t* n_path, int32_t pmax);
+int hdsm_swarm_route(void* swarm, int32_t* n_failed);
+int hdsm_swarm_get_paths(void* swarm, int32_t pmax, double* paths, int32_t* n_path);
+/* hdsm_swarm_reference_inputs for paths with more than two points: path[n_local][pmax][3]; a polyline longer than pmax is
+ * cut after pmax points, which changes nothing as long as the kept part is longer than n_hor * path_vel_max * dt (checked:
+ * otherwise HDSM_ERR_CAPACITY). */
+int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32_t* n_path);
+/* Number of local agents whose corridor generation failed in the last hdsm_swarm_prepare (seed outside the local grid, or a
+ * polyhedron with more rows than max_rows_static); codes[n_local] (may be NULL) receives the hdsm_error per agent. Those
+ * agents kept the polyhedra they had. */
+int hdsm_swarm_corridor_errors(void* swarm, int32_t* codes);
 
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);

@@ -1,9 +1,12 @@
 // swarm_host.cpp — host-side planner state around the solve (see include/hdsm_swarm.h).
 // AC = multi_agent_planner/src/agent_class.cpp of lis-epfl/multi_agent_pkgs. Pure host C++.
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <queue>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/hdsm_swarm.h"
@@ -33,6 +36,7 @@ struct Poly {  // LinearConstraint3D: rows A x <= b
 struct Agent {
   int id = 0;
   V3 start{}, goal{};
+  std::vector<V3> path;                            // path_curr_: global path start -> goal (straight unless routed / set)
   std::array<double, 9> state_curr{};
   std::vector<std::array<double, 9>> traj_curr;    // traj_curr_     (empty before the first solve)
   std::vector<std::array<double, 3>> control_curr; // control_curr_
@@ -43,6 +47,7 @@ struct Agent {
   bool external_ref = false;  // traj_ref was supplied by hdsm_swarm_set_reference() for the coming prepare()
   double path_vel = 0;
   int n_fail = 0;
+  int corridor_rc = 0;  // last error of the voxel decomposition for this agent (0 = none)
 };
 
 struct Swarm {
@@ -98,10 +103,11 @@ void free_space_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], 
 
 // Polyhedron around a seed on an occupied world: the agent's local voxel grid (what env_builder hands to the
 // planner, environment_builder.cpp:58-67) is cut out of the world grid and given to the voxel decomposition
-// (AC:1404-1416 -> hdsm_poly_octa3d = GetPolyOcta3D). Voxels below the ground are unknown -> occupied (AC:1302);
-// voxels outside the world grid are free. GetPolyOcta3DNew, which the reference switches to when the seed is squeezed
-// between occupied voxels (AC:1385-1397), is not restated: the original method is used there too.
-void world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int mark, Poly* out) {
+// (AC:1404-1416). Voxels below the ground are unknown -> occupied (AC:1302); voxels outside the world grid are free.
+// A seed pinched between two occupied voxels along an axis gets the shape-aware variant (AC:1385-1397:
+// hdsm_poly_octa3d_new = GetPolyOcta3DNew), every other seed the original one (hdsm_poly_octa3d = GetPolyOcta3D).
+// Returns the decomposition's return code; on failure `out` has no rows and must not be used.
+int world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int mark, Poly* out) {
   const hdsm_swarm_config& c = sw.cfg;
   const double vs = c.voxel_size;
   int32_t dim[3], off[3];
@@ -109,6 +115,9 @@ void world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int m
     dim[ax] = (int32_t)std::floor(c.grid_range[ax] / vs);
     off[ax] = (int32_t)std::lround((grid_origin[ax] - sw.worigin[ax]) / vs);  // local voxel 0 in world voxels
   }
+  out->rows = 0;
+  for (int ax = 0; ax < 3; ++ax)
+    if (seed[ax] < 0 || seed[ax] >= dim[ax]) return HDSM_ERR_BAD_ARG;
   std::vector<int8_t> local((size_t)dim[0] * dim[1] * dim[2], 0);
   const int first_free_z = (int)std::ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
   for (int k = 0; k < dim[2]; ++k)
@@ -121,25 +130,53 @@ void world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int m
           const int gi = i + off[0], gj = j + off[1], gk = k + off[2];
           if (gi >= 0 && gj >= 0 && gk >= 0 && gi < sw.wdim[0] && gj < sw.wdim[1] && gk < sw.wdim[2])
             v = sw.world[(size_t)gi + (size_t)gj * sw.wdim[0] + (size_t)gk * sw.wdim[0] * sw.wdim[1]];
+          if (v < 0) v = 100;  // OccupyUnknown, AC:1307
         }
         local[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] = v;
       }
+  auto occupied = [&](int i, int j, int k) {  // VoxelGrid::IsOccupied: == 100, outside the grid: not occupied
+    if (i < 0 || j < 0 || k < 0 || i >= dim[0] || j >= dim[1] || k >= dim[2]) return false;
+    return local[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] == 100;
+  };
+  const bool pinched = (occupied(seed[0] - 1, seed[1], seed[2]) && occupied(seed[0] + 1, seed[1], seed[2])) ||
+                       (occupied(seed[0], seed[1] - 1, seed[2]) && occupied(seed[0], seed[1] + 1, seed[2])) ||
+                       (occupied(seed[0], seed[1], seed[2] - 1) && occupied(seed[0], seed[1], seed[2] + 1));
   const int32_t sd[3] = {seed[0], seed[1], seed[2]};
   const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
   double rows[HDSM_MAX_ROWS_STATIC * 4];
   int32_t n = 0;
-  hdsm_poly_octa3d(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, HDSM_MAX_ROWS_STATIC, &n);
-  if (n > HDSM_MAX_ROWS_STATIC) n = HDSM_MAX_ROWS_STATIC;
+  const int cap = sw.prm.max_rows_static < HDSM_MAX_ROWS_STATIC ? sw.prm.max_rows_static : HDSM_MAX_ROWS_STATIC;
+  const int rc = (pinched || c.use_cvx_new)
+                     ? hdsm_poly_octa3d_new(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, cap, &n)
+                     : hdsm_poly_octa3d(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, cap, &n);
+  if (rc != HDSM_OK) return rc;
   out->rows = n;
   for (int r = 0; r < n; ++r) {
     for (int k = 0; k < 3; ++k) out->A[r][k] = rows[4 * r + k];
     out->b[r] = rows[4 * r + 3];
   }
+  return HDSM_OK;
+}
+
+// the part of the global path that is still ahead of `p`, a point ON the path (AC:1480-1495: the segment containing it is
+// found with IsOnSegment, the path is cut there): [p, waypoints after that segment...]
+bool on_segment(const V3& p, const V3& a, const V3& b);
+std::vector<V3> path_ahead(const Agent& ag, const V3& p) {
+  size_t start_idx = 0;
+  for (size_t i = 0; i + 1 < ag.path.size(); ++i)
+    if (on_segment(p, ag.path[i], ag.path[i + 1])) {
+      start_idx = i + 1;
+      break;
+    }
+  std::vector<V3> out = {p};
+  for (size_t i = start_idx; i < ag.path.size(); ++i) out.push_back(ag.path[i]);
+  return out;
 }
 
 // GenerateSafeCorridor, AC:1236-1447
 void generate_safe_corridor(const Swarm& sw, Agent& ag) {
   const hdsm_swarm_config& c = sw.cfg;
+  ag.corridor_rc = 0;
   const int P = sw.prm.poly_hor;
   std::vector<Poly> fresh;
   if (!ag.polys.empty()) {  // AC:1253-1267: the whole previous plan inside the LAST polyhedron -> keep only it
@@ -157,8 +194,10 @@ void generate_safe_corridor(const Swarm& sw, Agent& ag) {
 
   // path: current position pushed in front of the global path (AC:1286-1290). The path thread re-plans from
   // the kept reference points (AC:328-350), so in an empty world path_curr_ = [last reference start, goal].
-  const V3 path_head = ag.traj_ref.empty() ? ag.start : V3{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]};
-  std::vector<V3> path = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}, path_head, ag.goal};
+  // With a routed path (hdsm_swarm_route / hdsm_swarm_set_paths) the rest of that polyline follows the reference start.
+  const V3 path_head = ag.traj_ref.empty() ? ag.path.front() : V3{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]};
+  std::vector<V3> path = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
+  for (const V3& w : path_ahead(ag, path_head)) path.push_back(w);
   // local voxel grid origin (env_builder GenerateVoxelGridMSG, environment_builder.cpp:58-67)
   const double vs = c.voxel_size;
   V3 origin;
@@ -201,8 +240,17 @@ void generate_safe_corridor(const Swarm& sw, Agent& ag) {
       }
     if (previous_seed) continue;
     Poly np;
-    if (sw.has_world) world_poly(sw, origin, seed, -(n_poly + 1), &np);
-    else free_space_poly(sw, origin, seed, &np);
+    if (sw.has_world) {
+      // a seed outside the local grid or a polyhedron with more rows than the solver takes: stop generating for this
+      // agent this round (it keeps the polyhedra it has) and report through hdsm_swarm_prepare
+      const int rc = world_poly(sw, origin, seed, -(n_poly + 1), &np);
+      if (rc != HDSM_OK) {
+        ag.corridor_rc = rc;
+        break;
+      }
+    } else {
+      free_space_poly(sw, origin, seed, &np);
+    }
     np.seed = seed_world;
     fresh.push_back(np);
     ++n_poly;
@@ -274,43 +322,19 @@ bool on_segment(const V3& p, const V3& a, const V3& b) {
 // The polyline SamplePath walks this round (AC:1459-1496): starting point from the previous reference, then the
 // global path from the segment that contains it.
 std::vector<V3> reference_polyline(const Agent& ag) {
-  const std::vector<V3> path_curr = {ag.start, ag.goal};
   V3 starting;
   if (!ag.traj_ref.empty()) {
     const auto& r = ag.increment_traj_ref ? ag.traj_ref[1] : ag.traj_ref[0];
     starting = {r[0], r[1], r[2]};
   } else {
-    starting = path_curr[0];
+    starting = ag.path.front();
   }
-  size_t start_idx = 0;
-  for (size_t i = 0; i + 1 < path_curr.size(); ++i)
-    if (on_segment(starting, path_curr[i], path_curr[i + 1])) {
-      start_idx = i + 1;
-      break;
-    }
-  std::vector<V3> path_samp = {starting};
-  for (size_t i = start_idx; i < path_curr.size(); ++i) path_samp.push_back(path_curr[i]);
-  return path_samp;
+  return path_ahead(ag, starting);
 }
 
 // GenerateReferenceTrajectory, AC:1449-1553
 void generate_reference(const Swarm& sw, Agent& ag, const double* plans_all, const uint8_t* has_plan) {
-  const std::vector<V3> path_curr = {ag.start, ag.goal};
-  V3 starting;
-  if (!ag.traj_ref.empty()) {  // AC:1459-1470
-    const auto& r = ag.increment_traj_ref ? ag.traj_ref[1] : ag.traj_ref[0];
-    starting = {r[0], r[1], r[2]};
-  } else {
-    starting = path_curr[0];
-  }
-  size_t start_idx = 0;  // AC:1480-1488
-  for (size_t i = 0; i + 1 < path_curr.size(); ++i)
-    if (on_segment(starting, path_curr[i], path_curr[i + 1])) {
-      start_idx = i + 1;
-      break;
-    }
-  std::vector<V3> path_samp = {starting};
-  for (size_t i = start_idx; i < path_curr.size(); ++i) path_samp.push_back(path_curr[i]);
+  const std::vector<V3> path_samp = reference_polyline(ag);  // AC:1459-1496
   std::vector<V3> pts = sample_path(sw, ag, path_samp, plans_all, has_plan);
   // velocity reference, AC:1527-1547 (points backwards along the path; reproduced as is)
   ag.traj_ref.assign(pts.size(), {});
@@ -357,6 +381,176 @@ void check_reference_increment(const Swarm& sw, Agent& ag) {
   if (progress_final > 0 && proj_dist < sw.cfg.thresh_dist) ag.increment_traj_ref = true;
 }
 
+
+// ---- a minimal router on the world grid (see hdsm_swarm_route in hdsm_swarm.h) -------------------------------------
+struct Router {
+  const Swarm& sw;
+  std::vector<uint8_t> cls;  // 0 free, 1 within two voxels of an obstacle, 2 occupied (or below the ground)
+  int nx, ny, nz;
+  explicit Router(const Swarm& s) : sw(s), nx(s.wdim[0]), ny(s.wdim[1]), nz(s.wdim[2]) {
+    const size_t tot = (size_t)nx * ny * nz;
+    cls.assign(tot, 0);
+    const double vs = sw.cfg.voxel_size;
+    const int k_ground = (int)std::ceil((sw.cfg.grid_z_min - sw.worigin[2]) / vs - 1e-9);
+    for (int k = 0; k < nz; ++k)
+      for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+          const int8_t v = sw.world[idx(i, j, k)];
+          if (v >= 100 || v < 0 || k < k_ground) cls[idx(i, j, k)] = 2;
+        }
+    // "near" band: separable box dilation of the occupied set by two voxels
+    std::vector<uint8_t> a(tot), b(tot);
+    for (size_t t = 0; t < tot; ++t) a[t] = cls[t] == 2;
+    auto pass = [&](const std::vector<uint8_t>& in, std::vector<uint8_t>& out, int ax) {
+      const int n[3] = {nx, ny, nz};
+      const size_t st[3] = {1, (size_t)nx, (size_t)nx * ny};
+      for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+          for (int i = 0; i < nx; ++i) {
+            const int c[3] = {i, j, k};
+            uint8_t v = 0;
+            for (int d = -2; d <= 2 && !v; ++d) {
+              const int q = c[ax] + d;
+              if (q >= 0 && q < n[ax]) v = in[idx(i, j, k) + (size_t)((long)d * (long)st[ax])];
+            }
+            out[idx(i, j, k)] = v;
+          }
+    };
+    pass(a, b, 0), pass(b, a, 1), pass(a, b, 2);
+    for (size_t t = 0; t < tot; ++t)
+      if (b[t] && cls[t] == 0) cls[t] = 1;
+  }
+  size_t idx(int i, int j, int k) const { return (size_t)i + (size_t)j * nx + (size_t)k * nx * ny; }
+  bool in(int i, int j, int k) const { return i >= 0 && j >= 0 && k >= 0 && i < nx && j < ny && k < nz; }
+  bool blocked(int i, int j, int k) const { return !in(i, j, k) || cls[idx(i, j, k)] == 2; }
+  void voxel_of(const V3& p, int v[3]) const {
+    for (int ax = 0; ax < 3; ++ax) v[ax] = (int)std::floor((p[ax] - sw.worigin[ax]) / sw.cfg.voxel_size);
+  }
+  V3 centre(int i, int j, int k) const {
+    const double vs = sw.cfg.voxel_size;
+    return {sw.worigin[0] + (i + 0.5) * vs, sw.worigin[1] + (j + 0.5) * vs, sw.worigin[2] + (k + 0.5) * vs};
+  }
+  // every voxel touched by the segment (sampled at a quarter voxel) is free; points outside the world count as blocked
+  bool line_clear(const V3& a, const V3& b) const {
+    const double len = norm(sub(b, a)), step = sw.cfg.voxel_size / 4;
+    const int n = (int)std::ceil(len / step);
+    for (int t = 0; t <= n; ++t) {
+      const V3 p = axpy(a, n ? (double)t / n : 0.0, sub(b, a));
+      int v[3];
+      voxel_of(p, v);
+      if (blocked(v[0], v[1], v[2])) return false;
+    }
+    return true;
+  }
+  // nearest free voxel to v (breadth-first over a small cube), false if none within 6 voxels
+  bool nearest_free(int v[3]) const {
+    if (!blocked(v[0], v[1], v[2])) return true;
+    for (int r = 1; r <= 6; ++r) {
+      double best = 1e300;
+      int bv[3] = {0, 0, 0};
+      for (int dk = -r; dk <= r; ++dk)
+        for (int dj = -r; dj <= r; ++dj)
+          for (int di = -r; di <= r; ++di) {
+            if (std::max(std::abs(di), std::max(std::abs(dj), std::abs(dk))) != r) continue;
+            if (blocked(v[0] + di, v[1] + dj, v[2] + dk)) continue;
+            const double d2 = di * di + dj * dj + dk * dk;
+            if (d2 < best) best = d2, bv[0] = v[0] + di, bv[1] = v[1] + dj, bv[2] = v[2] + dk;
+          }
+      if (best < 1e300) {
+        v[0] = bv[0], v[1] = bv[1], v[2] = bv[2];
+        return true;
+      }
+    }
+    return false;
+  }
+  // weighted A* (26-connected, Euclidean heuristic x 1.2, cells of the near band cost 3x), then greedy shortening
+  bool route(const V3& start, const V3& goal, std::vector<V3>* out) const {
+    int s[3], g[3];
+    voxel_of(start, s), voxel_of(goal, g);
+    if (!in(s[0], s[1], s[2]) || !in(g[0], g[1], g[2])) return false;
+    if (!nearest_free(s) || !nearest_free(g)) return false;
+    // the planner only ever sees a local grid of grid_range[2] metres of height around the agent: the route stays within
+    // half of that above and below the start / goal altitudes (it does not climb over a forest)
+    const int band = (int)std::floor(0.5 * sw.cfg.grid_range[2] / sw.cfg.voxel_size);
+    const int k_lo = std::min(s[2], g[2]) - band, k_hi = std::max(s[2], g[2]) + band;
+    struct Node {
+      double f;
+      size_t id;
+      bool operator<(const Node& o) const { return f > o.f; }
+    };
+    struct Rec {
+      double g;
+      size_t parent;
+      bool closed;
+    };
+    std::unordered_map<size_t, Rec> rec;
+    std::priority_queue<Node> open;
+    const size_t sid = idx(s[0], s[1], s[2]), gid = idx(g[0], g[1], g[2]);
+    auto h = [&](int i, int j, int k) {
+      const double a = i - g[0], b = j - g[1], c = k - g[2];
+      return 1.2 * std::sqrt(a * a + b * b + c * c);
+    };
+    rec[sid] = {0.0, sid, false};
+    open.push({h(s[0], s[1], s[2]), sid});
+    bool found = false;
+    size_t expanded = 0;
+    const size_t budget = 4000000;
+    while (!open.empty() && expanded < budget) {
+      const Node cur = open.top();
+      open.pop();
+      Rec& rc = rec[cur.id];
+      if (rc.closed) continue;
+      rc.closed = true;
+      ++expanded;
+      if (cur.id == gid) {
+        found = true;
+        break;
+      }
+      const int ci = (int)(cur.id % nx), cj = (int)((cur.id / nx) % ny), ck = (int)(cur.id / ((size_t)nx * ny));
+      const double gc = rc.g;
+      for (int dk = -1; dk <= 1; ++dk)
+        for (int dj = -1; dj <= 1; ++dj)
+          for (int di = -1; di <= 1; ++di) {
+            if (!di && !dj && !dk) continue;
+            const int ni = ci + di, nj = cj + dj, nk = ck + dk;
+            if (nk < k_lo || nk > k_hi || blocked(ni, nj, nk)) continue;
+            // no squeezing diagonally between two blocked voxels
+            if (di && dj && (blocked(ci + di, cj, ck) || blocked(ci, cj + dj, ck))) continue;
+            if (di && dk && (blocked(ci + di, cj, ck) || blocked(ci, cj, ck + dk))) continue;
+            if (dj && dk && (blocked(ci, cj + dj, ck) || blocked(ci, cj, ck + dk))) continue;
+            const size_t nid = idx(ni, nj, nk);
+            const double w = std::sqrt((double)(di * di + dj * dj + dk * dk)) * (cls[nid] == 1 ? 3.0 : 1.0);
+            const double ng = gc + w;
+            auto it = rec.find(nid);
+            if (it == rec.end() || (!it->second.closed && ng < it->second.g)) {
+              rec[nid] = {ng, cur.id, false};
+              open.push({ng + h(ni, nj, nk), nid});
+            }
+          }
+    }
+    if (!found) return false;
+    std::vector<V3> raw;
+    for (size_t id = gid;; id = rec[id].parent) {
+      raw.push_back(centre((int)(id % nx), (int)((id / nx) % ny), (int)(id / ((size_t)nx * ny))));
+      if (id == sid) break;
+    }
+    std::reverse(raw.begin(), raw.end());
+    // the true end points replace the voxel centres when they can be reached in a straight line
+    if (line_clear(start, raw.front())) raw.insert(raw.begin(), start);
+    if (line_clear(raw.back(), goal)) raw.push_back(goal);
+    out->clear();
+    out->push_back(raw.front());
+    size_t i = 0;
+    while (i + 1 < raw.size()) {
+      size_t j = raw.size() - 1;
+      while (j > i + 1 && !line_clear(raw[i], raw[j])) --j;
+      out->push_back(raw[j]);
+      i = j;
+    }
+    return out->size() >= 2;
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -366,7 +560,7 @@ void hdsm_swarm_default_config(hdsm_swarm_config* c) {
   c->path_vel_min = 4.5, c->path_vel_max = 9.0, c->sens_dist = 0.05, c->sens_pot = 0.18;
   c->sens_other_agents = 1.0, c->path_vel_dec = 0.0, c->thresh_dist = 1.0, c->voxel_size = 0.3;
   c->grid_range[0] = 20.0, c->grid_range[1] = 20.0, c->grid_range[2] = 6.0, c->grid_z_min = 0.0;
-  c->n_it_decomp = 42, c->step_plan = 1;
+  c->n_it_decomp = 42, c->step_plan = 1, c->use_cvx_new = 0, c->reserved0 = 0;
 }
 
 int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int32_t n_rob, int32_t first_id,
@@ -384,6 +578,7 @@ int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int3
     Agent& a = sw->agents[k];
     a.id = first_id + k;
     for (int ax = 0; ax < 3; ++ax) a.start[ax] = starts[3 * k + ax], a.goal[ax] = goals[3 * k + ax];
+    a.path = {a.start, a.goal};
     a.state_curr.fill(0.0);
     for (int ax = 0; ax < 3; ++ax) a.state_curr[ax] = a.start[ax];
   }
@@ -463,16 +658,28 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
   return HDSM_OK;
 }
 
-int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path) {
+int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32_t* n_path) {
   Swarm* sw = static_cast<Swarm*>(swarm);
-  if (!sw || !path || !n_path) return HDSM_ERR_BAD_ARG;
+  if (!sw || !path || !n_path || pmax < 2) return HDSM_ERR_BAD_ARG;
+  const double need = sw->prm.n_hor * sw->cfg.path_vel_max * sw->prm.dt;  // SamplePath never walks further than this
   for (int k = 0; k < sw->n_local; ++k) {
     const std::vector<V3> pl = reference_polyline(sw->agents[k]);
-    n_path[k] = (int32_t)pl.size();
-    for (int i = 0; i < 3; ++i)
-      for (int c = 0; c < 3; ++c) path[((size_t)k * 3 + i) * 3 + c] = i < (int)pl.size() ? pl[i][c] : pl.back()[c];
+    int n = (int)pl.size();
+    if (n > pmax) {
+      double len = 0;
+      for (int i = 0; i + 1 < pmax; ++i) len += norm(sub(pl[i + 1], pl[i]));
+      if (len <= need) return HDSM_ERR_CAPACITY;
+      n = pmax;
+    }
+    n_path[k] = n;
+    for (int i = 0; i < pmax; ++i)
+      for (int c = 0; c < 3; ++c) path[((size_t)k * pmax + i) * 3 + c] = i < n ? pl[i][c] : pl[n - 1][c];
   }
   return HDSM_OK;
+}
+
+int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path) {
+  return hdsm_swarm_reference_inputs_n(swarm, 3, path, n_path);
 }
 
 int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel) {
@@ -507,6 +714,70 @@ int hdsm_swarm_set_world(void* swarm, const int8_t* occupancy, const int32_t dim
   sw->world.assign(occupancy, occupancy + (size_t)dim[0] * dim[1] * dim[2]);
   sw->has_world = true;
   return HDSM_OK;
+}
+
+int hdsm_swarm_set_paths(void* swarm, const double* paths, const int32_t* n_path, int32_t pmax) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !paths || !n_path || pmax < 2) return HDSM_ERR_BAD_ARG;
+  for (int k = 0; k < sw->n_local; ++k)
+    if (n_path[k] < 2 || n_path[k] > pmax) return HDSM_ERR_BAD_ARG;
+  for (int k = 0; k < sw->n_local; ++k) {
+    Agent& ag = sw->agents[k];
+    ag.path.clear();
+    for (int i = 0; i < n_path[k]; ++i) {
+      const double* p = paths + ((size_t)k * pmax + i) * 3;
+      ag.path.push_back({p[0], p[1], p[2]});
+    }
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_get_paths(void* swarm, int32_t pmax, double* paths, int32_t* n_path) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !paths || !n_path || pmax < 2) return HDSM_ERR_BAD_ARG;
+  int rc = HDSM_OK;
+  for (int k = 0; k < sw->n_local; ++k) {
+    const Agent& ag = sw->agents[k];
+    n_path[k] = (int32_t)ag.path.size();
+    if ((int)ag.path.size() > pmax) rc = HDSM_ERR_CAPACITY;
+    for (int i = 0; i < pmax; ++i) {
+      const V3& p = ag.path[i < (int)ag.path.size() ? i : (int)ag.path.size() - 1];
+      for (int c = 0; c < 3; ++c) paths[((size_t)k * pmax + i) * 3 + c] = p[c];
+    }
+  }
+  return rc;
+}
+
+int hdsm_swarm_route(void* swarm, int32_t* n_failed) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !sw->has_world) return HDSM_ERR_BAD_ARG;
+  const Router router(*sw);
+  int failed = 0;
+  for (Agent& ag : sw->agents) {
+    std::vector<V3> path;
+    if (router.route(ag.start, ag.goal, &path)) {
+      // the reference sampling starts ON the path and corridor seeds are taken along it: the first point is the start
+      if (norm(sub(path.front(), ag.start)) > 0) path.insert(path.begin(), ag.start);
+      if (norm(sub(path.back(), ag.goal)) > 0) path.push_back(ag.goal);
+      ag.path.swap(path);
+    } else {
+      ag.path = {ag.start, ag.goal};
+      ++failed;
+    }
+  }
+  if (n_failed) *n_failed = failed;
+  return HDSM_OK;
+}
+
+int hdsm_swarm_corridor_errors(void* swarm, int32_t* codes) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw) return HDSM_ERR_BAD_ARG;
+  int n = 0;
+  for (int k = 0; k < sw->n_local; ++k) {
+    if (codes) codes[k] = sw->agents[k].corridor_rc;
+    n += sw->agents[k].corridor_rc != 0;
+  }
+  return n;
 }
 
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail) {

@@ -19,7 +19,8 @@ HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACIT
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
            "hdsm_reset_warm_start", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new",
-           "hdsm_swarm_set_world", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")
+           "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
+           "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")
 
 
 class HdsmError(RuntimeError):

@@ -23,6 +23,7 @@ class SwarmConfig(C.Structure):
         ("sens_pot", C.c_double), ("sens_other_agents", C.c_double), ("path_vel_dec", C.c_double),
         ("thresh_dist", C.c_double), ("voxel_size", C.c_double), ("grid_range", C.c_double * 3),
         ("grid_z_min", C.c_double), ("n_it_decomp", C.c_int32), ("step_plan", C.c_int32),
+        ("use_cvx_new", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -32,16 +33,7 @@ def default_swarm_config():
     return cfg
 
 
-def circle_scenario(n, radius=None, cx=18.0, cy=15.0, z=1.5):
-    """start/goal of multi_agent_planner_circle.launch.py:36-44: agent k starts at angle 2 pi k / n, its goal
-    is the start of agent (k + n//2) mod n. The shipped radius (22 m) is kept while the chord between
-    neighbours stays >= 1 m; larger swarms use R = n / (2 pi)."""
-    if radius is None:
-        radius = max(22.0, n / (2 * np.pi))
-    ang = 2 * np.pi * np.arange(n) / n
-    starts = np.stack([cx + radius * np.cos(ang), cy + radius * np.sin(ang), np.full(n, z)], axis=1)
-    goals = starts[(np.arange(n) + n // 2) % n].copy()
-    return starts, goals
+from .scenarios import circle_scenario, lattice_scenario  # noqa: E402,F401  (scenario geometry lives in scenarios.py)
 
 
 def lane_forest_scenario(n_y, n_z=1, pitch=2.01, length=96.01, y0=5.0, z0=1.5, voxel=0.3, seed=0,
@@ -141,14 +133,42 @@ class SwarmShard:
             raise _lib.HdsmError(rc, "hdsm_swarm_prepare")
         return i
 
-    def reference_inputs(self):
+    def reference_inputs(self, pmax=3):
         """Polyline each agent's reference will be sampled along this round (for hdsm_reference, f1)."""
-        path = np.zeros((self.n_local, 3, 3))
+        path = np.zeros((self.n_local, pmax, 3))
         n_path = np.zeros(self.n_local, np.int32)
-        rc = self.lib.hdsm_swarm_reference_inputs(self.h, _p(path, C.c_double), _p(n_path, C.c_int32))
+        rc = self.lib.hdsm_swarm_reference_inputs_n(self.h, C.c_int32(pmax), _p(path, C.c_double), _p(n_path, C.c_int32))
         if rc:
-            raise _lib.HdsmError(rc, "hdsm_swarm_reference_inputs")
+            raise _lib.HdsmError(rc, "hdsm_swarm_reference_inputs_n")
         return path, n_path
+
+    def route(self):
+        """Global paths on the world given to set_world (hdsm_swarm_route); returns the number of agents without a route."""
+        nf = C.c_int32(0)
+        rc = self.lib.hdsm_swarm_route(self.h, C.byref(nf))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_route")
+        return nf.value
+
+    def set_paths(self, paths, n_path):
+        paths = np.ascontiguousarray(paths, dtype=np.float64)
+        n_path = np.ascontiguousarray(n_path, dtype=np.int32)
+        rc = self.lib.hdsm_swarm_set_paths(self.h, _p(paths, C.c_double), _p(n_path, C.c_int32), C.c_int32(paths.shape[1]))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_set_paths")
+
+    def get_paths(self, pmax=64):
+        paths = np.zeros((self.n_local, pmax, 3))
+        n_path = np.zeros(self.n_local, np.int32)
+        rc = self.lib.hdsm_swarm_get_paths(self.h, C.c_int32(pmax), _p(paths, C.c_double), _p(n_path, C.c_int32))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_get_paths")
+        return paths, n_path
+
+    def corridor_errors(self):
+        codes = np.zeros(self.n_local, np.int32)
+        n = self.lib.hdsm_swarm_corridor_errors(self.h, _p(codes, C.c_int32))
+        return n, codes
 
     def set_reference(self, ref_full, path_vel):
         ref_full = np.ascontiguousarray(ref_full, dtype=np.float64)
@@ -191,6 +211,7 @@ class SwarmLoop:
         starts / goals [n_rob][3]: explicit scenario (default: the circular exchange)."""
         self.prm, self.n_rob, self.rank, self.world = prm, n_rob, rank, world
         self.reference = reference
+        self.pmax = 3  # points of the reference polyline handed to `reference` (16 after route())
         if starts is None:
             starts, goals = circle_scenario(n_rob, radius)
         starts, goals = np.asarray(starts, dtype=np.float64), np.asarray(goals, dtype=np.float64)
@@ -203,9 +224,18 @@ class SwarmLoop:
         self.has_plan = np.zeros(n_rob, np.uint8)
         self.round_idx = 0
 
+    def set_world(self, occupancy, origin, route=True):
+        """Occupied world for the corridor generator (f2) and, with route=True, global paths from the built-in router."""
+        self.shard.set_world(occupancy, origin)
+        if route:
+            failed = self.shard.route()
+            self.pmax = 16
+            return failed
+        return 0
+
     def step(self, record=None):
         if self.reference is not None:
-            path, n_path = self.shard.reference_inputs()
+            path, n_path = self.shard.reference_inputs(self.pmax)
             ids = np.arange(self.first, self.first + self.n_local, dtype=np.int32)
             ref_full, pv = self.reference(ids, path, n_path, self.plans_all, self.has_plan)
             self.shard.set_reference(ref_full, pv)
