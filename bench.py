@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — agent-replans/s of the HIP hot path on BASELINE.json's circle-exchange workload.
+"""bench.py — agent-replans/s of the HIP hot path on BASELINE.json's workload.
 
-One "step" = one replan round of the local shard: ONE launch of the fused kernel (separating planes +
-exact MIQP for every local agent) and, for N > 1, ONE RCCL all-gather of the new plans.
+One "step" = one replan round of the local shard: ONE launch of the fused kernel (separating planes + exact MIQP for
+every local agent) and, for N > 1, ONE RCCL all-gather of the new plans (hdsm_exchange_device, include/hdsm.h).
 
-Workload (config.workload): BASELINE configs[1] at N=1 — 64 agents, circular exchange, empty environment,
-H = 10, agent_agile_config.yaml weights/limits. For N GPUs the swarm has 64*N agents, 64 per GPU (weak
-scaling; --agents overrides, e.g. --agents 1024 with --gpus 8 is BASELINE configs[3]).
+Workload (config.workload): the configuration BASELINE.json's metric is quoted on — 1024 agents, circular exchange with
+R = 1024 / (2 pi) = 163 m (chord 1 m; the shipped 22 m ring would put the agents 0.135 m apart), empty environment,
+H = 10, agent_agile_config.yaml weights / limits (BASELINE configs[3]; it fits one GPU). The SAME 1024 agents and the
+SAME rounds are used at every N: they are sharded 1024 / N per GPU ("scaling": "strong").
 
-Inputs are produced by SIMULATION, not drawn from a distribution: during the untimed
-set-up the swarm is flown in closed loop with the device solver; the inputs of rounds
-[--first-round, --first-round + warmup + steps) — when the agents converge on the centre and many separating
-planes are active — are kept resident in HBM and replayed, one recorded round per step.
+Inputs are produced by SIMULATION, not drawn from a distribution: during the untimed set-up the
+swarm is flown in closed loop with the device solver from round 0; the inputs of rounds
+[--first-round - warmup, --first-round + steps) are kept resident in HBM and replayed, one recorded round per step. The
+TIMED rounds are [--first-round, --first-round + steps) whatever --warmup is. Default --first-round 165: the rounds in
+which the contracting ring reaches the 0.5 m separation limit (from round 167 on, root relaxations turn infeasible by the
+hundred: 286 of 1024 instances in round 173; the caller's shift fallback handles them) — the hard part of the flight.
 
-Prints ONE JSON line (rank 0). `roofline.achieved` = algorithmic bytes per launch (SURVEY.md section 8d
-formula x agents per launch) / mean kernel duration measured with HIP events on the launch stream.
+Prints ONE JSON line (rank 0). `roofline.achieved` = algorithmic bytes per launch (SURVEY.md section 8d formula x agents
+per launch) / mean kernel duration measured with HIP events on the launch stream. `roofline.after_prefilter` prices the
+same launches by the bytes the kernel really has to touch once the sphere prefilter has discarded distant neighbours
+(32-B sphere record per neighbour + 24 B per surviving (neighbour, step) pair, counted by the kernel itself).
 """
 import argparse
 import json
@@ -36,34 +41,33 @@ def algorithmic_bytes(n_rob, N, P, rbar):
             + (N + 1) * 9 * 8 + N * 3 * 8 + P)
 
 
+def workload_key(scenario, n_rob, N, world, first, K):
+    return f"{scenario}_a{n_rob}_h{N}_g{world}_r{first}_k{K}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--agents", type=int, default=0, help="total agents (default 64 per GPU)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--agents", type=int, default=1024, help="total agents of the swarm (the same at every --gpus)")
     ap.add_argument("--horizon", type=int, default=10)
-    ap.add_argument("--first-round", type=int, default=25, help="first recorded closed-loop round")
-    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall-clock budget of the CPU baseline leg")
+    ap.add_argument("--first-round", type=int, default=-1, help="first TIMED closed-loop round (default: 165 for the "
+                    "1024-agent circle, 25 otherwise); the warm-up replays the rounds just before it")
+    ap.add_argument("--scenario", choices=("circle", "forest", "fwf", "lanes"), default="circle",
+                    help="circle: antipodal exchange in an empty world (the bench line). forest: the same circle through the "
+                    "pillar forest of env_default_config.yaml scaled to the ring (BASELINE configs[2]). fwf: y-z lattice "
+                    "through forest + wall + forest (configs[4]; use --horizon 15). lanes: line formation through a lane "
+                    "forest (plumbing check). The last three are single-GPU workloads.")
+    ap.add_argument("--radius", type=float, default=0.0, help="circle radius [m], default max(22, agents / 2 pi)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-clock budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cache", default="", help="npz file with the recorded rounds: written after the closed-loop "
-                    "set-up if missing, loaded instead of flying the swarm if present (profiling runs: only the "
-                    "timed launches remain in the process)")
-    ap.add_argument("--no-event-pass", action="store_true", help="skip the second (HIP-event) pass")
-    ap.add_argument("--radius", type=float, default=0.0, help="circle radius [m]. Default: 22 m x number of GPUs when the "
-                    "swarm is the default 64 agents per GPU (the ring density of BASELINE configs[1] at every N); with "
-                    "--agents, max(22, agents / 2 pi) (chord >= 1 m, SURVEY.md section 8d)")
-    ap.add_argument("--scenario", choices=("circle", "lanes"), default="circle", help="circle: the antipodal exchange "
-                    "of BASELINE configs[1] (the bench line). lanes: a line formation (32 lanes wide, stacked in z) flying "
-                    "through a pillar forest; corridors come from the voxel decomposition (next row f2). Single GPU.")
+    ap.add_argument("--no-event-pass", action="store_true", help="skip the HIP-event pass and the host-buffer pass")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
                     "flight on the host (csrc/swarm_host.cpp) instead of with the f1 device kernel (hdsm_reference)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI, the product path) or gloo "
-                    "(testing the multi-rank flow on a box with fewer GPUs than ranks: ranks share devices and the "
-                    "all-gather is staged through the host)")
-    ap.add_argument("--round-offset", type=int, default=-1, help="index of the first TIMED recorded round "
-                    "(default = warmup). A profiling run uses --warmup 0 --round-offset 10 to launch exactly the "
-                    "rounds the default run times")
+    ap.add_argument("--dist-backend", default="rccl", help="rccl: the product path (hdsm_comm_* / hdsm_exchange_device, "
+                    "RCCL linked into libhdsm.so). gloo: testing the multi-rank flow on a box with fewer GPUs than ranks "
+                    "(ranks share devices, the all-gather is staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -72,96 +76,103 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local_rank = local_rank % max(1, torch.cuda.device_count()) if args.dist_backend == "gloo" else local_rank
         torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # torch.distributed is the LAUNCHER-side plumbing only (rendezvous, broadcast of the RCCL unique id, the barrier
+        # and the max-over-ranks of the contract); the data path is hdsm_exchange_device
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
-    host_staged = world > 1 and args.dist_backend != "nccl"
-
-    def all_gather_dev(full, shard):
-        """one all-gather of the shard into the full buffer (RCCL on device memory; host-staged under gloo)"""
-        if not host_staged:
-            dist.all_gather_into_tensor(full, shard)
-        else:
-            f = torch.empty(full.shape, dtype=full.dtype)
-            dist.all_gather_into_tensor(f, shard.cpu())
-            full.copy_(f)
 
     from multi_agent_pkgs_amd import lib, swarm
-    from multi_agent_pkgs_amd.params import agile_params
+    from multi_agent_pkgs_amd import scenarios as sc
+    from multi_agent_pkgs_amd.params import agile_params, agile_ref_config
 
     N = args.horizon
     prm = agile_params(N, max_rows_static=18)
     P, RS = prm.poly_hor, prm.max_rows_static
-    n_rob = args.agents if args.agents > 0 else 64 * world
-    radius = args.radius if args.radius > 0 else (22.0 * world if args.agents <= 0 else max(22.0, n_rob / (2 * np.pi)))
+    n_rob = args.agents
+    radius = args.radius if args.radius > 0 else max(22.0, n_rob / (2 * np.pi))
     first, n_local = swarm.shard_range(n_rob, rank, world)
     per = (n_rob + world - 1) // world
     K, W = args.steps, args.warmup
-    off = args.round_offset if args.round_offset >= 0 else W
-    n_rec = max(K + W, off + K)
+    first_round = args.first_round if args.first_round >= 0 else (165 if (args.scenario == "circle" and n_rob == 1024 and N == 10) else 25)
+    W = min(W, first_round)
+    rec_from, rec_to = first_round - W, first_round + K   # recorded rounds [rec_from, rec_to)
+    key = workload_key(args.scenario, n_rob, N, world, first_round, K)
 
-    solver = lib.Solver(prm, max(n_local, 1), n_rob, device=dev.index)
+    solver = lib.Solver(prm, max(n_local, 1), max(n_rob, world * per), device=dev.index)
     stream = torch.cuda.current_stream()
+    comm = None
+    if world > 1 and args.dist_backend == "rccl":
+        uid = [lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = lib.Comm(solver, uid[0], rank, world)
+        assert comm.world == world and comm.rank == rank
 
     # ---------------------------------------------------------------- set-up: closed-loop flight, recording
-    def allgather_np(local):
-        t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
-        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        all_gather_dev(full, t)
-        return full.cpu().numpy()
+    def allgather_np(local):  # set-up flight only (host arrays): through the launcher's process group
+        t = torch.from_numpy(np.ascontiguousarray(local))
+        full = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(full, t)
+        return full.numpy()
 
     def solve_np(inp, plans, has):
         return solver.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"],
                              inp["A"], inp["b"], plans, has)
 
     cfg = swarm.default_swarm_config()
-    rec, fails, total_rounds = [], 0, args.first_round + n_rec
-    cache = (args.cache + f".rank{rank}" if world > 1 else args.cache) if args.cache else ""
-    keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
-    if cache and os.path.exists(cache):
-        z = np.load(cache)
-        assert int(z["n_rob"]) == n_rob and int(z["N"]) == N and z["state"].shape[0] >= n_rec
-        assert "radius" not in z or abs(float(z["radius"]) - radius) < 1e-9
-        rec = [{k: z[k][r] for k in keys} for r in range(n_rec)]
-        fails = int(z["fails"])
-    else:
-        from multi_agent_pkgs_amd.params import agile_ref_config
-        rcfg = agile_ref_config()
+    rcfg = agile_ref_config()
 
-        def ref_dev(ids, path, n_path, plans, has):  # row f1 on the device: removes the host's O(n_rob^2 N) step
-            full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has)
-            return full, pv
+    def ref_dev(ids, path, n_path, plans, has):  # row f1 on the device: removes the host's O(n_rob^2 N) step
+        full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has)
+        return full, pv
 
-        starts = goals = None
-        if args.scenario == "lanes":
-            assert world == 1, "--scenario lanes is a single-GPU workload"
-            n_y = min(n_rob, 32)
-            assert n_rob % n_y == 0
-            starts, goals, occ, occ_origin = swarm.lane_forest_scenario(n_y, n_rob // n_y, seed=7)
-        loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
-                               allgather=allgather_np if world > 1 else None, radius=radius,
-                               reference=None if args.host_reference else ref_dev, starts=starts, goals=goals)
-        if args.scenario == "lanes":
-            loop.shard.set_world(occ, occ_origin)
-        for r in range(total_rounds):
-            out = loop.step(record=rec if r >= args.first_round else None)
-            if r >= args.first_round:
-                fails += int((out["status"] == 2).sum())
-        if cache:
-            np.savez(cache, n_rob=n_rob, N=N, fails=fails, radius=radius,
-                     **{k: np.stack([x[k] for x in rec]) for k in keys})
+    starts = goals = None
+    world_occ = None
+    if args.scenario != "circle":
+        assert world == 1, "--scenario forest / fwf / lanes are single-GPU workloads"
+    if args.scenario == "lanes":
+        n_y = min(n_rob, 32)
+        assert n_rob % n_y == 0
+        starts, goals, world_occ, world_origin = swarm.lane_forest_scenario(n_y, n_rob // n_y, seed=7)
+    elif args.scenario == "forest":
+        raw, world_origin = sc.forest_for_circle(n_rob, radius=radius, seed=13)
+        world_occ = sc.inflate(raw)
+    elif args.scenario == "fwf":
+        n_y = int(round(np.sqrt(n_rob)))
+        assert n_y * n_y == n_rob, "--scenario fwf takes a square number of agents (n x n lattice)"
+        starts, goals = sc.lattice_scenario(n_y, n_y)
+        raw, world_origin = sc.forest_wall_forest(int(np.ceil((10 + 2.01 * n_y) / 30)), int(np.ceil((9 + 2.01 * n_y) / 15)), seed=0)
+        world_occ = sc.inflate(raw)
+        cfg.grid_range[2], cfg.grid_z_min = 12.0, -6.0
+    loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
+                           allgather=allgather_np if world > 1 else None, radius=radius,
+                           reference=None if args.host_reference else ref_dev, starts=starts, goals=goals)
+    if world_occ is not None:
+        unrouted = loop.set_world(world_occ, world_origin, route=args.scenario != "lanes")
+        assert unrouted == 0
+    rec, fails, fails_timed = [], 0, 0
+    t_setup = time.perf_counter()
+    for r in range(rec_to):
+        out = loop.step(record=rec if r >= rec_from else None)
+        if r >= rec_from:
+            fails += int((out["status"] == 2).sum())
+        if r >= first_round:
+            fails_timed += int((out["status"] == 2).sum())
+    t_setup = time.perf_counter() - t_setup
+    if world > 1:
+        cnt = torch.tensor([fails_timed, fails], dtype=torch.int64)
+        dist.all_reduce(cnt)
+        fails_timed, fails = int(cnt[0]), int(cnt[1])
 
-    def stack(key, dtype):
-        return torch.from_numpy(np.ascontiguousarray(np.stack([x[key] for x in rec]), dtype=dtype)).to(dev)
+    def stack(key_, dtype):
+        return torch.from_numpy(np.ascontiguousarray(np.stack([x[key_] for x in rec]), dtype=dtype)).to(dev)
 
     d_agent = stack("agent_id", np.int32)
     d_state, d_ref = stack("state", np.float64), stack("ref", np.float64)
@@ -176,13 +187,22 @@ def main():
     d_status = torch.zeros(per, dtype=torch.int32, device=dev)
     d_obj = torch.zeros(per, dtype=torch.float64, device=dev)
     d_next = torch.zeros((world * per, N + 1, 9), dtype=torch.float64, device=dev)
+    d_next_has = torch.zeros(world * per, dtype=torch.uint8, device=dev)
 
-    def step(r):
+    def launch(r):
         solver.replan_device(d_agent[r], d_state[r], d_ref[r], d_npoly[r], d_nrows[r], d_A[r], d_b[r],
                              d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
                              d_status[:n_local], d_obj[:n_local], stream=stream)
+
+    def step(r):
+        launch(r)
         if world > 1:
-            all_gather_dev(d_next, d_traj)
+            if comm is not None:   # ONE collective: plans and has_plan flags travel in the same message
+                comm.exchange_device(d_traj, d_next, d_next_has, stream=stream)
+            else:                  # gloo: host-staged (flow check only)
+                f = torch.empty(d_next.shape, dtype=d_next.dtype)
+                dist.all_gather_into_tensor(f, d_traj.cpu())
+                d_next.copy_(f)
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,27 +211,30 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- timed region (the contract)
-    for r in range(off - W, off):
+    for r in range(0, W):
         step(r)
     barrier()
     t0 = time.perf_counter()
-    for r in range(off, off + K):
+    for r in range(W, W + K):
         step(r)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if not host_staged else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---------------------------------------------------------------- second pass: per-launch kernel time
+    # ---------------------------------------------------------------- second pass: per-launch kernel time (HIP events)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for k, r in enumerate(range(off, off + K) if not args.no_event_pass else []):
+    sph, pairs, it_all, nodes_all = [], [], [], []
+    for k, r in enumerate(range(W, W + K) if not args.no_event_pass else []):
         ev[k][0].record(stream)
-        solver.replan_device(d_agent[r], d_state[r], d_ref[r], d_npoly[r], d_nrows[r], d_A[r], d_b[r],
-                             d_plans[r], d_has[r], d_traj[:n_local], d_ctrl[:n_local], d_used[:n_local],
-                             d_status[:n_local], d_obj[:n_local], stream=stream)
+        launch(r)
         ev[k][1].record(stream)
+        st = solver.last_stats(n_local)
+        sw = solver.last_sweep_stats(n_local)
+        sph.append(sw["sphere_records"].astype(np.int64).sum()), pairs.append(sw["pairs"].astype(np.int64).sum())
+        it_all.append(st["qp_iters"].copy()), nodes_all.append(st["nodes"].copy())
     torch.cuda.synchronize()
     kern_ms = (np.array([a.elapsed_time(b) for a, b in ev]) if not args.no_event_pass
                else np.full(K, elapsed / K * 1e3))
@@ -223,40 +246,46 @@ def main():
     host_ms = None
     if world == 1 and not args.no_event_pass:
         t1 = time.perf_counter()
-        for r in range(off, off + K):
+        for r in range(W, W + K):
             solve_np(rec[r], rec[r]["plans"], rec[r]["has_plan"])
         host_ms = (time.perf_counter() - t1) / K * 1e3
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU restatement (oracle/hdsm_oracle.c) on the SAME recorded rounds, farmed over all host cores:
-        # one task = one recorded round (its agents solved one after the other by one thread, mirroring the
-        # reference's one-process-per-agent, Threads=1 deployment); tasks repeat until ~cpu_seconds of work.
+        # CPU restatement (oracle/hdsm_oracle.c) on a BOUNDED SAMPLE of the same timed rounds, farmed over all host
+        # cores: one task = a block of 16 agents of one recorded round solved one after the other by one thread (the
+        # reference's one-process-per-agent, Threads=1 deployment); as many tasks as fit the budget.
         from concurrent.futures import ThreadPoolExecutor
         from oracle import pyoracle as orc
         orc.lib()
         cores = os.cpu_count() or 1
+        BLK = 16
+        blocks = [(r, a) for r in range(W, W + K) for a in range(0, n_local, BLK)]
+        rng = np.random.default_rng(0)
+        rng.shuffle(blocks)
 
-        def one(x):
-            orc.replan(prm, x["agent_id"], x["state"], x["ref"], x["n_poly"], x["n_rows"], x["A"], x["b"],
-                       x["plans"], x["has_plan"], n_threads=1)
-            return n_local
+        def one(ra):
+            r, a = ra
+            x = rec[r]
+            sl = slice(a, min(a + BLK, n_local))
+            orc.replan(prm, x["agent_id"][sl], x["state"][sl], x["ref"][sl], x["n_poly"][sl], x["n_rows"][sl], x["A"][sl],
+                       x["b"][sl], x["plans"], x["has_plan"], n_threads=1)
+            return sl.stop - sl.start
 
-        sample = rec[off:off + K]
         t1 = time.perf_counter()
-        one(sample[0])
+        one(blocks[0])
         per_task = max(time.perf_counter() - t1, 1e-4)
-        reps = int(min(max(1, args.cpu_seconds * cores / (per_task * len(sample))), 200))
-        tasks = sample * reps
+        n_tasks = int(min(max(cores, args.cpu_seconds * cores / per_task), 50 * len(blocks)))
+        tasks = [blocks[i % len(blocks)] for i in range(n_tasks)]
         t1 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as ex:
             done = sum(ex.map(one, tasks))
         dt_cpu = time.perf_counter() - t1
         cpu = {"value": done / dt_cpu, "unit": "agent-replans/s", "cores": cores, "kind": "port",
-               "sample": f"{len(sample)} recorded rounds x {n_local} agents x {reps} repeats of the same "
-                         f"workload on the CPU restatement (oracle/hdsm_oracle.c, not Gurobi), "
-                         f"one round per thread, {cores} threads",
+               "sample": f"{n_tasks} blocks of {BLK} agents drawn from the {K} timed rounds ({done} agent-replans) on the CPU "
+                         f"restatement (oracle/hdsm_oracle.c: cold-started dense active set, not Gurobi), one block per "
+                         f"thread, {cores} threads",
                "seconds": dt_cpu, "per_core_replans_per_s": done / dt_cpu / min(cores, len(tasks))}
 
     if rank == 0:
@@ -264,41 +293,61 @@ def main():
         B = algorithmic_bytes(n_rob, N, P, rows_mean)
         mean_ms = float(kern_ms.mean())
         achieved = B * n_local / (mean_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        after = None
+        if sph:
+            fixed = B - (n_rob - 1) * N * 24   # everything but the neighbour positions
+            need = (np.array(sph) * 32 + np.array(pairs) * 24 + fixed * n_local).mean()
+            a2 = need / (mean_ms * 1e-3) / 1e9
+            after = {"bytes_per_launch": float(need), "achieved": a2, "frac": a2 / HBM_PEAK_GBS,
+                     "what": "32 B per sphere record read + 24 B per (neighbour, step) pair that survived the prefilter, "
+                             "counted by the kernel over all sweeps, + the per-instance inputs / outputs"}
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_{key}.json")
+        if os.path.exists(pmc):   # only a PMC summary taken on THIS workload (same agents, rounds, GPUs) is quoted
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                z = json.load(open(pmc))
+                if z.get("workload_key") == key:
+                    traffic, traffic_src = z.get("hbm_bytes_per_launch"), os.path.relpath(pmc, ROOT)
             except Exception:
                 traffic = None
+        names = {"circle": f"{n_rob} agents circular exchange (R = {radius:g} m), empty env",
+                 "forest": f"{n_rob} agents circular exchange (R = {radius:g} m) through a pillar forest (0.2 pillars / m^2, "
+                           f"corridors by voxel decomposition, <= {int(max(x['n_rows'].max() for x in rec))} static rows)",
+                 "fwf": f"{n_rob} agents on a y-z lattice through forest + wall + forest (corridors by voxel decomposition)",
+                 "lanes": f"{n_rob} agents in line formation through a lane forest"}
+        it_cat = np.concatenate(it_all) if it_all else stats["qp_iters"]
         line = {
             "metric": "agent QP-replans/sec", "value": value, "unit": "agent-replans/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"{n_rob} agents circular exchange (R = {radius:g} m), empty env" if args.scenario == "circle"
-                                    else f"{n_rob} agents in line formation through a lane forest (corridors by voxel "
-                                         f"decomposition, <= {int(max(x['n_rows'].max() for x in rec))} static rows)") + f", H={N}, "
-                                   f"poly_hor={P}, closed-loop rounds {args.first_round}..{total_rounds - 1} replayed",
-                       "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
-                       "parallelism": f"agents sharded over {world} GPU(s), one all-gather per round"},
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": names[args.scenario] + f", H={N}, poly_hor={P}, closed-loop rounds "
+                                   f"{first_round}..{first_round + K - 1} replayed (warm-up: rounds {rec_from}..{first_round - 1})",
+                       "workload_key": key, "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
+                       "parallelism": f"agents sharded over {world} GPU(s), one RCCL all-gather per round"
+                                      if world > 1 else "one GPU"},
             "p50_solve_latency_ms": float(np.percentile(kern_ms, 50)),
             "p95_solve_latency_ms": float(np.percentile(kern_ms, 95)),
             "kernel_ms_mean": mean_ms,
             "host_buffer_path": None if host_ms is None else {
                 "ms_per_round": host_ms, "agent_replans_per_s": n_rob / (host_ms * 1e-3),
                 "what": "hdsm_replan with host pointers (PCIe-inclusive: H2D inputs, kernel, D2H outputs, sync)"},
-            "failed_instances_recorded": fails,
-            "solver_stats_last_round": {"qp_iters_max": int(stats["qp_iters"].max()),
-                                        "qp_iters_mean": float(stats["qp_iters"].mean()),
-                                        "nodes_max": int(stats["nodes"].max()),
-                                        "sweeps_max": int(stats["sweeps"].max()),
-                                        "staged_rows_max": int(stats["cand"].max())},
+            "failed_instances_timed_rounds": fails_timed, "failed_instances_recorded": fails,
+            "setup_flight_s": t_setup,
+            "k_replan_launch_sequence": {"setup_flight": rec_to, "warmup": W, "timed": K,
+                                         "event_pass": 0 if args.no_event_pass else K,
+                                         "host_pass": K if host_ms is not None else 0},
+            "solver_stats_timed_rounds": {"qp_iters_max": int(it_cat.max()), "qp_iters_mean": float(it_cat.mean()),
+                                          "qp_iters_p99": float(np.percentile(it_cat, 99)),
+                                          "nodes_max": int(np.concatenate(nodes_all).max()) if nodes_all else int(stats["nodes"].max()),
+                                          "staged_rows_max_last_round": int(stats["cand"].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_replan": B, "kernel": "k_replan"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_replan": B, "kernel": "k_replan", "after_prefilter": after},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -2,10 +2,12 @@
 // AC = multi_agent_planner/src/agent_class.cpp of lis-epfl/multi_agent_pkgs. Pure host C++.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
 #include <queue>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -430,8 +432,9 @@ struct Router {
     const double vs = sw.cfg.voxel_size;
     return {sw.worigin[0] + (i + 0.5) * vs, sw.worigin[1] + (j + 0.5) * vs, sw.worigin[2] + (k + 0.5) * vs};
   }
-  // every voxel touched by the segment (sampled at a quarter voxel) is free; points outside the world count as blocked
-  bool line_clear(const V3& a, const V3& b) const {
+  // every voxel touched by the segment (sampled at a quarter voxel) is free — with `strict`, also outside the band next to
+  // obstacles; points outside the world count as blocked
+  bool line_clear(const V3& a, const V3& b, bool strict = false) const {
     const double len = norm(sub(b, a)), step = sw.cfg.voxel_size / 4;
     const int n = (int)std::ceil(len / step);
     for (int t = 0; t <= n; ++t) {
@@ -439,6 +442,7 @@ struct Router {
       int v[3];
       voxel_of(p, v);
       if (blocked(v[0], v[1], v[2])) return false;
+      if (strict && cls[idx(v[0], v[1], v[2])] != 0) return false;
     }
     return true;
   }
@@ -463,8 +467,15 @@ struct Router {
     }
     return false;
   }
-  // weighted A* (26-connected, Euclidean heuristic x 1.2, cells of the near band cost 3x), then greedy shortening
-  bool route(const V3& start, const V3& goal, std::vector<V3>* out) const {
+  // weighted A* (26-connected, Euclidean heuristic x 2: greedy enough to run straight through a forest and to flood only
+  // the face of a wall until it finds a gap; cells of the near band cost 2x), searched inside a box around start and goal
+  // (dense arrays, one workspace per thread), then greedy shortening. The whole world is searched if the box has no route.
+  struct Work {
+    std::vector<float> g;
+    std::vector<int32_t> parent;
+    std::vector<uint8_t> state;
+  };
+  bool route(const V3& start, const V3& goal, std::vector<V3>* out, Work& wk) const {
     int s[3], g[3];
     voxel_of(start, s), voxel_of(goal, g);
     if (!in(s[0], s[1], s[2]) || !in(g[0], g[1], g[2])) return false;
@@ -472,69 +483,78 @@ struct Router {
     // the planner only ever sees a local grid of grid_range[2] metres of height around the agent: the route stays within
     // half of that above and below the start / goal altitudes (it does not climb over a forest)
     const int band = (int)std::floor(0.5 * sw.cfg.grid_range[2] / sw.cfg.voxel_size);
-    const int k_lo = std::min(s[2], g[2]) - band, k_hi = std::max(s[2], g[2]) + band;
-    struct Node {
-      double f;
-      size_t id;
-      bool operator<(const Node& o) const { return f > o.f; }
-    };
-    struct Rec {
-      double g;
-      size_t parent;
-      bool closed;
-    };
-    std::unordered_map<size_t, Rec> rec;
-    std::priority_queue<Node> open;
-    const size_t sid = idx(s[0], s[1], s[2]), gid = idx(g[0], g[1], g[2]);
-    auto h = [&](int i, int j, int k) {
-      const double a = i - g[0], b = j - g[1], c = k - g[2];
-      return 1.2 * std::sqrt(a * a + b * b + c * c);
-    };
-    rec[sid] = {0.0, sid, false};
-    open.push({h(s[0], s[1], s[2]), sid});
+    const int n[3] = {nx, ny, nz};
+    std::vector<int32_t> chain;
+    int lo[3], hi[3], ext[3];
     bool found = false;
-    size_t expanded = 0;
-    const size_t budget = 4000000;
-    while (!open.empty() && expanded < budget) {
-      const Node cur = open.top();
-      open.pop();
-      Rec& rc = rec[cur.id];
-      if (rc.closed) continue;
-      rc.closed = true;
-      ++expanded;
-      if (cur.id == gid) {
-        found = true;
-        break;
+    for (int attempt = 0; attempt < 2 && !found; ++attempt) {
+      const int margin[3] = {attempt ? nx : 12, attempt ? ny : 40, band};
+      size_t cells = 1;
+      for (int ax = 0; ax < 3; ++ax) {
+        lo[ax] = std::max(0, std::min(s[ax], g[ax]) - margin[ax]);
+        hi[ax] = std::min(n[ax] - 1, std::max(s[ax], g[ax]) + margin[ax]);
+        ext[ax] = hi[ax] - lo[ax] + 1;
+        cells *= (size_t)ext[ax];
       }
-      const int ci = (int)(cur.id % nx), cj = (int)((cur.id / nx) % ny), ck = (int)(cur.id / ((size_t)nx * ny));
-      const double gc = rc.g;
-      for (int dk = -1; dk <= 1; ++dk)
-        for (int dj = -1; dj <= 1; ++dj)
-          for (int di = -1; di <= 1; ++di) {
-            if (!di && !dj && !dk) continue;
-            const int ni = ci + di, nj = cj + dj, nk = ck + dk;
-            if (nk < k_lo || nk > k_hi || blocked(ni, nj, nk)) continue;
-            // no squeezing diagonally between two blocked voxels
-            if (di && dj && (blocked(ci + di, cj, ck) || blocked(ci, cj + dj, ck))) continue;
-            if (di && dk && (blocked(ci + di, cj, ck) || blocked(ci, cj, ck + dk))) continue;
-            if (dj && dk && (blocked(ci, cj + dj, ck) || blocked(ci, cj, ck + dk))) continue;
-            const size_t nid = idx(ni, nj, nk);
-            const double w = std::sqrt((double)(di * di + dj * dj + dk * dk)) * (cls[nid] == 1 ? 3.0 : 1.0);
-            const double ng = gc + w;
-            auto it = rec.find(nid);
-            if (it == rec.end() || (!it->second.closed && ng < it->second.g)) {
-              rec[nid] = {ng, cur.id, false};
-              open.push({ng + h(ni, nj, nk), nid});
+      if (cells > (size_t)400000000) return false;
+      wk.g.assign(cells, 0.0f), wk.parent.assign(cells, -1), wk.state.assign(cells, 0);
+      auto lid = [&](int i, int j, int k) { return (int32_t)((i - lo[0]) + ext[0] * ((j - lo[1]) + ext[1] * (k - lo[2]))); };
+      auto h = [&](int i, int j, int k) {
+        const double a = i - g[0], b = j - g[1], c = k - g[2];
+        return 2.0 * std::sqrt(a * a + b * b + c * c);
+      };
+      struct Node {
+        float f;
+        int32_t id;
+        bool operator<(const Node& o) const { return f > o.f; }
+      };
+      std::priority_queue<Node> open;
+      const int32_t sid = lid(s[0], s[1], s[2]), gid = lid(g[0], g[1], g[2]);
+      wk.state[sid] = 1, wk.parent[sid] = sid;
+      open.push({(float)h(s[0], s[1], s[2]), sid});
+      while (!open.empty()) {
+        const Node cur = open.top();
+        open.pop();
+        if (wk.state[cur.id] == 2) continue;
+        wk.state[cur.id] = 2;
+        if (cur.id == gid) {
+          found = true;
+          break;
+        }
+        const int ci = lo[0] + cur.id % ext[0], cj = lo[1] + (cur.id / ext[0]) % ext[1], ck = lo[2] + cur.id / (ext[0] * ext[1]);
+        const float gc = wk.g[cur.id];
+        for (int dk = -1; dk <= 1; ++dk)
+          for (int dj = -1; dj <= 1; ++dj)
+            for (int di = -1; di <= 1; ++di) {
+              if (!di && !dj && !dk) continue;
+              const int ni = ci + di, nj = cj + dj, nk = ck + dk;
+              if (ni < lo[0] || ni > hi[0] || nj < lo[1] || nj > hi[1] || nk < lo[2] || nk > hi[2]) continue;
+              if (blocked(ni, nj, nk)) continue;
+              // no squeezing diagonally between two blocked voxels
+              if (di && dj && (blocked(ci + di, cj, ck) || blocked(ci, cj + dj, ck))) continue;
+              if (di && dk && (blocked(ci + di, cj, ck) || blocked(ci, cj, ck + dk))) continue;
+              if (dj && dk && (blocked(ci, cj + dj, ck) || blocked(ci, cj, ck + dk))) continue;
+              const int32_t nid = lid(ni, nj, nk);
+              if (wk.state[nid] == 2) continue;
+              const float w = std::sqrt((float)(di * di + dj * dj + dk * dk)) * (cls[idx(ni, nj, nk)] == 1 ? 2.0f : 1.0f);
+              const float ng = gc + w;
+              if (wk.state[nid] == 0 || ng < wk.g[nid]) {
+                wk.state[nid] = 1, wk.g[nid] = ng, wk.parent[nid] = cur.id;
+                open.push({ng + (float)h(ni, nj, nk), nid});
+              }
             }
-          }
+      }
+      if (found) {
+        for (int32_t id = gid;; id = wk.parent[id]) {
+          chain.push_back(id);
+          if (id == sid) break;
+        }
+      }
     }
     if (!found) return false;
     std::vector<V3> raw;
-    for (size_t id = gid;; id = rec[id].parent) {
-      raw.push_back(centre((int)(id % nx), (int)((id / nx) % ny), (int)(id / ((size_t)nx * ny))));
-      if (id == sid) break;
-    }
-    std::reverse(raw.begin(), raw.end());
+    for (auto it = chain.rbegin(); it != chain.rend(); ++it)
+      raw.push_back(centre(lo[0] + *it % ext[0], lo[1] + (*it / ext[0]) % ext[1], lo[2] + *it / (ext[0] * ext[1])));
     // the true end points replace the voxel centres when they can be reached in a straight line
     if (line_clear(start, raw.front())) raw.insert(raw.begin(), start);
     if (line_clear(raw.back(), goal)) raw.push_back(goal);
@@ -543,7 +563,13 @@ struct Router {
     size_t i = 0;
     while (i + 1 < raw.size()) {
       size_t j = raw.size() - 1;
-      while (j > i + 1 && !line_clear(raw[i], raw[j])) --j;
+      // shortcuts keep the clearance the search paid for: they may not enter the band next to obstacles (where the raw path
+      // itself runs through that band — a narrow passage — its cells are kept one by one)
+      while (j > i + 1 && !line_clear(raw[i], raw[j], true)) --j;
+      if (j == i + 1) {  // inside the band: plain line of sight, over a short stretch only
+        j = std::min(raw.size() - 1, i + 20);
+        while (j > i + 1 && !line_clear(raw[i], raw[j])) --j;
+      }
       out->push_back(raw[j]);
       i = j;
     }
@@ -752,20 +778,31 @@ int hdsm_swarm_route(void* swarm, int32_t* n_failed) {
   Swarm* sw = static_cast<Swarm*>(swarm);
   if (!sw || !sw->has_world) return HDSM_ERR_BAD_ARG;
   const Router router(*sw);
-  int failed = 0;
-  for (Agent& ag : sw->agents) {
-    std::vector<V3> path;
-    if (router.route(ag.start, ag.goal, &path)) {
-      // the reference sampling starts ON the path and corridor seeds are taken along it: the first point is the start
-      if (norm(sub(path.front(), ag.start)) > 0) path.insert(path.begin(), ag.start);
-      if (norm(sub(path.back(), ag.goal)) > 0) path.push_back(ag.goal);
-      ag.path.swap(path);
-    } else {
-      ag.path = {ag.start, ag.goal};
-      ++failed;
+  std::atomic<int> failed{0}, next{0};
+  auto worker = [&]() {
+    Router::Work wk;
+    for (int k = next.fetch_add(1); k < sw->n_local; k = next.fetch_add(1)) {
+      Agent& ag = sw->agents[k];
+      std::vector<V3> path;
+      if (router.route(ag.start, ag.goal, &path, wk)) {
+        // the reference sampling starts ON the path and corridor seeds are taken along it: the first point is the start
+        if (norm(sub(path.front(), ag.start)) > 0) path.insert(path.begin(), ag.start);
+        if (norm(sub(path.back(), ag.goal)) > 0) path.push_back(ag.goal);
+        ag.path.swap(path);
+      } else {
+        ag.path = {ag.start, ag.goal};
+        failed.fetch_add(1);
+      }
     }
-  }
-  if (n_failed) *n_failed = failed;
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
+  if ((int)nt > sw->n_local) nt = (unsigned)(sw->n_local > 0 ? sw->n_local : 1);
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  if (n_failed) *n_failed = failed.load();
   return HDSM_OK;
 }
 

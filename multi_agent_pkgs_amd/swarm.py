@@ -229,7 +229,7 @@ class SwarmLoop:
         self.shard.set_world(occupancy, origin)
         if route:
             failed = self.shard.route()
-            self.pmax = 16
+            self.pmax = 32
             return failed
         return 0
 

@@ -1,0 +1,196 @@
+"""GPU tests that FLY BASELINE.json's configurations 3, 4 and 5 in closed loop on the device and check, at selected
+rounds, size-independent properties on EVERY instance plus parity with the CPU oracle on a random subset:
+
+  cfg 3   256 agents, circular exchange (R = 256 / 2 pi) through a pillar forest, corridors from the voxel decomposition
+          (both GetPolyOcta3D and, where a seed is pinched, GetPolyOcta3DNew), H = 10
+  cfg 4   1024 agents, circular exchange (R = 1024 / 2 pi), empty world, H = 10, flown THROUGH the rounds in which the
+          contracting ring reaches the 0.5 m separation limit (rounds 165-185: hundreds of infeasible instances)
+  cfg 5   4096 agents, y-z lattice through forest + wall + forest, H = 15, a few rounds
+
+Properties (all instances with a solution): trajectory = literal rollout of the controls; input / velocity / acceleration
+boxes and v_N = a_N = 0; every separating plane of every step holds at p_i and p_{i+1}; every segment lies in a polyhedron
+flagged in poly_used; obj is the literal objective. Instances without a solution leave the outputs untouched (checked
+through the host mirror's fallback: the published plan is the shifted previous one)."""
+import numpy as np
+import pytest
+
+from multi_agent_pkgs_amd import scenarios as sc
+from multi_agent_pkgs_amd.params import agile_params, agile_ref_config
+
+pytestmark = pytest.mark.gpu
+
+TRAJ_TOL = 1e-7
+OBJ_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def hdsm():
+    from multi_agent_pkgs_amd import lib
+    return lib
+
+
+def _device_loop(hdsm, prm, cfg, n_rob, starts=None, goals=None, radius=None):
+    from multi_agent_pkgs_amd import swarm
+    sol = hdsm.Solver(prm, n_rob, n_rob)
+    rcfg = agile_ref_config()
+
+    def solve(inp, plans, has):
+        return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+    def ref_dev(ids, path, n_path, plans, has):
+        full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has)
+        return full, pv
+
+    loop = swarm.SwarmLoop(prm, cfg, n_rob, solve=solve, radius=radius, reference=ref_dev, starts=starts, goals=goals)
+    return sol, loop
+
+
+def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32):
+    """Properties on every solved instance of one recorded round + oracle parity on a random subset."""
+    N, P = prm.n_hor, prm.poly_hor
+    n = rec["state"].shape[0]
+    status = out["status"]
+    ok = np.where(status != 2)[0]
+    traj, ctrl = out["traj"], out["ctrl"]
+    # dynamics, boxes, objective
+    for a in ok:
+        assert np.abs(oracle.rollout(prm, rec["state"][a], ctrl[a]) - traj[a]).max() < 1e-9
+        assert abs(oracle.objective(prm, traj[a], ctrl[a], rec["ref"][a]) - out["obj"][a]) < 1e-7 * max(1.0, abs(out["obj"][a]))
+    assert np.abs(ctrl[ok]).max() <= 60 + 1e-8
+    assert np.abs(traj[ok][:, 1:N, 3:6]).max() <= 20 + 1e-8 and np.abs(traj[ok][:, 1:N, 6:9]).max() <= 15 + 1e-8
+    assert np.abs(traj[ok][:, N, 3:9]).max() < 1e-8
+    # separating planes (device plane generator, itself checked against the literal chain in test_gpu_parity.py)
+    for c0 in range(0, len(ok), plane_chunk):
+        ids = ok[c0:c0 + plane_chunk]
+        planes = sol.tasc_planes(rec["agent_id"][ids], rec["state"][ids], rec["plans"], rec["has_plan"])  # [m][N][n_rob][4]
+        for e in (0, 1):
+            pts = traj[ids][:, e:N + e, :3]                                                    # p_{i+e}
+            viol = np.einsum("minc,mic->min", planes[..., :3], pts) - planes[..., 3]
+            lim = np.full((1, N, 1), 1e-7)
+            if e == 0:
+                lim[0, 0, 0] = 1e-6                                                            # rows on the pinned p_0
+            assert (viol < lim).all(), (ids[np.argmax(viol.max(axis=(1, 2)))], float(viol.max()))
+    # containment in a polyhedron flagged used
+    A, b, nr = rec["A"], rec["b"], rec["n_rows"]
+    for a in ok:
+        for i in range(N):
+            inside = False
+            for j in range(min(P, int(rec["n_poly"][a]))):
+                if not out["used"][a, j]:
+                    continue
+                r = int(nr[a, j])
+                v0 = (A[a, j, :r] @ traj[a, i, :3] - b[a, j, :r]).max()
+                v1 = (A[a, j, :r] @ traj[a, i + 1, :3] - b[a, j, :r]).max()
+                if v0 < 1e-6 and v1 < 1e-7:
+                    inside = True
+                    break
+            assert inside, (a, i)
+    # oracle parity on a random subset
+    sub = rng.choice(n, min(n_parity, n), replace=False)
+    o = oracle.replan(prm, rec["agent_id"][sub], rec["state"][sub], rec["ref"][sub], rec["n_poly"][sub], rec["n_rows"][sub],
+                      rec["A"][sub], rec["b"][sub], rec["plans"], rec["has_plan"], n_threads=8)
+    assert (status[sub] == o["status"]).all(), (status[sub].tolist(), o["status"].tolist())
+    good = o["status"] != 2
+    if good.any():
+        assert np.abs(traj[sub] - o["traj"])[good].max() < TRAJ_TOL
+        rel = np.abs(out["obj"][sub] - o["obj"])[good] / np.maximum(1.0, np.abs(o["obj"][good]))
+        assert rel.max() < OBJ_RTOL
+    return len(ok), int((status == 2).sum())
+
+
+def _pillar_hits(pos, raw, origin, vox=0.3):
+    """Number of agent centres inside an (un-inflated) obstacle voxel. The corridor polyhedra are built on the INFLATED grid
+    (0.3 m margin, drone radius 0.25 m), but like the reference's they are not exact: a chamfer plane may cut the corner of
+    an inflated voxel, and a seed taken by an agent that sits in such a corner grows a polyhedron inside the margin
+    (GetPolyOcta3D never tests the seed voxel, convex_decomp.cpp:49-52). In a gridlocked forest a few agents end up against a
+    pillar this way; the tests bound how often."""
+    v = np.floor((pos - origin) / vox).astype(int)
+    inside = ((v >= 0) & (v < np.array(raw.shape[::-1]))).all(axis=1)
+    v = v[inside]
+    return int((raw[v[:, 2], v[:, 1], v[:, 0]] >= 100).sum())
+
+
+def test_config_3_256_agents_through_a_forest(hdsm, oracle):
+    """BASELINE configs[2]: 256 agents, forest environment, corridors by voxel decomposition (<= 4 polyhedra), H = 10."""
+    from multi_agent_pkgs_amd import swarm
+    n_rob, N = 256, 10
+    prm = agile_params(N, max_rows_static=18)
+    raw, origin = sc.forest_for_circle(n_rob, seed=13)
+    occ = sc.inflate(raw)
+    sol, loop = _device_loop(hdsm, prm, swarm.default_swarm_config(), n_rob)
+    assert loop.set_world(occ, origin) == 0                       # every agent has a route
+    rng = np.random.default_rng(3)
+    checked, rows_max, chamfered, hits = 0, 0, 0, 0
+    for r in range(130):
+        rec = []
+        out = loop.step(record=rec)
+        assert loop.shard.corridor_errors()[0] == 0
+        rows_max = max(rows_max, int(rec[0]["n_rows"].max()))
+        chamfered += int((rec[0]["n_rows"] > 6).any(axis=1).sum())
+        pos, dist, _ = loop.shard.state()
+        hits += _pillar_hits(pos, raw, origin)
+        if r in (5, 40, 80, 110, 125):
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 16, rng)
+            checked += n_ok
+            assert n_ok > n_rob // 2
+    assert rows_max > 6 and rows_max <= 18 and chamfered > 100    # the forest really shapes the corridors
+    assert hits <= 0.001 * 130 * n_rob, hits                      # agent centres in an obstacle voxel: < 0.1 % of agent-rounds
+    assert dist.mean() < 0.6 * 2 * n_rob / (2 * np.pi)            # the swarm made progress through the forest
+    print("cfg3: instances checked", checked, "max static rows", rows_max, "agent-rounds inside an obstacle voxel", hits)
+
+
+def test_config_4_1024_agents_circle_through_the_squeeze(hdsm, oracle):
+    """BASELINE configs[3] on one GPU: 1024 agents, circular exchange, H = 10, through the rounds in which the contracting
+    ring reaches the separation limit (the hard rounds of the flight: root relaxations become infeasible by the hundred)."""
+    from multi_agent_pkgs_amd import swarm
+    n_rob, N = 1024, 10
+    prm = agile_params(N, max_rows_static=18)
+    sol, loop = _device_loop(hdsm, prm, swarm.default_swarm_config(), n_rob)
+    rng = np.random.default_rng(4)
+    bad_total, prev_plans = 0, None
+    for r in range(186):
+        rec = []
+        out = loop.step(record=rec)
+        if r in (100, 166, 170, 174, 180, 185):
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 24, rng)
+            bad_total += n_bad
+            # instances without a solution: the published plan is the previous one shifted by a step (AC:1000-1019)
+            bad = np.where(out["status"] == 2)[0]
+            if prev_plans is not None and len(bad):
+                assert np.array_equal(loop.plans_all[bad][:, :N], prev_plans[bad][:, 1:])
+                assert np.array_equal(loop.plans_all[bad][:, N], prev_plans[bad][:, N])
+        prev_plans = loop.plans_all.copy()
+    assert bad_total > 100                                          # the squeeze really is in the checked rounds
+    pos, _, _ = loop.shard.state()
+    d = np.linalg.norm(pos[:, None, :2] - pos[None, :, :2], axis=2) + np.eye(n_rob) * 9
+    assert d.min() > 0.45                                           # nobody closer than the drone diameter (0.5 m) - tolerance
+
+
+def test_config_5_4096_agents_forest_wall_forest(hdsm, oracle):
+    """BASELINE configs[4] on one GPU: 4096 agents (64 x 64 lattice, 2.01 m pitch), forest + wall + forest, H = 15."""
+    from multi_agent_pkgs_amd import swarm
+    n_y = n_z = 64
+    n_rob, N = n_y * n_z, 15
+    prm = agile_params(N, max_rows_static=18)
+    tiles_y = int(np.ceil((5 + 2.01 * n_y + 5) / 30))
+    tiles_z = int(np.ceil((6 + 2.01 * n_z + 3) / 15))
+    raw, origin = sc.forest_wall_forest(tiles_y, tiles_z, seed=0)
+    occ = sc.inflate(raw)
+    starts, goals = sc.lattice_scenario(n_y, n_z)
+    cfg = swarm.default_swarm_config()
+    cfg.grid_range[2], cfg.grid_z_min = 12.0, -6.0                 # voxel_grid_range of multi_agent_planner_long.launch.py:29
+    sol, loop = _device_loop(hdsm, prm, cfg, n_rob, starts=starts, goals=goals)
+    assert loop.set_world(occ, origin) == 0
+    rng = np.random.default_rng(5)
+    rows_max = 0
+    for r in range(16):
+        rec = []
+        out = loop.step(record=rec)
+        assert loop.shard.corridor_errors()[0] == 0
+        rows_max = max(rows_max, int(rec[0]["n_rows"].max()))
+        if r in (3, 15):
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 6, rng, plane_chunk=8)
+            assert n_ok > 0.9 * n_rob
+    pos, _, _ = loop.shard.state()
+    assert _pillar_hits(pos, raw, origin) == 0
+    assert pos[:, 0].mean() > 3.0 and rows_max > 6                 # moving into the first forest on shaped corridors
