@@ -50,7 +50,8 @@ typedef enum hdsm_error {
   HDSM_ERR_BAD_ARG = -1,    /* null pointer, size out of range, unsupported parameter combination        */
   HDSM_ERR_NO_DEVICE = -2,  /* no gfx950 HIP device / device index out of range                           */
   HDSM_ERR_DEVICE = -3,     /* HIP runtime error (allocation, launch, copy); see hdsm_last_error()       */
-  HDSM_ERR_CAPACITY = -4    /* n_inst > max_instances or n_rob > handle capacity                         */
+  HDSM_ERR_CAPACITY = -4,   /* n_inst > max_instances or n_rob > handle capacity                         */
+  HDSM_ERR_COMM = -5        /* RCCL error in hdsm_comm_* / hdsm_exchange_device; see hdsm_last_error()    */
 } hdsm_error;
 
 /* Per-instance outcome. The reference never inspects Gurobi's status (AC:959-995): a time-limit WITH an
@@ -91,7 +92,23 @@ typedef struct hdsm_params {
    * the work). The caller must then keep the agent <-> instance index mapping stable between calls, or call
    * hdsm_reset_warm_start() when it changes.                                                              */
   int32_t warm_start;
+  /* Execution knobs (0 = library default everywhere). They shape the work, never the answer; the HDSM_* environment
+   * variables of the same names remain as overrides for scripts (validated, out-of-range values are ignored).   */
+  int32_t threads_per_instance; /* 256 (default) or 64 threads per agent-replan                      HDSM_THREADS      */
+  int32_t prefilter_min_agents; /* swarms of at least this many agents get the sphere prefilter
+                                   (default 256; negative = never)                                  HDSM_BOUNDS_MIN   */
+  int32_t duo_min_instances;    /* batches of at least this many instances run two workgroups per CU
+                                   (default: compute units + 1; negative = never)                   HDSM_DUO_MIN      */
+  int32_t presweep;             /* neighbour rows staged before the first active-set run: 0 automatic,
+                                   1 never, 2 always                                                HDSM_PRESWEEP     */
+  int32_t branch_rule;          /* branch on: 0 the most infeasible segment (default), 1 the first in time HDSM_BRANCH_RULE */
   int32_t reserved0;
+  double stage_radius;          /* [m] slack below which a neighbour row is staged (default 0.6)     HDSM_CAND_TAU     */
+  /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
+   * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and
+   * returns the incumbent (HDSM_LIMIT) or HDSM_NO_SOLUTION — what Gurobi does, and just as irreproducible. 0 = none
+   * (the deterministic work budgets above are the default and what every parity test uses).                      */
+  double time_limit_s;
 } hdsm_params;
 
 /* Fills `p` with the agile configuration shipped by the reference
@@ -128,7 +145,12 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
 /* Same contract, every pointer is a DEVICE pointer, the launch is asynchronous on `hip_stream`
  * (a hipStream_t passed as void*; NULL = the default stream). Nothing is copied or synchronised: this is
  * the form the batched harness and bench.py time, with inputs resident in HBM. `traj_out` may alias the
- * caller's shard of the NEXT round's plans buffer (it must not alias `plans_all` of this call).           */
+ * caller's shard of the NEXT round's plans buffer (it must not alias `plans_all` of this call).
+ * Streams: a handle owns per-instance device state (branch-and-bound snapshots, warm-start sets, the prefilter
+ * records). Launches on ONE stream are ordered by the stream; when a call arrives on a different stream than the
+ * previous launch of the same handle, the library makes the new stream wait for that launch (event), so successive
+ * calls never overlap on the handle's state whatever streams they use. The host-pointer entry points use the handle's
+ * own stream. Every entry point selects the handle's device itself.                                          */
 int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
                        const double* state_curr, const double* traj_ref, const int32_t* n_poly,
                        const int32_t* n_rows_static, const double* A_static, const double* b_static,
@@ -136,9 +158,13 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
                        double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
                        void* hip_stream);
 
-/* Level 1 — exact stand-in for the Gurobi part alone (AC:870-1019): the caller passes the fully formed
+/* Level 1 — stand-in for the Gurobi part alone (AC:870-1019): the caller passes the fully formed
  * per-step polyhedra poly_const_final_vec_[N][<=P] (AH:471), i.e. static rows followed by the neighbour
- * planes AddHyperplane appended.
+ * planes AddHyperplane appended. Accepted input = what GenerateTimeAwareSafeCorridor produces: every step has the
+ * SAME number of polyhedra, polyhedron (i, j) = the static rows of polyhedron j (identical for every step, at most
+ * max_rows_static of them) followed by rows that are identical for every j of that step (AddHyperplane appends each
+ * plane to all polyhedra of the step, AC:1217-1234). Anything else is rejected with HDSM_ERR_BAD_ARG: the solver
+ * treats the common suffix as ordinary rows and only the static head as the disjunction.
  *
  *   n_poly  [n_inst][N]          poly_const_final_vec_[i].size()
  *   n_rows  [n_inst][N][P]       rows of polyhedron (i, j)
@@ -167,8 +193,10 @@ typedef struct hdsm_ref_config {
  *            on the host with the map; NULL = path_vel_max (obstacle-free world)
  *   ref_full [n_inst][N+1][6]  traj_ref_curr_ (all N+1 rows: the increment check AC:569-585 needs them)
  *   ref      [n_inst][N][6]    rows 0..N-1, the layout hdsm_replan* reads (may be NULL)
- *   path_vel [n_inst]          path_vel_
- * Host pointers / device pointers + stream, like hdsm_replan / hdsm_replan_device.                          */
+ *   path_vel [n_inst]          path_vel_ (a single-point path, n_path = 1, writes 0: the reference leaves path_vel_ at its
+ *                              previous value there, AC:1598-1611, and never uses it)
+ * Host pointers / device pointers + stream, like hdsm_replan / hdsm_replan_device. The host form checks
+ * 1 <= n_path[k] <= pmax (HDSM_ERR_BAD_ARG); the device form trusts its caller.                             */
 int hdsm_reference(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int32_t n_rob,
                    const int32_t* agent_id, const double* path, const int32_t* n_path, int32_t pmax,
                    const double* vel_cap, const double* plans_all, const uint8_t* has_plan,
@@ -213,13 +241,43 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
 int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
                     int32_t* cand);
 
+/* More diagnostics of the last launch (host arrays, may be NULL):
+ *   sphere_records[n_inst]  32-byte prefilter records read over all sweeps (0 when the prefilter is off),
+ *   pairs[n_inst]           (neighbour, step) positions loaded by the sweeps, 24 bytes each,
+ *   flags[n_inst]           HDSM_FLAG_* bits: why an instance stopped short of a proof.                          */
+#define HDSM_FLAG_NODE_LIMIT 1u       /* max_nodes spent                                                        */
+#define HDSM_FLAG_ITER_LIMIT 2u       /* max_qp_iters spent                                                     */
+#define HDSM_FLAG_TIME_LIMIT 4u       /* time_limit_s spent                                                     */
+#define HDSM_FLAG_STAGING_OVERFLOW 8u /* more violated neighbour rows than staging slots: not a search budget   */
+int hdsm_last_sweep_stats(void* handle, int32_t n_inst, int32_t* sphere_records, int32_t* pairs, uint32_t* flags);
+
+/* ---- multi-GPU: the per-round exchange of the published plans -------------------------------------------------
+ * Replaces the DDS all-to-all of the reference (publisher AC:46-48 / 645-677, n_rob - 1 subscriptions AC:610-627,
+ * callback AC:629-643) by ONE RCCL all-gather per replan round. Agents are sharded in contiguous id blocks of `per`
+ * agents per rank (the last block may be padded). A rank publishes plans_local[per][N+1][9]; an agent WITHOUT a
+ * plan (has_plan = 0: nothing solved yet, AC:1134, or padding) is published as a record whose first entry is NaN,
+ * so the flag travels inside the same message — hdsm_publish_device writes that form from (traj, has_plan).
+ * hdsm_exchange_device all-gathers the shards into plans_all[world * per][N+1][9] (rank r's block at r * per) and
+ * derives has_plan_all[world * per] from the sentinel; both feed the next hdsm_replan_device / hdsm_reference_device
+ * directly. Everything is asynchronous on `hip_stream`; no host round trip.                                       */
+#define HDSM_COMM_ID_BYTES 128
+int hdsm_comm_unique_id(uint8_t id[HDSM_COMM_ID_BYTES]);      /* rank 0 creates it (ncclGetUniqueId), the launcher
+                                                                 hands it to every rank                         */
+int hdsm_comm_create(void* handle, const uint8_t id[HDSM_COMM_ID_BYTES], int32_t rank, int32_t world, void** comm);
+int hdsm_comm_info(void* comm, int32_t* rank, int32_t* world);
+void hdsm_comm_destroy(void* comm);
+int hdsm_publish_device(void* handle, int32_t per, int32_t n_local, const double* traj, const uint8_t* has_plan_local,
+                        double* plans_local, void* hip_stream);
+int hdsm_exchange_device(void* comm, int32_t per, const double* plans_local, double* plans_all, uint8_t* has_plan_all,
+                         void* hip_stream);
+
 /* Forget the working sets kept for warm_start (e.g. after re-assigning agents to instance indices).      */
 int hdsm_reset_warm_start(void* handle);
 
 /* Text of the last error on this thread (HIP error string or argument check that failed).                 */
 const char* hdsm_last_error(void);
 
-/* Library/ABI version: (major << 16) | minor.                                                             */
+/* Library/ABI version: (major << 16) | minor. 1.1: hdsm_params grew the execution knobs and time_limit_s.   */
 int32_t hdsm_version(void);
 
 #ifdef __cplusplus

@@ -3,7 +3,9 @@
 // One workgroup solves one agent-replan (hdsm_core.h); the launch is a plain 1-D grid of n_inst blocks.
 // There is no CPU path in this library: without a HIP device hdsm_create() fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,30 +60,61 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
   Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
 }
 
-// bounds[n_rob][4]: centre of the bounding box of steps 1..N of each published plan and the radius of the sphere
-// around it that holds them (radius -1 = no plan). One thread per agent; the replan kernel's sweeps use it to skip
-// whole neighbours (hdsm_wave_gi.h, sweep_planes). Only launched for swarms of at least bounds_min agents.
-__global__ __launch_bounds__(256) void k_plan_bounds(int N, int n_rob, const double* __restrict__ plans,
-                                                     const uint8_t* __restrict__ has_plan,
-                                                     double* __restrict__ bounds) {
+// Pre-pass of every level-2 launch, one thread per agent of the swarm:
+//   pos[n_rob][N][3]   positions of steps 1..N of every published plan, packed: the sweeps of the replan kernel read 24 B
+//                      per (neighbour, step) instead of striding through 72-B state records (zeros for agents without a plan);
+//   bounds[n_rob][4]   (only for swarms of at least bounds_min agents) centre of the bounding box of those positions and the
+//                      radius of the sphere around it that holds them (radius -1 = no plan): the sweeps use it to skip
+//                      whole neighbours (hdsm_wave_gi.h, sweep_planes).
+__global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
+                                                      const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
+                                                      double* __restrict__ bounds) {
   const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (k >= n_rob) return;
   double4 out = {0.0, 0.0, 0.0, -1.0};
+  double* pk = pos + (int64_t)k * N * 3;
   if (has_plan[k]) {
     const double* rec = plans + ((int64_t)k * (N + 1) + 1) * 9;
     double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[0], rec[1], rec[2]};
-    for (int i = 1; i < N; ++i)
-      for (int ax = 0; ax < 3; ++ax) lo[ax] = fmin(lo[ax], rec[9 * i + ax]), hi[ax] = fmax(hi[ax], rec[9 * i + ax]);
-    out.x = 0.5 * (lo[0] + hi[0]), out.y = 0.5 * (lo[1] + hi[1]), out.z = 0.5 * (lo[2] + hi[2]);
-    double r2 = 0.0;
-    for (int i = 0; i < N; ++i) {
-      const double ux = rec[9 * i] - out.x, uy = rec[9 * i + 1] - out.y, uz = rec[9 * i + 2] - out.z;
-      r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
+    for (int i = 0; i < N; ++i)
+      for (int ax = 0; ax < 3; ++ax) {
+        const double v = rec[9 * i + ax];
+        pk[3 * i + ax] = v;
+        lo[ax] = fmin(lo[ax], v), hi[ax] = fmax(hi[ax], v);
+      }
+    if (bounds) {
+      out.x = 0.5 * (lo[0] + hi[0]), out.y = 0.5 * (lo[1] + hi[1]), out.z = 0.5 * (lo[2] + hi[2]);
+      double r2 = 0.0;
+      for (int i = 0; i < N; ++i) {
+        const double ux = rec[9 * i] - out.x, uy = rec[9 * i + 1] - out.y, uz = rec[9 * i + 2] - out.z;
+        r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
+      }
+      out.w = sqrt(r2) * (1.0 + 1e-9);
+      if (!(out.w >= 0.0)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
     }
-    out.w = sqrt(r2) * (1.0 + 1e-9);
-    if (!(out.w >= 0.0)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
+  } else {
+    for (int i = 0; i < 3 * N; ++i) pk[i] = 0.0;
   }
-  *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+  if (bounds) *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+}
+
+// hdsm_publish_device / hdsm_exchange_device: the has_plan flag travels inside the record (first entry NaN = no plan)
+__global__ __launch_bounds__(256) void k_publish(int rec, int per, int n_local, const double* __restrict__ traj,
+                                                 const uint8_t* __restrict__ has_local, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)per * rec) return;
+  const int k = (int)(idx / rec), e = (int)(idx % rec);
+  const bool has = k < n_local && has_local[k];
+  double v = has ? traj[idx] : 0.0;
+  if (!has && e == 0) v = __longlong_as_double(0x7ff8000000000000LL);
+  out[idx] = v;
+}
+__global__ __launch_bounds__(256) void k_has_from_sentinel(int rec, int n, const double* __restrict__ plans,
+                                                           uint8_t* __restrict__ has) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  const double v = plans[(int64_t)k * rec];
+  has[k] = (v == v) ? 1 : 0;
 }
 
 // planes[n_inst][N][n_rob][4] for tests / level-1 callers (AC:1100-1205)
@@ -236,11 +269,19 @@ struct Handle {
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   double* d_bounds = nullptr; // [n_rob_max][4]
+  double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
+  uint8_t* d_zero = nullptr;  // n_rob_max zero bytes (has_plan of level 1)
+  hipEvent_t ev_done = nullptr;  // recorded after every launch: orders launches that arrive on different streams
+  bool launched = false;
+  struct Buf {                // grow-only device scratch of the host-pointer entry points
+    void* p = nullptr;
+    size_t cap = 0;
+  } b_planes, b_common, b_ncommon, b_path, b_cap, b_full, b_pv, b_np;
   hdsm_params prm{};
   hdsm::Consts* d_consts = nullptr;
   double* d_scratch = nullptr;
   int64_t scratch_stride = 0;
-  int32_t* d_stats = nullptr;  // 4 * max_inst
+  int32_t* d_stats = nullptr;  // 7 * max_inst: iterations, nodes, sweeps, staged rows, sphere records, pairs, flags
   long long* d_prof = nullptr; // 24 * max_inst (HDSM_PROFILE builds)
   int32_t* d_warm = nullptr;   // (MAXNV + 2) * max_inst: previous optimal working sets (params.warm_start)
   // staging for the host-pointer entry points
@@ -292,26 +333,34 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.st_nodes = h->d_stats + h->max_inst;
   a.st_sweeps = h->d_stats + 2 * h->max_inst;
   a.st_cand = h->d_stats + 3 * h->max_inst;
+  a.st_sph = h->d_stats + 4 * h->max_inst;
+  a.st_pairs = h->d_stats + 5 * h->max_inst;
+  a.st_flags = reinterpret_cast<uint32_t*>(h->d_stats + 6 * h->max_inst);
   a.prof = h->d_prof;
   a.warm = (h->prm.warm_start && a.l1_rows == nullptr) ? h->d_warm : nullptr;
+  // the handle's device state (snapshots, warm-start sets, prefilter records) is shared by all launches: a launch that
+  // arrives on another stream than the previous one waits for it
+  if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   h->last_stream = st;
-  a.bounds = nullptr;
-  if (a.l1_rows == nullptr && a.n_rob >= h->bounds_min) {
-    hipLaunchKernelGGL(k_plan_bounds, dim3((a.n_rob + 255) / 256), dim3(256), 0, st, h->N, a.n_rob, a.plans,
-                       a.has_plan, h->d_bounds);
+  a.bounds = nullptr, a.pos = nullptr;
+  if (a.l1_rows == nullptr) {
+    const bool pre = a.n_rob >= h->bounds_min;
+    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 255) / 256), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
+                       h->d_pos, pre ? h->d_bounds : nullptr);
     HIP_TRY(hipGetLastError());
-    a.bounds = h->d_bounds;
+    a.pos = h->d_pos;
+    a.bounds = pre ? h->d_bounds : nullptr;
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
-  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) return launch_duo(h, a, st);
-  if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
-  return h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
-}
-
-int64_t scratch_stride_for(int n) {
-  return n <= hdsm::SPLIT_N_MAX ? (int64_t)hdsm::Solver<32, CMAX30>::SNAP_STRIDE * hdsm::MAXH
-                 : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
+  int rc;
+  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo(h, a, st);
+  else if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
+  else rc = h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->ev_done, st));
+  h->launched = true;
+  return HDSM_OK;
 }
 
 template <class T>
@@ -319,12 +368,31 @@ hipError_t dmalloc(T** p, size_t count) {
   return hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T));
 }
 
+// grow-only scratch: reallocated (after draining the handle's stream) only when a call needs more than any before
+hipError_t ensure(Handle* h, Handle::Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return hipSuccess;
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return e;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr, b.cap = 0;
+  e = hipMalloc(&b.p, bytes);
+  if (e == hipSuccess) b.cap = bytes;
+  return e;
+}
+
+int64_t scratch_stride_for(int n) {
+  return n <= hdsm::SPLIT_N_MAX ? (int64_t)hdsm::Solver<32, CMAX30>::SNAP_STRIDE * hdsm::MAXH
+                 : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
+}
+
 void free_all(Handle* h) {
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
-                  h->d_obj,    h->d_has,     h->d_used};
+                  h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_zero,  h->b_planes.p, h->b_common.p,
+                  h->b_ncommon.p, h->b_path.p, h->b_cap.p, h->b_full.p, h->b_pv.p, h->b_np.p};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->ev_done) (void)hipEventDestroy(h->ev_done);
   if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -340,7 +408,7 @@ int check_common(Handle* h, int n_inst, int n_rob) {
 
 extern "C" {
 
-int32_t hdsm_version(void) { return (1 << 16) | 0; }
+int32_t hdsm_version(void) { return (1 << 16) | 1; }
 
 const char* hdsm_last_error(void) { return g_err.c_str(); }
 
@@ -361,7 +429,7 @@ void hdsm_default_params(hdsm_params* p, int32_t n_hor) {
   }
   p->drone_radius = 0.25, p->drone_z_offset = 0.25, p->plane_perturb = 0.1;
   p->max_nodes = 0, p->max_qp_iters = 0, p->feas_tol_fixed = 1e-6, p->solver_tol = 1e-9;
-  p->warm_start = 1;
+  p->warm_start = 1;  // execution knobs and time_limit_s stay 0 = library defaults / no wall-clock limit
 }
 
 int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_max, int32_t device,
@@ -390,15 +458,33 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   }
   h->device = device, h->max_inst = max_instances, h->n_rob_max = n_rob_max, h->prm = *params;
   h->N = hc->N, h->P = hc->P, h->RS = hc->RS, h->n = hc->n;
-  if (const char* e = std::getenv("HDSM_THREADS")) {
-    const int t = std::atoi(e);
+  // execution knobs: hdsm_params, then the environment (scripts); out-of-range values are ignored
+  auto env_int = [](const char* name, long lo, long hi, int* out) {
+    if (const char* e = std::getenv(name)) {
+      char* end = nullptr;
+      const long v = std::strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= lo && v <= hi) *out = (int)v;
+    }
+  };
+  if (params->threads_per_instance == 64 || params->threads_per_instance == 256) h->threads = params->threads_per_instance;
+  {
+    int t = h->threads;
+    env_int("HDSM_THREADS", 64, 256, &t);
     if (t == 64 || t == 256) h->threads = t;
   }
-  if (const char* e = std::getenv("HDSM_BOUNDS_MIN")) h->bounds_min = std::atoi(e) > 0 ? std::atoi(e) : 1;
+  h->bounds_min = params->prefilter_min_agents > 0 ? params->prefilter_min_agents : (params->prefilter_min_agents < 0 ? INT_MAX : 256);
+  env_int("HDSM_BOUNDS_MIN", 1, INT_MAX, &h->bounds_min);
   {
     hipDeviceProp_t prop;
-    h->duo_min = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount + 1 : 257;
-    if (const char* e = std::getenv("HDSM_DUO_MIN")) h->duo_min = std::atoi(e);  // 0 = never
+    const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    h->duo_min = params->duo_min_instances > 0 ? params->duo_min_instances : (params->duo_min_instances < 0 ? 0 : cus + 1);
+    env_int("HDSM_DUO_MIN", 0, INT_MAX, &h->duo_min);  // 0 = never
+  }
+  if (params->time_limit_s > 0) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
+    hc->time_ticks = (long long)(params->time_limit_s * 1e3 * (double)khz);
+    if (hc->time_ticks < 1) hc->time_ticks = 1;
   }
   h->scratch_stride = scratch_stride_for(h->n);
   const size_t I = (size_t)max_instances, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
@@ -408,7 +494,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   };
   ok(dmalloc(&h->d_consts, 1));
   ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
-  ok(dmalloc(&h->d_stats, 4 * I));
+  ok(dmalloc(&h->d_stats, 7 * I));
   ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
 #ifdef HDSM_PROFILE
   ok(dmalloc(&h->d_prof, 24 * I));
@@ -423,6 +509,8 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_b, I * P * RS));
   ok(dmalloc(&h->d_plans, (size_t)n_rob_max * (N + 1) * 9));
   ok(dmalloc(&h->d_bounds, (size_t)n_rob_max * 4));
+  ok(dmalloc(&h->d_pos, (size_t)n_rob_max * N * 3));
+  ok(dmalloc(&h->d_zero, (size_t)n_rob_max));
   ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
   ok(dmalloc(&h->d_ctrl, I * N * 3));
   ok(dmalloc(&h->d_obj, I));
@@ -430,7 +518,10 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_used, I * P));
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 4 * I * sizeof(int32_t));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 7 * I * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(h->d_zero, 0, (size_t)n_rob_max);
+  if (e == hipSuccess) e = hipMemset(h->d_plans, 0, (size_t)n_rob_max * (N + 1) * 9 * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_warm, 0, (hdsm::MAXNV + 2) * I * sizeof(int32_t));
   delete hc;
   if (e != hipSuccess) {
@@ -464,6 +555,7 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
       !plans_all || !has_plan || !traj_out || !ctrl_out || !poly_used || !status || !obj)
     return set_err(HDSM_ERR_BAD_ARG, "null array argument");
   if (traj_out == plans_all) return set_err(HDSM_ERR_BAD_ARG, "traj_out must not alias plans_all");
+  HIP_TRY(hipSetDevice(h->device));
   hdsm::Args a{};
   a.n_inst = n_inst, a.n_rob = n_rob, a.agent_id = agent_id, a.state = state_curr, a.ref = traj_ref;
   a.n_poly = n_poly, a.n_rows = n_rows_static, a.A = A_static, a.b = b_static, a.plans = plans_all;
@@ -488,6 +580,7 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   hipStream_t st = h->stream;
   const auto H2D = hipMemcpyHostToDevice;
   const auto D2H = hipMemcpyDeviceToHost;
+  if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   HIP_TRY(hipMemcpyAsync(h->d_agent, agent_id, I * 4, H2D, st));
   HIP_TRY(hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, H2D, st));
   HIP_TRY(hipMemcpyAsync(h->d_ref, traj_ref, I * N * 6 * 8, H2D, st));
@@ -527,9 +620,10 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
   HIP_TRY(hipSetDevice(h->device));
   const size_t I = (size_t)n_inst, N = (size_t)h->N;
   const size_t total = I * N * (size_t)n_rob * 4;
-  double* d_planes = nullptr;
-  HIP_TRY(dmalloc(&d_planes, total));
+  HIP_TRY(ensure(h, h->b_planes, total * sizeof(double)));
+  double* d_planes = static_cast<double*>(h->b_planes.p);
   hipStream_t st = h->stream;
+  if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));  // staging buffers are shared
   hipError_t e = hipMemcpyAsync(h->d_agent, agent_id, I * 4, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, hipMemcpyHostToDevice, st);
   if (e == hipSuccess)
@@ -544,7 +638,6 @@ int hdsm_tasc_planes(void* handle, int32_t n_inst, int32_t n_rob, const int32_t*
   }
   if (e == hipSuccess) e = hipMemcpyAsync(planes, d_planes, total * 8, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_planes);
   if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_tasc_planes: ") + hipGetErrorString(e));
   return HDSM_OK;
 }
@@ -558,6 +651,7 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   if (n_inst == 0) return HDSM_OK;
   if (!cfg || !agent_id || !path || !n_path || !plans_all || !has_plan || !ref_full || !path_vel || pmax < 1)
     return set_err(HDSM_ERR_BAD_ARG, "null or empty argument");
+  HIP_TRY(hipSetDevice(h->device));
   RefArgs a{};
   a.n_inst = n_inst, a.n_rob = n_rob, a.pmax = pmax, a.N = h->N, a.dt = h->prm.dt, a.cfg = *cfg;
   a.agent_id = agent_id, a.path = path, a.n_path = n_path, a.vel_cap = vel_cap, a.plans = plans_all;
@@ -575,16 +669,21 @@ int hdsm_reference(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int
   if (n_inst == 0) return HDSM_OK;
   if (!cfg || !agent_id || !path || !n_path || !plans_all || !has_plan || !ref_full || !path_vel || pmax < 1)
     return set_err(HDSM_ERR_BAD_ARG, "null or empty argument");
+  for (int32_t k = 0; k < n_inst; ++k)
+    if (n_path[k] < 1 || n_path[k] > pmax) return set_err(HDSM_ERR_BAD_ARG, "n_path[k] must be in [1, pmax]");
   HIP_TRY(hipSetDevice(h->device));
   const size_t I = (size_t)n_inst, N = (size_t)h->N;
   hipStream_t st = h->stream;
-  double *d_path = nullptr, *d_cap = nullptr, *d_full = nullptr, *d_pv = nullptr;
-  int32_t* d_np = nullptr;
-  hipError_t e = dmalloc(&d_path, I * pmax * 3);
-  if (e == hipSuccess) e = dmalloc(&d_cap, I);
-  if (e == hipSuccess) e = dmalloc(&d_full, I * (N + 1) * 6);
-  if (e == hipSuccess) e = dmalloc(&d_pv, I);
-  if (e == hipSuccess) e = dmalloc(&d_np, I);
+  hipError_t e = ensure(h, h->b_path, I * pmax * 3 * sizeof(double));
+  if (e == hipSuccess) e = ensure(h, h->b_cap, I * sizeof(double));
+  if (e == hipSuccess) e = ensure(h, h->b_full, I * (N + 1) * 6 * sizeof(double));
+  if (e == hipSuccess) e = ensure(h, h->b_pv, I * sizeof(double));
+  if (e == hipSuccess) e = ensure(h, h->b_np, I * sizeof(int32_t));
+  if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_reference: ") + hipGetErrorString(e));
+  double *d_path = static_cast<double*>(h->b_path.p), *d_cap = static_cast<double*>(h->b_cap.p),
+         *d_full = static_cast<double*>(h->b_full.p), *d_pv = static_cast<double*>(h->b_pv.p);
+  int32_t* d_np = static_cast<int32_t*>(h->b_np.p);
+  if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   auto cp = [&](void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
     if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, kind, st);
   };
@@ -602,8 +701,6 @@ int hdsm_reference(void* handle, const hdsm_ref_config* cfg, int32_t n_inst, int
   if (ref) cp(ref, h->d_ref, I * N * 6 * 8, hipMemcpyDeviceToHost);
   cp(path_vel, d_pv, I * 8, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  for (void* p : {(void*)d_path, (void*)d_cap, (void*)d_full, (void*)d_pv, (void*)d_np})
-    if (p) (void)hipFree(p);
   if (rc) return rc;
   if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_reference: ") + hipGetErrorString(e));
   return HDSM_OK;
@@ -667,12 +764,11 @@ int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_
   HIP_TRY(hipSetDevice(h->device));
   const size_t I = (size_t)n_inst, N = (size_t)h->N, P = (size_t)h->P, RS = (size_t)h->RS;
   hipStream_t st = h->stream;
-  double* d_common = nullptr;
-  int32_t* d_ncommon = nullptr;
-  uint8_t* d_zero = nullptr;
-  HIP_TRY(dmalloc(&d_common, sp.common.size()));
-  hipError_t e = dmalloc(&d_ncommon, sp.n_common.size());
-  if (e == hipSuccess) e = dmalloc(&d_zero, 1);
+  HIP_TRY(ensure(h, h->b_common, sp.common.size() * sizeof(double)));
+  hipError_t e = ensure(h, h->b_ncommon, sp.n_common.size() * sizeof(int32_t));
+  double* d_common = static_cast<double*>(h->b_common.p);
+  int32_t* d_ncommon = static_cast<int32_t*>(h->b_ncommon.p);
+  if (e == hipSuccess && h->launched && st != h->last_stream) e = hipStreamWaitEvent(st, h->ev_done, 0);
   const auto H2D = hipMemcpyHostToDevice;
   const auto D2H = hipMemcpyDeviceToHost;
   std::vector<int32_t> ids(I, -1);
@@ -697,7 +793,7 @@ int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_
     hdsm::Args a{};
     a.n_inst = n_inst, a.n_rob = 0, a.agent_id = h->d_agent, a.state = h->d_state, a.ref = h->d_ref;
     a.n_poly = h->d_npoly, a.n_rows = h->d_nrows, a.A = h->d_A, a.b = h->d_b, a.plans = h->d_plans;
-    a.has_plan = d_zero, a.traj = h->d_traj, a.ctrl = h->d_ctrl, a.used = h->d_used, a.status = h->d_status;
+    a.has_plan = h->d_zero, a.traj = h->d_traj, a.ctrl = h->d_ctrl, a.used = h->d_used, a.status = h->d_status;
     a.obj = h->d_obj, a.l1_rows = d_common, a.l1_nrows = d_ncommon, a.l1_rmax = sp.rc_max;
     rc = launch(h, a, st);
   }
@@ -707,11 +803,111 @@ int hdsm_solve(void* handle, int32_t n_inst, int32_t r_max, const double* state_
   cp(status, h->d_status, I * 4, D2H);
   cp(obj, h->d_obj, I * 8, D2H);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(d_common);
-  (void)hipFree(d_ncommon);
-  (void)hipFree(d_zero);
   if (rc) return rc;
   if (e != hipSuccess) return set_err(HDSM_ERR_DEVICE, std::string("hdsm_solve: ") + hipGetErrorString(e));
+  return HDSM_OK;
+}
+
+int hdsm_last_sweep_stats(void* handle, int32_t n_inst, int32_t* sphere_records, int32_t* pairs, uint32_t* flags) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (int rc = check_common(h, n_inst, 0)) return rc;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
+  void* dst[3] = {sphere_records, pairs, flags};
+  for (int k = 0; k < 3; ++k)
+    if (dst[k])
+      HIP_TRY(hipMemcpy(dst[k], h->d_stats + (size_t)(4 + k) * h->max_inst, (size_t)n_inst * 4, hipMemcpyDeviceToHost));
+  return HDSM_OK;
+}
+
+// ---- multi-GPU exchange (RCCL) -------------------------------------------------------------------------------------
+struct Comm {
+  ncclComm_t nccl = nullptr;
+  int rank = 0, world = 1, device = 0, rec = 0;  // rec = doubles per published record, (N + 1) * 9
+};
+
+#define NCCL_TRY(expr)                                                                                 \
+  do {                                                                                                  \
+    ncclResult_t r_ = (expr);                                                                           \
+    if (r_ != ncclSuccess) return set_err(HDSM_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+  } while (0)
+
+int hdsm_comm_unique_id(uint8_t id[HDSM_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= HDSM_COMM_ID_BYTES, "ncclUniqueId does not fit HDSM_COMM_ID_BYTES");
+  if (!id) return set_err(HDSM_ERR_BAD_ARG, "null id");
+  ncclUniqueId u;
+  NCCL_TRY(ncclGetUniqueId(&u));
+  std::memset(id, 0, HDSM_COMM_ID_BYTES);
+  std::memcpy(id, &u, sizeof u);
+  return HDSM_OK;
+}
+
+int hdsm_comm_create(void* handle, const uint8_t id[HDSM_COMM_ID_BYTES], int32_t rank, int32_t world, void** comm) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !id || !comm || world < 1 || rank < 0 || rank >= world) return set_err(HDSM_ERR_BAD_ARG, "bad hdsm_comm_create argument");
+  *comm = nullptr;
+  HIP_TRY(hipSetDevice(h->device));
+  Comm* c = new (std::nothrow) Comm;
+  if (!c) return set_err(HDSM_ERR_DEVICE, "out of host memory");
+  c->rank = rank, c->world = world, c->device = h->device, c->rec = (h->N + 1) * 9;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return set_err(HDSM_ERR_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  }
+  *comm = c;
+  return HDSM_OK;
+}
+
+int hdsm_comm_info(void* comm, int32_t* rank, int32_t* world) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c) return set_err(HDSM_ERR_BAD_ARG, "null comm");
+  int r = -1, w = -1;
+  NCCL_TRY(ncclCommUserRank(c->nccl, &r));   // what RCCL itself says, not what the caller passed
+  NCCL_TRY(ncclCommCount(c->nccl, &w));
+  if (rank) *rank = r;
+  if (world) *world = w;
+  return HDSM_OK;
+}
+
+void hdsm_comm_destroy(void* comm) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  delete c;
+}
+
+int hdsm_publish_device(void* handle, int32_t per, int32_t n_local, const double* traj, const uint8_t* has_plan_local,
+                        double* plans_local, void* hip_stream) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || per < 0 || n_local < 0 || n_local > per) return set_err(HDSM_ERR_BAD_ARG, "bad hdsm_publish_device argument");
+  if (per == 0) return HDSM_OK;
+  if (!traj || !has_plan_local || !plans_local) return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  HIP_TRY(hipSetDevice(h->device));
+  const int rec = (h->N + 1) * 9;
+  const int64_t tot = (int64_t)per * rec;
+  hipLaunchKernelGGL(k_publish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream), rec, per,
+                     n_local, traj, has_plan_local, plans_local);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
+int hdsm_exchange_device(void* comm, int32_t per, const double* plans_local, double* plans_all, uint8_t* has_plan_all,
+                         void* hip_stream) {
+  Comm* c = static_cast<Comm*>(comm);
+  if (!c || per < 0) return set_err(HDSM_ERR_BAD_ARG, "bad hdsm_exchange_device argument");
+  if (per == 0) return HDSM_OK;
+  if (!plans_local || !plans_all || !has_plan_all) return set_err(HDSM_ERR_BAD_ARG, "null array argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  // ONE collective per replan round: rank r's shard lands at plans_all + r * per * rec (in place if it already is there)
+  NCCL_TRY(ncclAllGather(plans_local, plans_all, (size_t)per * c->rec, ncclDouble, c->nccl, st));
+  const int n = per * c->world;
+  hipLaunchKernelGGL(k_has_from_sentinel, dim3((n + 255) / 256), dim3(256), 0, st, c->rec, n, plans_all, has_plan_all);
+  HIP_TRY(hipGetLastError());
   return HDSM_OK;
 }
 

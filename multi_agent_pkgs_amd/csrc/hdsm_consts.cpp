@@ -60,15 +60,37 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->max_iters = prm->max_qp_iters > 0 ? prm->max_qp_iters : 100000;
   c->tol = prm->solver_tol > 0 ? prm->solver_tol : 1e-9;
   c->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
-  c->cand_tau = 0.6;  // [m] rows whose slack at the first converged iterate is below this are staged
-  if (const char* e = std::getenv("HDSM_CAND_TAU")) c->cand_tau = std::atof(e);
-  c->branch_rule = 1;  // most infeasible segment first: measured 4-6x shorter rounds where the search is deep
-  if (const char* e = std::getenv("HDSM_BRANCH_RULE")) c->branch_rule = std::atoi(e) != 0;
-  c->presweep = 2;  // 0 never, 1 always, 2 when it was measured to pay: long horizons and large (prefiltered) swarms
-  if (const char* e = std::getenv("HDSM_PRESWEEP")) c->presweep = std::atoi(e) != 0;
+  // Execution knobs: hdsm_params first, then the HDSM_* environment variables (for scripts); values out of range are ignored.
+  auto env_int = [](const char* name, int lo, int hi, int32_t* out) {
+    if (const char* e = std::getenv(name)) {
+      char* end = nullptr;
+      const long v = std::strtol(e, &end, 10);
+      if (end != e && *end == 0 && v >= lo && v <= hi) *out = (int32_t)v;
+    }
+  };
+  auto env_real = [](const char* name, double lo, double hi, double* out) {
+    if (const char* e = std::getenv(name)) {
+      char* end = nullptr;
+      const double v = std::strtod(e, &end);
+      if (end != e && *end == 0 && v >= lo && v <= hi) *out = v;
+    }
+  };
+  if (prm->presweep < 0 || prm->presweep > 2) return fail(err, "presweep must be 0 (automatic), 1 (never) or 2 (always)");
+  if (prm->branch_rule < 0 || prm->branch_rule > 1) return fail(err, "branch_rule must be 0 (most infeasible) or 1 (first in time)");
+  if (prm->stage_radius < 0 || prm->time_limit_s < 0) return fail(err, "stage_radius / time_limit_s must not be negative");
+  c->cand_tau = prm->stage_radius > 0 ? prm->stage_radius : 0.6;  // [m] rows whose slack at the staging point is below this are staged
+  env_real("HDSM_CAND_TAU", 0.01, 10.0, &c->cand_tau);
+  // step to branch on: 1 = most infeasible segment (measured 4-6x shorter rounds where the search is deep), 0 = first in time
+  c->branch_rule = prm->branch_rule == 0 ? 1 : 0;
+  env_int("HDSM_BRANCH_RULE", 0, 1, &c->branch_rule);
+  // pre-sweep: 0 never, 1 always, 2 automatic (always for swarms below the prefilter size; prefiltered swarms only when the
+  // warm start already holds neighbour rows)
+  c->presweep = prm->presweep == 0 ? 2 : (prm->presweep == 1 ? 0 : 1);
+  env_int("HDSM_PRESWEEP", 0, 2, &c->presweep);
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
                       // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.
-  if (const char* e = std::getenv("HDSM_HOT_TAU")) c->hot_tau = std::atof(e);
+  env_real("HDSM_HOT_TAU", 1e-3, 1e30, &c->hot_tau);
+  c->time_ticks = 0;  // set by hdsm_create from time_limit_s and the device's clock rate
   c->r_u = prm->r_u;
   for (int k = 0; k < 6; ++k) c->wx[k] = prm->r_x[k], c->wn[k] = prm->r_n[k];
   for (int ax = 0; ax < 3; ++ax) {

@@ -58,7 +58,8 @@ __device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); 
 
 namespace hdsm {
 
-enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4 };
+enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
+enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
 enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
 
 // constraint ids: kind in bits 28..30
@@ -89,6 +90,8 @@ struct Shm {
   int32_t cand_src[CMAX];               // origin of a staged row: (neighbour << 6) | (step << 1) | endpoint, -1 = explicit
   int32_t inc_act[NV], inc_nact;        // working set of the incumbent (portable ids) -> next replan's guess
   int32_t inf_id;                       // row whose addition proved the last node infeasible (ids as in act[])
+  int32_t st_sph, st_pairs;             // sweep counters: sphere records read, (neighbour, step) positions loaded
+  long long t_start;                    // constant-rate clock at the start of the instance (time_limit_s)
   long long prof_acc[16];
   long long prof_last;
 #endif
@@ -919,6 +922,8 @@ struct Solver {
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
+        s.st_sph = 0, s.st_pairs = 0;
+        s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
       SYNC();
@@ -1034,6 +1039,7 @@ struct Solver {
 #endif
 #endif
     bool limit = false;
+    unsigned flags = 0;
     bool run = np > 0;
     if (IS_T0) s.sw_tau = 0.0;
     SYNC();
@@ -1114,8 +1120,9 @@ struct Solver {
     while (run) {
       const int rc = gi_run(s, c, R, cutoff(s), iters);
       last_rc = rc;
-      if (rc == GI_ITERLIM) {
+      if (rc == GI_ITERLIM || rc == GI_TIMELIM) {
         limit = true;
+        flags |= rc == GI_ITERLIM ? FLAG_ITER_LIMIT : FLAG_TIME_LIMIT;
         break;
       }
       if (rc == GI_OK) {
@@ -1137,6 +1144,7 @@ struct Solver {
           if (s.ncand > before && s.nviol) continue;
           if (s.overflow) {  // staging capacity exhausted, a violated row could not be staged
             limit = true;
+            flags |= FLAG_STAGING_OVERFLOW;
             break;
           }
           PAR_FOR(k, n) s.inc_x[k] = s.x[k];
@@ -1177,7 +1185,9 @@ struct Solver {
         }
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
+      const bool lim_before = limit;
       run = select_child(s, c, R, snap, nodes, limit);
+      if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
@@ -1274,6 +1284,11 @@ struct Solver {
       if (a.st_nodes) a.st_nodes[inst] = nodes;
       if (a.st_sweeps) a.st_sweeps[inst] = sweeps;
       if (a.st_cand) a.st_cand[inst] = s.ncand + s.ncold;
+#ifndef HDSM_EMU
+      if (a.st_sph) a.st_sph[inst] = s.st_sph;
+      if (a.st_pairs) a.st_pairs[inst] = s.st_pairs;
+#endif
+      if (a.st_flags) a.st_flags[inst] = flags;
     }
     SYNC();
   }

@@ -30,6 +30,7 @@ struct Consts {
                         // (HDSM_BRANCH_RULE). Either is exact; 1 bisects the "where to switch polyhedron" choice
                         // instead of enumerating it: 509 -> 29 nodes on a gridlocked 128-agent ring
   double tol, ftol_fixed, cand_tau, hot_tau;
+  long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)
   double r_u, wx[6], wn[6];
   double lbu[3], ubu[3];       // input box (absent if |.| >= ABSENT)
   double lbs[3][3], ubs[3][3]; // state box [comp][ax], comp 1 = v, 2 = a
@@ -92,6 +93,12 @@ struct Args {
   // [n_rob][4] = (centre, radius) of a sphere around steps 1..N of every published plan, radius < 0 = no plan;
   // written by k_plan_bounds before the launch for large swarms, null = sweeps test every neighbour step by step
   const double* bounds;
+  // [n_rob][N][3]: positions of steps 1..N of every published plan, packed (24 B per (agent, step) instead of a 72-B
+  // stride through the full states); written by the same pre-pass for every launch of level 2
+  const double* pos;
+  int32_t* st_sph;    // sphere records read by the sweeps of this instance
+  int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance
+  uint32_t* st_flags; // HDSM_FLAG_* bits
 };
 
 }  // namespace hdsm

@@ -612,12 +612,14 @@ struct WaveGI {
         SW_PROF(9)
       }
       const int total = cnt * N;
+      if (lane == 0) s.st_sph += pre ? (end - base) : 0, s.st_pairs += total;
       for (int idx0 = 0; idx0 < total; idx0 += nt) {
         const int idx = idx0 + lane;
         const bool in = idx < total;
         const int j = in ? idx / N : 0, i = in ? idx - j * N : 0;
         const int k = in ? (pre ? s.list[j] : base + j) : 0;  // idle threads read agent 0's record (always there)
-        const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+        // packed positions [n_rob][N][3]: consecutive threads of a neighbour read consecutive 24-B records
+        const double* op = a.pos + ((int64_t)k * N + i) * 3;
         const double ox = op[0], oy = op[1], oz = op[2];
         const bool on = in && k != self && (pre || a.has_plan[k]);
         SW_PROF(10)
@@ -702,7 +704,7 @@ struct WaveGI {
       } else if (kind == K_C && a.l1_rows == nullptr) {
         const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
         if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
-          const double* op = a.plans + ((int64_t)k * (N + 1) + (i + 1)) * 9;
+          const double* op = a.pos + ((int64_t)k * N + i) * 3;
           if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
         }
       }
@@ -879,6 +881,7 @@ struct WaveGI {
     const int lane = (int)threadIdx.x;
     const int n = c.n, N = c.N, max_iters = c.max_iters;
     const double tol = c.tol;
+    const long long time_ticks = c.time_ticks;  // 0 = no wall-clock budget (the default)
     double f = s.f;
     int q = uni(s.q), neq = uni(s.neq_done);
     int rc = GI_OK;
@@ -908,6 +911,11 @@ struct WaveGI {
       for (;;) {
         if (iters >= max_iters) {
           rc = GI_ITERLIM;
+          stop = true;
+          break;
+        }
+        if (time_ticks > 0 && (long long)wall_clock64() - s.t_start > time_ticks) {
+          rc = GI_TIMELIM;
           stop = true;
           break;
         }

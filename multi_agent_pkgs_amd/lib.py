@@ -14,11 +14,14 @@ from .params import HdsmParams
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libhdsm.so")
 
-HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACITY = 0, -1, -2, -3, -4
+HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACITY, HDSM_ERR_COMM = 0, -1, -2, -3, -4, -5
+HDSM_FLAG_NODE_LIMIT, HDSM_FLAG_ITER_LIMIT, HDSM_FLAG_TIME_LIMIT, HDSM_FLAG_STAGING_OVERFLOW = 1, 2, 4, 8
+HDSM_COMM_ID_BYTES = 128
 
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
-           "hdsm_reset_warm_start", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new",
+           "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
+           "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
            "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")
 
@@ -171,11 +174,64 @@ class Solver:
     def reset_warm_start(self):
         _check(self.lib.hdsm_reset_warm_start(self.h))
 
+    def last_sweep_stats(self, n_inst):
+        st = dict(sphere_records=np.zeros(n_inst, dtype=np.int32), pairs=np.zeros(n_inst, dtype=np.int32),
+                  flags=np.zeros(n_inst, dtype=np.uint32))
+        _check(self.lib.hdsm_last_sweep_stats(self.h, n_inst, _p(st["sphere_records"], C.c_int32), _p(st["pairs"], C.c_int32),
+                                              _p(st["flags"], C.c_uint32)))
+        return st
+
     def last_stats(self, n_inst):
         st = {k: np.zeros(n_inst, dtype=np.int32) for k in ("qp_iters", "nodes", "sweeps", "cand")}
         _check(self.lib.hdsm_last_stats(self.h, n_inst, _p(st["qp_iters"], C.c_int32), _p(st["nodes"], C.c_int32),
                                         _p(st["sweeps"], C.c_int32), _p(st["cand"], C.c_int32)))
         return st
+
+
+def comm_unique_id():
+    """hdsm_comm_unique_id (rank 0): 128 opaque bytes the launcher hands to every rank."""
+    buf = (C.c_uint8 * HDSM_COMM_ID_BYTES)()
+    _check(load().hdsm_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """One RCCL communicator of the per-round plan exchange (hdsm_comm_* / hdsm_exchange_device)."""
+
+    def __init__(self, solver, unique_id, rank, world):
+        self.lib = load()
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * HDSM_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self.lib.hdsm_comm_create(solver.h, buf, int(rank), int(world), C.byref(self.h)))
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        _check(self.lib.hdsm_comm_info(self.h, C.byref(r), C.byref(w)))
+        self.rank, self.world, self.solver = r.value, w.value, solver
+
+    def publish_device(self, traj, has_local, plans_local, n_local=None, stream=None):
+        per = plans_local.shape[0]
+        n_local = per if n_local is None else int(n_local)
+        sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
+        _check(self.lib.hdsm_publish_device(self.solver.h, per, n_local, C.c_void_p(traj.data_ptr()),
+                                            C.c_void_p(has_local.data_ptr()), C.c_void_p(plans_local.data_ptr()), sp))
+
+    def exchange_device(self, plans_local, plans_all, has_all, stream=None):
+        """ONE all-gather: plans_local [per][N+1][9] of every rank -> plans_all [world*per][N+1][9], has_all [world*per]."""
+        per = plans_local.shape[0]
+        assert plans_all.shape[0] == per * self.world and has_all.shape[0] == per * self.world
+        sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
+        _check(self.lib.hdsm_exchange_device(self.h, per, C.c_void_p(plans_local.data_ptr()), C.c_void_p(plans_all.data_ptr()),
+                                             C.c_void_p(has_all.data_ptr()), sp))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.hdsm_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def map_preprocess(cfg, grids, device=0):

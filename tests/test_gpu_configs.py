@@ -162,7 +162,7 @@ def test_config_4_1024_agents_circle_through_the_squeeze(hdsm, oracle):
         prev_plans = loop.plans_all.copy()
     assert bad_total > 100                                          # the squeeze really is in the checked rounds
     pos, _, _ = loop.shard.state()
-    d = np.linalg.norm(pos[:, None, :2] - pos[None, :, :2], axis=2) + np.eye(n_rob) * 9
+    d = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=2) + np.eye(n_rob) * 9
     assert d.min() > 0.45                                           # nobody closer than the drone diameter (0.5 m) - tolerance
 
 
