@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Reduce the rocprofv3 CSVs of scripts/gpu_profile_bench.sh to profiles/<tag>_{kernel_stats.csv, summary.json} and
+profiles/pmc_<workload_key>.json. The profiled process is the driver's own command line, so it also contains the set-up
+flight; the k_replan dispatches of the TIMED region are selected by their position in the trace, using the launch sequence
+bench.py reports (setup_flight, warmup, timed, event_pass, host_pass)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "gpurun_out", tag)
+line = json.loads(open(os.path.join(out_dir, "trace_bench.json")).read().strip().splitlines()[-1])
+seq = line["k_replan_launch_sequence"]
+lo = seq["setup_flight"] + seq["warmup"]
+hi = lo + seq["timed"]
+key = line["config"]["workload_key"]
+summ = {"tag": tag, "workload_key": key, "command": "python bench.py " + " ".join(sys.argv[2:]) if len(sys.argv) > 2 else None,
+        "kernel": "k_replan", "launch_sequence": seq, "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "ms_per_step", "kernel_ms_mean")}}
+
+
+def replan_rows(path, name_col="Kernel_Name"):
+    rows = [r for r in csv.DictReader(open(path)) if "k_replan" in r[name_col]]
+    return rows
+
+
+tr = glob.glob(os.path.join(out_dir, "trace", "*kernel_trace.csv"))
+if tr:
+    rows = replan_rows(tr[0])
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    sel = rows[lo:hi]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
+    alldur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    summ["kernel_trace"] = {"k_replan_dispatches_in_process": len(rows), "timed_slice": [lo, hi],
+                            "timed_AverageNs": sum(dur) / max(1, len(dur)), "timed_MinNs": min(dur), "timed_MaxNs": max(dur),
+                            "whole_process_AverageNs": sum(alldur) / len(alldur),
+                            "kernel_name": sel[0]["Kernel_Name"][:80], "VGPR": sel[0]["VGPR_Count"], "AGPR": sel[0]["Accum_VGPR_Count"],
+                            "SGPR": sel[0]["SGPR_Count"], "LDS": sel[0]["LDS_Block_Size"], "scratch": sel[0]["Scratch_Size"],
+                            "grid": sel[0]["Grid_Size_X"], "workgroup": sel[0]["Workgroup_Size_X"]}
+    # the pre-pass kernel of the same launches
+    pre = [r for r in csv.DictReader(open(tr[0])) if "k_plan_prepass" in r["Kernel_Name"]]
+    pre.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if len(pre) == len(rows):
+        d2 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in pre[lo:hi]]
+        summ["kernel_trace"]["prepass_timed_AverageNs"] = sum(d2) / max(1, len(d2))
+st = glob.glob(os.path.join(out_dir, "trace", "*kernel_stats.csv"))
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+if st:
+    shutil.copy(st[0], os.path.join(root, "profiles", f"{tag}_kernel_stats_whole_process.csv"))
+counters = {}
+for f in glob.glob(os.path.join(out_dir, "pmc_*", "*counter_collection.csv")):
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_replan" not in r["Kernel_Name"]:
+            continue
+        per.setdefault(r["Counter_Name"], []).append((int(r["Start_Timestamp"]), float(r["Counter_Value"])))
+    for name, v in per.items():
+        v.sort()
+        vals = [x[1] for x in v[lo:hi]]
+        if vals:
+            counters[name] = {"mean_per_timed_launch": sum(vals) / len(vals), "launches": len(vals), "dispatches_in_process": len(v)}
+summ["pmc"] = counters
+pm = {k: v["mean_per_timed_launch"] for k, v in counters.items()}
+if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
+    # rocprofv3 reports KiB. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts the 128-B requests of wide coalesced
+    # streams at 64 B -> doubled as prescribed there (an upper estimate for this kernel, whose loads are 8-32 B per lane).
+    summ["hbm_bytes_per_launch_raw"] = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
+    summ["hbm_bytes_per_launch"] = (2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
+json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
+if "hbm_bytes_per_launch" in summ:
+    json.dump(summ, open(os.path.join(root, "profiles", f"pmc_{key}.json"), "w"), indent=1)
+shutil.copy(os.path.join(out_dir, "bench.json"), os.path.join(root, "profiles", f"{tag}_bench.json"))
+print(json.dumps(summ, indent=1)[:3000])

@@ -1,0 +1,178 @@
+"""GPU tests of the ABI 1.1 additions: execution knobs in hdsm_params, limit flags and the optional wall-clock budget,
+stream ordering on a handle, argument checks of the host-pointer reference entry point, sweep statistics, and the
+RCCL publish / exchange entry points (single-rank communicator here; world_size 2 runs in tests/test_distributed.py on gloo
+for the host mirror and on the driver's multi-GPU node for RCCL itself)."""
+import numpy as np
+import pytest
+
+import problems
+from multi_agent_pkgs_amd.params import agile_params, agile_ref_config
+
+pytestmark = pytest.mark.gpu
+ARG_KEYS = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+
+
+@pytest.fixture(scope="module")
+def hdsm():
+    from multi_agent_pkgs_amd import lib
+    return lib
+
+
+def test_execution_knobs_never_change_the_answer(hdsm, oracle):
+    """presweep / branch_rule / stage_radius / threads / prefilter / duo settings through hdsm_params (not the environment):
+    same statuses and trajectories as the oracle for every combination tried."""
+    base = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(base, 48, seed=77, spacing=1.2, turn=True, narrow=True)
+    args = [sn[k] for k in ARG_KEYS]
+    o = oracle.replan(base, *args, n_threads=8)
+    combos = [dict(), dict(presweep=1), dict(presweep=2), dict(branch_rule=1), dict(stage_radius=0.2),
+              dict(threads_per_instance=64), dict(prefilter_min_agents=1), dict(prefilter_min_agents=-1),
+              dict(duo_min_instances=1), dict(duo_min_instances=-1)]
+    for kw in combos:
+        prm = agile_params(10, max_rows_static=18, **kw)
+        g = hdsm.Solver(prm, 48, 48).replan(*args)
+        assert (g["status"] == o["status"]).all(), kw
+        ok = o["status"] != 2
+        assert np.abs(g["traj"] - o["traj"])[ok].max() < 1e-7, kw
+    with pytest.raises(hdsm.HdsmError) as e:
+        hdsm.Solver(agile_params(10, presweep=3), 4, 4)
+    assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
+    with pytest.raises(hdsm.HdsmError):
+        hdsm.Solver(agile_params(10, time_limit_s=-1.0), 4, 4)
+
+
+def test_limit_flags_and_time_limit(hdsm):
+    """Node / iteration budgets and the optional wall-clock budget (Gurobi TimeLimit, AC:952) are reported per instance through
+    hdsm_last_sweep_stats flags; an instance stopped without incumbent leaves its outputs untouched."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 32, seed=5, narrow=True, turn=True, chamfer=True)
+    args = [sn[k] for k in ARG_KEYS]
+    full = hdsm.Solver(prm, 32, 32)
+    g0 = full.replan(*args)
+    assert (full.last_sweep_stats(32)["flags"] == 0).all()
+    assert g0["qp_iters"].max() > 6
+    # iteration budget
+    sol = hdsm.Solver(agile_params(10, max_rows_static=18, max_qp_iters=4, warm_start=False), 32, 32)
+    out = dict(traj=np.full((32, 11, 9), 7.0), ctrl=np.full((32, 10, 3), 7.0), used=np.zeros((32, 4), np.uint8),
+               status=np.zeros(32, np.int32), obj=np.full(32, 7.0))
+    g = sol.replan(*args, out=out)
+    fl = sol.last_sweep_stats(32)["flags"]
+    hit = g0["qp_iters"] > 12
+    assert hit.any() and (fl[hit] & hdsm.HDSM_FLAG_ITER_LIMIT).all()
+    bad = g["status"] == 2
+    assert bad.any() and (g["traj"][bad] == 7.0).all() and (g["obj"][bad] == 7.0).all()
+    # node budget
+    sol = hdsm.Solver(agile_params(10, max_rows_static=18, max_nodes=1, warm_start=False), 32, 32)
+    g = sol.replan(*args)
+    fl = sol.last_sweep_stats(32)["flags"]
+    deep = g0["nodes"] > 1
+    assert deep.any() and (fl[deep] & hdsm.HDSM_FLAG_NODE_LIMIT).all() and not (fl[~deep] & hdsm.HDSM_FLAG_NODE_LIMIT).any()
+    # wall-clock budget: 50 ns is spent before the first iteration of anything that has to iterate at all
+    sol = hdsm.Solver(agile_params(10, max_rows_static=18, time_limit_s=5e-8, warm_start=False), 32, 32)
+    g = sol.replan(*args)
+    fl = sol.last_sweep_stats(32)["flags"]
+    timed = (fl & hdsm.HDSM_FLAG_TIME_LIMIT) != 0
+    assert timed.sum() >= 16 and (g["status"][timed] != 0).all() and (g["status"][~timed] == g0["status"][~timed]).all()
+    # a generous budget changes nothing
+    sol = hdsm.Solver(agile_params(10, max_rows_static=18, time_limit_s=0.08), 32, 32)
+    g = sol.replan(*args)
+    assert (g["status"] == g0["status"]).all() and np.abs(g["traj"] - g0["traj"]).max() < 1e-9
+    assert (sol.last_sweep_stats(32)["flags"] == 0).all()
+
+
+def test_launches_on_different_streams_are_ordered(hdsm):
+    """Two calls on one handle on different streams, no host synchronisation in between: the second must wait for the first
+    (they share branch-and-bound snapshots, warm-start sets and the prefilter records). Results = the serial ones."""
+    import torch
+    prm = agile_params(10, max_rows_static=18)
+    dev = torch.device("cuda", 0)
+    sns = [problems.swarm_snapshot(prm, 300, seed=s, spacing=1.1, turn=True, narrow=True) for s in (11, 12)]
+    ref = []
+    for sn in sns:  # serial, fresh handles
+        ref.append(hdsm.Solver(prm, 300, 300).replan(*[sn[k] for k in ARG_KEYS]))
+    dt = dict(agent_id=torch.int32, state=torch.float64, ref=torch.float64, n_poly=torch.int32, n_rows=torch.int32,
+              A=torch.float64, b=torch.float64, plans=torch.float64, has_plan=torch.uint8)
+    for trial in range(3):
+        sol = hdsm.Solver(agile_params(10, max_rows_static=18, warm_start=False), 300, 300)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        outs = []
+        torch.cuda.synchronize()
+        for sn, st in zip(sns, streams):
+            d = {k: torch.from_numpy(np.ascontiguousarray(sn[k])).to(dev).to(dt[k]).contiguous() for k in ARG_KEYS}
+            o = dict(traj=torch.zeros((300, 11, 9), dtype=torch.float64, device=dev), ctrl=torch.zeros((300, 10, 3), dtype=torch.float64, device=dev),
+                     used=torch.zeros((300, 4), dtype=torch.uint8, device=dev), status=torch.zeros(300, dtype=torch.int32, device=dev),
+                     obj=torch.zeros(300, dtype=torch.float64, device=dev))
+            outs.append((d, o))
+        torch.cuda.synchronize()
+        for (d, o), st in zip(outs, streams):
+            sol.replan_device(*[d[k] for k in ARG_KEYS], o["traj"], o["ctrl"], o["used"], o["status"], o["obj"], stream=st)
+        torch.cuda.synchronize()
+        for (d, o), r in zip(outs, ref):
+            assert (o["status"].cpu().numpy() == r["status"]).all()
+            ok = r["status"] != 2
+            assert np.abs(o["traj"].cpu().numpy() - r["traj"])[ok].max() < 1e-7
+
+
+def test_reference_host_argument_checks_and_sweep_stats(hdsm):
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 16, seed=3)
+    sol = hdsm.Solver(prm, 16, 16)
+    path = np.zeros((16, 3, 3))
+    path[:, 1] = [5.0, 0, 0]
+    ids = np.arange(16, dtype=np.int32)
+    for bad in (0, 4):
+        n_path = np.full(16, 2, np.int32)
+        n_path[5] = bad
+        with pytest.raises(hdsm.HdsmError) as e:
+            sol.reference(agile_ref_config(), ids, path, n_path, sn["plans"], sn["has_plan"])
+        assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
+    sol.reference(agile_ref_config(), ids, path, np.full(16, 2, np.int32), sn["plans"], sn["has_plan"])
+    # sweep statistics: without the prefilter every sweep loads (n_rob) x N positions and no sphere record
+    g = sol.replan(*[sn[k] for k in ARG_KEYS])
+    st = sol.last_sweep_stats(16)
+    assert (st["sphere_records"] == 0).all() and (st["pairs"] == g["sweeps"] * 16 * 10).all()
+    sol2 = hdsm.Solver(agile_params(10, max_rows_static=18, prefilter_min_agents=1), 16, 16)
+    g2 = sol2.replan(*[sn[k] for k in ARG_KEYS])
+    st2 = sol2.last_sweep_stats(16)
+    assert (st2["sphere_records"] == g2["sweeps"] * 16).all() and (st2["pairs"] <= st["pairs"]).all()
+
+
+def test_publish_and_exchange_single_rank(hdsm):
+    """hdsm_publish_device + hdsm_exchange_device on a one-rank RCCL communicator: the all-gather is the identity, the has_plan
+    flags travel inside the records (NaN sentinel) and come out as bytes, padding agents are published without a plan."""
+    import torch
+    prm = agile_params(10, max_rows_static=18)
+    dev = torch.device("cuda", 0)
+    sol = hdsm.Solver(prm, 8, 8)
+    comm = hdsm.Comm(sol, hdsm.comm_unique_id(), 0, 1)
+    assert (comm.rank, comm.world) == (0, 1)
+    per, n_local = 8, 6
+    rng = np.random.default_rng(0)
+    traj = torch.from_numpy(rng.normal(size=(per, 11, 9))).to(dev)
+    has = torch.tensor([1, 0, 1, 1, 0, 1, 1, 1], dtype=torch.uint8, device=dev)
+    local = torch.zeros((per, 11, 9), dtype=torch.float64, device=dev)
+    full = torch.zeros((per, 11, 9), dtype=torch.float64, device=dev)
+    has_all = torch.full((per,), 9, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream()
+    comm.publish_device(traj, has, local, n_local=n_local, stream=st)
+    comm.exchange_device(local, full, has_all, stream=st)
+    torch.cuda.synchronize()
+    want = np.array([1, 0, 1, 1, 0, 1, 0, 0], np.uint8)
+    assert (has_all.cpu().numpy() == want).all()
+    f, t = full.cpu().numpy(), traj.cpu().numpy()
+    assert np.array_equal(f[want == 1], t[want == 1])
+    assert np.isnan(f[want == 0][:, 0, 0]).all() and (f[want == 0].reshape(3, -1)[:, 1:] == 0).all()
+    comm.close()
+
+
+def test_cpp_sharded_loop_runs_one_rank_through_rccl(tmp_path):
+    """examples/sharded_loop.cpp: a C++ host driving reference -> replan -> publish -> exchange on one stream through the C ABI,
+    with a (one-rank) RCCL communicator built from a unique id handed over in a file."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "sharded_loop")
+    assert os.path.exists(exe), "examples/sharded_loop not built (__graft_entry__.build())"
+    r = subprocess.run([exe, "0", "1", str(tmp_path / "uid"), "32", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "agents with a plan 32" in r.stdout
