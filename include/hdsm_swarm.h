@@ -115,6 +115,14 @@ int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32
  * agents kept the polyhedra they had. */
 int hdsm_swarm_corridor_errors(void* swarm, int32_t* codes);
 
+/* Next row f3 (ROS-free half): every local agent keeps the records of Agent::TrajPlanningIteration — comp_time_sc_ (CPU time of
+ * its corridor generation), comp_time_opt_ (the duration of the fused launch, handed in with hdsm_swarm_record_solve_ms between
+ * prepare and commit; comp_time_tasc_ = 0 because the planes are generated inside that launch), comp_time_tot_,
+ * comp_time_tot_wall_ and state_hist_. hdsm_swarm_shutdown = Agent::OnShutdown (AC:2446-2466) for one local agent: the CSV
+ * files of hdsm_stats.h in `dir` (when save_stats) and the printed report. */
+int hdsm_swarm_record_solve_ms(void* swarm, double milliseconds);
+int hdsm_swarm_shutdown(void* swarm, int32_t local_index, const char* dir, int32_t save_stats, char* report, int32_t report_cap);
+
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);
 

@@ -11,6 +11,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <chrono>
+#include <ctime>
+
+#include "../../include/hdsm_stats.h"
 #include "../../include/hdsm_swarm.h"
 
 namespace {
@@ -50,6 +54,8 @@ struct Agent {
   double path_vel = 0;
   int n_fail = 0;
   int corridor_rc = 0;  // last error of the voxel decomposition for this agent (0 = none)
+  void* stats = nullptr;  // hdsm_stats record of this agent (comp_time_*_, state_hist_; f3)
+  double sc_ms = 0, ref_ms = 0;  // CPU time of this round's corridor / reference generation
 };
 
 struct Swarm {
@@ -62,7 +68,16 @@ struct Swarm {
   std::vector<int8_t> world;
   int wdim[3] = {0, 0, 0};
   double worigin[3] = {0, 0, 0};
+  // timing of the round in flight (f3): the duration of the fused launch as reported by the caller, wall clock at prepare
+  double solve_ms = 0;
+  std::chrono::steady_clock::time_point t_round{};
+  long long round_idx = 0;
+  ~Swarm() {
+    for (Agent& a : agents) hdsm_stats_destroy(a.stats);
+  }
 };
+
+inline double cpu_ms_since(clock_t t0) { return (double)(clock() - t0) / CLOCKS_PER_SEC * 1e3; }
 
 // GetVelocityLimit, AC:1805-1817
 double velocity_limit(const hdsm_swarm_config& c, double occ, double dist) {
@@ -605,6 +620,7 @@ int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int3
     a.id = first_id + k;
     for (int ax = 0; ax < 3; ++ax) a.start[ax] = starts[3 * k + ax], a.goal[ax] = goals[3 * k + ax];
     a.path = {a.start, a.goal};
+    a.stats = hdsm_stats_create(a.id, n_rob);
     a.state_curr.fill(0.0);
     for (int ax = 0; ax < 3; ++ax) a.state_curr[ax] = a.start[ax];
   }
@@ -622,10 +638,16 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
       !A_static || !b_static)
     return HDSM_ERR_BAD_ARG;
   const int N = sw->prm.n_hor, P = sw->prm.poly_hor, RS = sw->prm.max_rows_static;
+  sw->t_round = std::chrono::steady_clock::now();
+  sw->solve_ms = 0;
   for (int k = 0; k < sw->n_local; ++k) {
     Agent& ag = sw->agents[k];
+    clock_t t0 = clock();
     generate_safe_corridor(*sw, ag);                     // AC:165
+    ag.sc_ms = cpu_ms_since(t0);                         // comp_time_sc_, AC:1446
+    t0 = clock();
     if (!ag.external_ref) generate_reference(*sw, ag, plans_all, has_plan);  // AC:171 (or done on the device, f1)
+    ag.ref_ms = cpu_ms_since(t0);
     ag.external_ref = false;
     agent_id[k] = ag.id;
     for (int c = 0; c < 9; ++c) state_curr[9 * k + c] = ag.state_curr[c];
@@ -681,7 +703,33 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
       for (int c = 0; c < 9; ++c)
         plans_local[((size_t)k * (N + 1) + i) * 9 + c] = have_plan ? ag.traj_curr[i][c] : 0.0;
   }
+  // f3: the records Agent::TrajPlanningIteration keeps (AC:193-245). The separating planes are generated inside the fused
+  // launch: its duration (hdsm_swarm_record_solve_ms) is booked as comp_time_opt_, comp_time_tasc_ is 0.
+  const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sw->t_round).count();
+  const double stamp = (double)(sw->round_idx + 1) * sw->prm.dt * sw->cfg.step_plan;
+  for (Agent& ag : sw->agents) {
+    hdsm_stats_add(ag.stats, HDSM_STAT_SC, ag.sc_ms);
+    hdsm_stats_add(ag.stats, HDSM_STAT_TASC, 0.0);
+    hdsm_stats_add(ag.stats, HDSM_STAT_OPT, sw->solve_ms);
+    hdsm_stats_add(ag.stats, HDSM_STAT_TOT, ag.sc_ms + ag.ref_ms + sw->solve_ms);
+    hdsm_stats_add(ag.stats, HDSM_STAT_TOT_WALL, wall_ms);
+    hdsm_stats_add_state(ag.stats, stamp, ag.state_curr.data(), 9);
+  }
+  ++sw->round_idx;
   return HDSM_OK;
+}
+
+int hdsm_swarm_record_solve_ms(void* swarm, double milliseconds) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !(milliseconds >= 0)) return HDSM_ERR_BAD_ARG;
+  sw->solve_ms = milliseconds;
+  return HDSM_OK;
+}
+
+int hdsm_swarm_shutdown(void* swarm, int32_t local_index, const char* dir, int32_t save_stats, char* report, int32_t report_cap) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || local_index < 0 || local_index >= sw->n_local) return HDSM_ERR_BAD_ARG;
+  return hdsm_stats_shutdown(sw->agents[local_index].stats, dir, save_stats, report, report_cap);
 }
 
 int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32_t* n_path) {

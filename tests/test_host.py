@@ -22,7 +22,7 @@ def declared_functions(header):
 
 def test_library_exports_every_declared_symbol():
     L = lib.load()
-    names = declared_functions("hdsm.h") + declared_functions("hdsm_swarm.h")
+    names = declared_functions("hdsm.h") + declared_functions("hdsm_swarm.h") + declared_functions("hdsm_stats.h")
     assert len(names) >= 15
     for n in names:
         assert hasattr(L, n), n
@@ -299,3 +299,68 @@ def test_set_world_argument_checks():
     assert e.value.code == lib.HDSM_ERR_BAD_ARG
     sh.set_world(np.zeros((4, 4, 4), np.int8), origin=(-0.3, 0.6, 0.0))
     sh.set_world(None)                         # back to free space
+
+
+# ---- next row f3, ROS-free half: timing records and the shutdown report --------------------------------------------
+def test_shutdown_statistics_files_and_report(tmp_path):
+    """hdsm_stats_shutdown = Agent::OnShutdown (AC:2446-2466): comp_time_*_<id>.csv hold std::fixed values each followed by a
+    comma on one line (AC:1948-1952), state_hist_<id>.csv one 'stamp,s0,...,s8' line per record (AC:1978-1991),
+    com_latency_<id>.csv one line per OTHER agent (AC:2049-2059); the report is what the reference prints to std::cout
+    (default ostream formatting = %g)."""
+    L = lib.load()
+    L.hdsm_stats_create.restype = C.c_void_p
+    st = C.c_void_p(L.hdsm_stats_create(2, 4))
+    vals = {0: [1.5, 0.25, 3.0], 1: [0.0, 0.0], 2: [12.3456789, 0.001], 3: [20.0], 4: [21.5], 5: [100.125, 7.0]}
+    for kind, vs in vals.items():
+        for v in vs:
+            assert L.hdsm_stats_add(st, kind, C.c_double(v)) == 0
+    states = [[1, 2, 3, 3, 4, 0, 0, 0, 0], [1.5, 2, 3, 0, 0, 12, 0.1, 0.2, 0.3]]
+    for k, s_ in enumerate(states):
+        arr = (C.c_double * 9)(*s_)
+        assert L.hdsm_stats_add_state(st, C.c_double(100.5 + k), arr, 9) == 0
+    for frm, lat in ((0, 1.0), (0, 3.0), (1, 2.0), (3, 10.0)):
+        assert L.hdsm_stats_add_latency(st, frm, C.c_double(lat)) == 0
+    assert L.hdsm_stats_add_latency(st, 2, C.c_double(1.0)) == lib.HDSM_ERR_BAD_ARG   # no subscription to oneself (AC:617)
+    buf = C.create_string_buffer(4096)
+    n = L.hdsm_stats_shutdown(st, str(tmp_path).encode(), 1, buf, 4096)
+    text = buf.value.decode()
+    assert n == len(text)
+    names = ["sc", "tasc", "opt", "tot", "tot_wall", "path"]
+    want = ""
+    for kind, nm in enumerate(names):
+        f = tmp_path / f"comp_time_{nm}_2.csv"
+        assert f.read_text() == "".join("%f," % v for v in vals[kind])
+        v = vals[kind]
+        want += f"comp_time_{nm}_2.csv: \nmean: {'%g' % (sum(v) / len(v))}\nmax: {'%g' % max(v)}\nmin: {'%g' % min(v)}\n"
+    assert (tmp_path / "state_hist_2.csv").read_text() == "".join(
+        "%f," % (100.5 + k) + ",".join("%f" % x for x in s_) + "\n" for k, s_ in enumerate(states))
+    assert (tmp_path / "com_latency_2.csv").read_text() == "1.000000,3.000000,\n2.000000,\n10.000000,\n"
+    want += "\nvelocity for agent: 2\nmean: %g\nmax: %g\n" % ((5.0 + 12.0) / 2, 12.0)
+    want += "communication latency (ms) for agent 2: mean: %g max: %g\n" % ((2.0 + 2.0 + 10.0) / 3, 10.0)
+    assert text == want
+    L.hdsm_stats_destroy(st)
+
+
+def test_swarm_keeps_the_planner_records(oracle, tmp_path):
+    """The host mirror books one record per replan round and agent (AC:193-245) and hdsm_swarm_shutdown writes them."""
+    prm = agile_params(10, max_rows_static=18)
+
+    def cpu(inp, plans, has):
+        return oracle.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"],
+                             plans, has, n_threads=4)
+
+    loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), 4, solve=cpu)
+    L = lib.load()
+    for r in range(5):
+        loop.shard.prepare(loop.plans_all, loop.has_plan)
+        out = cpu(loop.shard.inp, loop.plans_all, loop.has_plan)
+        assert L.hdsm_swarm_record_solve_ms(loop.shard.h, C.c_double(0.5 + r)) == 0
+        loop.plans_all, loop.has_plan = loop.shard.commit(out)
+    buf = C.create_string_buffer(4096)
+    assert L.hdsm_swarm_shutdown(loop.shard.h, 1, str(tmp_path).encode(), 1, buf, 4096) > 0
+    opt = (tmp_path / "comp_time_opt_1.csv").read_text()
+    assert opt == "".join("%f," % (0.5 + r) for r in range(5))
+    assert (tmp_path / "comp_time_tasc_1.csv").read_text() == "0.000000," * 5
+    hist = (tmp_path / "state_hist_1.csv").read_text().strip().split("\n")
+    assert len(hist) == 5 and all(len(row.split(",")) == 10 for row in hist)
+    assert "comp_time_sc_1.csv: " in buf.value.decode() and "velocity for agent: 1" in buf.value.decode()
