@@ -273,14 +273,17 @@ def main():
                        x["b"][sl], x["plans"], x["has_plan"], n_threads=1)
             return sl.stop - sl.start
 
-        t1 = time.perf_counter()
-        one(blocks[0])
-        per_task = max(time.perf_counter() - t1, 1e-4)
-        n_tasks = int(min(max(cores, args.cpu_seconds * cores / per_task), 50 * len(blocks)))
-        tasks = [blocks[i % len(blocks)] for i in range(n_tasks)]
+        # first batch: one block per thread, timed in parallel (the oracle's plane sweeps are memory-heavy: throughput with
+        # all cores busy is not cores x the single-thread rate); then as many more batches as fit the budget
         t1 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as ex:
-            done = sum(ex.map(one, tasks))
+            done = sum(ex.map(one, [blocks[i % len(blocks)] for i in range(cores)]))
+            dt_first = time.perf_counter() - t1
+            extra = int(max(0, min((args.cpu_seconds - dt_first) / max(dt_first, 1e-3), 40))) * cores
+            if extra:
+                done += sum(ex.map(one, [blocks[(cores + i) % len(blocks)] for i in range(extra)]))
+        n_tasks = cores + extra
+        tasks = range(n_tasks)
         dt_cpu = time.perf_counter() - t1
         cpu = {"value": done / dt_cpu, "unit": "agent-replans/s", "cores": cores, "kind": "port",
                "sample": f"{n_tasks} blocks of {BLK} agents drawn from the {K} timed rounds ({done} agent-replans) on the CPU "

@@ -69,33 +69,47 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
 __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
                                                       const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
                                                       double* __restrict__ bounds) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k >= n_rob) return;
-  double4 out = {0.0, 0.0, 0.0, -1.0};
-  double* pk = pos + (int64_t)k * N * 3;
-  if (has_plan[k]) {
-    const double* rec = plans + ((int64_t)k * (N + 1) + 1) * 9;
-    double lo[3] = {rec[0], rec[1], rec[2]}, hi[3] = {rec[0], rec[1], rec[2]};
-    for (int i = 0; i < N; ++i)
-      for (int ax = 0; ax < 3; ++ax) {
-        const double v = rec[9 * i + ax];
-        pk[3 * i + ax] = v;
-        lo[ax] = fmin(lo[ax], v), hi[ax] = fmax(hi[ax], v);
-      }
-    if (bounds) {
-      out.x = 0.5 * (lo[0] + hi[0]), out.y = 0.5 * (lo[1] + hi[1]), out.z = 0.5 * (lo[2] + hi[2]);
-      double r2 = 0.0;
-      for (int i = 0; i < N; ++i) {
-        const double ux = rec[9 * i] - out.x, uy = rec[9 * i + 1] - out.y, uz = rec[9 * i + 2] - out.z;
-        r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
-      }
-      out.w = sqrt(r2) * (1.0 + 1e-9);
-      if (!(out.w >= 0.0)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
-    }
-  } else {
-    for (int i = 0; i < 3 * N; ++i) pk[i] = 0.0;
+  // 16 lanes per agent (N <= 16 = HDSM_MAX_HOR): lane i copies the position of step i + 1, the box / sphere reductions run
+  // over the 16-lane group with DPP-able shuffles — every load of a plan is issued at once instead of N dependent ones
+  const int tid = (int)threadIdx.x, i = tid & 15;
+  const int k = (int)blockIdx.x * 16 + (tid >> 4);
+  const bool live = k < n_rob;
+  const bool has = live && has_plan[k];
+  const bool on = has && i < N;
+  double p[3] = {0.0, 0.0, 0.0};
+  if (on) {
+    const double* rec = plans + ((int64_t)k * (N + 1) + 1 + i) * 9;
+    p[0] = rec[0], p[1] = rec[1], p[2] = rec[2];
   }
-  if (bounds) *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+  if (live && i < N) {
+    double* pk = pos + ((int64_t)k * N + i) * 3;
+    pk[0] = p[0], pk[1] = p[1], pk[2] = p[2];
+  }
+  if (!bounds) return;
+  double lo[3], hi[3];
+  for (int ax = 0; ax < 3; ++ax) lo[ax] = on ? p[ax] : 1e300, hi[ax] = on ? p[ax] : -1e300;
+  for (int off = 8; off > 0; off >>= 1)
+    for (int ax = 0; ax < 3; ++ax) {
+      lo[ax] = fmin(lo[ax], __shfl_xor(lo[ax], off, 16));
+      hi[ax] = fmax(hi[ax], __shfl_xor(hi[ax], off, 16));
+    }
+  const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+  const double ux = p[0] - cx, uy = p[1] - cy, uz = p[2] - cz;
+  double r2 = on ? ux * ux + uy * uy + uz * uz : 0.0;
+  bool finite = !on || (r2 == r2);
+  for (int off = 8; off > 0; off >>= 1) {
+    r2 = fmax(r2, __shfl_xor(r2, off, 16));
+    finite = finite && __shfl_xor((int)finite, off, 16);
+  }
+  if (live && i == 0) {
+    double4 out = {0.0, 0.0, 0.0, -1.0};
+    if (has) {
+      out.x = cx, out.y = cy, out.z = cz;
+      out.w = sqrt(r2) * (1.0 + 1e-9);
+      if (!finite || !(out.w >= 0.0) || !(out.w < 1e299)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
+    }
+    *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+  }
 }
 
 // hdsm_publish_device / hdsm_exchange_device: the has_plan flag travels inside the record (first entry NaN = no plan)
@@ -345,7 +359,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.bounds = nullptr, a.pos = nullptr;
   if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
-    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 255) / 256), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
+    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
                        h->d_pos, pre ? h->d_bounds : nullptr);
     HIP_TRY(hipGetLastError());
     a.pos = h->d_pos;

@@ -43,6 +43,13 @@ def load():
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise RuntimeError(f"{SO_PATH} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        # One ROCm runtime per process. libhdsm.so links /opt/rocm's libamdhip64 / librccl; PyTorch bundles its own copies under
+        # the SAME sonames, and whichever is mapped first serves both. A process that also uses torch (device tensors, streams)
+        # must let torch map its copies first, or torch no longer finds the GPU ("No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(SO_PATH)
         lib.hdsm_last_error.restype = C.c_char_p
         lib.hdsm_version.restype = C.c_int32
