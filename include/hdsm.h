@@ -102,7 +102,9 @@ typedef struct hdsm_params {
   int32_t presweep;             /* neighbour rows staged before the first active-set run: 0 automatic,
                                    1 never, 2 always                                                HDSM_PRESWEEP     */
   int32_t branch_rule;          /* branch on: 0 the most infeasible segment (default), 1 the first in time HDSM_BRANCH_RULE */
-  int32_t reserved0;
+  int32_t launch_order;         /* batches of at least this many instances are launched most-expensive-first, judged by
+                                   the previous launch (needs warm_start; default 2 x compute units + 1; negative = never)
+                                                                                                    HDSM_ORDER_MIN    */
   double stage_radius;          /* [m] slack below which a neighbour row is staged (default 0.6)     HDSM_CAND_TAU     */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
   typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
-  Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
+  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
 }
 
 // The same solver budgeted for TWO workgroups per CU (registers: 2 waves per SIMD; LDS: a staging area of CMAX_DUO
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
   typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
-  Sol::solve_instance(s, *cp, a, (int)blockIdx.x);
+  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
 }
 
 // Pre-pass of every level-2 launch, one thread per agent of the swarm:
@@ -109,6 +109,36 @@ __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const do
       if (!finite || !(out.w >= 0.0) || !(out.w < 1e299)) out.w = 1e300;  // non-finite plan: never culled, the step-by-step test decides
     }
     *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
+  }
+}
+
+// Longest-processing-time-first launch order. A launch lasts as long as its slowest workgroup chain: with more instances than
+// resident workgroups (2 per CU) an expensive instance that happens to start late sets the kernel time. Workgroups are
+// dispatched in index order, so workgroup w takes instance order[w], the instances sorted by the active-set operations they
+// needed in the PREVIOUS launch on this handle (most first; a counting sort on min(iters, 255)). The previous replan of the
+// same agent is a good predictor (gridlocked neighbourhoods persist); the answer of an instance does not depend on the order.
+__global__ __launch_bounds__(1024) void k_launch_order(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
+  __shared__ int bucket[256];
+  const int tid = (int)threadIdx.x;
+  if (tid < 256) bucket[tid] = 0;
+  __syncthreads();
+  for (int k = tid; k < n_inst; k += 1024) {
+    const int it = iters_prev[k];
+    atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int b = 0; b < 256; ++b) {
+      const int c = bucket[b];
+      bucket[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < n_inst; k += 1024) {
+    const int it = iters_prev[k];
+    order[atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1)] = k;
   }
 }
 
@@ -284,6 +314,8 @@ struct Handle {
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   double* d_bounds = nullptr; // [n_rob_max][4]
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
+  int32_t* d_order = nullptr; // [max_inst] launch order (k_launch_order)
+  int order_min = 0;          // batches of at least this many instances are launched most-expensive-first (0 = never)
   uint8_t* d_zero = nullptr;  // n_rob_max zero bytes (has_plan of level 1)
   hipEvent_t ev_done = nullptr;  // recorded after every launch: orders launches that arrive on different streams
   bool launched = false;
@@ -356,7 +388,12 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // arrives on another stream than the previous one waits for it
   if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   h->last_stream = st;
-  a.bounds = nullptr, a.pos = nullptr;
+  a.bounds = nullptr, a.pos = nullptr, a.order = nullptr;
+  if (a.warm != nullptr && h->order_min > 0 && a.n_inst >= h->order_min) {
+    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(1024), 0, st, a.n_inst, h->d_stats, h->d_order);
+    HIP_TRY(hipGetLastError());
+    a.order = h->d_order;
+  }
   if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
     hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
@@ -402,7 +439,7 @@ int64_t scratch_stride_for(int n) {
 void free_all(Handle* h) {
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
-                  h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_zero,  h->b_planes.p, h->b_common.p,
+                  h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
                   h->b_ncommon.p, h->b_path.p, h->b_cap.p, h->b_full.p, h->b_pv.p, h->b_np.p};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -493,6 +530,9 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
     h->duo_min = params->duo_min_instances > 0 ? params->duo_min_instances : (params->duo_min_instances < 0 ? 0 : cus + 1);
     env_int("HDSM_DUO_MIN", 0, INT_MAX, &h->duo_min);  // 0 = never
+    // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
+    h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
+    env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never
   }
   if (params->time_limit_s > 0) {
     int khz = 0;
@@ -525,6 +565,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_bounds, (size_t)n_rob_max * 4));
   ok(dmalloc(&h->d_pos, (size_t)n_rob_max * N * 3));
   ok(dmalloc(&h->d_zero, (size_t)n_rob_max));
+  ok(dmalloc(&h->d_order, I));
   ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
   ok(dmalloc(&h->d_ctrl, I * N * 3));
   ok(dmalloc(&h->d_obj, I));

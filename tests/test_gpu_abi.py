@@ -161,7 +161,7 @@ def test_publish_and_exchange_single_rank(hdsm):
     assert (has_all.cpu().numpy() == want).all()
     f, t = full.cpu().numpy(), traj.cpu().numpy()
     assert np.array_equal(f[want == 1], t[want == 1])
-    assert np.isnan(f[want == 0][:, 0, 0]).all() and (f[want == 0].reshape(3, -1)[:, 1:] == 0).all()
+    assert np.isnan(f[want == 0][:, 0, 0]).all() and (f[want == 0].reshape(4, -1)[:, 1:] == 0).all()
     comm.close()
 
 
