@@ -90,6 +90,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
                       // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.
   env_real("HDSM_HOT_TAU", 1e-3, 1e30, &c->hot_tau);
+  c->leaf_mfma = 1;
+  env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);
   c->time_ticks = 0;  // set by hdsm_create from time_limit_s and the device's clock rate
   c->r_u = prm->r_u;
   for (int k = 0; k < 6; ++k) c->wx[k] = prm->r_x[k], c->wn[k] = prm->r_n[k];

@@ -611,6 +611,45 @@ struct Solver {
   // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if the pinned p_0 is outside.
   static HD int leaf_check(S& s, const Consts& c) {
     const int N = c.N, np = s.n_poly;
+#ifndef HDSM_EMU
+    if (c.leaf_mfma && N <= 15 && blockDim.x == 256) {
+      // The slack of every static row at every trajectory point is ONE matrix product in homogeneous coordinates:
+      //   D[r][m] = (a_r, -b_r) . (p_m, 1),   rows r of a polyhedron (tiles of 16), points m = 0..N (<= 16 columns), K = 4
+      // — exactly the shape of v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+      // D: col = lane & 15, row = (lane >> 4) + 4 reg). Wave w takes polyhedra w and w + 4; the row maxima per point are
+      // reduced in the lane (4 registers x 2 tiles) and across the four 16-lane groups, and land in red_v[j * 16 + m].
+      using v4d = double __attribute__((ext_vector_type(4)));
+      const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+      const int col = lane & 15, kk = lane >> 4;
+      const double bop = (kk < 3) ? ((col <= N) ? s.st[col][kk] : 0.0) : 1.0;
+      for (int j = w; j < np; j += 4) {
+        const int rows = s.sp_rows[j];
+        double pmax = -DINF;
+        for (int t = 0; 16 * t < rows; ++t) {
+          const int r = 16 * t + col;
+          const double aop = (r < rows) ? ((kk < 3) ? s.sp[j][r][kk] : -s.sp[j][r][3]) : ((kk < 3) ? 0.0 : -1e300);
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+          pmax = fmax(pmax, fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3])));
+        }
+        pmax = fmax(pmax, __shfl_xor(pmax, 16));
+        pmax = fmax(pmax, __shfl_xor(pmax, 32));
+        if (lane < 16) s.red_v[j * 16 + lane] = pmax;
+      }
+      SYNC();
+      PAR_FOR(idx, N * np) {
+        const int i = idx / np, j = idx % np;
+        double vmax = -DINF;
+        if (s.assign[i] < 0) {
+          const double v0 = s.red_v[j * 16 + i], v1 = s.red_v[j * 16 + i + 1];
+          if (i == 0) vmax = (v0 > c.ftol_fixed) ? DINF : v1;   // rows on the pinned p_0 only gate the choice
+          else vmax = v0 > v1 ? v0 : v1;
+        }
+        s.keys[i][j] = vmax;
+      }
+      SYNC();
+    } else
+#endif
     PAR_FOR(idx, N * np) {
       const int i = idx / np, j = idx % np;
       double vmax = -DINF;

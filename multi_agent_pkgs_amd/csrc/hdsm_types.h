@@ -26,6 +26,7 @@ struct Consts {
                      // 1 always, 2 (default): always for swarms below the prefilter size; prefiltered swarms only when
                      // the warm start already holds neighbour rows. Measured with the final kernel: -8 % on the bench
                      // line, -11 % at 1024 agents late in the flight, -7 % at H=15 (it also spares B&B nodes)
+  int32_t leaf_mfma;    // leaf test through v_mfma_f64_16x16x4_f64 (HDSM_LEAF_MFMA, see hdsm_core.h leaf_check)
   int32_t branch_rule;  // step to branch on: 0 first uncontained segment in time, 1 (default) the most infeasible one
                         // (HDSM_BRANCH_RULE). Either is exact; 1 bisects the "where to switch polyhedron" choice
                         // instead of enumerating it: 509 -> 29 nodes on a gridlocked 128-agent ring
