@@ -1,0 +1,596 @@
+// corridor_core.h — next row f2: the convex voxel decomposition the reference's corridor generator calls for every seed
+// (GenerateSafeCorridor, agent_class.cpp:1236-1447 -> convex_decomp_lib::GetPolyOcta3D, convex_decomp_util/src/convex_decomp.cpp
+// :5-376, and its shape-aware variant GetPolyOcta3DNew, :590-1160, with the helpers FindCorners :378-564 and SideIsEmpty
+// :577-588; "CD" below). ONE source for the host entry points (corridor_host.cpp) and the device kernel (corridor_kernels.hip):
+// fixed-capacity containers, no allocation, no floating-point contraction, so both builds produce the same rows bit for bit.
+//
+// What the algorithm does (restated; the tables below are DERIVED from the cube's geometry, only the numbering of
+// faces and edges is taken over because it fixes the order of the output rows):
+//   * a cuboid of voxels grows from the seed, one face per iteration, round robin over (-y, +x, +y, -x, +z, -z)
+//     (CD:17-18, 54-55); a face advances by one voxel layer;
+//   * the new layer is itself grown in the face's plane from a 2-D seed, side by side (+u, +v, -u, -v round robin),
+//     over free voxels that sit on top of voxels already in the polyhedron; voxels next to the polyhedron but not on
+//     top of it are carried along as "virtual" cells so that the sides keep their shape (CD:112-200);
+//   * where a new layer comes out SHORTER than the previous one on some side, the edge shared with the neighbouring
+//     face becomes a chamfer with an integer slope; a small state machine per edge (slope, steps taken on the current
+//     stair, which of the two faces is the long direction, whether the slope is final) decides whether later layers
+//     are still consistent with ONE plane through that edge — if not, the face stops growing (CD:209-283);
+//   * a layer that reaches the full extent of the previous one on a side also extends the neighbouring face's
+//     outermost layer (CD:291-301);
+//   * the result: one half-space per chamfered edge (normal = slope * long-face normal + other-face normal) and one
+//     per face (CD:322-373). Rows are n . x <= n . p (decomp_geometry/polyhedron.h:98-147).
+// The shape-aware variant (`variant` = 1) adds, on top of that (CD:590-1160):
+//   * a layer that covers less than half of the area it was allowed is skipped for this turn (CD:691-693, 816-826);
+//   * a chamfer may only START where there really is an obstacle behind it: the voxels one step beyond the short
+//     side (and, for a one-voxel step, beyond the neighbouring face's edge row) must not all be empty (CD:933-975),
+//     and a trial growth of one more layer (FindCorners) must confirm the slope (CD:978-1066); during the first
+//     round of six turns no chamfer starts at all (CD:868-870);
+//   * layers may reach the last voxel of the grid (CD:705-707 tests < dim where the original tests < dim - 1), the
+//     chamfer point is placed half a voxel further out (CD:836-848), and an over-long step on an own fixed chamfer
+//     ends the edge scan without stopping the face (CD:875-878 lacks the original's valid_border = false).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CD_HD __host__ __device__ inline
+#else
+#define CD_HD inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)  // the plane offsets must come out bit-identical on the host and on the device
+#endif
+
+namespace hdsm_cd {
+
+constexpr int kOccupied = 100;  // CVX_DCMP_OCC (convex_decomp.hpp:11): values below it are free
+constexpr int CELLS = 768;      // capacity of a face's outermost layer (a layer is at most (2 n_it / 6 + 1)^2 voxels plus the
+                                // rows neighbouring faces hand over: 435 for n_it = 42, 700 for n_it = 54)
+constexpr int RIM = 160;        // capacity of one side of a growing layer (deque with room at both ends)
+constexpr int RIM0 = 64;        // where an empty deque starts inside its buffer
+
+enum { CD_OK = 0, CD_BAD_ARG = -1, CD_CAPACITY = -4, CD_WORK_OVERFLOW = -6 };
+
+struct Cell {
+  int x, y, z;
+};
+CD_HD bool same(Cell a, Cell b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+CD_HD Cell add(Cell a, Cell b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+CD_HD Cell sub(Cell a, Cell b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+CD_HD Cell neg(Cell a) { return {-a.x, -a.y, -a.z}; }
+CD_HD int dot(Cell a, Cell b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// outward normals in the order of the output rows (CD:17-18)
+CD_HD Cell normal_of(int f) {
+  const Cell n[6] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
+  return n[f];
+}
+CD_HD int face_with_normal(Cell n) {
+  for (int f = 0; f < 6; ++f)
+    if (same(normal_of(f), n)) return f;
+  return -1;
+}
+// the two faces meeting in edge e (numbering of CD:28-31: it fixes the order of the chamfer rows)
+CD_HD int edge_face(int e, int which) {
+  const int t[12][2] = {{0, 1}, {0, 4}, {0, 3}, {0, 5}, {1, 5}, {1, 4}, {3, 4}, {3, 5}, {1, 2}, {2, 4}, {2, 3}, {2, 5}};
+  return t[e][which];
+}
+
+struct Frame {      // in-plane frame of a face and what lies across each of its four sides
+  Cell side[4];     // +u, +v, -u, -v
+  int face[4];      // neighbouring face across that side
+  int edge[4];      // edge shared with that neighbour
+  int back[4];      // index, among the NEIGHBOUR's sides, of the direction this face grows in
+};
+
+// u = normal of the next lateral face and v = +z for the four lateral faces; (-y, +x) / (-y, -x) for top / bottom
+// (CD:33-41). Everything else follows from that.
+CD_HD void build_frames(Frame fr[6]) {
+  for (int f = 0; f < 6; ++f) {
+    Cell u, v;
+    if (f < 4) u = normal_of((f + 1) % 4), v = Cell{0, 0, 1};
+    else u = normal_of(0), v = (f == 4) ? normal_of(1) : normal_of(3);
+    fr[f].side[0] = u, fr[f].side[1] = v, fr[f].side[2] = neg(u), fr[f].side[3] = neg(v);
+  }
+  for (int f = 0; f < 6; ++f)
+    for (int j = 0; j < 4; ++j) {
+      const int g = face_with_normal(fr[f].side[j]);
+      fr[f].face[j] = g;
+      fr[f].edge[j] = -1;
+      for (int e = 0; e < 12; ++e)
+        if ((edge_face(e, 0) == f && edge_face(e, 1) == g) || (edge_face(e, 0) == g && edge_face(e, 1) == f)) fr[f].edge[j] = e;
+      fr[f].back[j] = -1;
+      for (int k = 0; k < 4; ++k)
+        if (same(fr[g].side[k], normal_of(f))) fr[f].back[j] = k;
+    }
+}
+
+struct Edge {      // Corner3D (convex_decomp.hpp:21-36)
+  double pos[3];
+  int slope;       // 0 = square edge
+  int dir;         // face along which the chamfer runs `slope` voxels per voxel of the other face; -1 = undecided
+  int fixed;
+  int steps;       // voxels taken on the current stair
+};
+CD_HD Edge fresh_edge() { return Edge{{0.0, 0.0, 0.0}, 0, -1, 0, 0}; }
+
+// cells are stored as offsets from the seed (a polyhedron never reaches further than n_it / 6 + 1 layers from it)
+struct Packed {
+  int8_t x, y, z;
+};
+
+struct CellList {   // std::vector<Vec3i> with a fixed capacity
+  int n;
+  Packed c[CELLS];
+};
+struct CellDeque {  // std::deque<Vec3i> with a fixed capacity and room at both ends
+  int b, e;
+  Packed c[RIM];
+};
+
+struct FaceState {  // Border3D (convex_decomp.hpp:39-43)
+  CellList outer;   // outermost layer of the face
+  int reach[4];     // extent of that layer along the face's four sides (dot products)
+};
+
+struct Layer {
+  int found;
+  CellList cells;       // border_real_tmp
+  CellDeque rim_real[4];  // borders_2d_real
+  Cell far[4];          // border_limit_tmp
+};
+
+// everything one decomposition needs; ~45 KB, provided by the caller (heap on the host, global scratch on the device)
+struct Work {
+  Frame fr[6];
+  FaceState faces[6], faces_t[6];
+  Layer L, L2;
+  CellDeque rim[4], moved, moved_real, edge_row;
+  Edge edges[12], edges_t[12];
+  Cell seed;
+  int overflow;
+};
+
+// The local voxel grid of one agent as a window into a WORLD grid (what env_builder's GenerateVoxelGridMSG cuts out,
+// environment_builder.cpp:58-67): local voxel (i, j, k) = world voxel (i, j, k) + off; voxels below local k = ground_k are
+// unknown -> occupied (AC:1302, 1307), unknown (negative) world voxels are occupied, voxels outside the world are free.
+// The polyhedron's voxels are kept in a bit overlay around the seed instead of being written into the (shared) world.
+struct WindowGrid {
+  const int8_t* world;
+  int wnx, wny, wnz;
+  int ox, oy, oz;      // off
+  int lnx, lny, lnz;   // local dimensions
+  int ground_k;
+  int mark;
+  Cell seed;
+  uint32_t* bits;      // overlay over offsets [-OV, OV)^3 from the seed
+  static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32;
+  CD_HD int nx() const { return lnx; }
+  CD_HD int ny() const { return lny; }
+  CD_HD int nz() const { return lnz; }
+  CD_HD bool inside(Cell c) const { return c.x >= 0 && c.y >= 0 && c.z >= 0 && c.x < lnx && c.y < lny && c.z < lnz; }
+  CD_HD int bit_index(Cell c) const {
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return -1;
+    return dx + OVW * (dy + OVW * dz);
+  }
+  CD_HD bool marked(Cell c) const {
+    const int b = bit_index(c);
+    return b >= 0 && ((bits[b >> 5] >> (b & 31)) & 1u);
+  }
+  CD_HD int value(Cell c) const {
+    if (marked(c)) return mark;
+    if (c.z < ground_k) return kOccupied;
+    const int gi = c.x + ox, gj = c.y + oy, gk = c.z + oz;
+    if (gi < 0 || gj < 0 || gk < 0 || gi >= wnx || gj >= wny || gk >= wnz) return 0;
+    const int v = world[(size_t)gi + (size_t)gj * wnx + (size_t)gk * wnx * wny];
+    return v < 0 ? kOccupied : v;
+  }
+  CD_HD void set(Cell c, int) {
+    const int b = bit_index(c);
+    if (b >= 0) bits[b >> 5] |= 1u << (b & 31);
+  }
+  CD_HD void trial_set(Cell c, int m) { set(c, m); }
+  CD_HD void trial_unset(Cell c) {
+    const int b = bit_index(c);
+    if (b >= 0) bits[b >> 5] &= ~(1u << (b & 31));
+  }
+  CD_HD int count() const {
+    int n = 0;
+    for (int w = 0; w < WORDS; ++w) {
+      uint32_t v = bits[w];
+      while (v) v &= v - 1, ++n;
+    }
+    return n;
+  }
+};
+
+struct Ctx {
+  Work* wk;
+  CD_HD Packed pack(Cell c) const {
+    const int dx = c.x - wk->seed.x, dy = c.y - wk->seed.y, dz = c.z - wk->seed.z;
+    if (dx < -127 || dx > 127 || dy < -127 || dy > 127 || dz < -127 || dz > 127) wk->overflow = 1;
+    return Packed{(int8_t)dx, (int8_t)dy, (int8_t)dz};
+  }
+  CD_HD Cell unpack(Packed p) const { return Cell{wk->seed.x + p.x, wk->seed.y + p.y, wk->seed.z + p.z}; }
+  CD_HD void push(CellList& l, Cell c) const {
+    if (l.n < CELLS) l.c[l.n++] = pack(c);
+    else wk->overflow = 1;
+  }
+  CD_HD Cell at(const CellList& l, int i) const { return unpack(l.c[i]); }
+  CD_HD void clear(CellDeque& d) const { d.b = d.e = RIM0; }
+  CD_HD void assign1(CellDeque& d, Cell c) const { d.b = RIM0, d.e = RIM0 + 1, d.c[RIM0] = pack(c); }
+  CD_HD bool empty(const CellDeque& d) const { return d.b == d.e; }
+  CD_HD int size(const CellDeque& d) const { return d.e - d.b; }
+  CD_HD Cell get(const CellDeque& d, int i) const { return unpack(d.c[d.b + i]); }
+  CD_HD Cell front(const CellDeque& d) const { return unpack(d.c[d.b]); }
+  CD_HD Cell back(const CellDeque& d) const { return unpack(d.c[d.e - 1]); }
+  CD_HD void push_back(CellDeque& d, Cell c) const {
+    if (d.e < RIM) d.c[d.e++] = pack(c);
+    else wk->overflow = 1;
+  }
+  CD_HD void push_front(CellDeque& d, Cell c) const {
+    if (d.b > 0) d.c[--d.b] = pack(c);
+    else wk->overflow = 1;
+  }
+  CD_HD void copy(CellDeque& dst, const CellDeque& src) const {
+    dst.b = src.b, dst.e = src.e;
+    for (int i = src.b; i < src.e; ++i) dst.c[i] = src.c[i];
+  }
+  CD_HD void copy(CellList& dst, const CellList& src) const {
+    dst.n = src.n;
+    for (int i = 0; i < src.n; ++i) dst.c[i] = src.c[i];
+  }
+};
+
+// how far the next layer of face f may extend on each side, given the chamfers already started (CD:71-91)
+CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* edges, int allow[4], Edge trial[4]) {
+  for (int j = 0; j < 4; ++j) {
+    allow[j] = fs.reach[j];
+    trial[j] = edges[fr[f].edge[j]];
+    const Edge& e = trial[j];
+    if (e.slope > 0) {
+      if (e.dir == f) allow[j] -= e.slope;                         // our layers retreat `slope` voxels each
+      else if (e.fixed && e.steps >= e.slope) allow[j] -= 1;       // the other face's stair is complete: step in
+    }
+  }
+}
+
+// One layer on top of face f: a free 2-D seed above the current outer layer, inside the allowance and inside voxels
+// [1, dim - 1 - margin] (CD:94-116: margin 1; CD:700-723: margin 0), grown in its plane (CD:118-200).
+// Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v).
+template <class G>
+CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+  Work& wk = *cx.wk;
+  const Frame* fr = wk.fr;
+  L.found = 0;
+  L.cells.n = 0;
+  const Cell up = normal_of(f);
+  const Cell* sd = fr[f].side;
+  Cell s2{0, 0, 0};
+  for (int q = 0; q < fs.outer.n; ++q) {
+    const Cell t = add(cx.at(fs.outer, q), up);
+    if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx() - margin || t.y >= g.ny() - margin || t.z >= g.nz() - margin) continue;
+    if (g.value(t) >= kOccupied) continue;
+    bool in = true;
+    for (int k = 0; k < 4; ++k) in = in && dot(t, sd[k]) <= allow[k];
+    if (in) {
+      s2 = t, L.found = 1;
+      break;
+    }
+  }
+  if (!L.found) return;
+  // current outline of the layer per side: all cells (rim) / cells of the layer (rim_real)
+  for (int j = 0; j < 4; ++j) cx.assign1(wk.rim[j], s2), cx.assign1(L.rim_real[j], s2), L.far[j] = s2;
+  cx.push(L.cells, s2);
+  bool alive[4] = {true, true, true, true};
+  for (int k = 0; alive[0] || alive[1] || alive[2] || alive[3]; ++k) {
+    if (wk.overflow) return;
+    const int s = k % 4, prev = (k + 3) % 4, next = (k + 1) % 4;
+    cx.clear(wk.moved), cx.clear(wk.moved_real);
+    bool ok = true;
+    const int cnt = cx.size(wk.rim[s]);
+    for (int q = 0; q < cnt; ++q) {
+      const Cell t = add(cx.get(wk.rim[s], q), sd[s]);
+      if (dot(t, sd[s]) > allow[s]) {
+        ok = false;
+        break;
+      }
+      const Cell below = sub(t, up);
+      if (g.inside(below) && g.value(below) == mark) {  // on top of the polyhedron: must be free
+        if (g.inside(t) && g.value(t) < kOccupied) {
+          cx.push_back(wk.moved, t), cx.push_back(wk.moved_real, t);
+        } else {
+          ok = false;
+          break;
+        }
+      } else {
+        cx.push_back(wk.moved, t);  // beside the polyhedron: carried along, not part of the layer
+      }
+    }
+    if (!ok) {
+      alive[s] = false;  // (a side that failed is still tried again on later turns, as in CD:128-133)
+      continue;
+    }
+    cx.copy(wk.rim[s], wk.moved);
+    for (int q = 0; q < cx.size(wk.moved_real); ++q) cx.push(L.cells, cx.get(wk.moved_real, q));
+    cx.copy(L.rim_real[s], wk.moved_real);
+    cx.push_back(wk.rim[prev], cx.front(wk.moved));
+    cx.push_front(wk.rim[next], cx.back(wk.moved));
+    if (!cx.empty(wk.moved_real)) {
+      if (same(cx.front(wk.moved), cx.front(wk.moved_real))) cx.push_back(L.rim_real[prev], cx.front(wk.moved));
+      if (same(cx.back(wk.moved), cx.back(wk.moved_real))) cx.push_front(L.rim_real[next], cx.back(wk.moved));
+    }
+    for (int j = 0; j < 4; ++j)
+      if (!cx.empty(L.rim_real[j])) L.far[j] = cx.front(L.rim_real[j]);
+  }
+}
+
+CD_HD double dabs(double v) { return v < 0 ? -v : v; }
+// |  |l0| - |l2|  | * |  |l1| - |l3|  |   (CD:691-693) — small integers: exact in double
+CD_HD double span_area(const int l[4]) {
+  return dabs(dabs((double)l[0]) - dabs((double)l[2])) * dabs(dabs((double)l[1]) - dabs((double)l[3]));
+}
+
+// extents of the grown layer as the reference reads them for its area test (CD:816-820): the front cell of every
+// side. A side without layer cells has no front in the reference (it reads an empty deque there); the last known
+// front (border_limit_tmp) stands in for it.
+CD_HD void layer_extent(const Ctx& cx, int f, const Layer& L, int ext[4]) {
+  for (int j = 0; j < 4; ++j) ext[j] = dot(cx.empty(L.rim_real[j]) ? L.far[j] : cx.front(L.rim_real[j]), cx.wk->fr[f].side[j]);
+}
+
+// SideIsEmpty, CD:577-588 (GetVoxel: outside the grid = occupied; any positive value, potential field included, counts)
+template <class G>
+CD_HD bool side_is_empty(const Ctx& cx, const G& g, const CellDeque& cells, Cell step) {
+  if (cx.empty(cells)) return false;
+  for (int q = 0; q < cx.size(cells); ++q) {
+    const Cell t = add(cx.get(cells, q), step);
+    const int v = g.inside(t) ? g.value(t) : kOccupied;
+    if (v > 0) return false;
+  }
+  return true;
+}
+
+// FindCorners, CD:378-564: a trial layer on face f from the given state; which square edges would become chamfers.
+template <class G>
+CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool growing[6], const FaceState* faces, const Edge* edges, int mark,
+                        bool& valid, Edge out[4]) {
+  if (!growing[f]) {
+    valid = false;
+    return;
+  }
+  Work& wk = *cx.wk;
+  int allow[4];
+  allowance(wk.fr, f, faces[f], edges, allow, out);
+  const double area = span_area(allow);
+  Layer& L = wk.L2;
+  grow_layer(cx, g, f, faces[f], allow, mark, 0, L);
+  if (!L.found) return;
+  int ext[4];
+  layer_extent(cx, f, L, ext);
+  if (span_area(ext) < area / 2) valid = false;
+  for (int j = 0; j < 4; ++j) {
+    if (cx.empty(L.rim_real[j])) continue;
+    const int gap = faces[f].reach[j] - dot(cx.front(L.rim_real[j]), wk.fr[f].side[j]);
+    if (out[j].slope == 0 && gap > 0) {
+      out[j].slope = out[j].steps = gap;
+      if (gap > 1) out[j].dir = f;
+    }
+  }
+}
+
+// rows[max_rows][4] = (n, n . p); returns CD_OK, CD_CAPACITY (n_rows = needed count) or CD_WORK_OVERFLOW (a fixed-capacity
+// container of `wk` was too small for this grid: the caller falls back to a bigger workspace / reports it)
+template <class G>
+CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, double res, int mark, const double origin[3], double* rows,
+                         int max_rows, int* n_rows) {
+  Ctx cx{&wk};
+  wk.overflow = 0;
+  wk.seed = seed;
+  build_frames(wk.fr);
+  const Frame* fr = wk.fr;
+  const bool aware = variant != 0;
+  FaceState* faces = wk.faces;
+  Edge* edges = wk.edges;
+  Cell anchor[6];              // a voxel of the outermost layer (gives the face plane)
+  bool growing[6];
+  for (int e = 0; e < 12; ++e) edges[e] = fresh_edge();
+  for (int f = 0; f < 6; ++f) {
+    faces[f].outer.n = 0;
+    cx.push(faces[f].outer, seed);
+    anchor[f] = seed;
+    growing[f] = true;
+    for (int j = 0; j < 4; ++j) faces[f].reach[j] = dot(seed, fr[f].side[j]);
+  }
+  g.set(seed, mark);
+
+  for (int it = 0; it < n_it; ++it) {
+    if (wk.overflow) return CD_WORK_OVERFLOW;
+    const int f = it % 6;
+    if (!growing[f]) continue;
+    const Cell up = normal_of(f);
+    const Cell* sd = fr[f].side;
+
+    int allow[4];
+    Edge trial[4];
+    allowance(fr, f, faces[f], edges, allow, trial);
+    Layer& L = wk.L;
+    grow_layer(cx, g, f, faces[f], allow, mark, aware ? 0 : 1, L);
+    if (wk.overflow) return CD_WORK_OVERFLOW;
+    if (!L.found) continue;
+
+    bool soft = true;  // shape-aware variant: layer acceptable this turn
+    if (aware) {
+      int ext[4];
+      layer_extent(cx, f, L, ext);
+      if (span_area(ext) < span_area(allow) / 2) soft = false;
+    }
+
+    // is the layer consistent with ONE plane through every edge? (CD:209-283 / CD:828-910)
+    bool accept = true;
+    int fresh[4] = {0, 0, 0, 0};  // corner_new_state: 1 = a one-voxel chamfer starts on this side, 2 = a longer one
+    for (int j = 0; j < 4 && accept; ++j) {
+      if (cx.empty(L.rim_real[j])) continue;
+      Edge e = trial[j];
+      const Cell c = cx.front(L.rim_real[j]);
+      const int gap = faces[f].reach[j] - dot(c, sd[j]);  // voxels this layer falls short of the last one
+      if (e.slope == 0) {
+        if (gap > 0) {  // a chamfer starts here: a point of its plane, between this layer and the neighbouring face
+          const Cell nb = normal_of(fr[f].face[j]);
+          const double extra = aware ? res / 2 : 0.0;  // (CD:836-848 adds res/2 twice)
+          // (written as the reference writes it: products first, then left-to-right sums; no contraction)
+          const double h = res / 2;
+          e.pos[0] = (((c.x * res - up.x * res / 2) + nb.x * res / 2) + h) + extra;
+          e.pos[1] = (((c.y * res - up.y * res / 2) + nb.y * res / 2) + h) + extra;
+          e.pos[2] = (((c.z * res - up.z * res / 2) + nb.z * res / 2) + h) + extra;
+          e.slope = e.steps = gap;
+          if (gap > 1) e.dir = f;
+          fresh[j] = gap > 1 ? 2 : 1;
+          if (aware && it < 6) soft = false;  // no chamfer during the first round of turns
+        }
+      } else if (e.fixed) {
+        if (e.dir == f || e.dir == -1) {
+          if (gap > e.slope) {
+            if (aware) break;  // CD:875-878: the scan of the edges ends here, this and the later sides keep their state
+            accept = false;
+          }
+        } else if (e.steps >= e.slope) {  // the other face has finished a stair: we may step in by one, once
+          if (gap > 1) accept = false;
+          else e.steps = 1;
+        } else {                          // in the middle of a stair: no step allowed
+          if (gap != 0) accept = false;
+          else e.steps += 1;
+        }
+      } else if (e.dir == -1) {           // slope 1 so far, long direction still open
+        if (gap == 0) e.dir = fr[f].face[j], e.steps += 1, e.slope += 1;
+        else if (gap == 1) e.fixed = 1;
+        else accept = false;
+      } else if (e.dir == f) {            // first layer after our own multi-voxel retreat fixes the slope
+        e.slope = gap, e.fixed = 1;
+      } else {                            // the other face is the long direction and is still lengthening its stair
+        if (gap == 0) e.slope += 1, e.steps += 1;
+        else if (gap == 1) e.fixed = 1, e.steps = 1;
+        else accept = false;
+      }
+      if (accept) trial[j] = e;
+    }
+    if (!accept) {
+      growing[f] = false;
+      continue;
+    }
+    if (!soft) continue;
+
+    if (aware) {  // CD:930-1066: does every chamfer that starts with this layer follow a real obstacle?
+      bool expand = true;
+      for (int j = 0; j < 4; ++j) {
+        if (!fresh[j]) continue;
+        const bool first = side_is_empty(cx, g, L.rim_real[j], up);
+        const int nbf = fr[f].face[j], ci = fr[f].back[j];
+        bool second = true;
+        if (fresh[j] == 1) {
+          cx.clear(wk.edge_row);  // the neighbouring face's cells along the shared edge
+          for (int q = 0; q < faces[nbf].outer.n; ++q) {
+            const Cell c = cx.at(faces[nbf].outer, q);
+            if (dot(c, fr[nbf].side[ci]) == faces[nbf].reach[ci]) cx.push_back(wk.edge_row, c);
+          }
+          second = side_is_empty(cx, g, wk.edge_row, normal_of(nbf));
+        }
+        expand = !(first && second);
+        if (!expand) {
+          growing[f] = false;
+          break;
+        }
+      }
+      if (expand && (fresh[0] || fresh[1] || fresh[2] || fresh[3])) {
+        // trial: put the layer in, grow one more on top of it, take it out again (its cells were free voxels)
+        for (int q = 0; q < L.cells.n; ++q) g.trial_set(cx.at(L.cells, q), mark);
+        FaceState* faces_t = wk.faces_t;
+        for (int k = 0; k < 6; ++k) {
+          cx.copy(faces_t[k].outer, k == f ? L.cells : faces[k].outer);
+          for (int j = 0; j < 4; ++j) faces_t[k].reach[j] = (k == f) ? dot(L.far[j], sd[j]) : faces[k].reach[j];
+        }
+        Edge* edges_t = wk.edges_t;
+        for (int k = 0; k < 12; ++k) edges_t[k] = edges[k];
+        for (int j = 0; j < 4; ++j)
+          if (!fresh[j]) edges_t[fr[f].edge[j]] = trial[j];
+        bool valid = true;
+        Edge fin[4];
+        find_corners(cx, g, f, growing, faces_t, edges_t, mark, valid, fin);
+        for (int q = 0; q < L.cells.n; ++q) g.trial_unset(cx.at(L.cells, q));
+        if (valid) {
+          for (int j = 0; j < 4; ++j)
+            if (fresh[j] == 2 && fin[j].slope < trial[j].slope) {
+              expand = false;
+              growing[f] = false;
+              break;
+            }
+          if (expand)
+            for (int j = 0; j < 4; ++j) {
+              if (fresh[j] != 1) continue;
+              const int nbf = fr[f].face[j];
+              bool v2 = true;
+              Edge fin2[4];
+              find_corners(cx, g, nbf, growing, faces_t, edges, mark, v2, fin2);
+              if (v2 && fin2[fr[f].back[j]].slope == 0 && fin[j].slope == 0) {
+                expand = false;
+                break;
+              }
+            }
+        }
+      }
+      if (wk.overflow) return CD_WORK_OVERFLOW;
+      if (!expand) continue;
+    }
+
+    cx.copy(faces[f].outer, L.cells);
+    for (int j = 0; j < 4; ++j) {
+      faces[f].reach[j] = dot(L.far[j], sd[j]);
+      edges[fr[f].edge[j]] = trial[j];
+      // full-width side on a square edge: these voxels are now also the outermost layer of the neighbouring face
+      if (trial[j].slope == 0 && !cx.empty(L.rim_real[j]) && faces[f].reach[j] == dot(cx.front(L.rim_real[j]), sd[j])) {
+        const int nbf = fr[f].face[j];
+        for (int q = 0; q < cx.size(L.rim_real[j]); ++q) cx.push(faces[nbf].outer, cx.get(L.rim_real[j], q));
+        faces[nbf].reach[fr[f].back[j]] += 1;
+      }
+    }
+    anchor[f] = cx.at(L.cells, 0);
+    for (int q = 0; q < L.cells.n; ++q) g.set(cx.at(L.cells, q), mark);
+  }
+  if (wk.overflow) return CD_WORK_OVERFLOW;
+
+  // half-spaces: chamfered edges first (edge numbering order), then the six faces (CD:322-373)
+  int n = 0;
+  for (int e = 0; e < 12; ++e) {
+    if (edges[e].slope <= 0) continue;
+    const int fa = edge_face(e, 0), fb = edge_face(e, 1);
+    const int lng = (edges[e].dir == fa) ? fa : fb, oth = (edges[e].dir == fa) ? fb : fa;
+    const Cell nl = normal_of(lng), no = normal_of(oth);
+    const double nrm[3] = {(double)(edges[e].slope * nl.x + no.x), (double)(edges[e].slope * nl.y + no.y),
+                           (double)(edges[e].slope * nl.z + no.z)};
+    const double p[3] = {edges[e].pos[0] + origin[0], edges[e].pos[1] + origin[1], edges[e].pos[2] + origin[2]};
+    if (n < max_rows) {
+      double* r = rows + 4 * n;
+      r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
+      r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
+    }
+    ++n;
+  }
+  for (int f = 0; f < 6; ++f) {
+    const Cell nf = normal_of(f);
+    const double nrm[3] = {(double)nf.x, (double)nf.y, (double)nf.z};
+    const double h = res / 2;
+    const double p[3] = {((anchor[f].x * res + nf.x * res / 2) + h) + origin[0], ((anchor[f].y * res + nf.y * res / 2) + h) + origin[1],
+                         ((anchor[f].z * res + nf.z * res / 2) + h) + origin[2]};
+    if (n < max_rows) {
+      double* r = rows + 4 * n;
+      r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
+      r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
+    }
+    ++n;
+  }
+  *n_rows = n;
+  return n <= max_rows ? CD_OK : CD_CAPACITY;
+}
+
+}  // namespace hdsm_cd
