@@ -23,6 +23,8 @@
 #ifndef HDSM_SWARM_H
 #define HDSM_SWARM_H
 
+#include <stddef.h>
+
 #include "hdsm.h"
 
 #ifdef __cplusplus
@@ -95,6 +97,27 @@ int hdsm_poly_octa3d(const int32_t seed[3], int8_t* grid, const int32_t dim[3], 
  * with a positive value below 100 (potential field) are free for the growth but count as "not empty" for the chamfer test. */
 int hdsm_poly_octa3d_new(const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double res,
                          int32_t mark, const double origin[3], double* rows, int32_t max_rows, int32_t* n_rows);
+
+/* Row f2 on the device: a BATCH of decompositions on local grids that are windows into one world grid (csrc/corridor_kernels.hip;
+ * one thread per seed, the same source as the two host functions above, rows bit-identical to theirs). For seed t:
+ *   off[t][3]      local voxel (0,0,0) in world voxels; ldim = dimensions of every local grid
+ *   ground_k[t]    local voxels with k < ground_k are unknown -> occupied (AC:1302, 1307); unknown (negative) world voxels are
+ *                  occupied, voxels outside the world are free (what hdsm_swarm_set_world's host path does)
+ *   seed[t][3]     local voxel; variant[t] 0 = GetPolyOcta3D, 1 = GetPolyOcta3DNew, -1 = decide like AC:1385-1395
+ *   origin[t][3]   world position of local voxel (0,0,0)
+ *   rows[t][max_rows][4], n_rows[t], rc[t] (hdsm_error per seed), cells[t] (voxels of the polyhedron; may be NULL)
+ * hdsm_poly_octa3d_batch: host pointers (copies the world in, PCIe-inclusive). hdsm_poly_octa3d_device: device pointers,
+ * asynchronous on hip_stream, `scratch` = hdsm_poly_octa3d_scratch_bytes(n) bytes of device memory. */
+int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                           const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                           const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                           int32_t* rc, int32_t* cells);
+int hdsm_poly_octa3d_device(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                            const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                            const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                            int32_t* rc, int32_t* cells, void* scratch, void* hip_stream);
+size_t hdsm_poly_octa3d_scratch_bytes(int32_t n);
+const char* hdsm_corridor_last_error(void);
 
 /* Global paths (path_curr_ of the reference, produced there by the path thread: JPS + DMP + shortening, AC:261-567 — out of
  * scope as such). Default: the straight segment start -> goal. hdsm_swarm_set_paths installs caller-supplied polylines

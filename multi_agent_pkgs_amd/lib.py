@@ -21,7 +21,8 @@ HDSM_COMM_ID_BYTES = 128
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
            "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
-           "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new",
+           "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new", "hdsm_poly_octa3d_batch",
+           "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_corridor_last_error",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
            "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_swarm_record_solve_ms", "hdsm_swarm_shutdown",
            "hdsm_stats_create", "hdsm_stats_destroy", "hdsm_stats_add", "hdsm_stats_add_state", "hdsm_stats_add_latency",
@@ -273,3 +274,26 @@ def map_preprocess_device(cfg, d_in, d_out, d_scratch, stream=None, device=0):
     if rc:
         L.hdsm_map_last_error.restype = C.c_char_p
         raise HdsmError(rc, L.hdsm_map_last_error().decode())
+
+
+def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32, device=0):
+    """hdsm_poly_octa3d_batch (row f2 on the device): world int8 [wz][wy][wx]; off/seed [n][3], ground_k/variant [n], origin [n][3].
+    Returns rows [n][max_rows][4], n_rows [n], rc [n], cells [n]."""
+    L = load()
+    world = np.ascontiguousarray(world, dtype=np.int8)
+    wdim = np.asarray(world.shape[::-1], dtype=np.int32)
+    ldim = np.asarray(ldim, dtype=np.int32)
+    off, seed = _i32(off), _i32(seed)
+    ground_k, variant = _i32(ground_k), _i32(variant)
+    origin = _f64(origin)
+    n = off.shape[0]
+    rows = np.zeros((n, max_rows, 4))
+    n_rows, rc, cells = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    i32, d = C.c_int32, C.c_double
+    r = L.hdsm_poly_octa3d_batch(C.c_int32(device), C.c_int32(n), world.ctypes.data_as(C.POINTER(C.c_int8)), _p(wdim, i32), _p(ldim, i32),
+                                 _p(off, i32), _p(ground_k, i32), _p(seed, i32), _p(variant, i32), _p(origin, d), C.c_int32(n_it),
+                                 C.c_double(res), _p(rows, d), C.c_int32(max_rows), _p(n_rows, i32), _p(rc, i32), _p(cells, i32))
+    if r:
+        L.hdsm_corridor_last_error.restype = C.c_char_p
+        raise HdsmError(r, L.hdsm_corridor_last_error().decode())
+    return rows, n_rows, rc, cells
