@@ -1,0 +1,352 @@
+// swarm_core.h — the part of multi_agent_planner::Agent that sits directly around the solve, as plain data + functions that
+// compile for the host mirror (swarm_host.cpp) AND for the device-resident loop (swarm_kernels.hip): one source, same
+// arithmetic (no floating-point contraction), so the two loops can be compared state by state.
+// AC = multi_agent_planner/src/agent_class.cpp of lis-epfl/multi_agent_pkgs.
+//
+//   corridor_step      GenerateSafeCorridor (AC:1236-1447): keep-last / keep-used polyhedra, walk along the path in steps of
+//                      voxel / 10, seed a new polyhedron where the walk leaves the kept ones (free-space closed form, or the
+//                      voxel decomposition of corridor_core.h on a window of the world grid)
+//   reference_polyline the polyline SamplePath walks this round (AC:1459-1496)
+//   check_increment    CheckReferenceTrajIncrement + GetPathProgress (AC:569-585, path_tools.cpp:419-479)
+//   commit_one         read-back bookkeeping, the shift-by-one fallback (AC:1000-1019), state advance (AC:233-238)
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/hdsm_swarm.h"
+#include "corridor_core.h"
+#include "hdsm_types.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace hdsm_sw {
+
+using hdsm_cd::Cell;
+using hdsm_cd::WindowGrid;
+using hdsm_cd::Work;
+
+constexpr int PATH_PTS = 48;  // points of a global path (router output: <= ~30)
+
+struct V3 {
+  double v[3];
+  CD_HD double& operator[](int i) { return v[i]; }
+  CD_HD const double& operator[](int i) const { return v[i]; }
+};
+CD_HD V3 sub(const V3& a, const V3& b) { return {{a[0] - b[0], a[1] - b[1], a[2] - b[2]}}; }
+CD_HD V3 axpy(const V3& a, double s, const V3& b) { return {{a[0] + s * b[0], a[1] + s * b[1], a[2] + s * b[2]}}; }
+CD_HD double dot(const V3& a, const V3& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+CD_HD double norm(const V3& a) { return sqrt(dot(a, a)); }
+
+struct Poly {  // LinearConstraint3D: rows A x <= b
+  int32_t rows;
+  int32_t pad;
+  double A[HDSM_MAX_ROWS_STATIC][3];
+  double b[HDSM_MAX_ROWS_STATIC];
+  V3 seed;  // poly_seeds_ entry (voxel centre in world coordinates)
+};
+// LinearConstraint::inside (decomp_geometry/polyhedron.h:130-137): rejected when A x - b > 0
+CD_HD bool inside(const Poly& p, const V3& x) {
+  for (int r = 0; r < p.rows; ++r)
+    if (((p.A[r][0] * x[0] + p.A[r][1] * x[1]) + p.A[r][2] * x[2]) - p.b[r] > 0) return false;
+  return true;
+}
+
+struct AgentS {
+  int32_t id, n_path;
+  V3 start, goal;
+  V3 path[PATH_PTS];            // path_curr_: global path start -> goal (straight unless routed / set)
+  double state_curr[9];
+  int32_t has_traj, n_ref;      // traj_curr_ empty before the first solve; traj_ref_curr_ rows
+  double traj_curr[hdsm::MAXH + 1][9];
+  double ctrl_curr[hdsm::MAXH][3];
+  double traj_ref[hdsm::MAXH + 1][6];
+  int32_t n_poly, increment;    // poly_const_vec_.size(), increment_traj_ref_
+  Poly polys[hdsm::MAXP];
+  uint8_t poly_used[hdsm::MAXP];
+  int32_t external_ref, n_fail, corridor_rc, pad;
+  double path_vel;
+};
+
+struct Cfg {                    // what the functions below read of hdsm_params / hdsm_swarm_config / the world
+  int32_t N, P, RS, step_plan, n_it_decomp, use_cvx_new, has_world, pad;
+  double voxel_size, grid_range[3], grid_z_min, thresh_dist;
+  const int8_t* world;          // [wz][wy][wx] or null
+  int32_t wdim[3], pad2;
+  double worigin[3];
+};
+
+// IsOnSegment, AC:1864-1884: |pa| + |pb| == |ab| within 1e-6 and (p - a).(p - b) <= 0
+CD_HD bool on_segment(const V3& p, const V3& a, const V3& b) {
+  const double d1 = norm(sub(p, a)), d2 = norm(sub(p, b)), d12 = norm(sub(a, b));
+  if (fabs(d1 + d2 - d12) < 1e-6) return dot(sub(p, a), sub(p, b)) <= 0;
+  return false;
+}
+
+// the part of the global path that is still ahead of `p`, a point ON the path (AC:1480-1495): out = [p, waypoints after the
+// segment that contains p ...]; returns the number of points (<= PATH_PTS + 1)
+CD_HD int path_ahead(const AgentS& ag, const V3& p, V3* out) {
+  int start_idx = 0;
+  for (int i = 0; i + 1 < ag.n_path; ++i)
+    if (on_segment(p, ag.path[i], ag.path[i + 1])) {
+      start_idx = i + 1;
+      break;
+    }
+  int n = 0;
+  out[n++] = p;
+  for (int i = start_idx; i < ag.n_path; ++i) out[n++] = ag.path[i];
+  return n;
+}
+
+// The polyline SamplePath walks this round (AC:1459-1496): starting point from the previous reference, then the rest of
+// the global path.
+CD_HD int reference_polyline(const AgentS& ag, V3* out) {
+  V3 starting;
+  if (ag.n_ref > 0) {
+    const double* r = ag.increment ? ag.traj_ref[1] : ag.traj_ref[0];
+    starting = {{r[0], r[1], r[2]}};
+  } else {
+    starting = ag.path[0];
+  }
+  return path_ahead(ag, starting, out);
+}
+
+// Free-space polyhedron of GetPolyOcta3D (convex_decomp.cpp:5-376) in closed form: every face advances
+// one voxel layer per visit, round robin, n_it/6 visits each; growth stays inside local voxels 1..dim-2 and above the ground
+// (voxels below world z = grid_z_min are unknown -> occupied).
+CD_HD void free_space_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Poly* out) {
+  const double vs = c.voxel_size;
+  const int layers = c.n_it_decomp / 6;
+  double lo[3], hi[3];
+  for (int ax = 0; ax < 3; ++ax) {
+    const int dim = (int)floor(c.grid_range[ax] / vs);
+    int lo_lim = 1, hi_lim = dim - 2;
+    if (ax == 2) {
+      const int first_free = (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
+      if (first_free > lo_lim) lo_lim = first_free;
+    }
+    int a = seed[ax] - layers, b = seed[ax] + layers;
+    if (a < lo_lim) a = lo_lim;
+    if (b > hi_lim) b = hi_lim;
+    lo[ax] = a * vs + grid_origin[ax];
+    hi[ax] = (b + 1) * vs + grid_origin[ax];
+  }
+  // face order of convex_decomp.cpp:361-373: -y, +x, +y, -x, +z, -z ; rows n.x <= n.p
+  const double n[6][3] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
+  const double rhs[6] = {-lo[1], hi[0], hi[1], -lo[0], hi[2], -lo[2]};
+  out->rows = 6;
+  for (int r = 0; r < 6; ++r) {
+    for (int k = 0; k < 3; ++k) out->A[r][k] = n[r][k];
+    out->b[r] = rhs[r];
+  }
+}
+
+// Polyhedron around a seed on an occupied world: the agent's local voxel grid (what env_builder hands to the planner,
+// environment_builder.cpp:58-67) is a WINDOW of the world grid (corridor_core.h WindowGrid: ground below, unknown = occupied,
+// outside the world = free). A seed pinched between two occupied voxels along an axis gets the shape-aware variant
+// (AC:1385-1397), every other seed the original one. `bits` = WindowGrid::WORDS words of scratch.
+CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Work* wk, uint32_t* bits, Poly* out) {
+  const double vs = c.voxel_size;
+  int dim[3], off[3];
+  for (int ax = 0; ax < 3; ++ax) {
+    dim[ax] = (int)floor(c.grid_range[ax] / vs);
+    off[ax] = (int)lround((grid_origin[ax] - c.worigin[ax]) / vs);  // local voxel 0 in world voxels
+  }
+  out->rows = 0;
+  for (int ax = 0; ax < 3; ++ax)
+    if (seed[ax] < 0 || seed[ax] >= dim[ax]) return HDSM_ERR_BAD_ARG;
+  for (int w = 0; w < WindowGrid::WORDS; ++w) bits[w] = 0u;
+  const Cell sc{seed[0], seed[1], seed[2]};
+  WindowGrid g{c.world, c.wdim[0], c.wdim[1], c.wdim[2], off[0], off[1], off[2], dim[0], dim[1], dim[2],
+               (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9), -1, sc, bits};
+  auto occupied = [&](int dx, int dy, int dz) {  // VoxelGrid::IsOccupied: == 100, outside the grid: not occupied
+    const Cell q{sc.x + dx, sc.y + dy, sc.z + dz};
+    return g.inside(q) && g.value(q) == hdsm_cd::kOccupied;
+  };
+  const bool pinched = (occupied(-1, 0, 0) && occupied(1, 0, 0)) || (occupied(0, -1, 0) && occupied(0, 1, 0)) ||
+                       (occupied(0, 0, -1) && occupied(0, 0, 1));
+  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
+  double rows[HDSM_MAX_ROWS_STATIC * 4];
+  int n = 0;
+  const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
+  const int rc = hdsm_cd::decompose_core(g, *wk, (pinched || c.use_cvx_new) ? 1 : 0, sc, c.n_it_decomp, vs, -1, org, rows, cap, &n);
+  if (rc != hdsm_cd::CD_OK) return HDSM_ERR_CAPACITY;
+  out->rows = n;
+  for (int r = 0; r < n; ++r) {
+    for (int k = 0; k < 3; ++k) out->A[r][k] = rows[4 * r + k];
+    out->b[r] = rows[4 * r + 3];
+  }
+  return HDSM_OK;
+}
+
+// GenerateSafeCorridor, AC:1236-1447. `wk`, `bits`: scratch of the voxel decomposition (unused in free space).
+CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
+  ag.corridor_rc = 0;
+  const int P = c.P, N = c.N;
+  Poly* fresh = ag.polys;  // the kept polyhedra are compacted in place (kept indices only move down)
+  int n_poly = 0;
+  bool kept_last = false;
+  if (ag.n_poly > 0) {  // AC:1253-1267: the whole previous plan inside the LAST polyhedron -> keep only it
+    bool all_in = true;
+    if (ag.has_traj)
+      for (int j = 0; j <= N; ++j)
+        if (!inside(ag.polys[ag.n_poly - 1], V3{{ag.traj_curr[j][0], ag.traj_curr[j][1], ag.traj_curr[j][2]}})) {
+          all_in = false;
+          break;
+        }
+    if (all_in) {
+      if (ag.n_poly - 1 != 0) fresh[0] = ag.polys[ag.n_poly - 1];
+      n_poly = 1, kept_last = true;
+    }
+  }
+  if (ag.n_poly > 0 && !kept_last)  // AC:1273-1282: keep the polyhedra used by the last solve
+    for (int i = 0; i < P && i < ag.n_poly; ++i)
+      if (ag.poly_used[i]) {
+        if (n_poly != i) fresh[n_poly] = ag.polys[i];
+        ++n_poly;
+      }
+
+  // path: current position pushed in front of the global path (AC:1286-1290). The path thread re-plans from the kept
+  // reference points (AC:328-350), so path_curr_ starts at the last reference start; the rest of the polyline follows.
+  V3 path[PATH_PTS + 2];
+  const V3 path_head = ag.n_ref == 0 ? ag.path[0] : V3{{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]}};
+  path[0] = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
+  const int n_path = 1 + path_ahead(ag, path_head, path + 1);
+  // local voxel grid origin (env_builder GenerateVoxelGridMSG, environment_builder.cpp:58-67)
+  const double vs = c.voxel_size;
+  V3 origin;
+  for (int ax = 0; ax < 3; ++ax) origin[ax] = floor((ag.state_curr[ax] - c.grid_range[ax] / 2) / vs) * vs;
+
+  int path_idx = 1;
+  V3 curr = path[0];
+  const double samp = vs / 10;  // AC:1316
+  while (n_poly < P) {
+    const V3 next = path[path_idx];
+    const V3 diff = sub(next, curr);
+    const double dist_next = norm(diff);
+    if (dist_next > samp) {
+      curr = axpy(curr, samp / dist_next, diff);
+    } else {
+      curr = next;
+      if (++path_idx == n_path) break;
+    }
+    bool inside_one = false;
+    for (int i = 0; i < n_poly; ++i)
+      if (inside(fresh[i], curr)) {
+        inside_one = true;
+        break;
+      }
+    if (inside_one) continue;
+    V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
+    if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
+    int seed[3];
+    V3 seed_world;
+    for (int ax = 0; ax < 3; ++ax) {
+      seed[ax] = (int)((seed_pt[ax] - origin[ax]) / vs);  // AC:1357-1359 (truncation)
+      seed_world[ax] = (seed[ax] * vs + vs / 2) + origin[ax];
+    }
+    bool previous_seed = false;  // AC:1361-1379
+    for (int i = 0; i < n_poly; ++i)
+      if (fresh[i].seed[0] == seed_world[0] && fresh[i].seed[1] == seed_world[1] && fresh[i].seed[2] == seed_world[2]) {
+        previous_seed = true;
+        break;
+      }
+    if (previous_seed) continue;
+    Poly& np = fresh[n_poly];
+    if (c.has_world) {
+      // a seed outside the local grid or a polyhedron with more rows than the solver takes: stop generating for this agent
+      // this round (it keeps the polyhedra it has) and report through hdsm_swarm_corridor_errors
+      const int rc = world_poly(c, origin, seed, wk, bits, &np);
+      if (rc != HDSM_OK) {
+        ag.corridor_rc = rc;
+        break;
+      }
+    } else {
+      free_space_poly(c, origin, seed, &np);
+    }
+    np.seed = seed_world;
+    ++n_poly;
+  }
+  ag.n_poly = n_poly;
+}
+
+// GetPathProgress (path_finding_util/src/path_tools.cpp:419-479) + CheckReferenceTrajIncrement (AC:569-585)
+CD_HD void check_increment(const Cfg& c, AgentS& ag) {
+  ag.increment = 0;
+  if (!ag.has_traj || ag.n_ref < 2) return;
+  const V3 pt = {{ag.traj_curr[1][0], ag.traj_curr[1][1], ag.traj_curr[1][2]}};
+  auto ref_pt = [&](int i) { return V3{{ag.traj_ref[i][0], ag.traj_ref[i][1], ag.traj_ref[i][2]}}; };
+  V3 curr = ref_pt(0);
+  double dist_min = norm(sub(pt, curr)), progress = 0, progress_final = 0, proj_dist = dist_min;
+  int idx = 1;
+  const double samp = 0.01;
+  while (idx < ag.n_ref) {
+    const V3 diff = sub(ref_pt(idx), curr);
+    const double dist_next = norm(diff);
+    if (dist_next > samp) {
+      curr = axpy(curr, samp / dist_next, diff);
+      progress += samp;
+    } else {
+      curr = ref_pt(idx);
+      ++idx;
+      progress += dist_next;
+    }
+    const double d = norm(sub(pt, curr));
+    if (d < dist_min) {
+      dist_min = d;
+      proj_dist = d;
+      progress_final = progress;
+    }
+  }
+  if (progress_final > 0 && proj_dist < c.thresh_dist) ag.increment = 1;
+}
+
+// Consumes one agent's solver outputs (AC:960-1019, 182, 233-238); returns 1 if the agent has a plan to publish.
+CD_HD int commit_one(const Cfg& c, AgentS& ag, const double* traj /*[N+1][9]*/, const double* ctrl /*[N][3]*/, const uint8_t* used /*[P]*/,
+                     int status) {
+  const int N = c.N, P = c.P;
+  if (status != HDSM_NO_SOLUTION) {  // AC:960-987
+    for (int i = 0; i <= N; ++i)
+      for (int k = 0; k < 9; ++k) ag.traj_curr[i][k] = traj[i * 9 + k];
+    for (int i = 0; i < N; ++i)
+      for (int k = 0; k < 3; ++k) ag.ctrl_curr[i][k] = ctrl[i * 3 + k];
+    for (int j = 0; j < P; ++j) ag.poly_used[j] = used[j];
+    ag.has_traj = 1;
+  } else {  // AC:1000-1019: drop the first state/control of the previous plan, duplicate the last
+    ++ag.n_fail;
+    if (ag.has_traj) {
+      for (int i = 0; i < N; ++i)
+        for (int k = 0; k < 9; ++k) ag.traj_curr[i][k] = ag.traj_curr[i + 1][k];
+      for (int i = 0; i + 1 < N; ++i)
+        for (int k = 0; k < 3; ++k) ag.ctrl_curr[i][k] = ag.ctrl_curr[i + 1][k];
+    }
+  }
+  if (ag.has_traj) {
+    check_increment(c, ag);  // AC:182
+    for (int k = 0; k < 9; ++k) ag.state_curr[k] = ag.traj_curr[c.step_plan][k];  // AC:233-238
+  }
+  return ag.has_traj;
+}
+
+// the solver inputs of one agent (layouts of include/hdsm.h)
+CD_HD void fill_inputs(const Cfg& c, const AgentS& ag, int32_t* agent_id, double* state_curr, double* traj_ref, int32_t* n_poly,
+                       int32_t* n_rows_static, double* A_static, double* b_static) {
+  const int N = c.N, P = c.P, RS = c.RS;
+  *agent_id = ag.id;
+  for (int k = 0; k < 9; ++k) state_curr[k] = ag.state_curr[k];
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < 6; ++k) traj_ref[i * 6 + k] = ag.traj_ref[i][k];
+  *n_poly = ag.n_poly;
+  for (int j = 0; j < P; ++j) {
+    const bool have = j < ag.n_poly;
+    n_rows_static[j] = have ? ag.polys[j].rows : 0;
+    for (int r = 0; r < RS; ++r) {
+      const bool hr = have && r < ag.polys[j].rows;
+      for (int k = 0; k < 3; ++k) A_static[(j * RS + r) * 3 + k] = hr ? ag.polys[j].A[r][k] : 0.0;
+      b_static[j * RS + r] = hr ? ag.polys[j].b[r] : 0.0;
+    }
+  }
+}
+
+}  // namespace hdsm_sw

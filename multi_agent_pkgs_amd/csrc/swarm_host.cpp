@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <queue>
 #include <thread>
@@ -16,45 +17,22 @@
 
 #include "../../include/hdsm_stats.h"
 #include "../../include/hdsm_swarm.h"
+#include "swarm_core.h"
 
 namespace {
 
-using V3 = std::array<double, 3>;
+using hdsm_sw::AgentS;
+using hdsm_sw::axpy;
+using hdsm_sw::dot;
+using hdsm_sw::norm;
+using hdsm_sw::on_segment;
+using hdsm_sw::Poly;
+using hdsm_sw::sub;
+using hdsm_sw::V3;
 
-inline V3 sub(const V3& a, const V3& b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
-inline V3 axpy(const V3& a, double s, const V3& b) { return {a[0] + s * b[0], a[1] + s * b[1], a[2] + s * b[2]}; }
-inline double dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline double norm(const V3& a) { return std::sqrt(dot(a, a)); }
-
-struct Poly {  // LinearConstraint3D: rows A x <= b
-  int rows = 0;
-  double A[HDSM_MAX_ROWS_STATIC][3];
-  double b[HDSM_MAX_ROWS_STATIC];
-  V3 seed{};  // poly_seeds_ entry (voxel centre in world coordinates)
-  // LinearConstraint::inside (decomp_geometry/polyhedron.h:130-137): rejected when A x - b > 0
-  bool inside(const V3& p) const {
-    for (int r = 0; r < rows; ++r)
-      if (A[r][0] * p[0] + A[r][1] * p[1] + A[r][2] * p[2] - b[r] > 0) return false;
-    return true;
-  }
-};
-
-struct Agent {
-  int id = 0;
-  V3 start{}, goal{};
-  std::vector<V3> path;                            // path_curr_: global path start -> goal (straight unless routed / set)
-  std::array<double, 9> state_curr{};
-  std::vector<std::array<double, 9>> traj_curr;    // traj_curr_     (empty before the first solve)
-  std::vector<std::array<double, 3>> control_curr; // control_curr_
-  std::vector<std::array<double, 6>> traj_ref;     // traj_ref_curr_ (N+1 rows)
-  std::vector<Poly> polys;                         // poly_const_vec_ / poly_seeds_
-  std::vector<uint8_t> poly_used;                  // poly_used_idx_
-  bool increment_traj_ref = false;
-  bool external_ref = false;  // traj_ref was supplied by hdsm_swarm_set_reference() for the coming prepare()
-  double path_vel = 0;
-  int n_fail = 0;
-  int corridor_rc = 0;  // last error of the voxel decomposition for this agent (0 = none)
-  void* stats = nullptr;  // hdsm_stats record of this agent (comp_time_*_, state_hist_; f3)
+// host-only companions of an agent's plain state (hdsm_sw::AgentS)
+struct AgentX {
+  void* stats = nullptr;         // hdsm_stats record of this agent (comp_time_*_, state_hist_; f3)
   double sc_ms = 0, ref_ms = 0;  // CPU time of this round's corridor / reference generation
 };
 
@@ -62,7 +40,19 @@ struct Swarm {
   hdsm_params prm;
   hdsm_swarm_config cfg;
   int n_rob = 0, first_id = 0, n_local = 0;
-  std::vector<Agent> agents;
+  std::vector<AgentS> agents;
+  std::vector<AgentX> extra;
+  std::unique_ptr<hdsm_cd::Work> work{new hdsm_cd::Work};  // scratch of the voxel decomposition
+  std::vector<uint32_t> bits = std::vector<uint32_t>(hdsm_cd::WindowGrid::WORDS);
+  hdsm_sw::Cfg core_cfg() const {
+    hdsm_sw::Cfg c{};
+    c.N = prm.n_hor, c.P = prm.poly_hor, c.RS = prm.max_rows_static, c.step_plan = cfg.step_plan;
+    c.n_it_decomp = cfg.n_it_decomp, c.use_cvx_new = cfg.use_cvx_new, c.has_world = has_world ? 1 : 0;
+    c.voxel_size = cfg.voxel_size, c.grid_z_min = cfg.grid_z_min, c.thresh_dist = cfg.thresh_dist;
+    for (int k = 0; k < 3; ++k) c.grid_range[k] = cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
+    c.world = has_world ? world.data() : nullptr;
+    return c;
+  }
   // optional occupancy of the world (hdsm_swarm_set_world): voxels of cfg.voxel_size, >= 100 occupied
   bool has_world = false;
   std::vector<int8_t> world;
@@ -73,7 +63,7 @@ struct Swarm {
   std::chrono::steady_clock::time_point t_round{};
   long long round_idx = 0;
   ~Swarm() {
-    for (Agent& a : agents) hdsm_stats_destroy(a.stats);
+    for (AgentX& a : extra) hdsm_stats_destroy(a.stats);
   }
 };
 
@@ -87,205 +77,17 @@ double velocity_limit(const hdsm_swarm_config& c, double occ, double dist) {
   return c.path_vel_min + (c.path_vel_max - c.path_vel_min) * alpha;
 }
 
-// Free-space polyhedron of GetPolyOcta3D (convex_decomp.cpp:5-376) in closed form:
-// every face advances one voxel layer per visit, round robin, n_it/6 visits each; growth stays inside local
-// voxels 1..dim-2 and above the ground (voxels below world z = grid_z_min are unknown -> occupied).
-void free_space_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], Poly* out) {
-  const hdsm_swarm_config& c = sw.cfg;
-  const double vs = c.voxel_size;
-  const int layers = c.n_it_decomp / 6;
-  double lo[3], hi[3];
-  for (int ax = 0; ax < 3; ++ax) {
-    const int dim = (int)std::floor(c.grid_range[ax] / vs);
-    int lo_lim = 1, hi_lim = dim - 2;
-    if (ax == 2) {
-      const int first_free = (int)std::ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
-      if (first_free > lo_lim) lo_lim = first_free;
-    }
-    int a = seed[ax] - layers, b = seed[ax] + layers;
-    if (a < lo_lim) a = lo_lim;
-    if (b > hi_lim) b = hi_lim;
-    lo[ax] = a * vs + grid_origin[ax];
-    hi[ax] = (b + 1) * vs + grid_origin[ax];
-  }
-  // face order of convex_decomp.cpp:361-373: -y, +x, +y, -x, +z, -z ; rows n.x <= n.p
-  const double n[6][3] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
-  const double rhs[6] = {-lo[1], hi[0], hi[1], -lo[0], hi[2], -lo[2]};
-  out->rows = 6;
-  for (int r = 0; r < 6; ++r) {
-    for (int k = 0; k < 3; ++k) out->A[r][k] = n[r][k];
-    out->b[r] = rhs[r];
-  }
-}
-
-// Polyhedron around a seed on an occupied world: the agent's local voxel grid (what env_builder hands to the
-// planner, environment_builder.cpp:58-67) is cut out of the world grid and given to the voxel decomposition
-// (AC:1404-1416). Voxels below the ground are unknown -> occupied (AC:1302); voxels outside the world grid are free.
-// A seed pinched between two occupied voxels along an axis gets the shape-aware variant (AC:1385-1397:
-// hdsm_poly_octa3d_new = GetPolyOcta3DNew), every other seed the original one (hdsm_poly_octa3d = GetPolyOcta3D).
-// Returns the decomposition's return code; on failure `out` has no rows and must not be used.
-int world_poly(const Swarm& sw, const V3& grid_origin, const int seed[3], int mark, Poly* out) {
-  const hdsm_swarm_config& c = sw.cfg;
-  const double vs = c.voxel_size;
-  int32_t dim[3], off[3];
-  for (int ax = 0; ax < 3; ++ax) {
-    dim[ax] = (int32_t)std::floor(c.grid_range[ax] / vs);
-    off[ax] = (int32_t)std::lround((grid_origin[ax] - sw.worigin[ax]) / vs);  // local voxel 0 in world voxels
-  }
-  out->rows = 0;
-  for (int ax = 0; ax < 3; ++ax)
-    if (seed[ax] < 0 || seed[ax] >= dim[ax]) return HDSM_ERR_BAD_ARG;
-  std::vector<int8_t> local((size_t)dim[0] * dim[1] * dim[2], 0);
-  const int first_free_z = (int)std::ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9);
-  for (int k = 0; k < dim[2]; ++k)
-    for (int j = 0; j < dim[1]; ++j)
-      for (int i = 0; i < dim[0]; ++i) {
-        int8_t v = 0;
-        if (k < first_free_z) {
-          v = 100;
-        } else {
-          const int gi = i + off[0], gj = j + off[1], gk = k + off[2];
-          if (gi >= 0 && gj >= 0 && gk >= 0 && gi < sw.wdim[0] && gj < sw.wdim[1] && gk < sw.wdim[2])
-            v = sw.world[(size_t)gi + (size_t)gj * sw.wdim[0] + (size_t)gk * sw.wdim[0] * sw.wdim[1]];
-          if (v < 0) v = 100;  // OccupyUnknown, AC:1307
-        }
-        local[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] = v;
-      }
-  auto occupied = [&](int i, int j, int k) {  // VoxelGrid::IsOccupied: == 100, outside the grid: not occupied
-    if (i < 0 || j < 0 || k < 0 || i >= dim[0] || j >= dim[1] || k >= dim[2]) return false;
-    return local[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] == 100;
-  };
-  const bool pinched = (occupied(seed[0] - 1, seed[1], seed[2]) && occupied(seed[0] + 1, seed[1], seed[2])) ||
-                       (occupied(seed[0], seed[1] - 1, seed[2]) && occupied(seed[0], seed[1] + 1, seed[2])) ||
-                       (occupied(seed[0], seed[1], seed[2] - 1) && occupied(seed[0], seed[1], seed[2] + 1));
-  const int32_t sd[3] = {seed[0], seed[1], seed[2]};
-  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
-  double rows[HDSM_MAX_ROWS_STATIC * 4];
-  int32_t n = 0;
-  const int cap = sw.prm.max_rows_static < HDSM_MAX_ROWS_STATIC ? sw.prm.max_rows_static : HDSM_MAX_ROWS_STATIC;
-  const int rc = (pinched || c.use_cvx_new)
-                     ? hdsm_poly_octa3d_new(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, cap, &n)
-                     : hdsm_poly_octa3d(sd, local.data(), dim, c.n_it_decomp, vs, mark, org, rows, cap, &n);
-  if (rc != HDSM_OK) return rc;
-  out->rows = n;
-  for (int r = 0; r < n; ++r) {
-    for (int k = 0; k < 3; ++k) out->A[r][k] = rows[4 * r + k];
-    out->b[r] = rows[4 * r + 3];
-  }
-  return HDSM_OK;
-}
-
-// the part of the global path that is still ahead of `p`, a point ON the path (AC:1480-1495: the segment containing it is
-// found with IsOnSegment, the path is cut there): [p, waypoints after that segment...]
-bool on_segment(const V3& p, const V3& a, const V3& b);
-std::vector<V3> path_ahead(const Agent& ag, const V3& p) {
-  size_t start_idx = 0;
-  for (size_t i = 0; i + 1 < ag.path.size(); ++i)
-    if (on_segment(p, ag.path[i], ag.path[i + 1])) {
-      start_idx = i + 1;
-      break;
-    }
-  std::vector<V3> out = {p};
-  for (size_t i = start_idx; i < ag.path.size(); ++i) out.push_back(ag.path[i]);
-  return out;
-}
-
-// GenerateSafeCorridor, AC:1236-1447
-void generate_safe_corridor(const Swarm& sw, Agent& ag) {
-  const hdsm_swarm_config& c = sw.cfg;
-  ag.corridor_rc = 0;
-  const int P = sw.prm.poly_hor;
-  std::vector<Poly> fresh;
-  if (!ag.polys.empty()) {  // AC:1253-1267: the whole previous plan inside the LAST polyhedron -> keep only it
-    bool all_in = true;
-    for (const auto& st : ag.traj_curr)
-      if (!ag.polys.back().inside({st[0], st[1], st[2]})) {
-        all_in = false;
-        break;
-      }
-    if (all_in) fresh.push_back(ag.polys.back());
-  }
-  if (!ag.polys.empty() && fresh.empty())  // AC:1273-1282: keep the polyhedra used by the last solve
-    for (size_t i = 0; i < ag.poly_used.size() && i < ag.polys.size(); ++i)
-      if (ag.poly_used[i]) fresh.push_back(ag.polys[i]);
-
-  // path: current position pushed in front of the global path (AC:1286-1290). The path thread re-plans from
-  // the kept reference points (AC:328-350), so in an empty world path_curr_ = [last reference start, goal].
-  // With a routed path (hdsm_swarm_route / hdsm_swarm_set_paths) the rest of that polyline follows the reference start.
-  const V3 path_head = ag.traj_ref.empty() ? ag.path.front() : V3{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]};
-  std::vector<V3> path = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
-  for (const V3& w : path_ahead(ag, path_head)) path.push_back(w);
-  // local voxel grid origin (env_builder GenerateVoxelGridMSG, environment_builder.cpp:58-67)
-  const double vs = c.voxel_size;
-  V3 origin;
-  for (int ax = 0; ax < 3; ++ax) origin[ax] = std::floor((ag.state_curr[ax] - c.grid_range[ax] / 2) / vs) * vs;
-
-  int n_poly = (int)fresh.size();
-  size_t path_idx = 1;
-  V3 curr = path[0];
-  const double samp = vs / 10;  // AC:1316
-  while (n_poly < P) {
-    const V3 next = path[path_idx];
-    const V3 diff = sub(next, curr);
-    const double dist_next = norm(diff);
-    if (dist_next > samp) {
-      curr = axpy(curr, samp / dist_next, diff);
-    } else {
-      curr = next;
-      if (++path_idx == path.size()) break;
-    }
-    bool inside_one = false;
-    for (const auto& p : fresh)
-      if (p.inside(curr)) {
-        inside_one = true;
-        break;
-      }
-    if (inside_one) continue;
-    V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
-    if (dist_next > 0) seed_pt = axpy(curr, -std::fmin(samp, dist_next) / dist_next, diff);
-    int seed[3];
-    V3 seed_world;
-    for (int ax = 0; ax < 3; ++ax) {
-      seed[ax] = (int)((seed_pt[ax] - origin[ax]) / vs);  // AC:1357-1359 (truncation)
-      seed_world[ax] = seed[ax] * vs + vs / 2 + origin[ax];
-    }
-    bool previous_seed = false;  // AC:1361-1379
-    for (const auto& p : fresh)
-      if (p.seed[0] == seed_world[0] && p.seed[1] == seed_world[1] && p.seed[2] == seed_world[2]) {
-        previous_seed = true;
-        break;
-      }
-    if (previous_seed) continue;
-    Poly np;
-    if (sw.has_world) {
-      // a seed outside the local grid or a polyhedron with more rows than the solver takes: stop generating for this
-      // agent this round (it keeps the polyhedra it has) and report through hdsm_swarm_prepare
-      const int rc = world_poly(sw, origin, seed, -(n_poly + 1), &np);
-      if (rc != HDSM_OK) {
-        ag.corridor_rc = rc;
-        break;
-      }
-    } else {
-      free_space_poly(sw, origin, seed, &np);
-    }
-    np.seed = seed_world;
-    fresh.push_back(np);
-    ++n_poly;
-  }
-  ag.polys.swap(fresh);
-}
-
 // ComputePathVelocity, AC:1695-1803: empty world -> only the neighbour term (AC:1769-1801) is active
-double compute_path_velocity(const Swarm& sw, const Agent& ag, const double* plans_all, const uint8_t* has_plan) {
+double compute_path_velocity(const Swarm& sw, const AgentS& ag, const double* plans_all, const uint8_t* has_plan) {
   const int N = sw.prm.n_hor;
   double path_vel = sw.cfg.path_vel_max;
-  for (size_t i = 0; i < ag.traj_curr.size(); ++i) {
-    const V3 start = {ag.traj_curr[i][0], ag.traj_curr[i][1], ag.traj_curr[i][2]};
+  for (int i = 0; i < (ag.has_traj ? N + 1 : 0); ++i) {
+    const V3 start = {{ag.traj_curr[i][0], ag.traj_curr[i][1], ag.traj_curr[i][2]}};
     const double occ = 100 * std::pow(sw.cfg.sens_other_agents, (double)i);
     for (int j = 0; j < sw.n_rob; ++j) {
       if (j == ag.id || !has_plan[j]) continue;
       const double* st = plans_all + ((size_t)j * (N + 1) + i) * 9;
-      const double d = norm(sub(start, {st[0], st[1], st[2]}));
+      const double d = norm(sub(start, V3{{st[0], st[1], st[2]}}));
       const double v = velocity_limit(sw.cfg, occ, d);
       if (v < path_vel) path_vel = v;
     }
@@ -294,7 +96,7 @@ double compute_path_velocity(const Swarm& sw, const Agent& ag, const double* pla
 }
 
 // SamplePath, AC:1591-1663
-std::vector<V3> sample_path(const Swarm& sw, Agent& ag, const std::vector<V3>& path, const double* plans_all,
+std::vector<V3> sample_path(const Swarm& sw, AgentS& ag, const std::vector<V3>& path, const double* plans_all,
                             const uint8_t* has_plan) {
   const int N = sw.prm.n_hor;
   std::vector<V3> ref;
@@ -329,32 +131,18 @@ std::vector<V3> sample_path(const Swarm& sw, Agent& ag, const std::vector<V3>& p
   return ref;
 }
 
-// IsOnSegment, AC:1864-1884: |pa| + |pb| == |ab| within 1e-6 and (p - a).(p - b) <= 0
-bool on_segment(const V3& p, const V3& a, const V3& b) {
-  const double d1 = norm(sub(p, a)), d2 = norm(sub(p, b)), d12 = norm(sub(a, b));
-  if (std::fabs(d1 + d2 - d12) < 1e-6) return dot(sub(p, a), sub(p, b)) <= 0;
-  return false;
-}
-
-// The polyline SamplePath walks this round (AC:1459-1496): starting point from the previous reference, then the
-// global path from the segment that contains it.
-std::vector<V3> reference_polyline(const Agent& ag) {
-  V3 starting;
-  if (!ag.traj_ref.empty()) {
-    const auto& r = ag.increment_traj_ref ? ag.traj_ref[1] : ag.traj_ref[0];
-    starting = {r[0], r[1], r[2]};
-  } else {
-    starting = ag.path.front();
-  }
-  return path_ahead(ag, starting);
+std::vector<V3> reference_polyline(const AgentS& ag) {
+  V3 buf[hdsm_sw::PATH_PTS + 1];
+  const int n = hdsm_sw::reference_polyline(ag, buf);
+  return std::vector<V3>(buf, buf + n);
 }
 
 // GenerateReferenceTrajectory, AC:1449-1553
-void generate_reference(const Swarm& sw, Agent& ag, const double* plans_all, const uint8_t* has_plan) {
+void generate_reference(const Swarm& sw, AgentS& ag, const double* plans_all, const uint8_t* has_plan) {
   const std::vector<V3> path_samp = reference_polyline(ag);  // AC:1459-1496
   std::vector<V3> pts = sample_path(sw, ag, path_samp, plans_all, has_plan);
   // velocity reference, AC:1527-1547 (points backwards along the path; reproduced as is)
-  ag.traj_ref.assign(pts.size(), {});
+  ag.n_ref = (int)pts.size();
   double v[3] = {0, 0, 0};
   for (size_t i = 0; i < pts.size(); ++i) {
     if (i + 1 < pts.size()) {
@@ -362,42 +150,9 @@ void generate_reference(const Swarm& sw, Agent& ag, const double* plans_all, con
       const double dist = norm(d);
       for (int k = 0; k < 3; ++k) v[k] = dist > 1e-2 ? ag.path_vel * d[k] / dist : 0.0;
     }
-    ag.traj_ref[i] = {pts[i][0], pts[i][1], pts[i][2], v[0], v[1], v[2]};
+    for (int k = 0; k < 3; ++k) ag.traj_ref[i][k] = pts[i][k], ag.traj_ref[i][3 + k] = v[k];
   }
 }
-
-// GetPathProgress (path_finding_util/src/path_tools.cpp:419-479) + CheckReferenceTrajIncrement (AC:569-585)
-void check_reference_increment(const Swarm& sw, Agent& ag) {
-  ag.increment_traj_ref = false;
-  if (ag.traj_curr.size() < 2 || ag.traj_ref.size() < 2) return;
-  const V3 pt = {ag.traj_curr[1][0], ag.traj_curr[1][1], ag.traj_curr[1][2]};
-  std::vector<V3> path;
-  for (const auto& r : ag.traj_ref) path.push_back({r[0], r[1], r[2]});
-  V3 curr = path[0];
-  double dist_min = norm(sub(pt, curr)), progress = 0, progress_final = 0, proj_dist = dist_min;
-  size_t idx = 1;
-  const double samp = 0.01;
-  while (idx < path.size()) {
-    const V3 diff = sub(path[idx], curr);
-    const double dist_next = norm(diff);
-    if (dist_next > samp) {
-      curr = axpy(curr, samp / dist_next, diff);
-      progress += samp;
-    } else {
-      curr = path[idx];
-      ++idx;
-      progress += dist_next;
-    }
-    const double d = norm(sub(pt, curr));
-    if (d < dist_min) {
-      dist_min = d;
-      proj_dist = d;
-      progress_final = progress;
-    }
-  }
-  if (progress_final > 0 && proj_dist < sw.cfg.thresh_dist) ag.increment_traj_ref = true;
-}
-
 
 // ---- a minimal router on the world grid (see hdsm_swarm_route in hdsm_swarm.h) -------------------------------------
 struct Router {
@@ -614,14 +369,14 @@ int hdsm_swarm_create(const hdsm_params* prm, const hdsm_swarm_config* cfg, int3
   Swarm* sw = new (std::nothrow) Swarm;
   if (!sw) return HDSM_ERR_DEVICE;
   sw->prm = *prm, sw->cfg = *cfg, sw->n_rob = n_rob, sw->first_id = first_id, sw->n_local = n_local;
-  sw->agents.resize(n_local);
+  sw->agents.assign(n_local, AgentS{});
+  sw->extra.assign(n_local, AgentX{});
   for (int k = 0; k < n_local; ++k) {
-    Agent& a = sw->agents[k];
+    AgentS& a = sw->agents[k];
     a.id = first_id + k;
     for (int ax = 0; ax < 3; ++ax) a.start[ax] = starts[3 * k + ax], a.goal[ax] = goals[3 * k + ax];
-    a.path = {a.start, a.goal};
-    a.stats = hdsm_stats_create(a.id, n_rob);
-    a.state_curr.fill(0.0);
+    a.n_path = 2, a.path[0] = a.start, a.path[1] = a.goal;
+    sw->extra[k].stats = hdsm_stats_create(a.id, n_rob);
     for (int ax = 0; ax < 3; ++ax) a.state_curr[ax] = a.start[ax];
   }
   *swarm = sw;
@@ -640,29 +395,18 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
   const int N = sw->prm.n_hor, P = sw->prm.poly_hor, RS = sw->prm.max_rows_static;
   sw->t_round = std::chrono::steady_clock::now();
   sw->solve_ms = 0;
+  const hdsm_sw::Cfg cc = sw->core_cfg();
   for (int k = 0; k < sw->n_local; ++k) {
-    Agent& ag = sw->agents[k];
+    AgentS& ag = sw->agents[k];
     clock_t t0 = clock();
-    generate_safe_corridor(*sw, ag);                     // AC:165
-    ag.sc_ms = cpu_ms_since(t0);                         // comp_time_sc_, AC:1446
+    hdsm_sw::corridor_step(cc, ag, sw->work.get(), sw->bits.data());  // AC:165
+    sw->extra[k].sc_ms = cpu_ms_since(t0);                               // comp_time_sc_, AC:1446
     t0 = clock();
     if (!ag.external_ref) generate_reference(*sw, ag, plans_all, has_plan);  // AC:171 (or done on the device, f1)
-    ag.ref_ms = cpu_ms_since(t0);
-    ag.external_ref = false;
-    agent_id[k] = ag.id;
-    for (int c = 0; c < 9; ++c) state_curr[9 * k + c] = ag.state_curr[c];
-    for (int i = 0; i < N; ++i)
-      for (int c = 0; c < 6; ++c) traj_ref[((size_t)k * N + i) * 6 + c] = ag.traj_ref[i][c];
-    n_poly[k] = (int32_t)ag.polys.size();
-    for (int j = 0; j < P; ++j) {
-      const bool have = j < (int)ag.polys.size();
-      n_rows_static[k * P + j] = have ? ag.polys[j].rows : 0;
-      for (int r = 0; r < RS; ++r) {
-        const bool hr = have && r < ag.polys[j].rows;
-        for (int c = 0; c < 3; ++c) A_static[(((size_t)k * P + j) * RS + r) * 3 + c] = hr ? ag.polys[j].A[r][c] : 0.0;
-        b_static[((size_t)k * P + j) * RS + r] = hr ? ag.polys[j].b[r] : 0.0;
-      }
-    }
+    sw->extra[k].ref_ms = cpu_ms_since(t0);
+    ag.external_ref = 0;
+    hdsm_sw::fill_inputs(cc, ag, agent_id + k, state_curr + 9 * (size_t)k, traj_ref + (size_t)k * N * 6, n_poly + k,
+                         n_rows_static + (size_t)k * P, A_static + (size_t)k * P * RS * 3, b_static + (size_t)k * P * RS);
   }
   return HDSM_OK;
 }
@@ -673,31 +417,11 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
   if (!sw || !traj_out || !ctrl_out || !poly_used || !status || !plans_local || !has_plan_local)
     return HDSM_ERR_BAD_ARG;
   const int N = sw->prm.n_hor, P = sw->prm.poly_hor;
+  const hdsm_sw::Cfg cc = sw->core_cfg();
   for (int k = 0; k < sw->n_local; ++k) {
-    Agent& ag = sw->agents[k];
-    if (status[k] != HDSM_NO_SOLUTION) {  // AC:960-987
-      ag.traj_curr.assign(N + 1, {});
-      ag.control_curr.assign(N, {});
-      for (int i = 0; i <= N; ++i)
-        for (int c = 0; c < 9; ++c) ag.traj_curr[i][c] = traj_out[((size_t)k * (N + 1) + i) * 9 + c];
-      for (int i = 0; i < N; ++i)
-        for (int c = 0; c < 3; ++c) ag.control_curr[i][c] = ctrl_out[((size_t)k * N + i) * 3 + c];
-      ag.poly_used.assign(P, 0);
-      for (int j = 0; j < P; ++j) ag.poly_used[j] = poly_used[k * P + j];
-    } else {  // AC:1000-1019: drop the first state/control of the previous plan, duplicate the last
-      ++ag.n_fail;
-      if (!ag.traj_curr.empty()) {
-        ag.traj_curr.erase(ag.traj_curr.begin());
-        ag.control_curr.erase(ag.control_curr.begin());
-        ag.traj_curr.push_back(ag.traj_curr.back());
-        ag.control_curr.push_back(ag.control_curr.back());
-      }
-    }
-    const bool have_plan = !ag.traj_curr.empty();
-    if (have_plan) {
-      check_reference_increment(*sw, ag);  // AC:182
-      ag.state_curr = ag.traj_curr[sw->cfg.step_plan];  // AC:233-238
-    }
+    AgentS& ag = sw->agents[k];
+    const int have_plan = hdsm_sw::commit_one(cc, ag, traj_out + (size_t)k * (N + 1) * 9, ctrl_out + (size_t)k * N * 3,
+                                              poly_used + (size_t)k * P, status[k]);
     has_plan_local[k] = have_plan ? 1 : 0;
     for (int i = 0; i <= N; ++i)
       for (int c = 0; c < 9; ++c)
@@ -707,13 +431,14 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
   // launch: its duration (hdsm_swarm_record_solve_ms) is booked as comp_time_opt_, comp_time_tasc_ is 0.
   const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sw->t_round).count();
   const double stamp = (double)(sw->round_idx + 1) * sw->prm.dt * sw->cfg.step_plan;
-  for (Agent& ag : sw->agents) {
-    hdsm_stats_add(ag.stats, HDSM_STAT_SC, ag.sc_ms);
-    hdsm_stats_add(ag.stats, HDSM_STAT_TASC, 0.0);
-    hdsm_stats_add(ag.stats, HDSM_STAT_OPT, sw->solve_ms);
-    hdsm_stats_add(ag.stats, HDSM_STAT_TOT, ag.sc_ms + ag.ref_ms + sw->solve_ms);
-    hdsm_stats_add(ag.stats, HDSM_STAT_TOT_WALL, wall_ms);
-    hdsm_stats_add_state(ag.stats, stamp, ag.state_curr.data(), 9);
+  for (int k = 0; k < sw->n_local; ++k) {
+    const AgentX& x = sw->extra[k];
+    hdsm_stats_add(x.stats, HDSM_STAT_SC, x.sc_ms);
+    hdsm_stats_add(x.stats, HDSM_STAT_TASC, 0.0);
+    hdsm_stats_add(x.stats, HDSM_STAT_OPT, sw->solve_ms);
+    hdsm_stats_add(x.stats, HDSM_STAT_TOT, x.sc_ms + x.ref_ms + sw->solve_ms);
+    hdsm_stats_add(x.stats, HDSM_STAT_TOT_WALL, wall_ms);
+    hdsm_stats_add_state(x.stats, stamp, sw->agents[k].state_curr, 9);
   }
   ++sw->round_idx;
   return HDSM_OK;
@@ -729,7 +454,7 @@ int hdsm_swarm_record_solve_ms(void* swarm, double milliseconds) {
 int hdsm_swarm_shutdown(void* swarm, int32_t local_index, const char* dir, int32_t save_stats, char* report, int32_t report_cap) {
   Swarm* sw = static_cast<Swarm*>(swarm);
   if (!sw || local_index < 0 || local_index >= sw->n_local) return HDSM_ERR_BAD_ARG;
-  return hdsm_stats_shutdown(sw->agents[local_index].stats, dir, save_stats, report, report_cap);
+  return hdsm_stats_shutdown(sw->extra[local_index].stats, dir, save_stats, report, report_cap);
 }
 
 int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32_t* n_path) {
@@ -761,12 +486,12 @@ int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* 
   if (!sw || !ref_full || !path_vel) return HDSM_ERR_BAD_ARG;
   const int N = sw->prm.n_hor;
   for (int k = 0; k < sw->n_local; ++k) {
-    Agent& ag = sw->agents[k];
-    ag.traj_ref.assign(N + 1, {});
+    AgentS& ag = sw->agents[k];
+    ag.n_ref = N + 1;
     for (int i = 0; i <= N; ++i)
       for (int c = 0; c < 6; ++c) ag.traj_ref[i][c] = ref_full[((size_t)k * (N + 1) + i) * 6 + c];
     ag.path_vel = path_vel[k];
-    ag.external_ref = true;
+    ag.external_ref = 1;
   }
   return HDSM_OK;
 }
@@ -794,13 +519,13 @@ int hdsm_swarm_set_paths(void* swarm, const double* paths, const int32_t* n_path
   Swarm* sw = static_cast<Swarm*>(swarm);
   if (!sw || !paths || !n_path || pmax < 2) return HDSM_ERR_BAD_ARG;
   for (int k = 0; k < sw->n_local; ++k)
-    if (n_path[k] < 2 || n_path[k] > pmax) return HDSM_ERR_BAD_ARG;
+    if (n_path[k] < 2 || n_path[k] > pmax || n_path[k] > hdsm_sw::PATH_PTS) return HDSM_ERR_BAD_ARG;
   for (int k = 0; k < sw->n_local; ++k) {
-    Agent& ag = sw->agents[k];
-    ag.path.clear();
+    AgentS& ag = sw->agents[k];
+    ag.n_path = n_path[k];
     for (int i = 0; i < n_path[k]; ++i) {
       const double* p = paths + ((size_t)k * pmax + i) * 3;
-      ag.path.push_back({p[0], p[1], p[2]});
+      ag.path[i] = V3{{p[0], p[1], p[2]}};
     }
   }
   return HDSM_OK;
@@ -811,11 +536,11 @@ int hdsm_swarm_get_paths(void* swarm, int32_t pmax, double* paths, int32_t* n_pa
   if (!sw || !paths || !n_path || pmax < 2) return HDSM_ERR_BAD_ARG;
   int rc = HDSM_OK;
   for (int k = 0; k < sw->n_local; ++k) {
-    const Agent& ag = sw->agents[k];
-    n_path[k] = (int32_t)ag.path.size();
-    if ((int)ag.path.size() > pmax) rc = HDSM_ERR_CAPACITY;
+    const AgentS& ag = sw->agents[k];
+    n_path[k] = ag.n_path;
+    if (ag.n_path > pmax) rc = HDSM_ERR_CAPACITY;
     for (int i = 0; i < pmax; ++i) {
-      const V3& p = ag.path[i < (int)ag.path.size() ? i : (int)ag.path.size() - 1];
+      const V3& p = ag.path[i < ag.n_path ? i : ag.n_path - 1];
       for (int c = 0; c < 3; ++c) paths[((size_t)k * pmax + i) * 3 + c] = p[c];
     }
   }
@@ -830,15 +555,20 @@ int hdsm_swarm_route(void* swarm, int32_t* n_failed) {
   auto worker = [&]() {
     Router::Work wk;
     for (int k = next.fetch_add(1); k < sw->n_local; k = next.fetch_add(1)) {
-      Agent& ag = sw->agents[k];
+      AgentS& ag = sw->agents[k];
       std::vector<V3> path;
-      if (router.route(ag.start, ag.goal, &path, wk)) {
+      bool ok = router.route(ag.start, ag.goal, &path, wk);
+      if (ok) {
         // the reference sampling starts ON the path and corridor seeds are taken along it: the first point is the start
         if (norm(sub(path.front(), ag.start)) > 0) path.insert(path.begin(), ag.start);
         if (norm(sub(path.back(), ag.goal)) > 0) path.push_back(ag.goal);
-        ag.path.swap(path);
+        ok = (int)path.size() <= hdsm_sw::PATH_PTS;
+      }
+      if (ok) {
+        ag.n_path = (int)path.size();
+        for (int i = 0; i < ag.n_path; ++i) ag.path[i] = path[i];
       } else {
-        ag.path = {ag.start, ag.goal};
+        ag.n_path = 2, ag.path[0] = ag.start, ag.path[1] = ag.goal;
         failed.fetch_add(1);
       }
     }
@@ -869,8 +599,8 @@ int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fai
   Swarm* sw = static_cast<Swarm*>(swarm);
   if (!sw) return HDSM_ERR_BAD_ARG;
   for (int k = 0; k < sw->n_local; ++k) {
-    const Agent& ag = sw->agents[k];
-    const V3 p = {ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]};
+    const AgentS& ag = sw->agents[k];
+    const V3 p = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
     if (pos)
       for (int c = 0; c < 3; ++c) pos[3 * k + c] = p[c];
     if (dist_goal) dist_goal[k] = norm(sub(p, ag.goal));
