@@ -138,6 +138,28 @@ int hdsm_swarm_reference_inputs_n(void* swarm, int32_t pmax, double* path, int32
  * agents kept the polyhedra they had. */
 int hdsm_swarm_corridor_errors(void* swarm, int32_t* codes);
 
+/* GenerateSafeCorridor alone (AC:165). With the reference generated elsewhere (hdsm_reference*, row f1) the reference's own order
+ * is: corridor from the PREVIOUS reference, then the new reference, then the solve — call this first, then
+ * hdsm_swarm_reference_inputs* / hdsm_reference* / hdsm_swarm_set_reference, then hdsm_swarm_prepare (which then skips the corridor). */
+int hdsm_swarm_prepare_corridor(void* swarm);
+
+/* ---- the device-resident closed loop ------------------------------------------------------------------------------------------
+ * The planner state of the shard moves into HBM (hdsm_dswarm_create copies it out of a host mirror that has been set up —
+ * starts, goals, world, paths — and possibly flown for some rounds) and one replan round becomes a chain of launches on one
+ * stream with no host round trip (csrc/swarm_kernels.hip):
+ *   corridor (AC:1236-1447, row f2 on the device) -> reference (row f1) -> solver inputs -> hdsm_replan_device -> commit
+ *   (AC:960-1019, 569-585, 233-238) -> published records -> ONE RCCL all-gather (hdsm_exchange_device; a copy on a single rank).
+ * `solver` is an hdsm handle with max_instances >= the shard and n_rob_max >= world_size * ceil(n_rob / world_size); `comm` an
+ * hdsm_comm (NULL when world_size == 1). hdsm_dswarm_round is asynchronous on hip_stream. hdsm_dswarm_download synchronises
+ * and copies out what the caller asks for (any pointer may be NULL): the agent states back into the host mirror `swarm`
+ * (so that every hdsm_swarm_* diagnostic works on them), the all-gathered plans [world_size * per][N+1][9] and flags, the
+ * statuses of the last round, the number of instances without solution so far. */
+int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_size, void** dswarm);
+int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream);
+int hdsm_dswarm_download(void* dswarm, void* swarm, double* plans_all, uint8_t* has_plan, int32_t* status, int32_t* failed_total);
+void hdsm_dswarm_destroy(void* dswarm);
+const char* hdsm_dswarm_last_error(void);
+
 /* Next row f3 (ROS-free half): every local agent keeps the records of Agent::TrajPlanningIteration — comp_time_sc_ (CPU time of
  * its corridor generation), comp_time_opt_ (the duration of the fused launch, handed in with hdsm_swarm_record_solve_ms between
  * prepare and commit; comp_time_tasc_ = 0 because the planes are generated inside that launch), comp_time_tot_,

@@ -62,6 +62,7 @@ struct Swarm {
   double solve_ms = 0;
   std::chrono::steady_clock::time_point t_round{};
   long long round_idx = 0;
+  bool corridor_done = false;  // hdsm_swarm_prepare_corridor already ran this round
   ~Swarm() {
     for (AgentX& a : extra) hdsm_stats_destroy(a.stats);
   }
@@ -399,8 +400,10 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
   for (int k = 0; k < sw->n_local; ++k) {
     AgentS& ag = sw->agents[k];
     clock_t t0 = clock();
-    hdsm_sw::corridor_step(cc, ag, sw->work.get(), sw->bits.data());  // AC:165
-    sw->extra[k].sc_ms = cpu_ms_since(t0);                               // comp_time_sc_, AC:1446
+    if (!sw->corridor_done) {
+      hdsm_sw::corridor_step(cc, ag, sw->work.get(), sw->bits.data());  // AC:165
+      sw->extra[k].sc_ms = cpu_ms_since(t0);                               // comp_time_sc_, AC:1446
+    }
     t0 = clock();
     if (!ag.external_ref) generate_reference(*sw, ag, plans_all, has_plan);  // AC:171 (or done on the device, f1)
     sw->extra[k].ref_ms = cpu_ms_since(t0);
@@ -408,6 +411,7 @@ int hdsm_swarm_prepare(void* swarm, const double* plans_all, const uint8_t* has_
     hdsm_sw::fill_inputs(cc, ag, agent_id + k, state_curr + 9 * (size_t)k, traj_ref + (size_t)k * N * 6, n_poly + k,
                          n_rows_static + (size_t)k * P, A_static + (size_t)k * P * RS * 3, b_static + (size_t)k * P * RS);
   }
+  sw->corridor_done = false;
   return HDSM_OK;
 }
 
@@ -593,6 +597,48 @@ int hdsm_swarm_corridor_errors(void* swarm, int32_t* codes) {
     n += sw->agents[k].corridor_rc != 0;
   }
   return n;
+}
+
+// ---- hooks of the device-resident loop (swarm_kernels.hip): the plain agent states and the configuration of a shard ----
+int hdsm_swarm_export_state(void* swarm, void* agents_out, int32_t* n_local, int32_t* n_rob, int32_t* first_id, hdsm_params* prm,
+                            hdsm_swarm_config* cfg, const int8_t** world, int32_t wdim[3], double worigin[3]) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw) return HDSM_ERR_BAD_ARG;
+  if (agents_out && sw->n_local) std::memcpy(agents_out, sw->agents.data(), sizeof(AgentS) * (size_t)sw->n_local);
+  if (n_local) *n_local = sw->n_local;
+  if (n_rob) *n_rob = sw->n_rob;
+  if (first_id) *first_id = sw->first_id;
+  if (prm) *prm = sw->prm;
+  if (cfg) *cfg = sw->cfg;
+  if (world) *world = sw->has_world ? sw->world.data() : nullptr;
+  for (int k = 0; k < 3; ++k) {
+    if (wdim) wdim[k] = sw->wdim[k];
+    if (worigin) worigin[k] = sw->worigin[k];
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_import_state(void* swarm, const void* agents_in, int32_t n_local) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !agents_in || n_local != sw->n_local) return HDSM_ERR_BAD_ARG;
+  std::memcpy(sw->agents.data(), agents_in, sizeof(AgentS) * (size_t)n_local);
+  return HDSM_OK;
+}
+
+// GenerateSafeCorridor alone (AC:165), for callers that generate the reference elsewhere (row f1 on the device) and want the
+// reference's own order: corridor from the PREVIOUS reference, then the new reference. The following hdsm_swarm_prepare of the
+// same round does not repeat it.
+int hdsm_swarm_prepare_corridor(void* swarm) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw) return HDSM_ERR_BAD_ARG;
+  const hdsm_sw::Cfg cc = sw->core_cfg();
+  for (int k = 0; k < sw->n_local; ++k) {
+    const clock_t t0 = clock();
+    hdsm_sw::corridor_step(cc, sw->agents[k], sw->work.get(), sw->bits.data());
+    sw->extra[k].sc_ms = cpu_ms_since(t0);
+  }
+  sw->corridor_done = true;
+  return HDSM_OK;
 }
 
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail) {

@@ -1,0 +1,287 @@
+// swarm_kernels.hip — the device-resident closed loop: the planner state of a shard of agents (hdsm_sw::AgentS) lives in HBM and
+// one replan round is a chain of launches on ONE stream with no host round trip:
+//   k_corridor   GenerateSafeCorridor (AC:1236-1447; row f2: voxel decomposition on a window of the world grid) + the polyline
+//                of this round's reference (AC:1459-1496)                                        one thread per agent
+//   k_reference  GenerateReferenceTrajectory's neighbour speed term + SamplePath (row f1)       hdsm_reference_device
+//   k_inputs     the new reference into the agent state, solver inputs in the layouts of hdsm.h  one thread per agent
+//   k_replan     planes + MIQP (the hot path)                                                   hdsm_replan_device
+//   k_commit     read-back, shift fallback, increment check, state advance, published record    one thread per agent
+//   exchange     ONE RCCL all-gather (hdsm_exchange_device), or a local copy on a single rank
+// The per-agent functions are the SAME source as the host mirror (swarm_core.h), which is how the two loops are compared in
+// tests/test_gpu_configs.py. AC = multi_agent_planner/src/agent_class.cpp of the reference.
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/hdsm.h"
+#include "../../include/hdsm_swarm.h"
+#include "swarm_core.h"
+
+extern "C" int hdsm_swarm_export_state(void* swarm, void* agents_out, int32_t* n_local, int32_t* n_rob, int32_t* first_id,
+                                       hdsm_params* prm, hdsm_swarm_config* cfg, const int8_t** world, int32_t wdim[3],
+                                       double worigin[3]);
+extern "C" int hdsm_swarm_import_state(void* swarm, const void* agents_in, int32_t n_local);
+
+namespace {
+
+using hdsm_sw::AgentS;
+using hdsm_sw::Cfg;
+using hdsm_sw::V3;
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(HDSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline handed to k_reference
+constexpr size_t SLAB = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16 + hdsm_cd::WindowGrid::WORDS * 4;
+
+__global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, unsigned char* scratch, double* path, int32_t* n_path) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  AgentS& ag = agents[k];
+  hdsm_cd::Work* wk = nullptr;
+  uint32_t* bits = nullptr;
+  if (c.has_world) {
+    unsigned char* slab = scratch + (size_t)k * SLAB;
+    wk = reinterpret_cast<hdsm_cd::Work*>(slab);
+    bits = reinterpret_cast<uint32_t*>(slab + ((sizeof(hdsm_cd::Work) + 15) / 16) * 16);
+  }
+  hdsm_sw::corridor_step(c, ag, wk, bits);
+  V3 pl[PTS];
+  const int np = hdsm_sw::reference_polyline(ag, pl);
+  n_path[k] = np;
+  for (int i = 0; i < PTS; ++i)
+    for (int a = 0; a < 3; ++a) path[((size_t)k * PTS + i) * 3 + a] = pl[i < np ? i : np - 1][a];
+}
+
+__global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, const double* ref_full, const double* path_vel,
+                                               int32_t* agent_id, double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A,
+                                               double* b) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  AgentS& ag = agents[k];
+  const int N = c.N, P = c.P, RS = c.RS;
+  ag.n_ref = N + 1;
+  for (int i = 0; i <= N; ++i)
+    for (int q = 0; q < 6; ++q) ag.traj_ref[i][q] = ref_full[((size_t)k * (N + 1) + i) * 6 + q];
+  ag.path_vel = path_vel[k];
+  double ref_unused[hdsm::MAXH * 6];  // k_reference already wrote the solver's traj_ref rows
+  hdsm_sw::fill_inputs(c, ag, agent_id + k, state_curr + 9 * (size_t)k, ref_unused, n_poly + k, n_rows + (size_t)k * P,
+                       A + (size_t)k * P * RS * 3, b + (size_t)k * P * RS);
+}
+
+__global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* agents, const double* traj, const double* ctrl,
+                                               const uint8_t* used, const int32_t* status, double* plans_local, int32_t* fails) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= per) return;
+  const int N = c.N, rec = (N + 1) * 9;
+  double* out = plans_local + (size_t)k * rec;
+  int have = 0;
+  if (k < n) {
+    AgentS& ag = agents[k];
+    have = hdsm_sw::commit_one(c, ag, traj + (size_t)k * rec, ctrl + (size_t)k * N * 3, used + (size_t)k * c.P, status[k]);
+    if (status[k] == HDSM_NO_SOLUTION) atomicAdd(fails, 1);
+    if (have)
+      for (int i = 0; i <= N; ++i)
+        for (int q = 0; q < 9; ++q) out[i * 9 + q] = ag.traj_curr[i][q];
+  }
+  if (!have) {  // no plan yet (or padding): the record carries the sentinel instead of a flag (hdsm_exchange_device)
+    for (int e = 1; e < rec; ++e) out[e] = 0.0;
+    out[0] = __longlong_as_double(0x7ff8000000000000LL);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flags(int rec, int n, const double* plans, uint8_t* has) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  const double v = plans[(size_t)k * rec];
+  has[k] = (v == v) ? 1 : 0;
+}
+
+struct DSwarm {
+  void* solver = nullptr;
+  int device = 0, n_local = 0, n_rob = 0, first = 0, per = 0, world = 1;
+  hdsm_params prm{};
+  hdsm_swarm_config cfg{};
+  hdsm_ref_config rcfg{};
+  Cfg c{};
+  AgentS* d_agents = nullptr;
+  int8_t* d_world = nullptr;
+  unsigned char* d_scratch = nullptr;
+  double *d_path = nullptr, *d_ref_full = nullptr, *d_ref = nullptr, *d_pv = nullptr, *d_state = nullptr, *d_A = nullptr, *d_b = nullptr,
+         *d_traj = nullptr, *d_ctrl = nullptr, *d_obj = nullptr, *d_local = nullptr, *d_plans = nullptr;
+  int32_t *d_npath = nullptr, *d_id = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr, *d_fails = nullptr;
+  uint8_t *d_used = nullptr, *d_has = nullptr;
+  long long rounds = 0;
+};
+
+template <class T>
+hipError_t dalloc(T** p, size_t count) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T));
+  if (e == hipSuccess) e = hipMemset(*p, 0, (count ? count : 1) * sizeof(T));
+  return e;
+}
+
+void free_all(DSwarm* d) {
+  void* ptrs[] = {d->d_agents, d->d_world, d->d_scratch, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
+                  d->d_ctrl, d->d_obj, d->d_local, d->d_plans, d->d_npath, d->d_id, d->d_npoly, d->d_nrows, d->d_status, d->d_fails,
+                  d->d_used, d->d_has};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hdsm_dswarm_last_error(void) { return g_err.c_str(); }
+
+int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_size, void** dswarm) {
+  if (!swarm || !solver || !dswarm || world_size < 1) return fail(HDSM_ERR_BAD_ARG, "null argument");
+  *dswarm = nullptr;
+  DSwarm* d = new (std::nothrow) DSwarm;
+  if (!d) return fail(HDSM_ERR_DEVICE, "out of host memory");
+  d->solver = solver, d->device = device, d->world = world_size;
+  const int8_t* hworld = nullptr;
+  int32_t wdim[3] = {0, 0, 0};
+  double worigin[3] = {0, 0, 0};
+  int rc = hdsm_swarm_export_state(swarm, nullptr, &d->n_local, &d->n_rob, &d->first, &d->prm, &d->cfg, &hworld, wdim, worigin);
+  if (rc) {
+    delete d;
+    return fail(rc, "hdsm_swarm_export_state");
+  }
+  d->per = (d->n_rob + world_size - 1) / world_size;
+  if (d->n_local > d->per) {
+    delete d;
+    return fail(HDSM_ERR_BAD_ARG, "the shard is larger than ceil(n_rob / world_size)");
+  }
+  d->rcfg = {d->cfg.path_vel_min, d->cfg.path_vel_max, d->cfg.sens_dist, d->cfg.sens_pot, d->cfg.sens_other_agents, d->cfg.path_vel_dec};
+  Cfg& c = d->c;
+  c.N = d->prm.n_hor, c.P = d->prm.poly_hor, c.RS = d->prm.max_rows_static, c.step_plan = d->cfg.step_plan;
+  c.n_it_decomp = d->cfg.n_it_decomp, c.use_cvx_new = d->cfg.use_cvx_new, c.has_world = hworld ? 1 : 0;
+  c.voxel_size = d->cfg.voxel_size, c.grid_z_min = d->cfg.grid_z_min, c.thresh_dist = d->cfg.thresh_dist;
+  for (int k = 0; k < 3; ++k) c.grid_range[k] = d->cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
+  if (hipSetDevice(device) != hipSuccess) {
+    delete d;
+    return fail(HDSM_ERR_NO_DEVICE, "hipSetDevice failed");
+  }
+  const size_t n = (size_t)d->n_local, L = (size_t)d->per, G = (size_t)d->per * world_size, N = (size_t)c.N, P = (size_t)c.P, RS = (size_t)c.RS,
+               REC = (N + 1) * 9;
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  ok(dalloc(&d->d_agents, n));
+  if (hworld) {
+    ok(dalloc(&d->d_world, (size_t)wdim[0] * wdim[1] * wdim[2]));
+    ok(dalloc(&d->d_scratch, n * SLAB));
+  }
+  ok(dalloc(&d->d_path, n * PTS * 3)), ok(dalloc(&d->d_npath, n)), ok(dalloc(&d->d_ref_full, n * (N + 1) * 6)), ok(dalloc(&d->d_ref, n * N * 6));
+  ok(dalloc(&d->d_pv, n)), ok(dalloc(&d->d_id, n)), ok(dalloc(&d->d_state, n * 9)), ok(dalloc(&d->d_npoly, n)), ok(dalloc(&d->d_nrows, n * P));
+  ok(dalloc(&d->d_A, n * P * RS * 3)), ok(dalloc(&d->d_b, n * P * RS)), ok(dalloc(&d->d_traj, L * REC)), ok(dalloc(&d->d_ctrl, L * N * 3));
+  ok(dalloc(&d->d_obj, L)), ok(dalloc(&d->d_used, L * P)), ok(dalloc(&d->d_status, L)), ok(dalloc(&d->d_local, L * REC));
+  ok(dalloc(&d->d_plans, G * REC)), ok(dalloc(&d->d_has, G)), ok(dalloc(&d->d_fails, 1));
+  if (e == hipSuccess && n) {
+    AgentS* tmp = static_cast<AgentS*>(std::malloc(n * sizeof(AgentS)));
+    if (!tmp) e = hipErrorOutOfMemory;
+    else {
+      rc = hdsm_swarm_export_state(swarm, tmp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (rc == HDSM_OK) e = hipMemcpy(d->d_agents, tmp, n * sizeof(AgentS), hipMemcpyHostToDevice);
+      std::free(tmp);
+    }
+  }
+  if (e == hipSuccess && n) {  // agent ids of the shard (contiguous block)
+    std::string ids(n * 4, '\0');
+    for (size_t k = 0; k < n; ++k) reinterpret_cast<int32_t*>(&ids[0])[k] = d->first + (int)k;
+    e = hipMemcpy(d->d_id, ids.data(), n * 4, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && hworld) e = hipMemcpy(d->d_world, hworld, (size_t)wdim[0] * wdim[1] * wdim[2], hipMemcpyHostToDevice);
+  c.world = d->d_world;
+  if (e != hipSuccess || rc) {
+    free_all(d);
+    delete d;
+    return fail(rc ? rc : HDSM_ERR_DEVICE, std::string("hdsm_dswarm_create: ") + (rc ? "export failed" : hipGetErrorString(e)));
+  }
+  *dswarm = d;
+  return HDSM_OK;
+}
+
+void hdsm_dswarm_destroy(void* dswarm) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  (void)hipDeviceSynchronize();
+  free_all(d);
+  delete d;
+}
+
+int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d) return fail(HDSM_ERR_BAD_ARG, "null dswarm");
+  if (d->world > 1 && !comm) return fail(HDSM_ERR_BAD_ARG, "a sharded swarm needs a communicator");
+  HIP_TRY(hipSetDevice(d->device));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;
+  const unsigned gb = (unsigned)((n + 63) / 64), gp = (unsigned)((d->per + 63) / 64);
+  if (n > 0) {
+    hipLaunchKernelGGL(k_corridor, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
+    HIP_TRY(hipGetLastError());
+    int rc = hdsm_reference_device(d->solver, &d->rcfg, n, G, d->d_id, d->d_path, d->d_npath, PTS, nullptr, d->d_plans, d->d_has,
+                                   d->d_ref_full, d->d_ref, d->d_pv, st);
+    if (rc) return fail(rc, std::string("hdsm_reference_device: ") + hdsm_last_error());
+    hipLaunchKernelGGL(k_inputs, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_pv, d->d_id, d->d_state, d->d_npoly,
+                       d->d_nrows, d->d_A, d->d_b);
+    HIP_TRY(hipGetLastError());
+    rc = hdsm_replan_device(d->solver, n, G, d->d_id, d->d_state, d->d_ref, d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_plans, d->d_has,
+                            d->d_traj, d->d_ctrl, d->d_used, d->d_status, d->d_obj, st);
+    if (rc) return fail(rc, std::string("hdsm_replan_device: ") + hdsm_last_error());
+  }
+  hipLaunchKernelGGL(k_commit, dim3(gp ? gp : 1), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
+                     d->d_local, d->d_fails);
+  HIP_TRY(hipGetLastError());
+  if (d->world > 1) {
+    const int rc = hdsm_exchange_device(comm, d->per, d->d_local, d->d_plans, d->d_has, st);
+    if (rc) return fail(rc, std::string("hdsm_exchange_device: ") + hdsm_last_error());
+  } else {
+    HIP_TRY(hipMemcpyAsync(d->d_plans, d->d_local, (size_t)d->per * rec * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_flags, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, rec, G, d->d_plans, d->d_has);
+    HIP_TRY(hipGetLastError());
+  }
+  ++d->rounds;
+  return HDSM_OK;
+}
+
+int hdsm_dswarm_download(void* dswarm, void* swarm, double* plans_all, uint8_t* has_plan, int32_t* status, int32_t* failed_total) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d) return fail(HDSM_ERR_BAD_ARG, "null dswarm");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = (size_t)d->n_local, G = (size_t)d->per * d->world, rec = (size_t)(d->c.N + 1) * 9;
+  if (swarm && n) {
+    AgentS* tmp = static_cast<AgentS*>(std::malloc(n * sizeof(AgentS)));
+    if (!tmp) return fail(HDSM_ERR_DEVICE, "out of host memory");
+    hipError_t e = hipMemcpy(tmp, d->d_agents, n * sizeof(AgentS), hipMemcpyDeviceToHost);
+    const int rc = e == hipSuccess ? hdsm_swarm_import_state(swarm, tmp, d->n_local) : HDSM_ERR_DEVICE;
+    std::free(tmp);
+    if (rc) return fail(rc, "state download failed");
+  }
+  if (plans_all) {
+    HIP_TRY(hipMemcpy(plans_all, d->d_plans, G * rec * 8, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < G; ++k)
+      if (plans_all[k * rec] != plans_all[k * rec]) plans_all[k * rec] = 0.0;  // the sentinel is for the wire only
+  }
+  if (has_plan) HIP_TRY(hipMemcpy(has_plan, d->d_has, G, hipMemcpyDeviceToHost));
+  if (status && n) HIP_TRY(hipMemcpy(status, d->d_status, n * 4, hipMemcpyDeviceToHost));
+  if (failed_total) HIP_TRY(hipMemcpy(failed_total, d->d_fails, 4, hipMemcpyDeviceToHost));
+  return HDSM_OK;
+}
+
+}  // extern "C"

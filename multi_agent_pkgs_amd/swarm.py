@@ -121,6 +121,13 @@ class SwarmShard:
         if rc:
             raise _lib.HdsmError(rc, "hdsm_swarm_set_world")
 
+    def prepare_corridor(self):
+        """GenerateSafeCorridor alone (hdsm_swarm_prepare_corridor): the reference's order when the reference trajectory is
+        generated elsewhere — corridor from the previous reference first."""
+        rc = self.lib.hdsm_swarm_prepare_corridor(self.h)
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_prepare_corridor")
+
     def prepare(self, plans_all, has_plan):
         i = self.inp
         d, i32, u8 = C.c_double, C.c_int32, C.c_uint8
@@ -235,6 +242,7 @@ class SwarmLoop:
 
     def step(self, record=None):
         if self.reference is not None:
+            self.shard.prepare_corridor()  # AC:165 before AC:171
             path, n_path = self.shard.reference_inputs(self.pmax)
             ids = np.arange(self.first, self.first + self.n_local, dtype=np.int32)
             ref_full, pv = self.reference(ids, path, n_path, self.plans_all, self.has_plan)
@@ -294,3 +302,51 @@ def torch_allgather(group=None):
         return full.cpu().numpy()
 
     return fn
+
+
+class DeviceSwarm:
+    """The device-resident closed loop of one shard (hdsm_dswarm_*): corridor -> reference -> replan -> commit -> exchange on one
+    stream. Built from a SwarmShard that has been set up (world, paths) and possibly flown, and an hdsm Solver."""
+
+    def __init__(self, shard, solver, world_size=1, device=0):
+        self.lib, self.shard, self.solver = _lib.load(), shard, solver
+        self.h = C.c_void_p()
+        self.world_size = int(world_size)
+        rc = self.lib.hdsm_dswarm_create(shard.h, solver.h, C.c_int32(device), C.c_int32(world_size), C.byref(self.h))
+        if rc:
+            self.lib.hdsm_dswarm_last_error.restype = C.c_char_p
+            raise _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
+        self.per = (shard.n_rob + self.world_size - 1) // self.world_size
+
+    def round(self, comm=None, stream=None):
+        sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
+        rc = self.lib.hdsm_dswarm_round(self.h, comm.h if comm is not None else None, sp)
+        if rc:
+            self.lib.hdsm_dswarm_last_error.restype = C.c_char_p
+            raise _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
+
+    def download(self, states=True):
+        """Synchronises; returns (plans_all, has_plan, status of the last round, instances without solution so far) and, with
+        states=True, copies the agent states back into the host mirror."""
+        N, G = self.shard.prm.n_hor, self.per * self.world_size
+        plans = np.zeros((G, N + 1, 9))
+        has = np.zeros(G, np.uint8)
+        status = np.zeros(self.shard.n_local, np.int32)
+        failed = C.c_int32(0)
+        rc = self.lib.hdsm_dswarm_download(self.h, self.shard.h if states else None, _p(plans, C.c_double), _p(has, C.c_uint8),
+                                           _p(status, C.c_int32), C.byref(failed))
+        if rc:
+            self.lib.hdsm_dswarm_last_error.restype = C.c_char_p
+            raise _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
+        return plans, has, status, failed.value
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.hdsm_dswarm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

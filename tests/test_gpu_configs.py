@@ -264,3 +264,47 @@ def test_voxel_decomposition_on_the_device_matches_the_host_bit_for_bit(hdsm):
                                                              n_it=int(z["n_it"][k]), res=float(z["res"]), max_rows=32)
             assert rc[0] == 0 and n_rows[0] == len(want) and np.array_equal(rows[0, : n_rows[0]], want), (k, key)
             assert cells[0] == int(z["cells_" + key][k])
+
+
+@pytest.mark.parametrize("scene", ["circle", "forest"])
+def test_device_resident_loop_follows_the_host_mirror(hdsm, scene):
+    """hdsm_dswarm_round (corridor -> reference -> replan -> commit -> publish, all on the device, one stream) against the
+    host-mirror loop that drives the same device kernels for the reference and the solve: same published plans round after
+    round. The per-agent code is one source (csrc/swarm_core.h); the solver's staging order is not deterministic (atomics),
+    so agreement is to 1e-7 over the first rounds, not bitwise. In the forest the corridors come from the device voxel
+    decomposition (row f2) on a window of the world grid."""
+    from multi_agent_pkgs_amd import swarm
+    n_rob, N, rounds = 48, 10, 36
+    prm = agile_params(N, max_rows_static=18)
+
+    def make():
+        sol, loop = _device_loop(hdsm, prm, swarm.default_swarm_config(), n_rob)
+        if scene == "forest":
+            raw, origin = sc.forest_for_circle(n_rob, seed=21)
+            assert loop.set_world(sc.inflate(raw), origin) == 0
+        return sol, loop
+
+    sol_h, host = make()
+    sol_d, dev_loop = make()
+    dsw = swarm.DeviceSwarm(dev_loop.shard, sol_d)
+    chamfered = 0
+    for r in range(rounds):
+        rec = []
+        out = host.step(record=rec)
+        dsw.round()
+        plans, has, status, failed = dsw.download(states=False)
+        assert (has == host.has_plan).all(), r
+        assert (status == out["status"]).all(), (r, status.tolist(), out["status"].tolist())
+        assert np.abs(plans - host.plans_all).max() < 1e-7, (r, float(np.abs(plans - host.plans_all).max()))
+        chamfered += int((rec[0]["n_rows"] > 6).any())
+    if scene == "forest":
+        assert chamfered > 5
+    # the states come back into a host mirror and every host diagnostic works on them
+    dsw.download(states=True)
+    pos_d, dist_d, nf_d = dev_loop.shard.state()
+    pos_h, dist_h, nf_h = host.shard.state()
+    assert np.abs(pos_d - pos_h).max() < 1e-7 and (nf_d == nf_h).all()
+    # ... and the host mirror can continue the flight from them
+    dev_loop.plans_all, dev_loop.has_plan = plans, has
+    out_d, out_h = dev_loop.step(), host.step()
+    assert (out_d["status"] == out_h["status"]).all() and np.abs(dev_loop.plans_all - host.plans_all).max() < 1e-6
