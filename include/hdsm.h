@@ -111,6 +111,10 @@ typedef struct hdsm_params {
    * returns the incumbent (HDSM_LIMIT) or HDSM_NO_SOLUTION — what Gurobi does, and just as irreproducible. 0 = none
    * (the deterministic work budgets above are the default and what every parity test uses).                      */
   double time_limit_s;
+  /* Gurobi's MIPGap (default 1e-4, never set by the reference: SURVEY section 7-4): a branch-and-bound node is cut off when its
+   * bound is within mip_gap * |incumbent| of the incumbent, so the returned assignment may be worse than the best one by that
+   * much — what Gurobi accepts. 0 (default) = prove optimality exactly (nodes are cut off only at 1e-9 relative).            */
+  double mip_gap;
 } hdsm_params;
 
 /* Fills `p` with the agile configuration shipped by the reference

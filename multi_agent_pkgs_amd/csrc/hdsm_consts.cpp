@@ -78,6 +78,7 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   if (prm->presweep < 0 || prm->presweep > 2) return fail(err, "presweep must be 0 (automatic), 1 (never) or 2 (always)");
   if (prm->branch_rule < 0 || prm->branch_rule > 1) return fail(err, "branch_rule must be 0 (most infeasible) or 1 (first in time)");
   if (prm->stage_radius < 0 || prm->time_limit_s < 0) return fail(err, "stage_radius / time_limit_s must not be negative");
+  if (!(prm->mip_gap >= 0) || prm->mip_gap >= 1) return fail(err, "mip_gap must be in [0, 1)");
   c->cand_tau = prm->stage_radius > 0 ? prm->stage_radius : 0.6;  // [m] rows whose slack at the staging point is below this are staged
   env_real("HDSM_CAND_TAU", 0.01, 10.0, &c->cand_tau);
   // step to branch on: 1 = most infeasible segment (measured 4-6x shorter rounds where the search is deep), 0 = first in time
@@ -90,6 +91,7 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
                       // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.
   env_real("HDSM_HOT_TAU", 1e-3, 1e30, &c->hot_tau);
+  c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);
   c->time_ticks = 0;  // set by hdsm_create from time_limit_s and the device's clock rate

@@ -750,8 +750,10 @@ struct Solver {
   static constexpr int SNAP_STRIDE = SNAP_DOUBLES + (NV + 2) / 2 + 1;  // doubles per level
 #endif
 
-  static HD double cutoff(const S& s) {
-    return s.have_inc ? s.inc_f - 1e-9 * fmax(1.0, fabs(s.inc_f)) : DINF;
+  static HD double cutoff(const S& s, const Consts& c) {
+    if (!s.have_inc) return DINF;
+    const double exact = 1e-9 * fmax(1.0, fabs(s.inc_f)), gap = c.mip_gap * fabs(s.inc_f);  // hdsm_params.mip_gap (Gurobi MIPGap)
+    return s.inc_f - (gap > exact ? gap : exact);
   }
 
   // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
@@ -762,7 +764,7 @@ struct Solver {
       if (level == 0) return false;
       const int L = level - 1;
       const int pos = s.br_pos[L];
-      if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s))) {
+      if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s, c))) {
         if (nodes >= c.max_nodes) {
           limit = true;
           return false;
@@ -1157,7 +1159,7 @@ struct Solver {
     }
     int last_rc = GI_OK;
     while (run) {
-      const int rc = gi_run(s, c, R, cutoff(s), iters);
+      const int rc = gi_run(s, c, R, cutoff(s, c), iters);
       last_rc = rc;
       if (rc == GI_ITERLIM || rc == GI_TIMELIM) {
         limit = true;

@@ -31,6 +31,7 @@ struct Consts {
                         // (HDSM_BRANCH_RULE). Either is exact; 1 bisects the "where to switch polyhedron" choice
                         // instead of enumerating it: 509 -> 29 nodes on a gridlocked 128-agent ring
   double tol, ftol_fixed, cand_tau, hot_tau;
+  double mip_gap;  // relative gap at which a node is cut off against the incumbent (0 = exact)
   long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)
   double r_u, wx[6], wn[6];
   double lbu[3], ubu[3];       // input box (absent if |.| >= ABSENT)

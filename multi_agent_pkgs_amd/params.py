@@ -45,6 +45,7 @@ class HdsmParams(C.Structure):
         ("launch_order", C.c_int32),
         ("stage_radius", C.c_double),
         ("time_limit_s", C.c_double),
+        ("mip_gap", C.c_double),
     ]
 
     def copy(self):
@@ -60,7 +61,7 @@ def make_params(n_hor=10, poly_hor=4, rk4=False, dt=0.1, drag=(0.0, 0.0, 0.0), r
                 max_jerk=60.0, drone_radius=0.25, drone_z_offset=0.25, plane_perturb=0.1,
                 max_rows_static=18, max_nodes=0, max_qp_iters=0, feas_tol_fixed=1e-6, solver_tol=1e-9,
                 warm_start=True, threads_per_instance=0, prefilter_min_agents=0, duo_min_instances=0, presweep=0,
-                branch_rule=0, launch_order=0, stage_radius=0.0, time_limit_s=0.0):
+                branch_rule=0, launch_order=0, stage_radius=0.0, time_limit_s=0.0, mip_gap=0.0):
     """Build an HdsmParams the way InitializePlannerParameters builds x_lb_/x_ub_/u_lb_/u_ub_ (n_x = 9)."""
     p = HdsmParams()
     p.n_hor, p.poly_hor, p.rk4, p.max_rows_static = n_hor, poly_hor, int(bool(rk4)), max_rows_static
@@ -81,7 +82,7 @@ def make_params(n_hor=10, poly_hor=4, rk4=False, dt=0.1, drag=(0.0, 0.0, 0.0), r
     p.warm_start = int(bool(warm_start))
     p.threads_per_instance, p.prefilter_min_agents, p.duo_min_instances = threads_per_instance, prefilter_min_agents, duo_min_instances
     p.presweep, p.branch_rule, p.stage_radius, p.time_limit_s = presweep, branch_rule, stage_radius, time_limit_s
-    p.launch_order = launch_order
+    p.launch_order, p.mip_gap = launch_order, mip_gap
     return p
 
 

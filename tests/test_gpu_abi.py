@@ -176,3 +176,19 @@ def test_cpp_sharded_loop_runs_one_rank_through_rccl(tmp_path):
     r = subprocess.run([exe, "0", "1", str(tmp_path / "uid"), "32", "50"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "agents with a plan 32" in r.stdout
+
+
+def test_mip_gap_accepts_what_gurobi_accepts(hdsm, oracle):
+    """hdsm_params.mip_gap (Gurobi's MIPGap, 1e-4 by default there): with a gap the search may stop on an assignment whose
+    objective is within gap * |J| of the optimum and needs no more nodes than the exact search; with gap 0 it is exact."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 64, seed=21, narrow=True, turn=True, chamfer=True, spacing=1.4)
+    args = [sn[k] for k in ARG_KEYS]
+    exact = hdsm.Solver(agile_params(10, max_rows_static=18, warm_start=False), 64, 64).replan(*args)
+    for gap in (1e-4, 5e-2):
+        g = hdsm.Solver(agile_params(10, max_rows_static=18, warm_start=False, mip_gap=gap), 64, 64).replan(*args)
+        assert (g["status"] == exact["status"]).all()
+        ok = exact["status"] == 0
+        assert (g["obj"][ok] <= exact["obj"][ok] * (1 + gap) + 1e-6).all() and (g["obj"][ok] >= exact["obj"][ok] - 1e-6).all()
+        assert (g["nodes"] <= exact["nodes"]).all()
+    assert exact["nodes"].max() > 1
