@@ -250,6 +250,31 @@ def main():
             solve_np(rec[r], rec[r]["plans"], rec[r]["has_plan"])
         host_ms = (time.perf_counter() - t1) / K * 1e3
 
+    # ---------------------------------------------------------------- fourth pass: the device-resident closed loop, LIVE
+    # hdsm_dswarm_round continues the flight where the set-up left it (round first_round + steps): corridor, reference,
+    # replan, commit, publish and the all-gather as one chain of launches per round, no host round trip. A secondary record.
+    dloop = None
+    if not args.no_event_pass:
+        dsw = swarm.DeviceSwarm(loop.shard, solver, world_size=world, device=dev.index)
+        dsw.upload_plans(loop.plans_all, loop.has_plan)
+        for _ in range(2):
+            dsw.round(comm, stream)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(K):
+            dsw.round(comm, stream)
+        barrier()
+        dl = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dl], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dl = float(t.item())
+        _, _, _, failed_d = dsw.download(states=False)
+        dloop = {"rounds": f"{rec_to + 2}..{rec_to + 1 + K}", "ms_per_round": dl / K * 1e3, "agent_replans_per_s": n_rob * K / dl,
+                 "instances_without_solution_this_rank": int(failed_d),
+                 "what": "hdsm_dswarm_round live: corridor (f2) -> reference (f1) -> replan -> commit -> publish -> exchange, one stream"}
+        dsw.close()
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -334,6 +359,7 @@ def main():
             "host_buffer_path": None if host_ms is None else {
                 "ms_per_round": host_ms, "agent_replans_per_s": n_rob / (host_ms * 1e-3),
                 "what": "hdsm_replan with host pointers (PCIe-inclusive: H2D inputs, kernel, D2H outputs, sync)"},
+            "device_resident_loop": dloop,
             "failed_instances_timed_rounds": fails_timed, "failed_instances_recorded": fails,
             "setup_flight_s": t_setup,
             "k_replan_launch_sequence": {"setup_flight": rec_to, "warmup": W, "timed": K,

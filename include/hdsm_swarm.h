@@ -155,6 +155,8 @@ int hdsm_swarm_prepare_corridor(void* swarm);
  * (so that every hdsm_swarm_* diagnostic works on them), the all-gathered plans [world_size * per][N+1][9] and flags, the
  * statuses of the last round, the number of instances without solution so far. */
 int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_size, void** dswarm);
+/* the all-gathered plans [n_rob][N+1][9] and flags [n_rob] the next round starts from (a swarm taken over in mid-flight) */
+int hdsm_dswarm_upload_plans(void* dswarm, const double* plans_all, const uint8_t* has_plan);
 int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream);
 int hdsm_dswarm_download(void* dswarm, void* swarm, double* plans_all, uint8_t* has_plan, int32_t* status, int32_t* failed_total);
 void hdsm_dswarm_destroy(void* dswarm);

@@ -259,6 +259,18 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   return HDSM_OK;
 }
 
+int hdsm_dswarm_upload_plans(void* dswarm, const double* plans_all, const uint8_t* has_plan) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d || !plans_all || !has_plan) return fail(HDSM_ERR_BAD_ARG, "null argument");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t G = (size_t)d->per * d->world, rec = (size_t)(d->c.N + 1) * 9, have = (size_t)d->n_rob < G ? (size_t)d->n_rob : G;
+  HIP_TRY(hipMemset(d->d_has, 0, G));
+  HIP_TRY(hipMemcpy(d->d_plans, plans_all, have * rec * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d->d_has, has_plan, have, hipMemcpyHostToDevice));
+  return HDSM_OK;
+}
+
 int hdsm_dswarm_download(void* dswarm, void* swarm, double* plans_all, uint8_t* has_plan, int32_t* status, int32_t* failed_total) {
   DSwarm* d = static_cast<DSwarm*>(dswarm);
   if (!d) return fail(HDSM_ERR_BAD_ARG, "null dswarm");

@@ -318,6 +318,13 @@ class DeviceSwarm:
             raise _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
         self.per = (shard.n_rob + self.world_size - 1) // self.world_size
 
+    def upload_plans(self, plans_all, has_plan):
+        plans_all = np.ascontiguousarray(plans_all, dtype=np.float64)
+        has_plan = np.ascontiguousarray(has_plan, dtype=np.uint8)
+        rc = self.lib.hdsm_dswarm_upload_plans(self.h, _p(plans_all, C.c_double), _p(has_plan, C.c_uint8))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_dswarm_upload_plans")
+
     def round(self, comm=None, stream=None):
         sp = C.c_void_p(stream.cuda_stream if stream is not None else 0)
         rc = self.lib.hdsm_dswarm_round(self.h, comm.h if comm is not None else None, sp)
