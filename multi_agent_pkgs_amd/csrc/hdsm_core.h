@@ -340,197 +340,8 @@ struct Solver {
   }
 
 #ifdef HDSM_EMU
-  // ---- factor updates -----------------------------------------------------------------------------------
-  // Append the incoming constraint (whose transformed normal is s.d, suffix sums of d^2 in s.suf) to the
-  // working set: Givens sweep on the columns q..n-1 of J, new column of R.
-  static HD void add_constraint(S& s, const Consts& c, int id, double lam_p) {
-    const int n = c.n, q = s.q;
-    PAR_FOR(j, n) {
-      if (j > q) {
-        const double h = sqrt(s.suf[j - 1]);
-        double cc = 1.0, ss = 0.0;
-        if (h > 0) {
-          cc = s.d[j - 1] / h;
-          ss = (j == n - 1 ? s.d[j] : sqrt(s.suf[j])) / h;
-        }
-        s.gc[j] = cc;
-        s.gs[j] = ss;
-      }
-    }
-    SYNC();
-    PAR_FOR(i, n) {
-      double* Ji = s.J + i * LD;
-      double carry = Ji[n - 1];
-      for (int j = n - 1; j > q; --j) {
-        const double t1 = Ji[j - 1];
-        Ji[j] = -s.gs[j] * t1 + s.gc[j] * carry;
-        carry = s.gc[j] * t1 + s.gs[j] * carry;
-      }
-      Ji[q] = carry;
-    }
-    PAR_FOR(i, q) s.R[i * LD + q] = s.d[i];
-    if (IS_T0) {
-      s.R[q * LD + q] = (q == n - 1) ? s.d[q] : sqrt(s.suf[q]);
-      s.act[q] = id;
-      s.lam[q] = lam_p;
-      s.q = q + 1;
-      if (id_kind(id) == K_E) s.neq_done++;
-    }
-    SYNC();
-  }
-
-  // Remove the constraint at position l of the working set.
-  static HD void drop_constraint(S& s, const Consts& c, int l) {
-    const int n = c.n, q = s.q;
-    PAR_FOR(i, q) {
-      double* Ri = s.R + i * LD;
-      for (int j = l; j < q - 1; ++j) Ri[j] = Ri[j + 1];
-    }
-    if (IS_T0) {
-      for (int j = l; j < q - 1; ++j) {
-        s.act[j] = s.act[j + 1];
-        s.lam[j] = s.lam[j + 1];
-      }
-      s.q = q - 1;
-    }
-    SYNC();
-    const int qn = q - 1;
-    for (int j = l; j < qn; ++j) {
-      const double a1 = s.R[j * LD + j], a2 = s.R[(j + 1) * LD + j];
-      const double h = sqrt(a1 * a1 + a2 * a2);
-      SYNC();  // every thread has read a1, a2 before anybody rewrites them
-      if (h == 0) continue;
-      const double cc = a1 / h, ss = a2 / h;
-      PAR_FOR(k, qn - j) {
-        const int col = j + k;
-        const double t1 = s.R[j * LD + col], t2 = s.R[(j + 1) * LD + col];
-        s.R[j * LD + col] = cc * t1 + ss * t2;
-        s.R[(j + 1) * LD + col] = -ss * t1 + cc * t2;
-      }
-      PAR_FOR(i, n) {
-        const double t1 = s.J[i * LD + j], t2 = s.J[i * LD + j + 1];
-        s.J[i * LD + j] = cc * t1 + ss * t2;
-        s.J[i * LD + j + 1] = -ss * t1 + cc * t2;
-      }
-      SYNC();
-    }
-  }
-
-  // ---- the dual active-set loop --------------------------------------------------------------------------
-  // Continues from the current (dual feasible) state until no row of the current node is violated.
-  static HD int gi_run(S& s, const Consts& c, double f_cut, int& iters) {
-    const int N = c.N, n = c.n;
-    double f = s.f;
-    int rc = GI_OK;
-    for (;;) {
-      compute_states(s, c);
-      int ip;
-      double vip;
-      if (s.neq_done < 6) {
-        ip = mk_id(K_E, s.neq_done);
-        vip = resid(s, c, ip);
-      } else {
-        select_violated(s, c, vip, ip);
-        if (ip < 0) break;
-      }
-      const bool is_eq = id_kind(ip) == K_E;
-      build_normal(s, c, ip);
-      double lam_p = 0;
-      bool stop = false;
-      for (;;) {
-        if (iters >= c.max_iters) {
-          rc = GI_ITERLIM;
-          stop = true;
-          break;
-        }
-        ++iters;
-        const int q = s.q;
-        PAR_FOR(j, n) {  // d = J^T (-a)
-          double t = 0;
-          for (int i = 0; i < n; ++i) t -= s.J[i * LD + j] * s.a[i];
-          s.d[j] = t;
-          s.w[j] = t;
-        }
-        SYNC();
-        PAR_FOR(j, n + 1) {  // suffix sums of d^2
-          double t = 0;
-          for (int k = j; k < n; ++k) t += s.d[k] * s.d[k];
-          s.suf[j] = t;
-        }
-        PAR_FOR(i, n) {  // z = J2 d2
-          double t = 0;
-          for (int j = q; j < n; ++j) t += s.J[i * LD + j] * s.d[j];
-          s.z[i] = t;
-        }
-        SYNC();
-        for (int j = q - 1; j > 0; --j) {  // back substitution R r = d1 (w is the work copy)
-          const double rj = s.w[j] / s.R[j * LD + j];
-          PAR_FOR(i, j) s.w[i] -= s.R[i * LD + j] * rj;
-          SYNC();
-        }
-        PAR_FOR(k, q) s.r[k] = s.w[k] / s.R[k * LD + k];
-        SYNC();
-        const double dd = s.suf[0], zz = s.suf[q];
-        const bool dependent = !(zz > 1e-20 * dd) || q >= n;
-        double t1 = DINF;
-        int l = -1;
-        if (!is_eq) {  // ratio test over the active inequalities
-          double nb;
-          block_argmax(
-              s, q, -DINF,
-              [&](int k, double& v, int& id) {
-                v = -DINF, id = -1;
-                if (id_kind(s.act[k]) != K_E && s.r[k] > 0) v = -(s.lam[k] / s.r[k]), id = k;
-              },
-              nb, l);
-          if (l >= 0) t1 = -nb;
-        }
-        if (dependent && l < 0) {
-          rc = GI_INFEASIBLE;
-          stop = true;
-          break;
-        }
-        if (dependent) {  // dual step only; constraint l leaves
-          PAR_FOR(k, q) s.lam[k] -= t1 * s.r[k];
-          lam_p += t1;
-          SYNC();
-          drop_constraint(s, c, l);
-          continue;
-        }
-        const double t2 = vip / zz;
-        const bool full = is_eq || t2 <= t1;
-        const double t = full ? t2 : t1;
-        PAR_FOR(i, n) s.x[i] += t * s.z[i];
-        PAR_FOR(k, q) s.lam[k] -= t * s.r[k];
-        f += t * zz * (0.5 * t + lam_p);
-        lam_p += t;
-        SYNC();
-        if (full) {
-          add_constraint(s, c, ip, lam_p);
-          break;
-        }
-        drop_constraint(s, c, l);
-        compute_states(s, c);
-        vip = resid(s, c, ip);
-        if (f >= f_cut) {
-          rc = GI_CUTOFF;
-          stop = true;
-          break;
-        }
-      }
-      if (stop) break;
-      if (f >= f_cut) {
-        rc = GI_CUTOFF;
-        break;
-      }
-    }
-    if (IS_T0) s.f = f;
-    SYNC();
-    (void)N;
-    return rc;
-  }
-
-#endif  // HDSM_EMU (the device build uses hdsm_wave_gi.h)
+#include "hdsm_emu_gi.inc"  // tests/emu: textbook Givens formulation of the active-set loop for the CPU logic build
+#endif  // (the device build uses hdsm_wave_gi.h)
 
   // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
   static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
