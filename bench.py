@@ -129,8 +129,8 @@ def main():
     cfg = swarm.default_swarm_config()
     rcfg = agile_ref_config()
 
-    def ref_dev(ids, path, n_path, plans, has):  # row f1 on the device: removes the host's O(n_rob^2 N) step
-        full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has)
+    def ref_dev(ids, path, n_path, plans, has, vel_cap=None):  # row f1 on the device: removes the host's O(n_rob^2 N) step
+        full, _, pv = solver.reference(rcfg, ids, path, n_path, plans, has, vel_cap=vel_cap)
         return full, pv
 
     starts = goals = None

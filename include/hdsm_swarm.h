@@ -69,6 +69,11 @@ int hdsm_swarm_commit(void* swarm, const double* traj_out, const double* ctrl_ou
  * hdsm_reference / hdsm_reference_device; (3) hdsm_swarm_set_reference() hands the result back — the next
  * hdsm_swarm_prepare() then uses it instead of generating the reference on the host.                        */
 int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path);
+/* vel_cap[n_local] for hdsm_reference*: the voxel / potential-field term of ComputePathVelocity (AC:1709-1766: raycast of the
+ * polyline through the agent's local grid, GetVelocityLimit of every voxel crossed) on the world of hdsm_swarm_set_world;
+ * path_vel_max in free space. hdsm_swarm_set_reference then applies KeepOnlyFreeReference (AC:1665-1693) to what comes back.
+ * (The device-resident loop does both on the device: k_vel_cap, k_keep_free.) */
+int hdsm_swarm_vel_cap(void* swarm, double* vel_cap);
 int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel);
 
 /* Next row f2: an occupied world. occupancy [dim[2]][dim[1]][dim[0]] int8 (x fastest), voxels of cfg.voxel_size,

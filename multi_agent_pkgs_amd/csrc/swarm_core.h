@@ -271,6 +271,163 @@ CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
   ag.n_poly = n_poly;
 }
 
+// ---- the map-dependent half of the reference trajectory (row f1): ComputePathVelocity's voxel term + KeepOnlyFreeReference ----
+// The planner's own voxel grid (voxel_grid_, AH:439) as a window of the world: raw values, -1 = unknown (below the ground,
+// unknown in the world) — NOT turned into occupied here (only GenerateSafeCorridor does that, AC:1307); outside the local grid
+// GetVoxelInt returns -1 (voxel_grid.cpp:110-117); outside the world = free.
+struct RawWindow {
+  const Cfg* c;
+  int off[3], dim[3], ground_k;
+  CD_HD bool inside(int i, int j, int k) const { return i >= 0 && j >= 0 && k >= 0 && i < dim[0] && j < dim[1] && k < dim[2]; }
+  CD_HD int value(int i, int j, int k) const {
+    if (!inside(i, j, k)) return -1;
+    if (k < ground_k) return -1;
+    const int gi = i + off[0], gj = j + off[1], gk = k + off[2];
+    if (gi < 0 || gj < 0 || gk < 0 || gi >= c->wdim[0] || gj >= c->wdim[1] || gk >= c->wdim[2]) return 0;
+    return c->world[(size_t)gi + (size_t)gj * c->wdim[0] + (size_t)gk * c->wdim[0] * c->wdim[1]];
+  }
+};
+CD_HD RawWindow raw_window(const Cfg& c, const V3& grid_origin) {
+  RawWindow w;
+  w.c = &c;
+  for (int ax = 0; ax < 3; ++ax) {
+    w.dim[ax] = (int)floor(c.grid_range[ax] / c.voxel_size);
+    w.off[ax] = (int)lround((grid_origin[ax] - c.worigin[ax]) / c.voxel_size);
+  }
+  w.ground_k = (int)ceil((c.grid_z_min - grid_origin[2]) / c.voxel_size - 1e-9);
+  return w;
+}
+CD_HD V3 local_grid_origin(const Cfg& c, const AgentS& ag) {  // env_builder GenerateVoxelGridMSG, environment_builder.cpp:58-67
+  V3 o;
+  for (int ax = 0; ax < 3; ++ax) o[ax] = floor((ag.state_curr[ax] - c.grid_range[ax] / 2) / c.voxel_size) * c.voxel_size;
+  return o;
+}
+
+// GetVelocityLimit, AC:1805-1817
+CD_HD double velocity_limit(const hdsm_ref_config& rc, double occ, double dist) {
+  if (occ < 0) occ = 0;
+  if (occ > 100) occ = 100;
+  const double alpha = 1 - pow(occ / 100, rc.sens_pot) * (1 / exp(rc.sens_dist * dist));
+  return rc.path_vel_min + (rc.path_vel_max - rc.path_vel_min) * alpha;
+}
+
+CD_HD double rc_mod1(double v) { return fmod(fmod(v, 1.0) + 1.0, 1.0); }
+CD_HD double rc_intbound(double s, double ds) {  // raycast.cpp:11-20: smallest positive t with s + t ds integer
+  if (ds < 0) return rc_intbound(-s, -ds);
+  return (1 - rc_mod1(s)) / ds;
+}
+CD_HD int rc_signum(int x) { return x == 0 ? 0 : (x < 0 ? -1 : 1); }
+
+// voxel_grid_util::Raycast (raycast.cpp:22-183, Amanatides-Woo with the reference's modifications) from `start` to `end`, both
+// in LOCAL VOXEL units. visit(pt) is called for every point the reference appends to its output (the real intersection points
+// with the voxel boundaries), in order. Returns true when the ray hit an occupied voxel; `hit` = the collision point.
+template <class F>
+CD_HD bool raycast(const RawWindow& g, const V3& start, const V3& end, double max_dist, V3* hit, F visit) {
+  int x = (int)floor(start[0]), y = (int)floor(start[1]), z = (int)floor(start[2]);
+  const int ex = (int)floor(end[0]), ey = (int)floor(end[1]), ez = (int)floor(end[2]);
+  const double max2 = max_dist * max_dist;
+  const double dx = end[0] - start[0], dy = end[1] - start[1], dz = end[2] - start[2];
+  const int sx = rc_signum(ex - x), sy = rc_signum(ey - y), sz = rc_signum(ez - z);
+  double tmx = rc_intbound(start[0], dx), tmy = rc_intbound(start[1], dy), tmz = rc_intbound(start[2], dz);
+  const double tdx = (double)sx / dx, tdy = (double)sy / dy, tdz = (double)sz / dz;
+  if (sx == 0 && sy == 0 && sz == 0) {  // raycast.cpp:96-100: same voxel, no occupancy test
+    visit(end);
+    visit(start);
+    return false;
+  }
+  double tmax = 0;
+  int count = 0;
+  for (;;) {
+    const double tt = tmax < 1.0 ? tmax : 1.0;
+    const V3 real = {{start[0] + tt * dx, start[1] + tt * dy, start[2] + tt * dz}};
+    if (g.inside(x, y, z)) {
+      if (g.value(x, y, z) == 100 && tmax <= 1) {
+        *hit = real;
+        visit(real);
+        return true;
+      }
+      visit(real);
+      const double ux = x - start[0], uy = y - start[1], uz = z - start[2];
+      if ((ux * ux + uy * uy) + uz * uz > max2) break;
+      if (++count > 1500) break;  // (the reference throws here)
+    }
+    if (tmax >= 1) break;
+    if ((tmx < tmy && sx != 0) || sy == 0) {
+      if ((tmx < tmz && sx != 0) || sz == 0) tmax = tmx, x += sx, tmx += tdx;
+      else tmax = tmz, z += sz, tmz += tdz;
+    } else {
+      if ((tmy < tmz && sy != 0) || sz == 0) tmax = tmy, y += sy, tmy += tdy;
+      else tmax = tmz, z += sz, tmz += tdz;
+    }
+  }
+  return false;
+}
+
+// The voxel / potential-field term of Agent::ComputePathVelocity (AC:1709-1766) for the polyline `pts` (world coordinates;
+// pts[0] = the sampling start): the minimum of GetVelocityLimit over the voxels the path crosses inside the agent's local grid.
+// Quirks kept: the distance of a visited voxel is measured between path_start in WORLD metres and the visited point in LOCAL
+// voxel units, times the voxel size (AC:1739); after a collision the distance is in voxel units (AC:1755) and the walk stops.
+CD_HD double voxel_velocity_cap(const Cfg& c, const hdsm_ref_config& rc, const V3& grid_origin, const V3* pts, int n) {
+  double path_vel = rc.path_vel_max;
+  if (!c.has_world || n < 1) return path_vel;
+  const RawWindow g = raw_window(c, grid_origin);
+  const V3 path_start = pts[0];
+  const double vs = c.voxel_size;
+  auto local = [&](const V3& p) { return V3{{(p[0] - grid_origin[0]) / vs, (p[1] - grid_origin[1]) / vs, (p[2] - grid_origin[2]) / vs}}; };
+  auto consider = [&](const V3& pt) {
+    double val = (double)g.value((int)pt[0], (int)pt[1], (int)pt[2]);  // GetVoxelInt(Vector3d): truncation
+    if (val == -1) val = 100;
+    const double v = velocity_limit(rc, val, norm(sub(path_start, pt)) * vs);
+    if (v < path_vel) path_vel = v;
+  };
+  for (int i = 0; i + 1 < n; ++i) {
+    const V3 start = local(pts[i]), end = local(pts[i + 1]);
+    V3 hit = {{-1, -1, -1}};
+    // a segment is scanned twice in the reference too: IsLineClear decides, then the visited points are weighed
+    const bool collided = raycast(g, start, end, norm(sub(start, end)), &hit, [](const V3&) {});
+    if (!collided) {
+      raycast(g, start, end, norm(sub(start, end)), &hit, consider);
+      consider(start);
+    } else {
+      const double val = (double)(int8_t)g.value((int)hit[0], (int)hit[1], (int)hit[2]);
+      const double v = velocity_limit(rc, val, norm(sub(start, hit)));
+      if (v < path_vel) path_vel = v;
+      break;
+    }
+  }
+  return path_vel;
+}
+
+// Agent::KeepOnlyFreeReference (AC:1665-1693) on the n reference points `ref` (rows of 6: position, velocity) followed by the
+// velocity references of AC:1527-1547 recomputed on the result: from the first point that lies in an unknown or occupied voxel
+// of the local grid (outside the grid = unknown) the last free point is repeated.
+CD_HD void keep_only_free(const Cfg& c, const V3& grid_origin, double path_vel, double (*ref)[6], int n) {
+  if (!c.has_world || n < 2) return;
+  const RawWindow g = raw_window(c, grid_origin);
+  const double vs = c.voxel_size;
+  int stop = n;
+  for (int i = 1; i < n; ++i) {
+    const int v = g.value((int)((ref[i][0] - grid_origin[0]) / vs), (int)((ref[i][1] - grid_origin[1]) / vs),
+                          (int)((ref[i][2] - grid_origin[2]) / vs));
+    if (v == -1 || v == 100) {
+      stop = i;
+      break;
+    }
+  }
+  if (stop == n) return;
+  for (int i = stop; i < n; ++i)
+    for (int k = 0; k < 3; ++k) ref[i][k] = ref[stop - 1][k];
+  double v[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    if (i + 1 < n) {
+      const V3 d = {{ref[i][0] - ref[i + 1][0], ref[i][1] - ref[i + 1][1], ref[i][2] - ref[i + 1][2]}};
+      const double dist = norm(d);
+      for (int k = 0; k < 3; ++k) v[k] = dist > 1e-2 ? path_vel * d[k] / dist : 0.0;
+    }
+    for (int k = 0; k < 3; ++k) ref[i][3 + k] = v[k];
+  }
+}
+
 // GetPathProgress (path_finding_util/src/path_tools.cpp:419-479) + CheckReferenceTrajIncrement (AC:569-585)
 CD_HD void check_increment(const Cfg& c, AgentS& ag) {
   ag.increment = 0;

@@ -79,9 +79,16 @@ double velocity_limit(const hdsm_swarm_config& c, double occ, double dist) {
 }
 
 // ComputePathVelocity, AC:1695-1803: empty world -> only the neighbour term (AC:1769-1801) is active
-double compute_path_velocity(const Swarm& sw, const AgentS& ag, const double* plans_all, const uint8_t* has_plan) {
+hdsm_ref_config ref_config(const Swarm& sw) {
+  return {sw.cfg.path_vel_min, sw.cfg.path_vel_max, sw.cfg.sens_dist, sw.cfg.sens_pot, sw.cfg.sens_other_agents, sw.cfg.path_vel_dec};
+}
+
+double compute_path_velocity(const Swarm& sw, const AgentS& ag, const std::vector<V3>& path, const double* plans_all,
+                             const uint8_t* has_plan) {
   const int N = sw.prm.n_hor;
-  double path_vel = sw.cfg.path_vel_max;
+  // voxel / potential-field term (AC:1709-1766) on the agent's local grid, then the neighbour term (AC:1769-1801)
+  const hdsm_sw::Cfg cc = sw.core_cfg();
+  double path_vel = hdsm_sw::voxel_velocity_cap(cc, ref_config(sw), hdsm_sw::local_grid_origin(cc, ag), path.data(), (int)path.size());
   for (int i = 0; i < (ag.has_traj ? N + 1 : 0); ++i) {
     const V3 start = {{ag.traj_curr[i][0], ag.traj_curr[i][1], ag.traj_curr[i][2]}};
     const double occ = 100 * std::pow(sw.cfg.sens_other_agents, (double)i);
@@ -105,7 +112,7 @@ std::vector<V3> sample_path(const Swarm& sw, AgentS& ag, const std::vector<V3>& 
     for (int i = 0; i < N; ++i) ref.push_back(path[0]);
     return ref;
   }
-  ag.path_vel = compute_path_velocity(sw, ag, plans_all, has_plan);
+  ag.path_vel = compute_path_velocity(sw, ag, path, plans_all, has_plan);
   const double samp_dist = ag.path_vel * sw.prm.dt;
   size_t path_idx = 1;
   int ref_idx = 0;
@@ -153,6 +160,8 @@ void generate_reference(const Swarm& sw, AgentS& ag, const double* plans_all, co
     }
     for (int k = 0; k < 3; ++k) ag.traj_ref[i][k] = pts[i][k], ag.traj_ref[i][3 + k] = v[k];
   }
+  const hdsm_sw::Cfg cc = sw.core_cfg();
+  hdsm_sw::keep_only_free(cc, hdsm_sw::local_grid_origin(cc, ag), ag.path_vel, ag.traj_ref, ag.n_ref);  // AC:1512-1514
 }
 
 // ---- a minimal router on the world grid (see hdsm_swarm_route in hdsm_swarm.h) -------------------------------------
@@ -485,10 +494,25 @@ int hdsm_swarm_reference_inputs(void* swarm, double* path, int32_t* n_path) {
   return hdsm_swarm_reference_inputs_n(swarm, 3, path, n_path);
 }
 
+int hdsm_swarm_vel_cap(void* swarm, double* vel_cap) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || !vel_cap) return HDSM_ERR_BAD_ARG;
+  const hdsm_sw::Cfg cc = sw->core_cfg();
+  const hdsm_ref_config rc = ref_config(*sw);
+  for (int k = 0; k < sw->n_local; ++k) {
+    const AgentS& ag = sw->agents[k];
+    V3 pl[hdsm_sw::PATH_PTS + 1];
+    const int n = hdsm_sw::reference_polyline(ag, pl);
+    vel_cap[k] = hdsm_sw::voxel_velocity_cap(cc, rc, hdsm_sw::local_grid_origin(cc, ag), pl, n);
+  }
+  return HDSM_OK;
+}
+
 int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* path_vel) {
   Swarm* sw = static_cast<Swarm*>(swarm);
   if (!sw || !ref_full || !path_vel) return HDSM_ERR_BAD_ARG;
   const int N = sw->prm.n_hor;
+  const hdsm_sw::Cfg cc = sw->core_cfg();
   for (int k = 0; k < sw->n_local; ++k) {
     AgentS& ag = sw->agents[k];
     ag.n_ref = N + 1;
@@ -496,6 +520,7 @@ int hdsm_swarm_set_reference(void* swarm, const double* ref_full, const double* 
       for (int c = 0; c < 6; ++c) ag.traj_ref[i][c] = ref_full[((size_t)k * (N + 1) + i) * 6 + c];
     ag.path_vel = path_vel[k];
     ag.external_ref = 1;
+    hdsm_sw::keep_only_free(cc, hdsm_sw::local_grid_origin(cc, ag), ag.path_vel, ag.traj_ref, ag.n_ref);  // AC:1512-1514
   }
   return HDSM_OK;
 }

@@ -62,6 +62,34 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, u
     for (int a = 0; a < 3; ++a) path[((size_t)k * PTS + i) * 3 + a] = pl[i < np ? i : np - 1][a];
 }
 
+// the map-dependent half of the reference (row f1 remainder): ComputePathVelocity's voxel term before k_reference ...
+__global__ __launch_bounds__(64) void k_vel_cap(Cfg c, hdsm_ref_config rc, int n, const AgentS* agents, const double* path, const int32_t* n_path,
+                                                double* vel_cap) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  V3 pl[PTS];
+  const int np = n_path[k];
+  for (int i = 0; i < np; ++i)
+    for (int a = 0; a < 3; ++a) pl[i][a] = path[((size_t)k * PTS + i) * 3 + a];
+  vel_cap[k] = hdsm_sw::voxel_velocity_cap(c, rc, hdsm_sw::local_grid_origin(c, agents[k]), pl, np);
+}
+
+// ... and KeepOnlyFreeReference (AC:1665-1693) after it, on the rows k_reference wrote
+__global__ __launch_bounds__(64) void k_keep_free(Cfg c, int n, const AgentS* agents, double* ref_full, double* ref, const double* path_vel) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k >= n) return;
+  const int N = c.N;
+  double rows[hdsm::MAXH + 1][6];
+  for (int i = 0; i <= N; ++i)
+    for (int q = 0; q < 6; ++q) rows[i][q] = ref_full[((size_t)k * (N + 1) + i) * 6 + q];
+  hdsm_sw::keep_only_free(c, hdsm_sw::local_grid_origin(c, agents[k]), path_vel[k], rows, N + 1);
+  for (int i = 0; i <= N; ++i)
+    for (int q = 0; q < 6; ++q) {
+      ref_full[((size_t)k * (N + 1) + i) * 6 + q] = rows[i][q];
+      if (i < N) ref[((size_t)k * N + i) * 6 + q] = rows[i][q];
+    }
+}
+
 __global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, const double* ref_full, const double* path_vel,
                                                int32_t* agent_id, double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A,
                                                double* b) {
@@ -116,7 +144,7 @@ struct DSwarm {
   AgentS* d_agents = nullptr;
   int8_t* d_world = nullptr;
   unsigned char* d_scratch = nullptr;
-  double *d_path = nullptr, *d_ref_full = nullptr, *d_ref = nullptr, *d_pv = nullptr, *d_state = nullptr, *d_A = nullptr, *d_b = nullptr,
+  double *d_cap = nullptr, *d_path = nullptr, *d_ref_full = nullptr, *d_ref = nullptr, *d_pv = nullptr, *d_state = nullptr, *d_A = nullptr, *d_b = nullptr,
          *d_traj = nullptr, *d_ctrl = nullptr, *d_obj = nullptr, *d_local = nullptr, *d_plans = nullptr;
   int32_t *d_npath = nullptr, *d_id = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr, *d_fails = nullptr;
   uint8_t *d_used = nullptr, *d_has = nullptr;
@@ -131,7 +159,7 @@ hipError_t dalloc(T** p, size_t count) {
 }
 
 void free_all(DSwarm* d) {
-  void* ptrs[] = {d->d_agents, d->d_world, d->d_scratch, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
+  void* ptrs[] = {d->d_cap, d->d_agents, d->d_world, d->d_scratch, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
                   d->d_ctrl, d->d_obj, d->d_local, d->d_plans, d->d_npath, d->d_id, d->d_npoly, d->d_nrows, d->d_status, d->d_fails,
                   d->d_used, d->d_has};
   for (void* p : ptrs)
@@ -185,7 +213,7 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
     ok(dalloc(&d->d_scratch, n * SLAB));
   }
   ok(dalloc(&d->d_path, n * PTS * 3)), ok(dalloc(&d->d_npath, n)), ok(dalloc(&d->d_ref_full, n * (N + 1) * 6)), ok(dalloc(&d->d_ref, n * N * 6));
-  ok(dalloc(&d->d_pv, n)), ok(dalloc(&d->d_id, n)), ok(dalloc(&d->d_state, n * 9)), ok(dalloc(&d->d_npoly, n)), ok(dalloc(&d->d_nrows, n * P));
+  ok(dalloc(&d->d_cap, n)), ok(dalloc(&d->d_pv, n)), ok(dalloc(&d->d_id, n)), ok(dalloc(&d->d_state, n * 9)), ok(dalloc(&d->d_npoly, n)), ok(dalloc(&d->d_nrows, n * P));
   ok(dalloc(&d->d_A, n * P * RS * 3)), ok(dalloc(&d->d_b, n * P * RS)), ok(dalloc(&d->d_traj, L * REC)), ok(dalloc(&d->d_ctrl, L * N * 3));
   ok(dalloc(&d->d_obj, L)), ok(dalloc(&d->d_used, L * P)), ok(dalloc(&d->d_status, L)), ok(dalloc(&d->d_local, L * REC));
   ok(dalloc(&d->d_plans, G * REC)), ok(dalloc(&d->d_has, G)), ok(dalloc(&d->d_fails, 1));
@@ -234,9 +262,17 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   if (n > 0) {
     hipLaunchKernelGGL(k_corridor, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
     HIP_TRY(hipGetLastError());
-    int rc = hdsm_reference_device(d->solver, &d->rcfg, n, G, d->d_id, d->d_path, d->d_npath, PTS, nullptr, d->d_plans, d->d_has,
-                                   d->d_ref_full, d->d_ref, d->d_pv, st);
+    if (d->c.has_world) {
+      hipLaunchKernelGGL(k_vel_cap, dim3(gb), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
+      HIP_TRY(hipGetLastError());
+    }
+    int rc = hdsm_reference_device(d->solver, &d->rcfg, n, G, d->d_id, d->d_path, d->d_npath, PTS, d->c.has_world ? d->d_cap : nullptr,
+                                   d->d_plans, d->d_has, d->d_ref_full, d->d_ref, d->d_pv, st);
     if (rc) return fail(rc, std::string("hdsm_reference_device: ") + hdsm_last_error());
+    if (d->c.has_world) {
+      hipLaunchKernelGGL(k_keep_free, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_ref, d->d_pv);
+      HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_inputs, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_pv, d->d_id, d->d_state, d->d_npoly,
                        d->d_nrows, d->d_A, d->d_b);
     HIP_TRY(hipGetLastError());

@@ -149,6 +149,14 @@ class SwarmShard:
             raise _lib.HdsmError(rc, "hdsm_swarm_reference_inputs_n")
         return path, n_path
 
+    def vel_cap(self):
+        """vel_cap for hdsm_reference: the voxel / potential-field term of ComputePathVelocity on the current world."""
+        cap = np.zeros(self.n_local)
+        rc = self.lib.hdsm_swarm_vel_cap(self.h, _p(cap, C.c_double))
+        if rc:
+            raise _lib.HdsmError(rc, "hdsm_swarm_vel_cap")
+        return cap
+
     def route(self):
         """Global paths on the world given to set_world (hdsm_swarm_route); returns the number of agents without a route."""
         nf = C.c_int32(0)
@@ -218,6 +226,7 @@ class SwarmLoop:
         starts / goals [n_rob][3]: explicit scenario (default: the circular exchange)."""
         self.prm, self.n_rob, self.rank, self.world = prm, n_rob, rank, world
         self.reference = reference
+        self.has_world = False
         self.pmax = 3  # points of the reference polyline handed to `reference` (16 after route())
         if starts is None:
             starts, goals = circle_scenario(n_rob, radius)
@@ -234,6 +243,7 @@ class SwarmLoop:
     def set_world(self, occupancy, origin, route=True):
         """Occupied world for the corridor generator (f2) and, with route=True, global paths from the built-in router."""
         self.shard.set_world(occupancy, origin)
+        self.has_world = occupancy is not None
         if route:
             failed = self.shard.route()
             self.pmax = 32
@@ -245,7 +255,7 @@ class SwarmLoop:
             self.shard.prepare_corridor()  # AC:165 before AC:171
             path, n_path = self.shard.reference_inputs(self.pmax)
             ids = np.arange(self.first, self.first + self.n_local, dtype=np.int32)
-            ref_full, pv = self.reference(ids, path, n_path, self.plans_all, self.has_plan)
+            ref_full, pv = self.reference(ids, path, n_path, self.plans_all, self.has_plan, **({"vel_cap": self.shard.vel_cap()} if self.has_world else {}))
             self.shard.set_reference(ref_full, pv)
         inputs = self.shard.prepare(self.plans_all, self.has_plan)
         if record is not None:

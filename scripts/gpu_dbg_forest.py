@@ -10,8 +10,8 @@ sol = lib.Solver(prm, n, n)
 rcfg = agile_ref_config()
 def solve(inp, plans, has):
     return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
-def ref_dev(ids, path, n_path, plans, has):
-    full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has)
+def ref_dev(ids, path, n_path, plans, has, vel_cap=None):
+    full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has, vel_cap=vel_cap)
     return full, pv
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 raw, org = sc.forest_for_circle(n, seed=SEED)

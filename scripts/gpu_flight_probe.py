@@ -27,8 +27,8 @@ def solve(inp, plans, has):
     return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
 
 
-def ref_dev(ids, path, n_path, plans, has):
-    full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has)
+def ref_dev(ids, path, n_path, plans, has, vel_cap=None):
+    full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has, vel_cap=vel_cap)
     return full, pv
 
 

@@ -37,8 +37,8 @@ def _device_loop(hdsm, prm, cfg, n_rob, starts=None, goals=None, radius=None):
     def solve(inp, plans, has):
         return sol.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
 
-    def ref_dev(ids, path, n_path, plans, has):
-        full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has)
+    def ref_dev(ids, path, n_path, plans, has, vel_cap=None):
+        full, _, pv = sol.reference(rcfg, ids, path, n_path, plans, has, vel_cap=vel_cap)
         return full, pv
 
     loop = swarm.SwarmLoop(prm, cfg, n_rob, solve=solve, radius=radius, reference=ref_dev, starts=starts, goals=goals)

@@ -364,3 +364,132 @@ def test_swarm_keeps_the_planner_records(oracle, tmp_path):
     hist = (tmp_path / "state_hist_1.csv").read_text().strip().split("\n")
     assert len(hist) == 5 and all(len(row.split(",")) == 10 for row in hist)
     assert "comp_time_sc_1.csv: " in buf.value.decode() and "velocity for agent: 1" in buf.value.decode()
+
+
+# ---- row f1, map-dependent half: ComputePathVelocity's voxel term and KeepOnlyFreeReference on the host mirror --------
+def _py_raycast(val, dim, start, end, max_dist):
+    """voxel_grid_util::Raycast (raycast.cpp:22-183) statement by statement; val(i,j,k) raw voxel, -1 outside."""
+    import math
+    mod = lambda v, m: math.fmod(math.fmod(v, m) + m, m)
+
+    def intbound(s, ds):
+        if ds < 0:
+            return intbound(-s, -ds)
+        s = mod(s, 1)
+        return (1 - s) / ds if ds != 0 else math.inf
+
+    sg = lambda x: 0 if x == 0 else (-1 if x < 0 else 1)
+    x, y, z = (int(math.floor(c)) for c in start)
+    ex, ey, ez = (int(math.floor(c)) for c in end)
+    d = [end[k] - start[k] for k in range(3)]
+    st = [sg(ex - x), sg(ey - y), sg(ez - z)]
+    tm = [intbound(start[k], d[k]) for k in range(3)]
+    td = [(st[k] / d[k]) if d[k] != 0 else math.nan for k in range(3)]
+    out, hit = [], None
+    if st == [0, 0, 0]:
+        return [list(end), list(start)], None
+    tmax = 0.0
+    inside = lambda i, j, k: 0 <= i < dim[0] and 0 <= j < dim[1] and 0 <= k < dim[2]
+    while True:
+        real = [start[k] + min(1.0, tmax) * d[k] for k in range(3)]
+        if inside(x, y, z):
+            if val(x, y, z) == 100 and tmax <= 1:
+                hit = real
+                out.append(real)
+                break
+            out.append(real)
+            if (x - start[0]) ** 2 + (y - start[1]) ** 2 + (z - start[2]) ** 2 > max_dist ** 2:
+                break
+        if tmax >= 1:
+            break
+        if (tm[0] < tm[1] and st[0] != 0) or st[1] == 0:
+            ax = 0 if ((tm[0] < tm[2] and st[0] != 0) or st[2] == 0) else 2
+        else:
+            ax = 1 if ((tm[1] < tm[2] and st[1] != 0) or st[2] == 0) else 2
+        tmax = tm[ax]
+        if ax == 0:
+            x += st[0]
+        elif ax == 1:
+            y += st[1]
+        else:
+            z += st[2]
+        tm[ax] += td[ax]
+    return out, hit
+
+
+def test_voxel_velocity_cap_and_keep_only_free_follow_the_reference_statements():
+    """hdsm_swarm_vel_cap = the voxel term of Agent::ComputePathVelocity (AC:1709-1766) and hdsm_swarm_set_reference's
+    KeepOnlyFreeReference (AC:1665-1693), against a statement-by-statement Python rendering of the reference (Raycast,
+    GetVelocityLimit, the world-metres-vs-voxel-units distance of AC:1739) on worlds with a potential field."""
+    import math
+    from multi_agent_pkgs_amd import scenarios as sc
+    rng = np.random.default_rng(8)
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+    vs, vmin, vmax, sd, sp = 0.3, cfg.path_vel_min, cfg.path_vel_max, cfg.sens_dist, cfg.sens_pot
+    lowered = 0
+    for case in range(12):
+        raw = np.zeros((30, 120, 120), np.int8)
+        for _ in range(60):
+            i, j = rng.integers(5, 115, 2)
+            raw[:, j, i] = 100
+        occ = sc.inflate(raw)
+        halo = sc.inflate(occ, inflation_dist=0.6)
+        world = np.where(occ >= 100, 100, np.where(halo >= 100, int(rng.integers(20, 90)), 0)).astype(np.int8)  # a crude potential field
+        origin = np.array([-3.0, -6.0, -0.9])
+        starts = np.array([[rng.uniform(6, 24), rng.uniform(3, 24), 1.5] for _ in range(6)])
+        goals = starts + rng.uniform(-9, 9, (6, 3)) * [1, 1, 0.05]
+        sh = swarm.SwarmShard(prm, cfg, 6, 0, starts, goals)
+        sh.set_world(world, origin)
+        cap = sh.vel_cap()
+        for k in range(6):
+            go = np.floor((starts[k] - np.array([10.0, 10.0, 3.0])) / vs) * vs
+            off = np.round((go - origin) / vs).astype(int)
+            gk = int(math.ceil((0.0 - go[2]) / vs - 1e-9))
+
+            def val(i, j, kk):
+                if not (0 <= i < 66 and 0 <= j < 66 and 0 <= kk < 20):
+                    return -1
+                if kk < gk:
+                    return -1
+                g = (i + off[0], j + off[1], kk + off[2])
+                if not (0 <= g[0] < 120 and 0 <= g[1] < 120 and 0 <= g[2] < 30):
+                    return 0
+                return int(world[g[2], g[1], g[0]])
+
+            pts = [starts[k], goals[k]]
+            loc = [(p - go) / vs for p in pts]
+            want = vmax
+            visited, hit = _py_raycast(val, (66, 66, 20), list(loc[0]), list(loc[1]), float(np.linalg.norm(loc[0] - loc[1])))
+            lim = lambda o, d: vmin + (vmax - vmin) * (1 - (min(max(o, 0), 100) / 100) ** sp * (1 / math.exp(sd * d)))
+            if hit is None:
+                for pt in visited + [list(loc[0])]:
+                    v = val(int(pt[0]), int(pt[1]), int(pt[2]))
+                    v = 100 if v == -1 else v
+                    want = min(want, lim(v, float(np.linalg.norm(pts[0] - np.array(pt))) * vs))
+            else:
+                want = min(want, lim(val(int(hit[0]), int(hit[1]), int(hit[2])), float(np.linalg.norm(loc[0] - np.array(hit)))))
+            assert abs(cap[k] - want) < 1e-9, (case, k, cap[k], want)
+            lowered += want < vmax - 1e-6
+        # KeepOnlyFreeReference: a straight reference of 11 points along the path; the first point in an occupied / unknown voxel
+        # stops it (AC:1677-1688) and the velocity references are rebuilt on the result (AC:1527-1547)
+        ref = np.zeros((6, 11, 6))
+        for k in range(6):
+            ref[k, :, :3] = starts[k] + np.linspace(0, 1, 11)[:, None] * (goals[k] - starts[k])
+        sh.set_reference(ref, np.full(6, 5.0))
+        sh.prepare(np.zeros((6, 11, 9)), np.zeros(6, np.uint8))
+        got = sh.inp["ref"]
+        for k in range(6):
+            go = np.floor((starts[k] - np.array([10.0, 10.0, 3.0])) / vs) * vs
+            pts = ref[k, :, :3].copy()
+            for i in range(1, 11):
+                c = ((pts[i] - go) / vs).astype(int)
+                g = c + np.round((go - origin) / vs).astype(int)
+                inside = (c >= 0).all() and c[0] < 66 and c[1] < 66 and c[2] < 20
+                v = -1 if (not inside or c[2] < int(math.ceil((0.0 - go[2]) / vs - 1e-9))) else (
+                    int(world[g[2], g[1], g[0]]) if (0 <= g[0] < 120 and 0 <= g[1] < 120 and 0 <= g[2] < 30) else 0)
+                if v in (-1, 100):
+                    pts[i:] = pts[i - 1]
+                    break
+            assert np.abs(got[k, :, :3] - pts[:10]).max() < 1e-12, (case, k)
+    assert lowered > 10
