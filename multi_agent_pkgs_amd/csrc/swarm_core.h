@@ -437,16 +437,18 @@ CD_HD void check_increment(const Cfg& c, AgentS& ag) {
   V3 curr = ref_pt(0);
   double dist_min = norm(sub(pt, curr)), progress = 0, progress_final = 0, proj_dist = dist_min;
   int idx = 1;
+  V3 target = ref_pt(1);  // (kept in registers: it changes N times, the loop runs ~100 times per metre of reference)
   const double samp = 0.01;
   while (idx < ag.n_ref) {
-    const V3 diff = sub(ref_pt(idx), curr);
+    const V3 diff = sub(target, curr);
     const double dist_next = norm(diff);
     if (dist_next > samp) {
       curr = axpy(curr, samp / dist_next, diff);
       progress += samp;
     } else {
-      curr = ref_pt(idx);
+      curr = target;
       ++idx;
+      if (idx < ag.n_ref) target = ref_pt(idx);
       progress += dist_next;
     }
     const double d = norm(sub(pt, curr));

@@ -43,8 +43,138 @@ int fail(int code, const std::string& m) {
 constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline handed to k_reference
 constexpr size_t SLAB = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16 + hdsm_cd::WindowGrid::WORDS * 4;
 
+// GenerateSafeCorridor (AC:1236-1447), ONE WAVEFRONT PER AGENT. The walk along the path (steps of voxel / 10: hundreds of
+// them per round) tests every sample against every row of the kept polyhedra; with one thread per agent each test was a chain of
+// global loads (1.3 ms per round for 1024 agents). Here the rows live in the registers of the 64 lanes (two rows per lane,
+// P * RS <= 128), a sample is tested against all of them at once and `inside` is a ballot; the walk state is computed redundantly
+// by every lane (wave-uniform), so the arithmetic — and the result — is exactly that of hdsm_sw::corridor_step. New polyhedra
+// (closed form in free space, voxel decomposition on a window of the world grid) are produced by lane 0 with the shared code.
+__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, V3* path, int lane) {
+  using namespace hdsm_sw;
+  const int P = c.P, N = c.N, RS = c.RS;
+  __shared__ int sh_npoly, sh_npath, sh_flag;
+  if (lane == 0) {  // keep-last / keep-used (AC:1253-1282) and the path ahead (AC:1286-1290): a handful of operations
+    ag.corridor_rc = 0;
+    Poly* fresh = ag.polys;
+    int n_poly = 0;
+    bool kept_last = false;
+    if (ag.n_poly > 0) {
+      bool all_in = true;
+      if (ag.has_traj)
+        for (int j = 0; j <= N; ++j)
+          if (!inside(ag.polys[ag.n_poly - 1], V3{{ag.traj_curr[j][0], ag.traj_curr[j][1], ag.traj_curr[j][2]}})) {
+            all_in = false;
+            break;
+          }
+      if (all_in) {
+        if (ag.n_poly - 1 != 0) fresh[0] = ag.polys[ag.n_poly - 1];
+        n_poly = 1, kept_last = true;
+      }
+    }
+    if (ag.n_poly > 0 && !kept_last)
+      for (int i = 0; i < P && i < ag.n_poly; ++i)
+        if (ag.poly_used[i]) {
+          if (n_poly != i) fresh[n_poly] = ag.polys[i];
+          ++n_poly;
+        }
+    const V3 path_head = ag.n_ref == 0 ? ag.path[0] : V3{{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]}};
+    path[0] = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
+    sh_npath = 1 + path_ahead(ag, path_head, path + 1);
+    sh_npoly = n_poly;
+  }
+  __syncthreads();
+  int n_poly = sh_npoly;
+  const int n_path = sh_npath;
+  const double vs = c.voxel_size;
+  V3 origin;
+  for (int ax = 0; ax < 3; ++ax) origin[ax] = floor((ag.state_curr[ax] - c.grid_range[ax] / 2) / vs) * vs;
+  // rows lane and lane + 64 of the flattened [P][RS] table
+  double ra[2][4];
+  bool rv[2];
+  unsigned long long pm[2][hdsm::MAXP];  // which ballot bits belong to polyhedron j
+  auto load_rows = [&]() {
+    for (int h = 0; h < 2; ++h) {
+      const int lin = lane + 64 * h, j = lin / RS, r = lin % RS;
+      rv[h] = j < n_poly && r < ag.polys[j].rows;
+      for (int q = 0; q < 3; ++q) ra[h][q] = rv[h] ? ag.polys[j].A[r][q] : 0.0;
+      ra[h][3] = rv[h] ? ag.polys[j].b[r] : 0.0;
+      for (int jj = 0; jj < hdsm::MAXP; ++jj) {
+        unsigned long long m = 0;
+        for (int bit = 0; bit < 64; ++bit) {
+          const int l2 = bit + 64 * h;
+          if (l2 / RS == jj) m |= 1ull << bit;
+        }
+        pm[h][jj] = m;
+      }
+    }
+  };
+  load_rows();
+  int path_idx = 1;
+  V3 curr = path[0];
+  V3 next = path[1];
+  const double samp = vs / 10;  // AC:1316
+  while (n_poly < P) {
+    const V3 diff = sub(next, curr);
+    const double dist_next = norm(diff);
+    if (dist_next > samp) {
+      curr = axpy(curr, samp / dist_next, diff);
+    } else {
+      curr = next;
+      if (++path_idx == n_path) break;
+      next = path[path_idx];
+    }
+    // inside at least one kept polyhedron? (LinearConstraint::inside: no row with A x - b > 0)
+    unsigned long long viol[2];
+    for (int h = 0; h < 2; ++h) {
+      const bool bad = rv[h] && (((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]) - ra[h][3] > 0);
+      viol[h] = __ballot(bad);
+    }
+    bool inside_one = false;
+    for (int j = 0; j < n_poly; ++j)
+      if (((viol[0] & pm[0][j]) | (viol[1] & pm[1][j])) == 0) {
+        inside_one = true;
+        break;
+      }
+    if (inside_one) continue;
+    V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
+    if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
+    int seed[3];
+    V3 seed_world;
+    for (int ax = 0; ax < 3; ++ax) {
+      seed[ax] = (int)((seed_pt[ax] - origin[ax]) / vs);
+      seed_world[ax] = (seed[ax] * vs + vs / 2) + origin[ax];
+    }
+    bool previous_seed = false;  // AC:1361-1379
+    for (int i = 0; i < n_poly; ++i)
+      if (ag.polys[i].seed[0] == seed_world[0] && ag.polys[i].seed[1] == seed_world[1] && ag.polys[i].seed[2] == seed_world[2]) {
+        previous_seed = true;
+        break;
+      }
+    if (previous_seed) continue;
+    if (lane == 0) {
+      Poly& np = ag.polys[n_poly];
+      int rc = HDSM_OK;
+      if (c.has_world) rc = world_poly(c, origin, seed, wk, bits, &np);
+      else free_space_poly(c, origin, seed, &np);
+      if (rc != HDSM_OK) ag.corridor_rc = rc;
+      else np.seed = seed_world;
+      sh_flag = rc;
+    }
+    __syncthreads();
+    const int rc = sh_flag;
+    __syncthreads();
+    if (rc != HDSM_OK) break;
+    ++n_poly;
+    load_rows();
+  }
+  if (lane == 0) ag.n_poly = n_poly;
+}
+
 __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, unsigned char* scratch, double* path, int32_t* n_path) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  __shared__ V3 path_s[hdsm_sw::PATH_PTS + 2];
+  __shared__ V3 poly_s[PTS];
+  __shared__ int np_s;
+  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (k >= n) return;
   AgentS& ag = agents[k];
   hdsm_cd::Work* wk = nullptr;
@@ -54,12 +184,17 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, u
     wk = reinterpret_cast<hdsm_cd::Work*>(slab);
     bits = reinterpret_cast<uint32_t*>(slab + ((sizeof(hdsm_cd::Work) + 15) / 16) * 16);
   }
-  hdsm_sw::corridor_step(c, ag, wk, bits);
-  V3 pl[PTS];
-  const int np = hdsm_sw::reference_polyline(ag, pl);
-  n_path[k] = np;
-  for (int i = 0; i < PTS; ++i)
-    for (int a = 0; a < 3; ++a) path[((size_t)k * PTS + i) * 3 + a] = pl[i < np ? i : np - 1][a];
+  if (c.P * c.RS <= 128) {
+    corridor_step_wave(c, ag, wk, bits, path_s, lane);
+  } else if (lane == 0) {
+    hdsm_sw::corridor_step(c, ag, wk, bits);  // more rows than two per lane: the plain per-agent code
+  }
+  __syncthreads();
+  if (lane == 0) np_s = hdsm_sw::reference_polyline(ag, poly_s);
+  __syncthreads();
+  const int np = np_s;
+  if (lane == 0) n_path[k] = np;
+  for (int i = lane; i < PTS * 3; i += 64) path[(size_t)k * PTS * 3 + i] = poly_s[(i / 3) < np ? i / 3 : np - 1][i % 3];
 }
 
 // the map-dependent half of the reference (row f1 remainder): ComputePathVelocity's voxel term before k_reference ...
@@ -93,17 +228,22 @@ __global__ __launch_bounds__(64) void k_keep_free(Cfg c, int n, const AgentS* ag
 __global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, const double* ref_full, const double* path_vel,
                                                int32_t* agent_id, double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A,
                                                double* b) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  // one wavefront per agent: the lanes share the copies (the new reference into the agent state, the solver inputs out)
+  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (k >= n) return;
   AgentS& ag = agents[k];
   const int N = c.N, P = c.P, RS = c.RS;
-  ag.n_ref = N + 1;
-  for (int i = 0; i <= N; ++i)
-    for (int q = 0; q < 6; ++q) ag.traj_ref[i][q] = ref_full[((size_t)k * (N + 1) + i) * 6 + q];
-  ag.path_vel = path_vel[k];
-  double ref_unused[hdsm::MAXH * 6];  // k_reference already wrote the solver's traj_ref rows
-  hdsm_sw::fill_inputs(c, ag, agent_id + k, state_curr + 9 * (size_t)k, ref_unused, n_poly + k, n_rows + (size_t)k * P,
-                       A + (size_t)k * P * RS * 3, b + (size_t)k * P * RS);
+  for (int t = lane; t < (N + 1) * 6; t += 64) ag.traj_ref[t / 6][t % 6] = ref_full[(size_t)k * (N + 1) * 6 + t];
+  if (lane < 9) state_curr[9 * (size_t)k + lane] = ag.state_curr[lane];
+  if (lane == 0) ag.n_ref = N + 1, ag.path_vel = path_vel[k], agent_id[k] = ag.id, n_poly[k] = ag.n_poly;
+  const int np = ag.n_poly;
+  if (lane < P) n_rows[(size_t)k * P + lane] = lane < np ? ag.polys[lane].rows : 0;
+  for (int t = lane; t < P * RS; t += 64) {
+    const int j = t / RS, r = t % RS;
+    const bool hr = j < np && r < ag.polys[j].rows;
+    for (int q = 0; q < 3; ++q) A[((size_t)k * P * RS + t) * 3 + q] = hr ? ag.polys[j].A[r][q] : 0.0;
+    b[(size_t)k * P * RS + t] = hr ? ag.polys[j].b[r] : 0.0;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* agents, const double* traj, const double* ctrl,
@@ -260,7 +400,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;
   const unsigned gb = (unsigned)((n + 63) / 64), gp = (unsigned)((d->per + 63) / 64);
   if (n > 0) {
-    hipLaunchKernelGGL(k_corridor, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
+    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_vel_cap, dim3(gb), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
@@ -273,7 +413,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
       hipLaunchKernelGGL(k_keep_free, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_ref, d->d_pv);
       HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_inputs, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_pv, d->d_id, d->d_state, d->d_npoly,
+    hipLaunchKernelGGL(k_inputs, dim3((unsigned)n), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_pv, d->d_id, d->d_state, d->d_npoly,
                        d->d_nrows, d->d_A, d->d_b);
     HIP_TRY(hipGetLastError());
     rc = hdsm_replan_device(d->solver, n, G, d->d_id, d->d_state, d->d_ref, d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_plans, d->d_has,
