@@ -66,9 +66,16 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
 //   bounds[n_rob][4]   (only for swarms of at least bounds_min agents) centre of the bounding box of those positions and the
 //                      radius of the sphere around it that holds them (radius -1 = no plan): the sweeps use it to skip
 //                      whole neighbours (hdsm_wave_gi.h, sweep_planes).
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order);
+
 __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
                                                       const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
-                                                      double* __restrict__ bounds) {
+                                                      double* __restrict__ bounds, int n_order, const int32_t* __restrict__ iters_prev,
+                                                      int32_t* __restrict__ order) {
+  if (order != nullptr && blockIdx.x == gridDim.x - 1) {  // one extra workgroup: the launch order of the solve that follows
+    launch_order_block(n_order, iters_prev, order);
+    return;
+  }
   // 16 lanes per agent (N <= 16 = HDSM_MAX_HOR): lane i copies the position of step i + 1, the box / sphere reductions run
   // over the 16-lane group with DPP-able shuffles — every load of a plan is issued at once instead of N dependent ones
   const int tid = (int)threadIdx.x, i = tid & 15;
@@ -117,12 +124,12 @@ __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const do
 // dispatched in index order, so workgroup w takes instance order[w], the instances sorted by the active-set operations they
 // needed in the PREVIOUS launch on this handle (most first; a counting sort on min(iters, 255)). The previous replan of the
 // same agent is a good predictor (gridlocked neighbourhoods persist); the answer of an instance does not depend on the order.
-__global__ __launch_bounds__(1024) void k_launch_order(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
   __shared__ int bucket[256];
-  const int tid = (int)threadIdx.x;
-  if (tid < 256) bucket[tid] = 0;
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  for (int b = tid; b < 256; b += nt) bucket[b] = 0;
   __syncthreads();
-  for (int k = tid; k < n_inst; k += 1024) {
+  for (int k = tid; k < n_inst; k += nt) {
     const int it = iters_prev[k];
     atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1);
   }
@@ -136,10 +143,13 @@ __global__ __launch_bounds__(1024) void k_launch_order(int n_inst, const int32_t
     }
   }
   __syncthreads();
-  for (int k = tid; k < n_inst; k += 1024) {
+  for (int k = tid; k < n_inst; k += nt) {
     const int it = iters_prev[k];
     order[atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1)] = k;
   }
+}
+__global__ __launch_bounds__(256) void k_launch_order(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
+  launch_order_block(n_inst, iters_prev, order);  // level 1 has no pre-pass to ride on
 }
 
 // hdsm_publish_device / hdsm_exchange_device: the has_plan flag travels inside the record (first entry NaN = no plan)
@@ -389,18 +399,18 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   h->last_stream = st;
   a.bounds = nullptr, a.pos = nullptr, a.order = nullptr;
-  if (a.warm != nullptr && h->order_min > 0 && a.n_inst >= h->order_min) {
-    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(1024), 0, st, a.n_inst, h->d_stats, h->d_order);
-    HIP_TRY(hipGetLastError());
-    a.order = h->d_order;
-  }
+  const bool ordered = a.warm != nullptr && h->order_min > 0 && a.n_inst >= h->order_min;
+  if (ordered) a.order = h->d_order;
   if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
-    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
-                       h->d_pos, pre ? h->d_bounds : nullptr);
+    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
+                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, h->d_stats, ordered ? h->d_order : nullptr);
     HIP_TRY(hipGetLastError());
     a.pos = h->d_pos;
     a.bounds = pre ? h->d_bounds : nullptr;
+  } else if (ordered) {
+    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(256), 0, st, a.n_inst, h->d_stats, h->d_order);
+    HIP_TRY(hipGetLastError());
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.

@@ -10,6 +10,7 @@
 //   check_increment    CheckReferenceTrajIncrement + GetPathProgress (AC:569-585, path_tools.cpp:419-479)
 //   commit_one         read-back bookkeeping, the shift-by-one fallback (AC:1000-1019), state advance (AC:233-238)
 #pragma once
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -461,9 +462,9 @@ CD_HD void check_increment(const Cfg& c, AgentS& ag) {
   if (progress_final > 0 && proj_dist < c.thresh_dist) ag.increment = 1;
 }
 
-// Consumes one agent's solver outputs (AC:960-1019, 182, 233-238); returns 1 if the agent has a plan to publish.
-CD_HD int commit_one(const Cfg& c, AgentS& ag, const double* traj /*[N+1][9]*/, const double* ctrl /*[N][3]*/, const uint8_t* used /*[P]*/,
-                     int status) {
+// Read-back of one agent's solver outputs (AC:960-987) or the shift-by-one fallback (AC:1000-1019)
+CD_HD void commit_copy(const Cfg& c, AgentS& ag, const double* traj /*[N+1][9]*/, const double* ctrl /*[N][3]*/, const uint8_t* used /*[P]*/,
+                       int status) {
   const int N = c.N, P = c.P;
   if (status != HDSM_NO_SOLUTION) {  // AC:960-987
     for (int i = 0; i <= N; ++i)
@@ -481,6 +482,37 @@ CD_HD int commit_one(const Cfg& c, AgentS& ag, const double* traj /*[N+1][9]*/, 
         for (int k = 0; k < 3; ++k) ag.ctrl_curr[i][k] = ag.ctrl_curr[i + 1][k];
     }
   }
+}
+
+// One segment of the walk of check_increment, on its own: the walker always lands exactly ON a reference point before it
+// starts the next segment, so the samples of segment `seg` (from ref[seg] towards ref[seg + 1], steps of 0.01 m, then the end
+// point) — and their distances to `pt` — do not depend on the other segments. Returns the smallest distance of the segment.
+CD_HD double increment_segment_min(const AgentS& ag, int seg, const V3& pt) {
+  V3 curr = {{ag.traj_ref[seg][0], ag.traj_ref[seg][1], ag.traj_ref[seg][2]}};
+  const V3 target = {{ag.traj_ref[seg + 1][0], ag.traj_ref[seg + 1][1], ag.traj_ref[seg + 1][2]}};
+  const double samp = 0.01;
+  double best = DBL_MAX;
+  for (;;) {
+    const V3 diff = sub(target, curr);
+    const double dist_next = norm(diff);
+    const bool last = !(dist_next > samp);
+    curr = last ? target : axpy(curr, samp / dist_next, diff);
+    const double d = norm(sub(pt, curr));
+    if (d < best) best = d;
+    if (last) break;
+  }
+  return best;
+}
+// check_increment from the per-segment minima: the reference advances iff some sample after the starting point is STRICTLY
+// closer to p_1 than the starting point (then progress_final > 0) and the closest sample is within thresh_dist.
+CD_HD int increment_from_minima(const Cfg& c, double d_start, double d_min_rest) {
+  return (d_min_rest < d_start && d_min_rest < c.thresh_dist) ? 1 : 0;
+}
+
+// Consumes one agent's solver outputs (AC:960-1019, 182, 233-238); returns 1 if the agent has a plan to publish.
+CD_HD int commit_one(const Cfg& c, AgentS& ag, const double* traj /*[N+1][9]*/, const double* ctrl /*[N][3]*/, const uint8_t* used /*[P]*/,
+                     int status) {
+  commit_copy(c, ag, traj, ctrl, used, status);
   if (ag.has_traj) {
     check_increment(c, ag);  // AC:182
     for (int k = 0; k < 9; ++k) ag.state_curr[k] = ag.traj_curr[c.step_plan][k];  // AC:233-238

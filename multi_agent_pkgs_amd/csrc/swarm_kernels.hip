@@ -248,22 +248,41 @@ __global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, con
 
 __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* agents, const double* traj, const double* ctrl,
                                                const uint8_t* used, const int32_t* status, double* plans_local, int32_t* fails) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  // one wavefront per published record. Lane 0 does the read-back / fallback; the increment check — a walk of ~100 samples per
+  // metre of reference — is split by reference segment over the lanes (the samples of a segment do not depend on the others,
+  // hdsm_sw::increment_segment_min), the minima meet in a wave reduction; then all lanes write the record.
+  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (k >= per) return;
   const int N = c.N, rec = (N + 1) * 9;
   double* out = plans_local + (size_t)k * rec;
-  int have = 0;
+  __shared__ int have_s;
+  if (lane == 0) have_s = 0;
+  __syncthreads();
   if (k < n) {
     AgentS& ag = agents[k];
-    have = hdsm_sw::commit_one(c, ag, traj + (size_t)k * rec, ctrl + (size_t)k * N * 3, used + (size_t)k * c.P, status[k]);
-    if (status[k] == HDSM_NO_SOLUTION) atomicAdd(fails, 1);
-    if (have)
-      for (int i = 0; i <= N; ++i)
-        for (int q = 0; q < 9; ++q) out[i * 9 + q] = ag.traj_curr[i][q];
+    if (lane == 0) {
+      hdsm_sw::commit_copy(c, ag, traj + (size_t)k * rec, ctrl + (size_t)k * N * 3, used + (size_t)k * c.P, status[k]);
+      if (status[k] == HDSM_NO_SOLUTION) atomicAdd(fails, 1);
+      have_s = ag.has_traj;
+    }
+    __syncthreads();
+    if (have_s) {
+      int inc = 0;
+      if (ag.n_ref >= 2) {
+        const V3 pt = {{ag.traj_curr[1][0], ag.traj_curr[1][1], ag.traj_curr[1][2]}};
+        double best = DBL_MAX;
+        if (lane < ag.n_ref - 1) best = hdsm_sw::increment_segment_min(ag, lane, pt);
+        for (int off = 32; off > 0; off >>= 1) best = fmin(best, __shfl_xor(best, off));
+        const double d0 = hdsm_sw::norm(hdsm_sw::sub(pt, V3{{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]}}));
+        inc = hdsm_sw::increment_from_minima(c, d0, best);
+      }
+      if (lane == 0) ag.increment = inc;
+      if (lane < 9) ag.state_curr[lane] = ag.traj_curr[c.step_plan][lane];  // AC:233-238
+      for (int e = lane; e < rec; e += 64) out[e] = ag.traj_curr[e / 9][e % 9];
+    }
   }
-  if (!have) {  // no plan yet (or padding): the record carries the sentinel instead of a flag (hdsm_exchange_device)
-    for (int e = 1; e < rec; ++e) out[e] = 0.0;
-    out[0] = __longlong_as_double(0x7ff8000000000000LL);
+  if (!have_s) {  // no plan yet (or padding): the record carries the sentinel instead of a flag (hdsm_exchange_device)
+    for (int e = lane; e < rec; e += 64) out[e] = e == 0 ? __longlong_as_double(0x7ff8000000000000LL) : 0.0;
   }
 }
 
@@ -398,7 +417,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   HIP_TRY(hipSetDevice(d->device));
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;
-  const unsigned gb = (unsigned)((n + 63) / 64), gp = (unsigned)((d->per + 63) / 64);
+  const unsigned gb = (unsigned)((n + 63) / 64);
   if (n > 0) {
     hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
     HIP_TRY(hipGetLastError());
@@ -420,7 +439,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
                             d->d_traj, d->d_ctrl, d->d_used, d->d_status, d->d_obj, st);
     if (rc) return fail(rc, std::string("hdsm_replan_device: ") + hdsm_last_error());
   }
-  hipLaunchKernelGGL(k_commit, dim3(gp ? gp : 1), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
+  hipLaunchKernelGGL(k_commit, dim3((unsigned)(d->per > 0 ? d->per : 1)), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
                      d->d_local, d->d_fails);
   HIP_TRY(hipGetLastError());
   if (d->world > 1) {
