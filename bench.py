@@ -254,7 +254,7 @@ def main():
     # hdsm_dswarm_round continues the flight where the set-up left it (round first_round + steps): corridor, reference,
     # replan, commit, publish and the all-gather as one chain of launches per round, no host round trip. A secondary record.
     dloop = None
-    if not args.no_event_pass:
+    if not args.no_event_pass and (world == 1 or comm is not None):
         dsw = swarm.DeviceSwarm(loop.shard, solver, world_size=world, device=dev.index)
         dsw.upload_plans(loop.plans_all, loop.has_plan)
         for _ in range(2):
