@@ -422,7 +422,10 @@ struct Solver {
   // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if the pinned p_0 is outside.
   static HD int leaf_check(S& s, const Consts& c) {
     const int N = c.N, np = s.n_poly;
-#ifndef HDSM_EMU
+#if !defined(HDSM_EMU) && defined(HDSM_LEAF_MFMA)
+    // Opt-in build (-DHDSM_LEAF_MFMA): measured on MI355X it is performance-neutral on every workload tried but costs the
+    // two-workgroups-per-CU kernel 9 more spilled VGPRs (scratch 24 -> 60 B/lane, HBM writes 3.9 -> 8.7 MB per launch), so the
+    // default build keeps the scalar leaf test. Counters of both builds: profiles/r02_mfma_ab.json.
     if (c.leaf_mfma && N <= 15 && blockDim.x == 256) {
       // The slack of every static row at every trajectory point is ONE matrix product in homogeneous coordinates:
       //   D[r][m] = (a_r, -b_r) . (p_m, 1),   rows r of a polyhedron (tiles of 16), points m = 0..N (<= 16 columns), K = 4
