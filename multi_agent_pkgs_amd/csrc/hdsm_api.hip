@@ -561,7 +561,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_stats, 7 * I));
   ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
 #ifdef HDSM_PROFILE
-  ok(dmalloc(&h->d_prof, 24 * I));
+  ok(dmalloc(&h->d_prof, 32 * I));
 #endif
   ok(dmalloc(&h->d_agent, I));
   ok(dmalloc(&h->d_npoly, I));
@@ -788,21 +788,22 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
   HIP_TRY(hipStreamSynchronize(h->last_stream));
 #ifdef HDSM_PROFILE
   {  // development aid: phase cycle counters of the slowest instance and the batch mean
-    std::vector<long long> pr((size_t)n_inst * 24);
+    std::vector<long long> pr((size_t)n_inst * 32);
     HIP_TRY(hipMemcpy(pr.data(), h->d_prof, pr.size() * sizeof(long long), hipMemcpyDeviceToHost));
     int worst = 0;
-    double mean[24] = {0};
+    double mean[32] = {0};
     for (int k = 0; k < n_inst; ++k) {
-      if (pr[(size_t)k * 24 + 11] > pr[(size_t)worst * 24 + 11]) worst = k;
-      for (int j = 0; j < 24; ++j) mean[j] += (double)pr[(size_t)k * 24 + j] / n_inst;
+      if (pr[(size_t)k * 32 + 11] > pr[(size_t)worst * 32 + 11]) worst = k;
+      for (int j = 0; j < 32; ++j) mean[j] += (double)pr[(size_t)k * 32 + j] / n_inst;
     }
-    static const char* nm[24] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
+    static const char* nm[32] = {"states", "select", "normal", "d", "sums", "upd", "add", "drop", "setup", "sweep",
                                  "leaf", "TOTAL", "iters", "sweeps", "warm_ops", "warm_cycles", "sw_cull", "sw_filter",
-                                 "sw_load", "sw_body", "sw_tail", "su_stage", "su_grad", "su_fact"};
+                                 "sw_load", "sw_body", "sw_tail", "su_stage", "su_grad", "su_fact",
+                                 "w_prep", "w_fetch", "w_normal", "w_dir", "w_add", "w_pair", "w_drop", "w_7"};
     std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);
-    for (int j = 0; j < 24; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 24 + j]);
+    for (int j = 0; j < 32; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 32 + j]);
     std::fprintf(stderr, "\nHDSM_PROFILE mean:");
-    for (int j = 0; j < 24; ++j) std::fprintf(stderr, " %s=%.0f", nm[j], mean[j]);
+    for (int j = 0; j < 32; ++j) std::fprintf(stderr, " %s=%.0f", nm[j], mean[j]);
     std::fprintf(stderr, "\n");
   }
 #endif

@@ -92,7 +92,7 @@ struct Shm {
   int32_t inf_id;                       // row whose addition proved the last node infeasible (ids as in act[])
   int32_t st_sph, st_pairs;             // sweep counters: sphere records read, (neighbour, step) positions loaded
   long long t_start;                    // constant-rate clock at the start of the instance (time_limit_s)
-  long long prof_acc[16];
+  long long prof_acc[24];  // 0..7 iteration phases, 8..15 sweeps / set-up, 16..23 inside the warm start
   long long prof_last;
 #endif
   double x[NV], lam[NV], d[NV], w[NV], z[NV], r[NV], a[NV], suf[NV + 1], gc[NV], gs[NV], grad[NV];
@@ -615,7 +615,7 @@ struct Solver {
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
-    if (threadIdx.x < 16) s.prof_acc[threadIdx.x] = 0;
+    if (threadIdx.x < 24) s.prof_acc[threadIdx.x] = 0;
     SYNC();
     PROF_DECL
 #define SU_PROF(k) PROF(k)
@@ -1047,8 +1047,8 @@ struct Solver {
 
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     if (IS_T0 && a.prof) {
-      long long* pr = a.prof + (int64_t)inst * 24;
-      for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k], pr[16 + k] = s.prof_acc[8 + k];  // 16..23: inside the sweeps
+      long long* pr = a.prof + (int64_t)inst * 32;
+      for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k], pr[16 + k] = s.prof_acc[8 + k], pr[24 + k] = s.prof_acc[16 + k];  // 16..23: inside the sweeps, 24..31: inside the warm start
       pr[8] = t_setup_, pr[9] = t_sweep_, pr[10] = t_leaf_, pr[11] = clock64() - t_begin_;
       pr[12] = iters, pr[13] = sweeps, pr[14] = it_warm_, pr[15] = t_warm_;
     }

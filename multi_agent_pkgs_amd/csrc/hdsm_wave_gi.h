@@ -688,6 +688,7 @@ struct WaveGI {
     int nw = uni(wp[0]);
     if (nw <= 0) return;
     if (nw > NV) nw = NV;
+    PROF_DECL
     // Lane g prepares entry g of the guess — translation of the id to this replan's indices and, for a neighbour row,
     // the global reads and the plane itself — so the sequential loop below only broadcasts (v_readlane) what it needs.
     int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
@@ -710,6 +711,7 @@ struct WaveGI {
       }
     }
     int q = uni(s.q);
+    PROF(16)
     for (int g = 0; g < nw && q < n; ++g) {
       int id = __builtin_amdgcn_readlane(pre, g);
       if (id == -2) {
@@ -730,12 +732,16 @@ struct WaveGI {
         }
       }
       if (id < 0) continue;
+      PROF(17)
       const double ai = normal_entry(s, R, id, row_of(lane), N, n);
+      PROF(18)
       double dv[NC], dd, zz, dq, zi, ri;
       direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
+      PROF(19)
       ++iters;
       if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
       householder_add(s, R, id, 0.0, q, lane, dv, zz, dq, zi, ri);
+      PROF(20)
       ++q;
     }
     if (q == uni(s.q)) return;  // nothing usable
@@ -792,6 +798,7 @@ struct WaveGI {
         }
         if (lane == 0) s.f = s.fx0 + 0.5 * bcast64(tt, 0), s.q = q;
         wsync();
+        PROF(21)
 #ifdef HDSM_DEBUG
         states(s, R, lane, N);
         if (blockIdx.x == 2 && lane < q)
@@ -801,7 +808,9 @@ struct WaveGI {
         return;
       }
       const int l = uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1);
+      PROF(21)
       drop(s, R, l, q, lane);
+      PROF(22)
       --q;
       ++iters;
     }

@@ -14,7 +14,7 @@ for tag in ("default", "mfma"):
     for f in sorted(glob.glob(os.path.join(out, f"{tag}_bench?.json"))):
         d = json.loads(open(f).read().strip().splitlines()[-1])
         r["bench"].append({k: d[k] for k in ("value", "ms_per_step", "kernel_ms_mean", "p95_solve_latency_ms")})
-    for grp in ("mfma", "hbm"):
+    for grp in ("mfma", "WRITE_SIZE", "FETCH_SIZE"):
         jf = os.path.join(out, f"{tag}_pmc_{grp}.json")
         if not os.path.exists(jf):
             continue
