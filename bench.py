@@ -110,9 +110,17 @@ def main():
     stream = torch.cuda.current_stream()
     comm = None
     if world > 1 and args.dist_backend == "rccl":
-        uid = [lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = lib.Comm(solver, uid[0], rank, world)
+        # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = [lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = lib.Comm(solver, uid[0], rank, world)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         assert comm.world == world and comm.rank == rank
 
     # ---------------------------------------------------------------- set-up: closed-loop flight, recording
