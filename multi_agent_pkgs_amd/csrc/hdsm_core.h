@@ -424,7 +424,7 @@ struct Solver {
     const int N = c.N, np = s.n_poly;
 #if !defined(HDSM_EMU) && defined(HDSM_LEAF_MFMA)
     // Opt-in build (-DHDSM_LEAF_MFMA): measured on MI355X it is performance-neutral on every workload tried but costs the
-    // two-workgroups-per-CU kernel 9 more spilled VGPRs (scratch 24 -> 60 B/lane, HBM writes 3.9 -> 8.7 MB per launch), so the
+    // two-workgroups-per-CU kernel spilled VGPRs (scratch 24 -> 68 B/lane, HBM writes 3.9 -> 10.4 MB per launch), so the
     // default build keeps the scalar leaf test. Counters of both builds: profiles/r02_mfma_ab.json.
     if (c.leaf_mfma && N <= 15 && blockDim.x == 256) {
       // The slack of every static row at every trajectory point is ONE matrix product in homogeneous coordinates:
