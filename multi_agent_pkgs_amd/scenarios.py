@@ -138,33 +138,46 @@ def forest_wall_forest(tiles_y=1, tiles_z=1, seed=0, n_cyl=(90, 180), vox=VOX):
     np.logical_or.at(wall, (kk[:, None].repeat(len(ys), 1), jj[None, :].repeat(len(zs), 0)), ~in_gap)
     ix_wall = 159                                     # x samples 47.7 and 47.85 -> voxel 159
     listed[:, :, ix_wall] = np.tile(wall, (tiles_z, tiles_y))
+    # RandomVolume([[x0, 0, -6], [30, 30, 15]]).add_random_cylinders(n, direction +z, radius 0.05, height 20) (shapes.py:423-446):
+    # the cylinder's CENTRE is uniform in the 30 x 30 x 15 m box, it reaches 10 m up and down and is clipped by the box — so a pillar
+    # spans the full height only when its centre lies in z in [-1, 4]. With tiles in z the box grows and the count is scaled so that
+    # a horizontal slice meets about as many pillars as in the shipped world.
     rng = np.random.default_rng(seed)
+    z_lo, z_hi = -6.0, -6.0 + 15.0 * tiles_z
+    scale = tiles_y * (1.0 if tiles_z == 1 else 0.75 * tiles_z)
     for (x_lo, cnt) in ((3.0, n_cyl[0]), (63.0, n_cyl[1])):
-        for _ in range(cnt * tiles_y):
-            cx, cy = rng.uniform(x_lo, x_lo + 30.0), rng.uniform(0.0, 30.0 * tiles_y)
+        for _ in range(int(round(cnt * scale))):
+            cx, cy, cz = rng.uniform(x_lo, x_lo + 30.0), rng.uniform(0.0, 30.0 * tiles_y), rng.uniform(z_lo, z_hi)
+            k0 = max(0, int(np.floor((max(z_lo, cz - 10.0) - z_lo) / vox)))
+            k1 = min(nz, int(np.ceil((min(z_hi, cz + 10.0) - z_lo) / vox)))
             for sx in (-0.05, 0.05):                  # the mesh circle of radius 0.05 m
                 for sy in (-0.05, 0.05):
                     i, j = int(np.floor((cx + sx) / vox)), int(np.floor((cy + sy) / vox))
                     if 0 <= i < nx and 0 <= j < ny:
-                        listed[:, j, i] = True
+                        listed[k0:k1, j, i] = True
     occ = _listed_to_occupied(listed)
     return (occ.astype(np.int8) * 100), np.array([0.0, 0.0, -6.0])
 
 
 def inflate(occ, inflation_dist=0.3, vox=VOX):
-    """VoxelGrid::InflateObstacles (voxel_grid.cpp:249-276) with the mask of CreateMask (:192-226): every voxel whose centre
-    offset (dx, dy, dz) from an occupied voxel has vox * |offset| <= inflation_dist becomes occupied. numpy harness version;
-    the device version (bit-exact against the literal loops) is hdsm_map_preprocess (row f4)."""
-    r = int(np.floor(inflation_dist / vox + 1e-9))
+    """VoxelGrid::InflateObstacles (voxel_grid.cpp:249-276) with the mask of CreateMask(inflation_dist, 1) (:192-226): with
+    rn = ceil(dist / vox), every offset n in [-rn, rn]^3 with |hypot(n) - 1| * vox < dist (one voxel is taken off the distance)
+    and 100 * (1 - hypot(n) / (rn + 1)) > 1e-3 — for the shipped 0.3 m that is the whole 3 x 3 x 3 cube around an occupied voxel.
+    numpy harness version; the device version (bit-exact against the literal loops) is hdsm_map_preprocess (row f4)."""
     src = occ >= 100
     out = src.copy()
+    if not inflation_dist > 0:
+        return np.where(out, np.int8(100), np.int8(0)).astype(np.int8)
+    rn = int(np.ceil(inflation_dist / vox))
     nz, ny, nx = occ.shape
-    for dz in range(-r, r + 1):
-        for dy in range(-r, r + 1):
-            for dx in range(-r, r + 1):
-                if (dx or dy or dz) and vox * np.sqrt(dx * dx + dy * dy + dz * dz) <= inflation_dist + 1e-12:
-                    zs, zd = slice(max(0, -dz), nz - max(0, dz)), slice(max(0, dz), nz - max(0, -dz))
-                    ys, yd = slice(max(0, -dy), ny - max(0, dy)), slice(max(0, dy), ny - max(0, -dy))
-                    xs, xd = slice(max(0, -dx), nx - max(0, dx)), slice(max(0, dx), nx - max(0, -dx))
-                    out[zd, yd, xd] |= src[zs, ys, xs]
+    for dx in range(-rn, rn + 1):
+        for dy in range(-rn, rn + 1):
+            for dz in range(-rn, rn + 1):
+                h3 = np.hypot(np.hypot(dx, dy), dz)
+                if abs(h3 - 1) * vox >= inflation_dist or not (100.0 * (1 - h3 / (rn + 1)) > 1e-3):
+                    continue
+                zs, zd = slice(max(0, -dz), nz - max(0, dz)), slice(max(0, dz), nz - max(0, -dz))
+                ys, yd = slice(max(0, -dy), ny - max(0, dy)), slice(max(0, dy), ny - max(0, -dy))
+                xs, xd = slice(max(0, -dx), nx - max(0, dx)), slice(max(0, dx), nx - max(0, -dx))
+                out[zd, yd, xd] |= src[zs, ys, xs]
     return np.where(out, np.int8(100), np.int8(0)).astype(np.int8)

@@ -1,0 +1,111 @@
+"""CPU tests of the scenario pieces for BASELINE configs 3 and 5 (multi_agent_pkgs_amd/scenarios.py, harness code) and of
+the host mirror's router: known answers from the reference's launch files, the shipped forest + wall + forest instance
+(tests/golden/env_long_occupancy.npz, minted from the reference's env_long_config.yaml), the literal inflation loops of the
+oracle, and size-independent properties of the routes."""
+import os
+
+import numpy as np
+import pytest
+
+from multi_agent_pkgs_amd import scenarios as sc
+from multi_agent_pkgs_amd import swarm
+from multi_agent_pkgs_amd.params import agile_params
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_lattice_scenario_known_answers():
+    """multi_agent_planner_long.launch.py:36-42 (n_rob = 10): start_i = (0, 5 + 2.01 i, 0), goal_i = start_i + (96.01, 0, 0)."""
+    s, g = sc.lattice_scenario(10)
+    assert np.allclose(s[0], [0, 5.0, 0]) and np.allclose(s[9], [0, 5.0 + 9 * 2.01, 0]) and np.allclose(g - s, [96.01, 0, 0])
+    s, g = sc.lattice_scenario(64, 64)
+    assert s.shape == (4096, 3) and np.allclose(s[64], [0, 5.0, 2.01]) and np.allclose(s[4095], [0, 5 + 63 * 2.01, 63 * 2.01])
+
+
+def test_forest_wall_forest_reproduces_the_shipped_wall_and_density():
+    """The wall (x = 48, 0.3 m thick, fifteen gaps, generate_random_grid.py:60-82) is deterministic: the generator must give the
+    shipped instance's wall voxel for voxel, after EnvironmentBuilder::AddObstacles' two-voxels-per-axis marking. The cylinders
+    are random (own PRNG): same bands, comparable number of occupied columns."""
+    z = np.load(os.path.join(GOLD, "env_long_occupancy.npz"))
+    ref = np.unpackbits(z["packed"])[: np.prod(z["shape"])].reshape(z["shape"]).astype(bool)
+    occ, origin = sc.forest_wall_forest(1, 1, seed=0)
+    mine = occ >= 100
+    assert mine.shape == ref.shape and np.allclose(origin, z["origin"])
+    for x in range(150, 170):
+        if ref[:, :, x].sum() > 2000:                               # the two voxel planes of the wall
+            assert np.array_equal(mine[:, :, x], ref[:, :, x]), x
+    assert ref[:, :, 158].sum() > 4000 and (~ref[:, :, 158]).sum() > 300   # ... with its gaps
+    for lo, hi in ((8, 114), (206, 314)):                           # the two forest bands, x in [3, 33] and [63, 93]
+        for sel in (lambda o: o.any(axis=0), lambda o: o.all(axis=0), lambda o: o[20]):   # touched / full-height columns, the slice z = 0
+            a, b = sel(ref)[:, lo:hi].sum(), sel(mine)[:, lo:hi].sum()
+            assert 0.65 * a < b < 1.5 * a, (lo, a, b)
+    cols = mine.any(axis=0)
+    assert not cols[:, 116:150].any() and not cols[:, 170:204].any()   # nothing between forests and wall
+    big, _ = sc.forest_wall_forest(2, 3, seed=1)                    # tiles repeat the cross-section
+    assert big.shape == (150, 200, 334) and np.array_equal(big[:50, :100, 158], occ[:, :, 158]) and np.array_equal(big[100:, 100:, 158], occ[:, :, 158])
+
+
+def test_pillar_forest_follows_add_obstacles():
+    """EnvironmentBuilder::AddObstacles (environment_builder.cpp:189-231) with env_default_config.yaml: 180 pillars of
+    0.1 x 0.1 x 10 m, centres on whole metres relative to origin_obst (the integer division), voxelised by AddObstacle."""
+    occ, origin = sc.pillar_forest([0.0, 0.0, -8.0], [40.0, 40.0, 20.0], [6.5, 6.5, 0.0], [30.0, 30.0, 0.0], 180, seed=13)
+    assert occ.shape == (67, 134, 134)
+    zz, yy, xx = np.nonzero(occ)
+    assert zz.min() == 10 and zz.max() == 43                         # z in [3, 13] m of the grid -> voxels floor(3/0.3)..floor(13/0.3)
+    cols = occ.any(axis=0)
+    ys, xs = np.nonzero(cols)
+    # every occupied column belongs to a pillar whose centre (6.5 + k) m lies within 0.05 m of the voxel's extent
+    for x, y in zip(xs, ys):
+        for v in (x, y):
+            lo, hi = v * 0.3 - 0.05, (v + 1) * 0.3 + 0.05
+            k = np.arange(0, 31)
+            assert ((6.5 + k >= lo - 1e-9) & (6.5 + k <= hi + 1e-9)).any(), (x, y)
+    assert 100 < cols.sum() <= 2 * 2 * 180
+
+
+def test_inflate_equals_the_literal_loops(oracle):
+    """scenarios.inflate (numpy, harness) against the oracle's literal InflateObstacles (voxel_grid.cpp:249-276)."""
+    rng = np.random.default_rng(2)
+    g = np.zeros((12, 30, 30), np.int8)
+    g[rng.integers(0, 12, 40), rng.integers(0, 30, 40), rng.integers(0, 30, 40)] = 100
+    for dist in (0.3, 0.45, 0.6, 0.9):
+        from multi_agent_pkgs_amd.params import default_map_config
+        want = oracle.map_preprocess(default_map_config(voxel_size=0.3, inflation_dist=dist, potential_dist=0.0, potential_pow=1), g[None])[0]
+        got = sc.inflate(g, inflation_dist=dist)
+        assert np.array_equal(got >= 100, want >= 100), dist
+
+
+def test_router_gives_collision_free_bounded_polylines():
+    """hdsm_swarm_route: every route starts at the start and ends at the goal, has at most PATH_PTS points, and every point of
+    every segment (sampled at a quarter voxel) lies in a free voxel of the inflated world; in an empty world it is the
+    straight segment."""
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+    raw, origin = sc.forest_for_circle(32, seed=5)
+    occ = sc.inflate(raw)
+    starts, goals = sc.circle_scenario(32)
+    sh = swarm.SwarmShard(prm, cfg, 32, 0, starts, goals)
+    sh.set_world(occ, origin)
+    assert sh.route() == 0
+    paths, n = sh.get_paths()
+    bent = 0
+    for k in range(32):
+        p = paths[k, : n[k]]
+        assert 2 <= n[k] <= 48 and np.allclose(p[0], starts[k]) and np.allclose(p[-1], goals[k])
+        bent += n[k] > 2
+        vox_of = lambda q: tuple(np.floor((q - origin) / 0.3).astype(int)[::-1])
+        ends_free = occ[vox_of(starts[k])] < 100 and occ[vox_of(goals[k])] < 100
+        for si, (a, b) in enumerate(zip(p[:-1], p[1:])):
+            if not ends_free and si in (0, n[k] - 2):
+                continue  # a start / goal inside the inflation margin can only be left through it
+            m = int(np.ceil(np.linalg.norm(b - a) / 0.075)) + 1
+            pts = a + np.linspace(0, 1, m)[:, None] * (b - a)
+            v = np.floor((pts - origin) / 0.3).astype(int)
+            assert (occ[v[:, 2], v[:, 1], v[:, 0]] < 100).all(), k
+            assert (pts[:, 2] > 0).all() and (pts[:, 2] < 1.5 + 3.0 + 0.31).all()      # altitude band of the local grid
+    assert bent >= 16                                                 # the forest really is in the way
+    empty = swarm.SwarmShard(prm, cfg, 4, 0, starts[:4], goals[:4])
+    empty.set_world(np.zeros_like(occ), origin)
+    assert empty.route() == 0
+    paths, n = empty.get_paths()
+    assert (n == 2).all()
