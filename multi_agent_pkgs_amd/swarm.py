@@ -266,10 +266,15 @@ class SwarmLoop:
         if self.world > 1:
             per = (self.n_rob + self.world - 1) // self.world
             pad = per - self.n_local  # equal-size shards for the collective
-            pl = np.concatenate([plans_local, np.zeros((pad,) + plans_local.shape[1:])]) if pad else plans_local
+            pl = np.concatenate([plans_local, np.zeros((pad,) + plans_local.shape[1:])]) if pad else plans_local.copy()
             hl = np.concatenate([has_local, np.zeros(pad, np.uint8)]) if pad else has_local
-            self.plans_all = self.allgather(pl)[: self.n_rob]
-            self.has_plan = self.allgather(hl)[: self.n_rob]
+            # ONE collective per round: the has_plan flag travels inside the record (first entry NaN = no plan), exactly like
+            # hdsm_publish_device / hdsm_exchange_device do on the device
+            pl[hl == 0, 0, 0] = np.nan
+            full = self.allgather(pl)[: self.n_rob]
+            self.has_plan = (~np.isnan(full[:, 0, 0])).astype(np.uint8)
+            full[self.has_plan == 0, 0, 0] = 0.0
+            self.plans_all = full
         else:
             self.plans_all, self.has_plan = plans_local, has_local
         self.round_idx += 1
