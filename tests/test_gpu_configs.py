@@ -253,7 +253,7 @@ def test_voxel_decomposition_on_the_device_matches_the_host_bit_for_bit(hdsm):
             assert cells[t] == np.count_nonzero(gm == -1), (wname, t)
             aware_cnt += v
             chamfered += len(want) > 6
-        assert aware_cnt > 20 and chamfered > 200, (aware_cnt, chamfered)
+        assert aware_cnt > 20 and chamfered > 100, (aware_cnt, chamfered)
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corridor_cases.npz"))
     for k in range(z["grids"].shape[0]):
         for v, key in ((0, "octa3d"), (1, "octa3d_new")):
