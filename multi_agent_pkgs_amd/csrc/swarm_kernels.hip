@@ -129,13 +129,37 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       const bool bad = rv[h] && (((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]) - ra[h][3] > 0);
       viol[h] = __ballot(bad);
     }
-    bool inside_one = false;
+    int j_in = -1;
     for (int j = 0; j < n_poly; ++j)
       if (((viol[0] & pm[0][j]) | (viol[1] & pm[1][j])) == 0) {
-        inside_one = true;
+        j_in = j;
         break;
       }
-    if (inside_one) continue;
+    if (j_in >= 0) {
+      // The sample lies in polyhedron j_in. While the walk keeps its direction, every sample closer than the exit distance of the
+      // ray from that polyhedron is inside it too and the reference loop would just `continue`: those samples are generated
+      // (same statements, same rounding) without being tested. The exit distance is a min over the rows held by the lanes; three
+      // samples of margin cover the rounding of the accumulated positions.
+      if (dist_next > samp) {
+        double t_exit = DBL_MAX;
+        for (int h = 0; h < 2; ++h)
+          if (rv[h] && ((pm[h][j_in] >> lane) & 1ull)) {
+            const double rate = ((ra[h][0] * diff[0] + ra[h][1] * diff[1]) + ra[h][2] * diff[2]) / dist_next;
+            const double slack = ra[h][3] - ((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]);
+            if (rate > 0) t_exit = fmin(t_exit, slack / rate);
+          }
+        for (int off = 32; off > 0; off >>= 1) t_exit = fmin(t_exit, __shfl_xor(t_exit, off));
+        const double cap = t_exit / samp - 3.0;
+        int n_safe = cap > 1e6 ? 1000000 : (cap > 0 ? (int)cap : 0);
+        for (; n_safe > 0; --n_safe) {
+          const V3 df = sub(next, curr);
+          const double dn = norm(df);
+          if (!(dn > samp)) break;  // the end of the segment: the regular loop takes over
+          curr = axpy(curr, samp / dn, df);
+        }
+      }
+      continue;
+    }
     V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
     if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
     int seed[3];
