@@ -40,6 +40,8 @@ CD_HD V3 axpy(const V3& a, double s, const V3& b) { return {{a[0] + s * b[0], a[
 CD_HD double dot(const V3& a, const V3& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 CD_HD double norm(const V3& a) { return sqrt(dot(a, a)); }
 
+constexpr double kWalkTol = 1e-6;  // slack every sample skipped by the walk's shortcut keeps in every row (corridor_step)
+
 struct Poly {  // LinearConstraint3D: rows A x <= b
   int32_t rows;
   int32_t pad;
@@ -71,7 +73,8 @@ struct AgentS {
 };
 
 struct Cfg {                    // what the functions below read of hdsm_params / hdsm_swarm_config / the world
-  int32_t N, P, RS, step_plan, n_it_decomp, use_cvx_new, has_world, pad;
+  int32_t N, P, RS, step_plan, n_it_decomp, use_cvx_new, has_world;
+  int32_t fast_walk;            // device corridor walk: skip the tests of samples provably inside (HDSM_FAST_WALK, default 1)
   double voxel_size, grid_range[3], grid_z_min, thresh_dist;
   const int8_t* world;          // [wz][wy][wx] or null
   int32_t wdim[3], pad2;
@@ -232,13 +235,33 @@ CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
       curr = next;
       if (++path_idx == n_path) break;
     }
-    bool inside_one = false;
+    int j_in = -1;
     for (int i = 0; i < n_poly; ++i)
       if (inside(fresh[i], curr)) {
-        inside_one = true;
+        j_in = i;
         break;
       }
-    if (inside_one) continue;
+    if (j_in >= 0) {
+      if (c.fast_walk && dist_next > samp) {  // (scalar twin of the device walk's shortcut, see swarm_kernels.hip; for tests)
+        double t_exit = DBL_MAX;
+        const Poly& pj = fresh[j_in];
+        for (int r = 0; r < pj.rows; ++r) {
+          const double rate = ((pj.A[r][0] * diff[0] + pj.A[r][1] * diff[1]) + pj.A[r][2] * diff[2]) / dist_next;
+          const double slack = pj.b[r] - ((pj.A[r][0] * curr[0] + pj.A[r][1] * curr[1]) + pj.A[r][2] * curr[2]);
+          if (!(slack > kWalkTol)) t_exit = 0;
+          else if (rate > 0) t_exit = fmin(t_exit, (slack - kWalkTol) / rate);
+        }
+        const double cap = t_exit / samp - 3.0;
+        int n_safe = cap > 1e6 ? 1000000 : (cap > 0 ? (int)cap : 0);
+        for (; n_safe > 0; --n_safe) {
+          const V3 df = sub(next, curr);
+          const double dn = norm(df);
+          if (!(dn > samp)) break;
+          curr = axpy(curr, samp / dn, df);
+        }
+      }
+      continue;
+    }
     V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
     if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
     int seed[3];

@@ -4,6 +4,7 @@
 #include <array>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -51,6 +52,8 @@ struct Swarm {
     c.voxel_size = cfg.voxel_size, c.grid_z_min = cfg.grid_z_min, c.thresh_dist = cfg.thresh_dist;
     for (int k = 0; k < 3; ++k) c.grid_range[k] = cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
     c.world = has_world ? world.data() : nullptr;
+    c.fast_walk = 0;
+    if (const char* e = std::getenv("HDSM_FAST_WALK_HOST")) c.fast_walk = std::atoi(e) != 0;  // test hook: scalar twin of the device shortcut
     return c;
   }
   // optional occupancy of the world (hdsm_swarm_set_world): voxels of cfg.voxel_size, >= 100 occupied

@@ -11,6 +11,7 @@
 // tests/test_gpu_configs.py. AC = multi_agent_planner/src/agent_class.cpp of the reference.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <new>
 #include <string>
 
@@ -140,13 +141,17 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       // ray from that polyhedron is inside it too and the reference loop would just `continue`: those samples are generated
       // (same statements, same rounding) without being tested. The exit distance is a min over the rows held by the lanes; three
       // samples of margin cover the rounding of the accumulated positions.
-      if (dist_next > samp) {
+      if (c.fast_walk && dist_next > samp) {
         double t_exit = DBL_MAX;
         for (int h = 0; h < 2; ++h)
           if (rv[h] && ((pm[h][j_in] >> lane) & 1ull)) {
             const double rate = ((ra[h][0] * diff[0] + ra[h][1] * diff[1]) + ra[h][2] * diff[2]) / dist_next;
             const double slack = ra[h][3] - ((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]);
-            if (rate > 0) t_exit = fmin(t_exit, slack / rate);
+            // every skipped sample keeps a slack >= kWalkTol in every row, far above the rounding of A x - b: a path
+            // that slides along a face (slack ~ 0, rate ~ 0) is left to the regular loop, whose outcome there depends
+            // on the last bit exactly as the reference's does
+            if (!(slack > kWalkTol)) t_exit = 0;
+            else if (rate > 0) t_exit = fmin(t_exit, (slack - kWalkTol) / rate);
           }
         for (int off = 32; off > 0; off >>= 1) t_exit = fmin(t_exit, __shfl_xor(t_exit, off));
         const double cap = t_exit / samp - 3.0;
@@ -379,6 +384,8 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
   c.N = d->prm.n_hor, c.P = d->prm.poly_hor, c.RS = d->prm.max_rows_static, c.step_plan = d->cfg.step_plan;
   c.n_it_decomp = d->cfg.n_it_decomp, c.use_cvx_new = d->cfg.use_cvx_new, c.has_world = hworld ? 1 : 0;
   c.voxel_size = d->cfg.voxel_size, c.grid_z_min = d->cfg.grid_z_min, c.thresh_dist = d->cfg.thresh_dist;
+  c.fast_walk = 1;
+  if (const char* e = std::getenv("HDSM_FAST_WALK")) c.fast_walk = std::atoi(e) != 0;
   for (int k = 0; k < 3; ++k) c.grid_range[k] = d->cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
   if (hipSetDevice(device) != hipSuccess) {
     delete d;

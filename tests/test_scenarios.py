@@ -109,3 +109,35 @@ def test_router_gives_collision_free_bounded_polylines():
     assert empty.route() == 0
     paths, n = empty.get_paths()
     assert (n == 2).all()
+
+
+def test_walk_shortcut_leaves_the_corridor_unchanged(oracle, monkeypatch):
+    """The device corridor walk skips the inside tests of samples that provably stay inside a kept polyhedron
+    (swarm_kernels.hip corridor_step_wave); swarm_core.h carries a scalar twin of that shortcut behind
+    HDSM_FAST_WALK_HOST. In a forest the path slides along polyhedron faces (slack ~ 0, rate ~ 0), where the reference's
+    sample-by-sample outcome depends on the last bit: the shortcut must leave those to the regular loop. Flown twice,
+    the corridor inputs of every round are bit-identical."""
+    from oracle import pyoracle as orc
+    n, rounds = 48, 18
+    prm = agile_params(10, max_rows_static=18)
+    raw, org = sc.forest_for_circle(n, seed=21)
+    occ = sc.inflate(raw)
+
+    def cpu(inp, plans, has):
+        return orc.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    def fly(mode):
+        monkeypatch.setenv("HDSM_FAST_WALK_HOST", mode)
+        loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), n, solve=cpu)
+        loop.set_world(occ, org)
+        out = []
+        for _ in range(rounds):
+            rec = []
+            loop.step(record=rec)
+            out.append({k: rec[0][k].copy() for k in ("n_poly", "n_rows", "A", "b")})
+        return out
+
+    plain, fast = fly("0"), fly("1")
+    for r in range(rounds):
+        for k in plain[r]:
+            assert np.array_equal(plain[r][k], fast[r][k]), (r, k)
