@@ -3,6 +3,8 @@
 // One workgroup solves one agent-replan (hdsm_core.h); the launch is a plain 1-D grid of n_inst blocks.
 // There is no CPU path in this library: without a HIP device hdsm_create() fails.
 #include <hip/hip_runtime.h>
+
+#include <cfloat>
 #include <rccl/rccl.h>
 
 #include <climits>
@@ -217,19 +219,90 @@ struct RefArgs {
   double* ref_full;
   double* ref;
   double* path_vel;
+  const double* rpos;  // [n_rob][N + 1][3] positions of steps 0..N, packed (k_ref_pack)
+  const double* rsph;  // [n_rob][4] enclosing sphere of those positions (radius < 0: no plan)
 };
+
+// Positions of steps 0..N of every published plan, packed, and their enclosing sphere: 16 lanes per agent (N + 1 <= 17: lane
+// 15 also takes step 16). The velocity limit reads 24 B per (neighbour, step) from here instead of a 72-B stride of the
+// records, and skips a neighbour whose sphere is further away than the closest one found.
+__global__ __launch_bounds__(256) void k_ref_pack(int N, int n_rob, const double* __restrict__ plans,
+                                                   const uint8_t* __restrict__ has_plan, double* __restrict__ rpos,
+                                                   double* __restrict__ rsph) {
+  const int tid = (int)threadIdx.x, i = tid & 15;
+  const int k = (int)blockIdx.x * 16 + (tid >> 4);
+  const bool live = k < n_rob;
+  const bool has = live && has_plan[k];
+  double p[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  bool on[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int st = i + 16 * u;
+    on[u] = has && st <= N && (u == 0 || i == 0);
+    if (on[u]) {
+      const double* rec = plans + ((int64_t)k * (N + 1) + st) * 9;
+      p[u][0] = rec[0], p[u][1] = rec[1], p[u][2] = rec[2];
+    }
+    if (live && st <= N && (u == 0 || i == 0)) {
+      double* pk = rpos + ((int64_t)k * (N + 1) + st) * 3;
+      pk[0] = p[u][0], pk[1] = p[u][1], pk[2] = p[u][2];
+    }
+  }
+  double lo[3], hi[3];
+  for (int ax = 0; ax < 3; ++ax) {
+    lo[ax] = on[0] ? p[0][ax] : 1e300, hi[ax] = on[0] ? p[0][ax] : -1e300;
+    if (on[1]) lo[ax] = fmin(lo[ax], p[1][ax]), hi[ax] = fmax(hi[ax], p[1][ax]);
+  }
+  for (int off = 8; off > 0; off >>= 1)
+    for (int ax = 0; ax < 3; ++ax) {
+      lo[ax] = fmin(lo[ax], __shfl_xor(lo[ax], off, 16));
+      hi[ax] = fmax(hi[ax], __shfl_xor(hi[ax], off, 16));
+    }
+  const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+  double r2 = 0.0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (on[u]) {
+      const double ux = p[u][0] - cx, uy = p[u][1] - cy, uz = p[u][2] - cz;
+      r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
+    }
+  bool finite = r2 == r2;
+  for (int off = 8; off > 0; off >>= 1) {
+    r2 = fmax(r2, __shfl_xor(r2, off, 16));
+    finite = finite && __shfl_xor((int)finite, off, 16);
+  }
+  if (live && i == 0) {
+    double4 out = {0.0, 0.0, 0.0, -1.0};
+    if (has) {
+      out.x = cx, out.y = cy, out.z = cz;
+      out.w = sqrt(r2) * (1.0 + 1e-9);
+      if (!finite || !(out.w >= 0.0) || !(out.w < 1e299)) out.w = 1e300;  // a non-finite plan is never skipped
+    }
+    *reinterpret_cast<double4*>(rsph + (int64_t)k * 4) = out;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
   __shared__ double own[hdsm::MAXH + 1][3];
   __shared__ double wocc[hdsm::MAXH + 1];
   __shared__ double red[256];
+  __shared__ double d2w[4][hdsm::MAXH + 1];
+  __shared__ int idx[256];
+  constexpr int PATH_LDS = 64;
+  __shared__ double spath[PATH_LDS * 3];
   __shared__ double pts[hdsm::MAXH + 1][3];
   __shared__ int cnt_s;
   const int inst = blockIdx.x, tid = threadIdx.x, N = a.N;
   const int self = a.agent_id[inst];
   const int np = a.n_path[inst];
   const bool own_has = self >= 0 && self < a.n_rob && a.has_plan[self];
-  const double* pth = a.path + (int64_t)inst * a.pmax * 3;
+  // the polyline goes through LDS: the sampling walk below is one thread's chain, and every global read in it was a
+  // dependent round trip
+  const double* pth_g = a.path + (int64_t)inst * a.pmax * 3;
+  const bool path_fits = np <= PATH_LDS;
+  if (path_fits)
+    for (int e = tid; e < np * 3; e += 256) spath[e] = pth_g[e];
+  const double* pth = path_fits ? spath : pth_g;
   if (tid <= N) {
     for (int c = 0; c < 3; ++c) own[tid][c] = own_has ? a.plans[((int64_t)self * (N + 1) + tid) * 9 + c] : 0.0;
     double occ = 100 * pow(a.cfg.sens_other_agents, (double)tid);  // AC:1791-1795
@@ -239,7 +312,83 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
   __syncthreads();
   double pv = a.vel_cap ? a.vel_cap[inst] : a.cfg.path_vel_max;
   if (pv > a.cfg.path_vel_max) pv = a.cfg.path_vel_max;
-  if (own_has && np >= 2) {
+  // The limit of one (neighbour, step) pair, v = v_min + (v_max - v_min) (1 - w_i / exp(k d)), does not decrease with the
+  // distance d (k >= 0, w_i >= 0, v_max >= v_min; every operation of the chain is monotone), so the minimum over the
+  // neighbours is taken on the SQUARED distances — three subtractions and three multiply-adds per pair — and the square root,
+  // the exponential and the division are evaluated once per step on the closest neighbour instead of once per pair.
+  const bool monotone = a.cfg.sens_dist >= 0 && a.cfg.path_vel_max >= a.cfg.path_vel_min;
+  if (own_has && np >= 2 && monotone) {
+    // (1) the neighbour whose sphere is closest: its exact squared distances bound the minima from above
+    const double4 ss = *reinterpret_cast<const double4*>(a.rsph + (int64_t)self * 4);
+    double gbest = DBL_MAX;
+    int jbest = -1;
+    for (int j = tid; j < a.n_rob; j += 256) {
+      if (j == self) continue;
+      const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
+      if (sj.w < 0) continue;  // no plan
+      const double cx = sj.x - ss.x, cy = sj.y - ss.y, cz = sj.z - ss.z;
+      const double g = sqrt(cx * cx + cy * cy + cz * cz) - sj.w - ss.w;  // every step of j is at least this far (g may be < 0)
+      if (g < gbest || jbest < 0) gbest = g, jbest = j;
+    }
+    red[tid] = gbest;
+    idx[tid] = jbest;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (tid < off && idx[tid + off] >= 0 && (idx[tid] < 0 || red[tid + off] < red[tid])) red[tid] = red[tid + off], idx[tid] = idx[tid + off];
+      __syncthreads();
+    }
+    const int jstar = idx[0];
+    __syncthreads();
+    if (tid <= N) {
+      double u = 0.0;
+      if (jstar >= 0) {
+        const double* rp = a.rpos + ((int64_t)jstar * (N + 1) + tid) * 3;
+        const double dx = own[tid][0] - rp[0], dy = own[tid][1] - rp[1], dz = own[tid][2] - rp[2];
+        u = dx * dx + dy * dy + dz * dz;
+      }
+      red[tid] = (u == u) ? u : DBL_MAX;  // (a non-finite plan bounds nothing)
+    }
+    __syncthreads();
+    double umax = 0.0;
+    for (int i = 0; i <= N; ++i) umax = fmax(umax, red[i]);
+    __syncthreads();
+    // (2) minima of the squared distances over the neighbours that can still lower one of them
+    double d2min[hdsm::MAXH + 1];
+#pragma unroll
+    for (int i = 0; i <= hdsm::MAXH; ++i) d2min[i] = DBL_MAX;
+    for (int j = tid; j < a.n_rob; j += 256) {
+      if (j == self) continue;
+      const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
+      if (sj.w < 0) continue;
+      const double cx = sj.x - ss.x, cy = sj.y - ss.y, cz = sj.z - ss.z;
+      const double g = sqrt(cx * cx + cy * cy + cz * cz) - sj.w - ss.w;
+      if (g > 0 && g * g * (1.0 - 1e-9) > umax) continue;  // all its steps are further than the closest neighbour's
+      const double* rp = a.rpos + (int64_t)j * (N + 1) * 3;
+#pragma unroll
+      for (int i = 0; i <= hdsm::MAXH; ++i)
+        if (i <= N) {
+          const double dx = own[i][0] - rp[3 * i], dy = own[i][1] - rp[3 * i + 1], dz = own[i][2] - rp[3 * i + 2];
+          d2min[i] = fmin(d2min[i], dx * dx + dy * dy + dz * dz);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i <= hdsm::MAXH; ++i)
+      if (i <= N) {
+        double m = d2min[i];
+        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+        if ((tid & 63) == 0) d2w[tid >> 6][i] = m;
+      }
+    __syncthreads();
+    if (tid <= N) {
+      const double m = fmin(fmin(d2w[0][tid], d2w[1][tid]), fmin(d2w[2][tid], d2w[3][tid]));
+      if (m < DBL_MAX) {
+        const double d = sqrt(m);
+        const double alpha = (1 - wocc[tid] * (1 / exp(a.cfg.sens_dist * d)));
+        const double v = a.cfg.path_vel_min + (a.cfg.path_vel_max - a.cfg.path_vel_min) * alpha;
+        if (v < pv) pv = v;
+      }
+    }
+  } else if (own_has && np >= 2) {  // (a configuration whose limit is not monotone in the distance: every pair is evaluated)
     for (int j = tid; j < a.n_rob; j += 256) {
       if (j == self || !a.has_plan[j]) continue;
       const double* rec = a.plans + (int64_t)j * (N + 1) * 9;
@@ -324,6 +473,8 @@ struct Handle {
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   double* d_bounds = nullptr; // [n_rob_max][4]
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
+  double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
+  double* d_rsph = nullptr;   // [n_rob_max][4] their spheres
   int32_t* d_order = nullptr; // [max_inst] launch order (k_launch_order)
   int order_min = 0;          // batches of at least this many instances are launched most-expensive-first (0 = never)
   uint8_t* d_zero = nullptr;  // n_rob_max zero bytes (has_plan of level 1)
@@ -449,7 +600,7 @@ int64_t scratch_stride_for(int n) {
 void free_all(Handle* h) {
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
-                  h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
+                  h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_rpos,  h->d_rsph,  h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
                   h->b_ncommon.p, h->b_path.p, h->b_cap.p, h->b_full.p, h->b_pv.p, h->b_np.p};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -560,7 +711,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
   ok(dmalloc(&h->d_stats, 7 * I));
   ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
-#ifdef HDSM_PROFILE
+#if defined(HDSM_PROFILE) || defined(HDSM_TIMELINE)
   ok(dmalloc(&h->d_prof, 32 * I));
 #endif
   ok(dmalloc(&h->d_agent, I));
@@ -574,6 +725,8 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_plans, (size_t)n_rob_max * (N + 1) * 9));
   ok(dmalloc(&h->d_bounds, (size_t)n_rob_max * 4));
   ok(dmalloc(&h->d_pos, (size_t)n_rob_max * N * 3));
+  ok(dmalloc(&h->d_rpos, (size_t)n_rob_max * (N + 1) * 3));
+  ok(dmalloc(&h->d_rsph, (size_t)n_rob_max * 4));
   ok(dmalloc(&h->d_zero, (size_t)n_rob_max));
   ok(dmalloc(&h->d_order, I));
   ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
@@ -721,6 +874,9 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   a.n_inst = n_inst, a.n_rob = n_rob, a.pmax = pmax, a.N = h->N, a.dt = h->prm.dt, a.cfg = *cfg;
   a.agent_id = agent_id, a.path = path, a.n_path = n_path, a.vel_cap = vel_cap, a.plans = plans_all;
   a.has_plan = has_plan, a.ref_full = ref_full, a.ref = ref, a.path_vel = path_vel;
+  a.rpos = h->d_rpos, a.rsph = h->d_rsph;
+  hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(hip_stream), h->N, n_rob, plans_all,
+                     has_plan, h->d_rpos, h->d_rsph);
   hipLaunchKernelGGL(k_reference, dim3(n_inst), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
@@ -786,6 +942,31 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
   if (int rc = check_common(h, n_inst, 0)) return rc;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->last_stream));
+#ifdef HDSM_TIMELINE
+  {  // development aid: the launch seen from the instances (100 MHz clock): span, the slowest instance, late starters
+    std::vector<long long> pr((size_t)n_inst * 32);
+    HIP_TRY(hipMemcpy(pr.data(), h->d_prof, pr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = pr[0], t1 = pr[1];
+    int worst = 0, last = 0;
+    double busy = 0;
+    for (int k = 0; k < n_inst; ++k) {
+      const long long b = pr[(size_t)k * 32], e = pr[(size_t)k * 32 + 1];
+      if (b < t0) t0 = b;
+      if (e > t1) t1 = e, last = k;
+      if (e - b > pr[(size_t)worst * 32 + 1] - pr[(size_t)worst * 32]) worst = k;
+      busy += (double)(e - b);
+    }
+    int late = 0;
+    for (int k = 0; k < n_inst; ++k) late += pr[(size_t)k * 32] - t0 > 200;  // started more than 2 us after the first
+    auto us = [](long long ticks) { return (double)ticks * 0.01; };
+    const long long *w = &pr[(size_t)worst * 32], *l = &pr[(size_t)last * 32];
+    std::fprintf(stderr,
+                 "HDSM_TIMELINE span %.2f us | slowest inst %d: %.2f us, start +%.2f, block %lld, iters %lld | last to finish inst %d: "
+                 "start +%.2f dur %.2f block %lld iters %lld | %d of %d started > 2 us late | sum of instance times %.1f us (%.2f per span-slot of 512)\n",
+                 us(t1 - t0), worst, us(w[1] - w[0]), us(w[0] - t0), w[2], w[4], last, us(l[0] - t0), us(l[1] - l[0]), l[2], l[4], late,
+                 n_inst, us((long long)busy), busy / (double)(t1 - t0) / 512.0);
+  }
+#endif
 #ifdef HDSM_PROFILE
   {  // development aid: phase cycle counters of the slowest instance and the batch mean
     std::vector<long long> pr((size_t)n_inst * 32);

@@ -612,6 +612,9 @@ struct Solver {
     const int self = a.agent_id[inst];
     double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
 
+#if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)
+    const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock, common to all CUs
+#endif
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
@@ -1131,6 +1134,14 @@ struct Solver {
       const int cnt = s.have_inc ? s.inc_nact : (certificate ? s.q + 1 : 0);
       PAR_FOR(k, NV) if (k < cnt) wp[1 + k] = s.inc_act[k];
       if (IS_T0) wp[0] = cnt;
+    }
+#endif
+#if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)
+    if (IS_T0 && a.prof) {  // development aid (scripts/gpu_timeline.sh): when and where this instance ran
+      long long* pr = a.prof + (int64_t)inst * 32;
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw, pr[4] = iters;
     }
 #endif
     if (IS_T0) {

@@ -289,10 +289,43 @@ __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* ag
   __syncthreads();
   if (k < n) {
     AgentS& ag = agents[k];
-    if (lane == 0) {
-      hdsm_sw::commit_copy(c, ag, traj + (size_t)k * rec, ctrl + (size_t)k * N * 3, used + (size_t)k * c.P, status[k]);
-      if (status[k] == HDSM_NO_SOLUTION) atomicAdd(fails, 1);
-      have_s = ag.has_traj;
+    {  // hdsm_sw::commit_copy with the copies spread over the lanes (one lane doing them was a chain of ~130 dependent
+       // global accesses, 35 of the kernel's 40 us): flat element e of traj_curr[][9] / ctrl_curr[][3]
+      const int st = status[k];
+      double* tc = &ag.traj_curr[0][0];
+      double* cc = &ag.ctrl_curr[0][0];
+      if (st != HDSM_NO_SOLUTION) {  // AC:960-987
+        const double* tin = traj + (size_t)k * rec;
+        const double* cin = ctrl + (size_t)k * N * 3;
+        for (int e = lane; e < rec; e += 64) tc[e] = tin[e];
+        for (int e = lane; e < N * 3; e += 64) cc[e] = cin[e];
+        if (lane < c.P) ag.poly_used[lane] = used[(size_t)k * c.P + lane];
+        if (lane == 0) ag.has_traj = 1, have_s = 1;
+      } else {  // AC:1000-1019: every lane reads what it moves before anybody writes
+        constexpr int PER = (hdsm::MAXH * 9 + 63) / 64;
+        const bool shift = ag.has_traj != 0;
+        double tv[PER], cv[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int e = lane + 64 * u;
+          tv[u] = (shift && e < N * 9) ? tc[e + 9] : 0.0;
+          cv[u] = (shift && e < (N - 1) * 3) ? cc[e + 3] : 0.0;
+        }
+        __syncthreads();
+        if (shift) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) {
+            const int e = lane + 64 * u;
+            if (e < N * 9) tc[e] = tv[u];
+            if (e < (N - 1) * 3) cc[e] = cv[u];
+          }
+        }
+        if (lane == 0) {
+          ++ag.n_fail;
+          atomicAdd(fails, 1);
+          have_s = shift ? 1 : 0;
+        }
+      }
     }
     __syncthreads();
     if (have_s) {

@@ -245,10 +245,18 @@ def test_reference_kernel_matches_oracle(hdsm, oracle):
     """Row f1 on the device vs its oracle: exp/pow differ from glibc by an ulp or two -> 1e-10 relative."""
     from multi_agent_pkgs_amd.params import agile_ref_config
     rng = np.random.default_rng(5)
-    for n_hor, n_rob, sens_other in [(10, 64, 1.0), (15, 200, 0.8), (7, 9, 1.0)]:
+    # (16, ...): the last step of the longest horizon (second slot of lane 0 in k_ref_pack); 1500 agents in two far clusters:
+    # the sphere cull of the velocity limit skips most neighbours; sens_dist < 0: the limit is not monotone in the distance
+    # and every pair is evaluated
+    for n_hor, n_rob, sens_other, sens_dist in [(10, 64, 1.0, None), (15, 200, 0.8, None), (7, 9, 1.0, None), (16, 300, 0.9, None),
+                                                (10, 1500, 1.0, None), (10, 130, 1.0, -0.2)]:
         prm = agile_params(n_hor, max_rows_static=18)
-        rcfg = agile_ref_config(sens_other_agents=sens_other, path_vel_dec=0.5 if n_hor == 7 else 0.0)
+        kw = {} if sens_dist is None else {"sens_dist": sens_dist}
+        rcfg = agile_ref_config(sens_other_agents=sens_other, path_vel_dec=0.5 if n_hor == 7 else 0.0, **kw)
         sn = problems.swarm_snapshot(prm, n_rob, seed=70 + n_hor, spacing=1.5)
+        if n_rob == 1500:  # second cluster 400 m away
+            sn["plans"][750:, :, 0] += 400.0
+            sn["state"][750:, 0] += 400.0
         sn["has_plan"][rng.random(n_rob) < 0.1] = 0
         path = np.zeros((n_rob, 3, 3))
         n_path = np.full(n_rob, 3, np.int32)
