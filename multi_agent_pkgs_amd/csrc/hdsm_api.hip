@@ -68,14 +68,14 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
 //   bounds[n_rob][4]   (only for swarms of at least bounds_min agents) centre of the bounding box of those positions and the
 //                      radius of the sphere around it that holds them (radius -1 = no plan): the sweeps use it to skip
 //                      whole neighbours (hdsm_wave_gi.h, sweep_planes).
-__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order);
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order);
 
 __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
                                                       const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
-                                                      double* __restrict__ bounds, int n_order, const int32_t* __restrict__ iters_prev,
+                                                      double* __restrict__ bounds, int n_order, const int32_t* __restrict__ key_prev,
                                                       int32_t* __restrict__ order) {
   if (order != nullptr && blockIdx.x == gridDim.x - 1) {  // one extra workgroup: the launch order of the solve that follows
-    launch_order_block(n_order, iters_prev, order);
+    launch_order_block(n_order, key_prev, order);
     return;
   }
   // 16 lanes per agent (N <= 16 = HDSM_MAX_HOR): lane i copies the position of step i + 1, the box / sphere reductions run
@@ -123,16 +123,17 @@ __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const do
 
 // Longest-processing-time-first launch order. A launch lasts as long as its slowest workgroup chain: with more instances than
 // resident workgroups (2 per CU) an expensive instance that happens to start late sets the kernel time. Workgroups are
-// dispatched in index order, so workgroup w takes instance order[w], the instances sorted by the active-set operations they
-// needed in the PREVIOUS launch on this handle (most first; a counting sort on min(iters, 255)). The previous replan of the
-// same agent is a good predictor (gridlocked neighbourhoods persist); the answer of an instance does not depend on the order.
-__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
+// dispatched in index order, so workgroup w takes instance order[w], the instances sorted by the key they left in the
+// PREVIOUS launch on this handle (largest first; a counting sort on 256 values): the time the instance took, or the maximum if it
+// found no solution (hdsm_core.h, st_key). The previous replan of the same agent is a good predictor (gridlocked neighbourhoods
+// persist); the answer of an instance does not depend on the order.
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order) {
   __shared__ int bucket[256];
   const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
   for (int b = tid; b < 256; b += nt) bucket[b] = 0;
   __syncthreads();
   for (int k = tid; k < n_inst; k += nt) {
-    const int it = iters_prev[k];
+    const int it = key_prev[k];
     atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1);
   }
   __syncthreads();
@@ -146,12 +147,12 @@ __device__ void launch_order_block(int n_inst, const int32_t* __restrict__ iters
   }
   __syncthreads();
   for (int k = tid; k < n_inst; k += nt) {
-    const int it = iters_prev[k];
+    const int it = key_prev[k];
     order[atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1)] = k;
   }
 }
-__global__ __launch_bounds__(256) void k_launch_order(int n_inst, const int32_t* __restrict__ iters_prev, int32_t* __restrict__ order) {
-  launch_order_block(n_inst, iters_prev, order);  // level 1 has no pre-pass to ride on
+__global__ __launch_bounds__(256) void k_launch_order(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order) {
+  launch_order_block(n_inst, key_prev, order);  // level 1 has no pre-pass to ride on
 }
 
 // hdsm_publish_device / hdsm_exchange_device: the has_plan flag travels inside the record (first entry NaN = no plan)
@@ -488,7 +489,7 @@ struct Handle {
   hdsm::Consts* d_consts = nullptr;
   double* d_scratch = nullptr;
   int64_t scratch_stride = 0;
-  int32_t* d_stats = nullptr;  // 7 * max_inst: iterations, nodes, sweeps, staged rows, sphere records, pairs, flags
+  int32_t* d_stats = nullptr;  // 8 * max_inst: iterations, nodes, sweeps, staged rows, sphere records, pairs, flags, launch-order key
   long long* d_prof = nullptr; // 24 * max_inst (HDSM_PROFILE builds)
   int32_t* d_warm = nullptr;   // (MAXNV + 2) * max_inst: previous optimal working sets (params.warm_start)
   // staging for the host-pointer entry points
@@ -543,6 +544,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.st_sph = h->d_stats + 4 * h->max_inst;
   a.st_pairs = h->d_stats + 5 * h->max_inst;
   a.st_flags = reinterpret_cast<uint32_t*>(h->d_stats + 6 * h->max_inst);
+  a.st_key = h->d_stats + 7 * h->max_inst;
   a.prof = h->d_prof;
   a.warm = (h->prm.warm_start && a.l1_rows == nullptr) ? h->d_warm : nullptr;
   // the handle's device state (snapshots, warm-start sets, prefilter records) is shared by all launches: a launch that
@@ -555,12 +557,12 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
     hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
-                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, h->d_stats, ordered ? h->d_order : nullptr);
+                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, ordered ? h->d_order : nullptr);
     HIP_TRY(hipGetLastError());
     a.pos = h->d_pos;
     a.bounds = pre ? h->d_bounds : nullptr;
   } else if (ordered) {
-    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(256), 0, st, a.n_inst, h->d_stats, h->d_order);
+    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(256), 0, st, a.n_inst, a.st_key, h->d_order);
     HIP_TRY(hipGetLastError());
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
@@ -709,7 +711,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   };
   ok(dmalloc(&h->d_consts, 1));
   ok(dmalloc(&h->d_scratch, I * (size_t)h->scratch_stride));
-  ok(dmalloc(&h->d_stats, 7 * I));
+  ok(dmalloc(&h->d_stats, 8 * I));
   ok(dmalloc(&h->d_warm, (hdsm::MAXNV + 2) * I));
 #if defined(HDSM_PROFILE) || defined(HDSM_TIMELINE)
   ok(dmalloc(&h->d_prof, 32 * I));
@@ -737,7 +739,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 7 * I * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * I * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(h->d_zero, 0, (size_t)n_rob_max);
   if (e == hipSuccess) e = hipMemset(h->d_plans, 0, (size_t)n_rob_max * (N + 1) * 9 * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_warm, 0, (hdsm::MAXNV + 2) * I * sizeof(int32_t));
@@ -961,9 +963,9 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
     auto us = [](long long ticks) { return (double)ticks * 0.01; };
     const long long *w = &pr[(size_t)worst * 32], *l = &pr[(size_t)last * 32];
     std::fprintf(stderr,
-                 "HDSM_TIMELINE span %.2f us | slowest inst %d: %.2f us, start +%.2f, block %lld, iters %lld | last to finish inst %d: "
+                 "HDSM_TIMELINE span %.2f us | slowest inst %d: %.2f us, start +%.2f, block %lld, iters %lld nodes %lld sweeps %lld staged %lld+%lld flags %lld status %lld | last to finish inst %d: "
                  "start +%.2f dur %.2f block %lld iters %lld | %d of %d started > 2 us late | sum of instance times %.1f us (%.2f per span-slot of 512)\n",
-                 us(t1 - t0), worst, us(w[1] - w[0]), us(w[0] - t0), w[2], w[4], last, us(l[0] - t0), us(l[1] - l[0]), l[2], l[4], late,
+                 us(t1 - t0), worst, us(w[1] - w[0]), us(w[0] - t0), w[2], w[4], w[5], w[6], w[7], w[9], w[8], w[10], last, us(l[0] - t0), us(l[1] - l[0]), l[2], l[4], late,
                  n_inst, us((long long)busy), busy / (double)(t1 - t0) / 512.0);
   }
 #endif

@@ -59,6 +59,7 @@ __device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); 
 namespace hdsm {
 
 enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
+constexpr int WARM_CERT = 1 << 30;  // bit of the stored working-set size: the set is an infeasibility certificate
 enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
 enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
 
@@ -612,8 +613,8 @@ struct Solver {
     const int self = a.agent_id[inst];
     double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
 
-#if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)
-    const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock, common to all CUs
+#ifndef HDSM_EMU
+    const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
 #endif
 #if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
     const long long t_begin_ = clock64();
@@ -882,7 +883,12 @@ struct Solver {
 #ifdef HDSM_PROFILE
     const long long tw_ = clock64();
 #endif
+    // the guess is an infeasibility certificate (see the hand-over below): its minimiser is a far-away point, staging the
+    // neighbour rows around it means thousands of rows and a retry per radius — the automatic pre-sweep is left out, and a
+    // certificate that still holds ends the instance after a few operations without any sweep
+    bool warm_cert = false;
     if (a.warm != nullptr && np > 0) {
+      warm_cert = (a.warm[(int64_t)inst * (MAXNV + 2)] & WARM_CERT) != 0;
       if (threadIdx.x < 64) {
         W::warm_start(s, c, a, R, inst, self, iters);
         if (threadIdx.x == 0) s.iters_sh = iters;
@@ -951,8 +957,12 @@ struct Solver {
         ++sweeps;
         if (!s.overflow || thresh <= -c.tol) break;
         SYNC();
+        const int wanted = (s.ncand - before) + (s.ncold - before_cold);  // rows that asked for a slot (counted past the capacity)
+        SYNC();
         if (IS_T0) s.ncand = before, s.ncold = before_cold, s.overflow = 0;
-        thresh = (thresh > 0.02) ? 0.25 * thresh : -c.tol;
+        // far more rows than slots (a start point in the middle of a gridlock: thousands of rows): a quarter of the radius
+        // would overflow again, and every retry is a full sweep — stage the violated rows only
+        thresh = (thresh > 0.02 && wanted <= 4 * CMAX) ? 0.25 * thresh : -c.tol;
       }
       if (thresh > 0 && !s.overflow) {  // a staging sweep went through: remember where, and with what radius
         SYNC();
@@ -961,7 +971,10 @@ struct Solver {
         SYNC();
       }
     };
-    if (run && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
+#ifdef HDSM_EMU
+    const bool warm_cert = false;
+#endif
+    if (run && (c.presweep == 1 || (c.presweep == 2 && !warm_cert && (a.bounds == nullptr || s.ncand > 0)))) {
       // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
       // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
       // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
@@ -975,6 +988,7 @@ struct Solver {
       if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
     }
     int last_rc = GI_OK;
+    (void)last_rc;  // (read by the warm-start hand-over of the device build only)
     while (run) {
       const int rc = gi_run(s, c, R, cutoff(s, c), iters);
       last_rc = rc;
@@ -1133,7 +1147,7 @@ struct Solver {
       }
       const int cnt = s.have_inc ? s.inc_nact : (certificate ? s.q + 1 : 0);
       PAR_FOR(k, NV) if (k < cnt) wp[1 + k] = s.inc_act[k];
-      if (IS_T0) wp[0] = cnt;
+      if (IS_T0) wp[0] = cnt | (certificate ? WARM_CERT : 0);
     }
 #endif
 #if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)
@@ -1142,6 +1156,7 @@ struct Solver {
       unsigned hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw, pr[4] = iters;
+      pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
     }
 #endif
     if (IS_T0) {
@@ -1155,6 +1170,15 @@ struct Solver {
       if (a.st_pairs) a.st_pairs[inst] = s.st_pairs;
 #endif
       if (a.st_flags) a.st_flags[inst] = flags;
+#ifndef HDSM_EMU
+      if (a.st_key) {
+        // what the next launch sorts by (hdsm_api.hip, launch_order_block): how long this instance took; an instance without
+        // a solution goes first whatever it took — its next replan either ends on the certificate at once or is among the
+        // longest of the launch, and starting a short one early costs nothing
+        const long long ticks = ((long long)wall_clock64() - tl_begin_) >> 6;
+        a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
+      }
+#endif
     }
     SYNC();
   }

@@ -685,7 +685,7 @@ struct WaveGI {
     const int lane = (int)threadIdx.x;
     const int N = c.N, n = c.n;
     const int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
-    int nw = uni(wp[0]);
+    int nw = uni(wp[0]) & ~WARM_CERT;
     if (nw <= 0) return;
     if (nw > NV) nw = NV;
     PROF_DECL
