@@ -960,6 +960,14 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
     }
     int late = 0;
     for (int k = 0; k < n_inst; ++k) late += pr[(size_t)k * 32] - t0 > 200;  // started more than 2 us after the first
+    if (const char* path = std::getenv("HDSM_TIMELINE_DUMP")) {  // raw rows for offline analysis, one block per launch
+      if (FILE* f = std::fopen(path, "ab")) {
+        const long long head[2] = {0x54494d454c494e45LL, n_inst};
+        std::fwrite(head, sizeof(long long), 2, f);
+        for (int k = 0; k < n_inst; ++k) std::fwrite(&pr[(size_t)k * 32], sizeof(long long), 16, f);
+        std::fclose(f);
+      }
+    }
     auto us = [](long long ticks) { return (double)ticks * 0.01; };
     const long long *w = &pr[(size_t)worst * 32], *l = &pr[(size_t)last * 32];
     std::fprintf(stderr,

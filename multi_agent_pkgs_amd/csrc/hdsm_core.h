@@ -1157,6 +1157,7 @@ struct Solver {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw, pr[4] = iters;
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
+      pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q;
     }
 #endif
     if (IS_T0) {
@@ -1175,7 +1176,9 @@ struct Solver {
         // what the next launch sorts by (hdsm_api.hip, launch_order_block): how long this instance took; an instance without
         // a solution goes first whatever it took — its next replan either ends on the certificate at once or is among the
         // longest of the launch, and starting a short one early costs nothing
-        const long long ticks = ((long long)wall_clock64() - tl_begin_) >> 6;
+        // (+ 9 units per row of the final working set: next to the duration, the size of the active set is what predicts the
+        // next replan's length best on the crossing rounds — list-scheduling replay of recorded launches, profiles/README.md)
+        const long long ticks = (((long long)wall_clock64() - tl_begin_) >> 6) + 9 * s.q;
         a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
 #endif

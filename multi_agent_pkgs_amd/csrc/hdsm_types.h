@@ -103,7 +103,7 @@ struct Args {
   int32_t* st_sph;    // sphere records read by the sweeps of this instance
   int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance
   uint32_t* st_flags; // HDSM_FLAG_* bits
-  int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units (<= 254), 255 = no solution
+  int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units + 9 per active row (<= 254), 255 = no solution
 };
 
 }  // namespace hdsm
