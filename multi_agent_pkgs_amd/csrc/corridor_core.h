@@ -165,7 +165,12 @@ struct WindowGrid {
   int mark;
   Cell seed;
   uint32_t* bits;      // overlay over offsets [-OV, OV)^3 from the seed
-  static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32;
+  // optional cache of the world under the overlay, 2 bits per voxel, same indexing (device corridor kernel: built by the
+  // whole wavefront in LDS, so that the one lane that runs the decomposition does not wait for a global read per voxel):
+  // 0 = free (any value below kOccupied), 1 = exactly kOccupied (also: below the ground, unknown), 2 = above kOccupied
+  const uint32_t* occ2 = nullptr;
+  static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32, OCC2_WORDS = OVW * OVW * OVW / 16;
+  static constexpr bool kAtomicMarks = true;  // set_atomic / unset_atomic exist (cooperative mode)
   CD_HD int nx() const { return lnx; }
   CD_HD int ny() const { return lny; }
   CD_HD int nz() const { return lnz; }
@@ -179,13 +184,24 @@ struct WindowGrid {
     const int b = bit_index(c);
     return b >= 0 && ((bits[b >> 5] >> (b & 31)) & 1u);
   }
-  CD_HD int value(Cell c) const {
-    if (marked(c)) return mark;
+  CD_HD int world_value(Cell c) const {  // what lies under the overlay
     if (c.z < ground_k) return kOccupied;
     const int gi = c.x + ox, gj = c.y + oy, gk = c.z + oz;
     if (gi < 0 || gj < 0 || gk < 0 || gi >= wnx || gj >= wny || gk >= wnz) return 0;
     const int v = world[(size_t)gi + (size_t)gj * wnx + (size_t)gk * wnx * wny];
     return v < 0 ? kOccupied : v;
+  }
+  CD_HD static uint32_t occ2_class(int v) { return v < kOccupied ? 0u : (v == kOccupied ? 1u : 2u); }
+  CD_HD int value(Cell c) const {
+    const int b = bit_index(c);
+    if (b >= 0) {
+      if ((bits[b >> 5] >> (b & 31)) & 1u) return mark;
+      if (occ2) {  // (the decomposition only compares values with kOccupied and the mark: the class is enough)
+        const uint32_t cls = (occ2[b >> 4] >> ((b & 15) * 2)) & 3u;
+        return cls == 0 ? 0 : (cls == 1 ? kOccupied : kOccupied + 1);
+      }
+    }
+    return world_value(c);
   }
   CD_HD void set(Cell c, int) {
     const int b = bit_index(c);
@@ -196,6 +212,17 @@ struct WindowGrid {
     const int b = bit_index(c);
     if (b >= 0) bits[b >> 5] &= ~(1u << (b & 31));
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // cooperative mode (Ctx::coop): the lanes of a wavefront mark different voxels at once
+  __device__ void set_atomic(Cell c) const {
+    const int b = bit_index(c);
+    if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
+  }
+  __device__ void unset_atomic(Cell c) const {
+    const int b = bit_index(c);
+    if (b >= 0) atomicAnd(&bits[b >> 5], ~(1u << (b & 31)));
+  }
+#endif
   CD_HD int count() const {
     int n = 0;
     for (int w = 0; w < WORDS; ++w) {
@@ -206,8 +233,33 @@ struct WindowGrid {
   }
 };
 
+// Cooperative mode (device, corridor kernel of the swarm loop): ALL 64 lanes of a wavefront run the decomposition with the same
+// data — the control flow is uniform and every lane stores the same values — and the loops over the cells of a layer / a rim
+// (where one lane spent its time: a chain of LDS round trips per cell) are spread over the lanes, with ballots where the serial
+// loop stops at the first hit or appends in order. The results are those of the serial code, statement for statement.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CD_NO_COOP)
+#define CD_HAS_COOP 1
+#define CD_COOP(cx) ((cx).coop)
+#define CD_SYNC() __syncthreads()
+#else
+#define CD_HAS_COOP 0
+#define CD_COOP(cx) false
+#define CD_SYNC()
+#endif
+// grow_layer and find_corners are real calls on the device. Inlined everywhere (three copies of grow_layer in one kernel),
+// hipcc -O3 produced gfx950 code for the one-thread-per-seed kernel that faulted on some seeds (memory aperture violation;
+// fine at -O2, with -fno-unroll-loops or -fno-vectorize, with either function out of line, and the same source is clean on the
+// host under ASan / UBSan). The calls also keep the kernels a third of the size.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CD_NOINLINE __attribute__((noinline))
+#else
+#define CD_NOINLINE
+#endif
+
 struct Ctx {
   Work* wk;
+  bool coop = false;  // device only: see above
+  int lane = 0;
   CD_HD Packed pack(Cell c) const {
     const int dx = c.x - wk->seed.x, dy = c.y - wk->seed.y, dz = c.z - wk->seed.z;
     if (dx < -127 || dx > 127 || dy < -127 || dy > 127 || dz < -127 || dz > 127) wk->overflow = 1;
@@ -235,12 +287,39 @@ struct Ctx {
     else wk->overflow = 1;
   }
   CD_HD void copy(CellDeque& dst, const CellDeque& src) const {
-    dst.b = src.b, dst.e = src.e;
-    for (int i = src.b; i < src.e; ++i) dst.c[i] = src.c[i];
+    const int b = src.b, e = src.e;
+    dst.b = b, dst.e = e;
+    if (CD_COOP(*this)) {
+      for (int i = b + lane; i < e; i += 64) dst.c[i] = src.c[i];
+      CD_SYNC();
+      return;
+    }
+    for (int i = b; i < e; ++i) dst.c[i] = src.c[i];
   }
   CD_HD void copy(CellList& dst, const CellList& src) const {
-    dst.n = src.n;
-    for (int i = 0; i < src.n; ++i) dst.c[i] = src.c[i];
+    const int n = src.n;
+    dst.n = n;
+    if (CD_COOP(*this)) {
+      for (int i = lane; i < n; i += 64) dst.c[i] = src.c[i];
+      CD_SYNC();
+      return;
+    }
+    for (int i = 0; i < n; ++i) dst.c[i] = src.c[i];
+  }
+  // l += the cells of d, in order (push() for each)
+  CD_HD void append(CellList& l, const CellDeque& d) const {
+    const int cnt = d.e - d.b;
+    if (CD_COOP(*this)) {
+      const int n0 = l.n;
+      for (int q = lane; q < cnt; q += 64)
+        if (n0 + q < CELLS) l.c[n0 + q] = d.c[d.b + q];
+      if (n0 + cnt > CELLS) wk->overflow = 1;
+      CD_SYNC();
+      l.n = n0 + cnt > CELLS ? CELLS : n0 + cnt;
+      CD_SYNC();
+      return;
+    }
+    for (int q = 0; q < cnt; ++q) push(l, get(d, q));
   }
 };
 
@@ -259,9 +338,10 @@ CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* ed
 
 // One layer on top of face f: a free 2-D seed above the current outer layer, inside the allowance and inside voxels
 // [1, dim - 1 - margin] (CD:94-116: margin 1; CD:700-723: margin 0), grown in its plane (CD:118-200).
-// Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v).
+// Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v),
+// trial_set / trial_unset, and kAtomicMarks (true: set_atomic / unset_atomic for the cooperative mode).
 template <class G>
-CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+CD_NOINLINE CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
   Work& wk = *cx.wk;
   const Frame* fr = wk.fr;
   L.found = 0;
@@ -269,18 +349,34 @@ CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, con
   const Cell up = normal_of(f);
   const Cell* sd = fr[f].side;
   Cell s2{0, 0, 0};
-  for (int q = 0; q < fs.outer.n; ++q) {
-    const Cell t = add(cx.at(fs.outer, q), up);
-    if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx() - margin || t.y >= g.ny() - margin || t.z >= g.nz() - margin) continue;
-    if (g.value(t) >= kOccupied) continue;
+  auto seed_ok = [&](Cell t) {
+    if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx() - margin || t.y >= g.ny() - margin || t.z >= g.nz() - margin) return false;
+    if (g.value(t) >= kOccupied) return false;
     bool in = true;
     for (int k = 0; k < 4; ++k) in = in && dot(t, sd[k]) <= allow[k];
-    if (in) {
-      s2 = t, L.found = 1;
+    return in;
+  };
+  bool found = false;
+#if CD_HAS_COOP
+  if (cx.coop) {  // the first cell of the list that qualifies: 64 candidates per trip
+    const int n = fs.outer.n;
+    for (int base = 0; base < n && !found; base += 64) {
+      const int q = base + cx.lane;
+      const bool hit = q < n && seed_ok(add(cx.at(fs.outer, q < n ? q : 0), up));
+      const unsigned long long m = __ballot(hit);
+      if (m) s2 = add(cx.at(fs.outer, base + __ffsll((long long)m) - 1), up), found = true;
+    }
+  } else
+#endif
+  for (int q = 0; q < fs.outer.n; ++q) {
+    const Cell t = add(cx.at(fs.outer, q), up);
+    if (seed_ok(t)) {
+      s2 = t, found = true;
       break;
     }
   }
-  if (!L.found) return;
+  L.found = found ? 1 : 0;
+  if (!found) return;
   // current outline of the layer per side: all cells (rim) / cells of the layer (rim_real)
   for (int j = 0; j < 4; ++j) cx.assign1(wk.rim[j], s2), cx.assign1(L.rim_real[j], s2), L.far[j] = s2;
   cx.push(L.cells, s2);
@@ -291,6 +387,53 @@ CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, con
     cx.clear(wk.moved), cx.clear(wk.moved_real);
     bool ok = true;
     const int cnt = cx.size(wk.rim[s]);
+#if CD_HAS_COOP
+    if (cx.coop) {
+      // every cell of the side at once: a cell that stops the serial loop stops the side (what was pushed before it is
+      // discarded there too); otherwise `moved` takes all the cells and `moved_real` those on top of the polyhedron, in order
+      const int rb = wk.rim[s].b;
+      int n_real = 0;
+      for (int base = 0; base < cnt && ok; base += 64) {
+        const int q = base + cx.lane;
+        const bool act = q < cnt;
+        const Cell t = add(cx.unpack(wk.rim[s].c[rb + (act ? q : 0)]), sd[s]);
+        bool fail = false, real = false;
+        if (act) {
+          if (dot(t, sd[s]) > allow[s]) {
+            fail = true;
+          } else {
+            const Cell below = sub(t, up);
+            if (g.inside(below) && g.value(below) == mark) {
+              if (g.inside(t) && g.value(t) < kOccupied) real = true;
+              else fail = true;
+            }
+          }
+        }
+        if (__ballot(fail)) {
+          ok = false;
+          break;
+        }
+        const unsigned long long rm = __ballot(real);
+        if (act) {
+          const Packed pk = cx.pack(t);
+          if (RIM0 + q < RIM) wk.moved.c[RIM0 + q] = pk;
+          else wk.overflow = 1;
+          if (real) {
+            const int rpos = RIM0 + n_real + __popcll(rm & ((1ull << cx.lane) - 1ull));
+            if (rpos < RIM) wk.moved_real.c[rpos] = pk;
+            else wk.overflow = 1;
+          }
+        }
+        n_real += __popcll(rm);
+      }
+      CD_SYNC();
+      if (ok) {
+        wk.moved.b = RIM0, wk.moved.e = RIM0 + cnt < RIM ? RIM0 + cnt : RIM;
+        wk.moved_real.b = RIM0, wk.moved_real.e = RIM0 + n_real < RIM ? RIM0 + n_real : RIM;
+      }
+      CD_SYNC();
+    } else
+#endif
     for (int q = 0; q < cnt; ++q) {
       const Cell t = add(cx.get(wk.rim[s], q), sd[s]);
       if (dot(t, sd[s]) > allow[s]) {
@@ -314,7 +457,7 @@ CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, con
       continue;
     }
     cx.copy(wk.rim[s], wk.moved);
-    for (int q = 0; q < cx.size(wk.moved_real); ++q) cx.push(L.cells, cx.get(wk.moved_real, q));
+    cx.append(L.cells, wk.moved_real);
     cx.copy(L.rim_real[s], wk.moved_real);
     cx.push_back(wk.rim[prev], cx.front(wk.moved));
     cx.push_front(wk.rim[next], cx.back(wk.moved));
@@ -344,6 +487,17 @@ CD_HD void layer_extent(const Ctx& cx, int f, const Layer& L, int ext[4]) {
 template <class G>
 CD_HD bool side_is_empty(const Ctx& cx, const G& g, const CellDeque& cells, Cell step) {
   if (cx.empty(cells)) return false;
+#if CD_HAS_COOP
+  if (cx.coop) {
+    const int cnt = cx.size(cells);
+    bool any = false;
+    for (int q = cx.lane; q < cnt; q += 64) {
+      const Cell t = add(cx.get(cells, q), step);
+      any = any || (g.inside(t) ? g.value(t) : kOccupied) > 0;
+    }
+    return __ballot(any) == 0;
+  }
+#endif
   for (int q = 0; q < cx.size(cells); ++q) {
     const Cell t = add(cx.get(cells, q), step);
     const int v = g.inside(t) ? g.value(t) : kOccupied;
@@ -354,7 +508,7 @@ CD_HD bool side_is_empty(const Ctx& cx, const G& g, const CellDeque& cells, Cell
 
 // FindCorners, CD:378-564: a trial layer on face f from the given state; which square edges would become chamfers.
 template <class G>
-CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool growing[6], const FaceState* faces, const Edge* edges, int mark,
+CD_NOINLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool growing[6], const FaceState* faces, const Edge* edges, int mark,
                         bool& valid, Edge out[4]) {
   if (!growing[f]) {
     valid = false;
@@ -384,8 +538,28 @@ CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool growing[6],
 // container of `wk` was too small for this grid: the caller falls back to a bigger workspace / reports it)
 template <class G>
 CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, double res, int mark, const double origin[3], double* rows,
-                         int max_rows, int* n_rows) {
-  Ctx cx{&wk};
+                         int max_rows, int* n_rows, bool coop = false, int lane = 0) {
+  Ctx cx{&wk, coop, lane};
+  // mark / unmark every cell of a list
+  auto mark_cells = [&](const CellList& l, int how) {  // 0 set, 1 trial_set, 2 trial_unset
+#if CD_HAS_COOP
+    if constexpr (G::kAtomicMarks) {
+      if (cx.coop) {
+        for (int q = cx.lane; q < l.n; q += 64) {
+          if (how == 2) g.unset_atomic(cx.at(l, q));
+          else g.set_atomic(cx.at(l, q));
+        }
+        CD_SYNC();
+        return;
+      }
+    }
+#endif
+    for (int q = 0; q < l.n; ++q) {
+      if (how == 0) g.set(cx.at(l, q), mark);
+      else if (how == 1) g.trial_set(cx.at(l, q), mark);
+      else g.trial_unset(cx.at(l, q));
+    }
+  };
   wk.overflow = 0;
   wk.seed = seed;
   build_frames(wk.fr);
@@ -504,7 +678,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       }
       if (expand && (fresh[0] || fresh[1] || fresh[2] || fresh[3])) {
         // trial: put the layer in, grow one more on top of it, take it out again (its cells were free voxels)
-        for (int q = 0; q < L.cells.n; ++q) g.trial_set(cx.at(L.cells, q), mark);
+        mark_cells(L.cells, 1);
         FaceState* faces_t = wk.faces_t;
         for (int k = 0; k < 6; ++k) {
           cx.copy(faces_t[k].outer, k == f ? L.cells : faces[k].outer);
@@ -517,7 +691,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
         bool valid = true;
         Edge fin[4];
         find_corners(cx, g, f, growing, faces_t, edges_t, mark, valid, fin);
-        for (int q = 0; q < L.cells.n; ++q) g.trial_unset(cx.at(L.cells, q));
+        mark_cells(L.cells, 2);
         if (valid) {
           for (int j = 0; j < 4; ++j)
             if (fresh[j] == 2 && fin[j].slope < trial[j].slope) {
@@ -550,12 +724,12 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       // full-width side on a square edge: these voxels are now also the outermost layer of the neighbouring face
       if (trial[j].slope == 0 && !cx.empty(L.rim_real[j]) && faces[f].reach[j] == dot(cx.front(L.rim_real[j]), sd[j])) {
         const int nbf = fr[f].face[j];
-        for (int q = 0; q < cx.size(L.rim_real[j]); ++q) cx.push(faces[nbf].outer, cx.get(L.rim_real[j], q));
+        cx.append(faces[nbf].outer, L.rim_real[j]);
         faces[nbf].reach[fr[f].back[j]] += 1;
       }
     }
     anchor[f] = cx.at(L.cells, 0);
-    for (int q = 0; q < L.cells.n; ++q) g.set(cx.at(L.cells, q), mark);
+    mark_cells(L.cells, 0);
   }
   if (wk.overflow) return CD_WORK_OVERFLOW;
 

@@ -150,20 +150,39 @@ CD_HD void free_space_poly(const Cfg& c, const V3& grid_origin, const int seed[3
 // environment_builder.cpp:58-67) is a WINDOW of the world grid (corridor_core.h WindowGrid: ground below, unknown = occupied,
 // outside the world = free). A seed pinched between two occupied voxels along an axis gets the shape-aware variant
 // (AC:1385-1397), every other seed the original one. `bits` = WindowGrid::WORDS words of scratch.
-CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Work* wk, uint32_t* bits, Poly* out) {
+
+// the agent's local grid as a window of the world, overlay centred on `seed`
+CD_HD WindowGrid make_window(const Cfg& c, const V3& grid_origin, const int seed[3], uint32_t* bits, const uint32_t* occ2) {
   const double vs = c.voxel_size;
   int dim[3], off[3];
   for (int ax = 0; ax < 3; ++ax) {
     dim[ax] = (int)floor(c.grid_range[ax] / vs);
     off[ax] = (int)lround((grid_origin[ax] - c.worigin[ax]) / vs);  // local voxel 0 in world voxels
   }
-  out->rows = 0;
+  return WindowGrid{c.world, c.wdim[0], c.wdim[1], c.wdim[2], off[0], off[1], off[2], dim[0], dim[1], dim[2],
+                    (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9), -1, Cell{seed[0], seed[1], seed[2]}, bits, occ2};
+}
+CD_HD bool seed_in_grid(const Cfg& c, const int seed[3]) {
   for (int ax = 0; ax < 3; ++ax)
-    if (seed[ax] < 0 || seed[ax] >= dim[ax]) return HDSM_ERR_BAD_ARG;
-  for (int w = 0; w < WindowGrid::WORDS; ++w) bits[w] = 0u;
+    if (seed[ax] < 0 || seed[ax] >= (int)floor(c.grid_range[ax] / c.voxel_size)) return false;
+  return true;
+}
+
+// `occ2`: optional cache of the world under the overlay (WindowGrid::occ2), already built for this seed
+// `coop`, `lane`: device only, the whole wavefront calls with the same arguments (corridor_core.h, cooperative mode)
+CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Work* wk, uint32_t* bits, Poly* out,
+                     const uint32_t* occ2 = nullptr, bool coop = false, int lane = 0) {
+  const double vs = c.voxel_size;
+  out->rows = 0;
+  if (!seed_in_grid(c, seed)) return HDSM_ERR_BAD_ARG;
+  if (coop) {
+    for (int w = lane; w < WindowGrid::WORDS; w += 64) bits[w] = 0u;
+    CD_SYNC();
+  } else {
+    for (int w = 0; w < WindowGrid::WORDS; ++w) bits[w] = 0u;
+  }
   const Cell sc{seed[0], seed[1], seed[2]};
-  WindowGrid g{c.world, c.wdim[0], c.wdim[1], c.wdim[2], off[0], off[1], off[2], dim[0], dim[1], dim[2],
-               (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9), -1, sc, bits};
+  WindowGrid g = make_window(c, grid_origin, seed, bits, occ2);
   auto occupied = [&](int dx, int dy, int dz) {  // VoxelGrid::IsOccupied: == 100, outside the grid: not occupied
     const Cell q{sc.x + dx, sc.y + dy, sc.z + dz};
     return g.inside(q) && g.value(q) == hdsm_cd::kOccupied;
@@ -174,7 +193,7 @@ CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Wor
   double rows[HDSM_MAX_ROWS_STATIC * 4];
   int n = 0;
   const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
-  const int rc = hdsm_cd::decompose_core(g, *wk, (pinched || c.use_cvx_new) ? 1 : 0, sc, c.n_it_decomp, vs, -1, org, rows, cap, &n);
+  const int rc = hdsm_cd::decompose_core(g, *wk, (pinched || c.use_cvx_new) ? 1 : 0, sc, c.n_it_decomp, vs, -1, org, rows, cap, &n, coop, lane);
   if (rc != hdsm_cd::CD_OK) return HDSM_ERR_CAPACITY;
   out->rows = n;
   for (int r = 0; r < n; ++r) {

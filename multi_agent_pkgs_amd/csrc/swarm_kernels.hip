@@ -42,7 +42,11 @@ int fail(int code, const std::string& m) {
   } while (0)
 
 constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline handed to k_reference
-constexpr size_t SLAB = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16 + hdsm_cd::WindowGrid::WORDS * 4;
+// scratch of one agent's voxel decompositions, in LDS (dynamic shared memory of k_corridor): the workspace, the overlay bits and
+// the 2-bit cache of the world under the overlay. The decomposition is one lane's chain of small dependent accesses — in global
+// memory every one of them was a round trip (33 ms per round for 256 agents in the pillar forest).
+constexpr size_t WORK_BYTES = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16;
+constexpr size_t SLAB = WORK_BYTES + hdsm_cd::WindowGrid::WORDS * 4 + hdsm_cd::WindowGrid::OCC2_WORDS * 4;
 
 // GenerateSafeCorridor (AC:1236-1447), ONE WAVEFRONT PER AGENT. The walk along the path (steps of voxel / 10: hundreds of
 // them per round) tests every sample against every row of the kept polyhedra; with one thread per agent each test was a chain of
@@ -50,10 +54,27 @@ constexpr size_t SLAB = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16 + hdsm_cd::Wind
 // P * RS <= 128), a sample is tested against all of them at once and `inside` is a ballot; the walk state is computed redundantly
 // by every lane (wave-uniform), so the arithmetic — and the result — is exactly that of hdsm_sw::corridor_step. New polyhedra
 // (closed form in free space, voxel decomposition on a window of the world grid) are produced by lane 0 with the shared code.
-__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, V3* path, int lane) {
+// the world under the overlay of `seed`, classified (WindowGrid::occ2): one word = 16 voxels along x, a word per lane and trip
+__device__ void build_occ2(const Cfg& c, const V3& origin, const int seed[3], uint32_t* occ2, int lane) {
+  using hdsm_cd::WindowGrid;
+  const WindowGrid g = hdsm_sw::make_window(c, origin, seed, nullptr, nullptr);
+  for (int w = lane; w < WindowGrid::OCC2_WORDS; w += 64) {
+    const int b0 = w * 16;
+    const int dx0 = b0 & (WindowGrid::OVW - 1), dy = (b0 / WindowGrid::OVW) & (WindowGrid::OVW - 1), dz = b0 / (WindowGrid::OVW * WindowGrid::OVW);
+    uint32_t word = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const hdsm_cd::Cell cell{seed[0] + dx0 + u - WindowGrid::OV, seed[1] + dy - WindowGrid::OV, seed[2] + dz - WindowGrid::OV};
+      word |= WindowGrid::occ2_class(g.world_value(cell)) << (2 * u);
+    }
+    occ2[w] = word;
+  }
+}
+
+__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, uint32_t* occ2, V3* path, int lane) {
   using namespace hdsm_sw;
   const int P = c.P, N = c.N, RS = c.RS;
-  __shared__ int sh_npoly, sh_npath, sh_flag;
+  __shared__ int sh_npoly, sh_npath;
   if (lane == 0) {  // keep-last / keep-used (AC:1253-1282) and the path ahead (AC:1286-1290): a handful of operations
     ag.corridor_rc = 0;
     Poly* fresh = ag.polys;
@@ -180,17 +201,19 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
         break;
       }
     if (previous_seed) continue;
-    if (lane == 0) {
-      Poly& np = ag.polys[n_poly];
-      int rc = HDSM_OK;
-      if (c.has_world) rc = world_poly(c, origin, seed, wk, bits, &np);
-      else free_space_poly(c, origin, seed, &np);
-      if (rc != HDSM_OK) ag.corridor_rc = rc;
-      else np.seed = seed_world;
-      sh_flag = rc;
+    if (c.has_world && hdsm_sw::seed_in_grid(c, seed)) {  // all lanes: the world around the seed -> LDS
+      build_occ2(c, origin, seed, occ2, lane);
+      __syncthreads();
     }
-    __syncthreads();
-    const int rc = sh_flag;
+    int rc = HDSM_OK;
+    if (c.has_world) {  // the whole wavefront, cooperatively (corridor_core.h): same arguments, same result in every lane
+      rc = world_poly(c, origin, seed, wk, bits, &ag.polys[n_poly], occ2, true, lane);
+      if (rc != HDSM_OK) ag.corridor_rc = rc;
+      else ag.polys[n_poly].seed = seed_world;
+    } else if (lane == 0) {
+      free_space_poly(c, origin, seed, &ag.polys[n_poly]);
+      ag.polys[n_poly].seed = seed_world;
+    }
     __syncthreads();
     if (rc != HDSM_OK) break;
     ++n_poly;
@@ -199,22 +222,23 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
   if (lane == 0) ag.n_poly = n_poly;
 }
 
-__global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, unsigned char* scratch, double* path, int32_t* n_path) {
+__global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, double* path, int32_t* n_path) {
   __shared__ V3 path_s[hdsm_sw::PATH_PTS + 2];
   __shared__ V3 poly_s[PTS];
   __shared__ int np_s;
   const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (k >= n) return;
   AgentS& ag = agents[k];
+  extern __shared__ __attribute__((aligned(16))) unsigned char slab[];  // SLAB bytes when there is a world, else none
   hdsm_cd::Work* wk = nullptr;
-  uint32_t* bits = nullptr;
+  uint32_t *bits = nullptr, *occ2 = nullptr;
   if (c.has_world) {
-    unsigned char* slab = scratch + (size_t)k * SLAB;
     wk = reinterpret_cast<hdsm_cd::Work*>(slab);
-    bits = reinterpret_cast<uint32_t*>(slab + ((sizeof(hdsm_cd::Work) + 15) / 16) * 16);
+    bits = reinterpret_cast<uint32_t*>(slab + WORK_BYTES);
+    occ2 = bits + hdsm_cd::WindowGrid::WORDS;
   }
   if (c.P * c.RS <= 128) {
-    corridor_step_wave(c, ag, wk, bits, path_s, lane);
+    corridor_step_wave(c, ag, wk, bits, occ2, path_s, lane);
   } else if (lane == 0) {
     hdsm_sw::corridor_step(c, ag, wk, bits);  // more rows than two per lane: the plain per-agent code
   }
@@ -364,7 +388,6 @@ struct DSwarm {
   Cfg c{};
   AgentS* d_agents = nullptr;
   int8_t* d_world = nullptr;
-  unsigned char* d_scratch = nullptr;
   double *d_cap = nullptr, *d_path = nullptr, *d_ref_full = nullptr, *d_ref = nullptr, *d_pv = nullptr, *d_state = nullptr, *d_A = nullptr, *d_b = nullptr,
          *d_traj = nullptr, *d_ctrl = nullptr, *d_obj = nullptr, *d_local = nullptr, *d_plans = nullptr;
   int32_t *d_npath = nullptr, *d_id = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr, *d_fails = nullptr;
@@ -380,7 +403,7 @@ hipError_t dalloc(T** p, size_t count) {
 }
 
 void free_all(DSwarm* d) {
-  void* ptrs[] = {d->d_cap, d->d_agents, d->d_world, d->d_scratch, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
+  void* ptrs[] = {d->d_cap, d->d_agents, d->d_world, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
                   d->d_ctrl, d->d_obj, d->d_local, d->d_plans, d->d_npath, d->d_id, d->d_npoly, d->d_nrows, d->d_status, d->d_fails,
                   d->d_used, d->d_has};
   for (void* p : ptrs)
@@ -433,7 +456,6 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
   ok(dalloc(&d->d_agents, n));
   if (hworld) {
     ok(dalloc(&d->d_world, (size_t)wdim[0] * wdim[1] * wdim[2]));
-    ok(dalloc(&d->d_scratch, n * SLAB));
   }
   ok(dalloc(&d->d_path, n * PTS * 3)), ok(dalloc(&d->d_npath, n)), ok(dalloc(&d->d_ref_full, n * (N + 1) * 6)), ok(dalloc(&d->d_ref, n * N * 6));
   ok(dalloc(&d->d_cap, n)), ok(dalloc(&d->d_pv, n)), ok(dalloc(&d->d_id, n)), ok(dalloc(&d->d_state, n * 9)), ok(dalloc(&d->d_npoly, n)), ok(dalloc(&d->d_nrows, n * P));
@@ -483,7 +505,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;
   const unsigned gb = (unsigned)((n + 63) / 64);
   if (n > 0) {
-    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), 0, st, d->c, n, d->d_agents, d->d_scratch, d->d_path, d->d_npath);
+    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? SLAB : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_vel_cap, dim3(gb), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
