@@ -260,12 +260,13 @@ struct Ctx {
   Work* wk;
   bool coop = false;  // device only: see above
   int lane = 0;
+  Cell seed{0, 0, 0};  // = wk->seed, by value (every pack / unpack would re-read it from the workspace otherwise)
   CD_HD Packed pack(Cell c) const {
-    const int dx = c.x - wk->seed.x, dy = c.y - wk->seed.y, dz = c.z - wk->seed.z;
+    const int dx = c.x - seed.x, dy = c.y - seed.y, dz = c.z - seed.z;
     if (dx < -127 || dx > 127 || dy < -127 || dy > 127 || dz < -127 || dz > 127) wk->overflow = 1;
     return Packed{(int8_t)dx, (int8_t)dy, (int8_t)dz};
   }
-  CD_HD Cell unpack(Packed p) const { return Cell{wk->seed.x + p.x, wk->seed.y + p.y, wk->seed.z + p.z}; }
+  CD_HD Cell unpack(Packed p) const { return Cell{seed.x + p.x, seed.y + p.y, seed.z + p.z}; }
   CD_HD void push(CellList& l, Cell c) const {
     if (l.n < CELLS) l.c[l.n++] = pack(c);
     else wk->overflow = 1;
@@ -539,7 +540,7 @@ CD_NOINLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool
 template <class G>
 CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, double res, int mark, const double origin[3], double* rows,
                          int max_rows, int* n_rows, bool coop = false, int lane = 0) {
-  Ctx cx{&wk, coop, lane};
+  Ctx cx{&wk, coop, lane, seed};
   // mark / unmark every cell of a list
   auto mark_cells = [&](const CellList& l, int how) {  // 0 set, 1 trial_set, 2 trial_unset
 #if CD_HAS_COOP
