@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--radius", type=float, default=0.0, help="circle radius [m], default max(22, agents / 2 pi)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall-clock budget of the CPU baseline leg")
     ap.add_argument("--repeats", type=int, default=3, help="repetitions of the (warm-up + timed) region; the median is reported")
+    ap.add_argument("--mip-gap", type=float, default=0.0, help="hdsm_params.mip_gap (0 = exact, the default; the reference runs "
+                    "Gurobi at its default MIPGap 1e-4)")
+    ap.add_argument("--time-limit-s", type=float, default=0.0, help="hdsm_params.time_limit_s (0 = none; AC:952 sets 0.08)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the HIP-event pass and the host-buffer pass")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
@@ -95,7 +98,7 @@ def main():
     from multi_agent_pkgs_amd.params import agile_params, agile_ref_config
 
     N = args.horizon
-    prm = agile_params(N, max_rows_static=18)
+    prm = agile_params(N, max_rows_static=18, mip_gap=args.mip_gap, time_limit_s=args.time_limit_s)
     P, RS = prm.poly_hor, prm.max_rows_static
     n_rob = args.agents
     radius = args.radius if args.radius > 0 else max(22.0, n_rob / (2 * np.pi))
@@ -367,7 +370,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": names[args.scenario] + f", H={N}, poly_hor={P}, closed-loop rounds "
                                    f"{first_round}..{first_round + K - 1} replayed (warm-up: rounds {rec_from}..{first_round - 1})",
-                       "workload_key": key, "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
+                       "workload_key": key, "mip_gap": args.mip_gap, "time_limit_s": args.time_limit_s, "agents": n_rob, "agents_per_gpu": n_local, "horizon": N, "poly_hor": P,
                        "parallelism": f"agents sharded over {world} GPU(s), one RCCL all-gather per round"
                                       if world > 1 else "one GPU"},
             "p50_solve_latency_ms": float(np.percentile(kern_ms, 50)),

@@ -59,6 +59,7 @@ __device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); 
 namespace hdsm {
 
 enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
+constexpr int NOGOODS = 48;      // conflicts kept per instance (branch and bound)
 constexpr int WARM_CERT = 1 << 30;  // bit of the stored working-set size: the set is an infeasibility certificate
 enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
 enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
@@ -90,7 +91,6 @@ struct Shm {
   double fx0;                           // J(x0)
   int32_t cand_src[CMAX];               // origin of a staged row: (neighbour << 6) | (step << 1) | endpoint, -1 = explicit
   int32_t inc_act[NV], inc_nact;        // working set of the incumbent (portable ids) -> next replan's guess
-  int32_t inf_id;                       // row whose addition proved the last node infeasible (ids as in act[])
   int32_t st_sph, st_pairs;             // sweep counters: sphere records read, (neighbour, step) positions loaded
   long long t_start;                    // constant-rate clock at the start of the instance (time_limit_s)
   long long prof_acc[24];  // 0..7 iteration phases, 8..15 sweeps / set-up, 16..23 inside the warm start
@@ -118,6 +118,11 @@ struct Shm {
   int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
   int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
+  // conflicts learned by the branch and bound: a set of (step, polyhedron) assignments, as a bit mask (bit 4 i + j), that
+  // makes the QP infeasible together with the rows common to every node — no node containing it needs to be opened
+  int32_t inf_id;  // row whose addition proved the last node infeasible (ids as in act[])
+  unsigned long long nogood[NOGOODS];
+  int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
@@ -580,6 +585,19 @@ struct Solver {
       const int L = level - 1;
       const int pos = s.br_pos[L];
       if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s, c))) {
+        if (s.n_nogood > 0) {  // a child whose assignments contain a learned conflict is infeasible: not opened, not counted
+          unsigned long long cur = 1ull << (4 * s.br_step[L] + s.br_order[L][pos]);
+          for (int i = 0; i < c.N; ++i)
+            if (s.assign[i] >= 0 && i != s.br_step[L]) cur |= 1ull << (4 * i + s.assign[i]);
+          bool blocked = false;
+          for (int k = 0; k < s.n_nogood; ++k) blocked = blocked || (s.nogood[k] & ~cur) == 0ull;
+          if (blocked) {
+            SYNC();
+            if (IS_T0) s.br_pos[L] = pos + 1, ++s.ng_skipped;
+            SYNC();
+            continue;
+          }
+        }
         if (nodes >= c.max_nodes) {
           limit = true;
           return false;
@@ -651,6 +669,7 @@ struct Solver {
     if (IS_T0) {
       s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
       s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
+      s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
     }
     SYNC();
     // x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at u = 0, the residual
@@ -781,7 +800,7 @@ struct Solver {
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
-        s.st_sph = 0, s.st_pairs = 0;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -1056,6 +1075,32 @@ struct Solver {
           SYNC();
         }
       }
+      if (rc == GI_INFEASIBLE && c.P <= 4 && N <= 16) {
+        // Conflict learning. The dual method stopped because row inf_id depends on the working set and no multiplier can
+        // give way: working set + that row are infeasible TOGETHER. Apart from the rows of assigned polyhedra, everything
+        // in there (terminal equalities, boxes, neighbour planes) holds at every node, so the assignments those rows come
+        // from — usually one or two, decided high in the tree — are a conflict wherever they appear again. No assignment
+        // involved at all: the instance is infeasible whatever the choice, the search ends.
+        SYNC();
+        if (IS_T0) {
+          unsigned long long m = 0;
+          for (int k = 0; k <= s.q && k < NV + 1; ++k) {
+            const int code = (k < s.q) ? s.act[k] : s.inf_id;
+            if (id_kind(code) == K_P) {
+              const int i = id_payload(code) >> 7;
+              if (s.assign[i] >= 0) m |= 1ull << (4 * i + s.assign[i]);
+            }
+          }
+          if (m == 0ull) {
+            if (!s.have_inc) s.level = 0, s.ng_global = 1;  // (with an incumbent in hand the proof can only be a numerical artefact: ignored)
+          } else {
+            bool known = false;
+            for (int k = 0; k < s.n_nogood; ++k) known = known || (s.nogood[k] & ~m) == 0ull;
+            if (!known && s.n_nogood < NOGOODS) s.nogood[s.n_nogood++] = m;
+          }
+        }
+        SYNC();
+      }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
       const bool lim_before = limit;
       run = select_child(s, c, R, snap, nodes, limit);
@@ -1131,7 +1176,7 @@ struct Solver {
       // tends to persist for several rounds): hand over the certificate — the working set at the moment of the proof
       // and the row that could not join it. Seeded with it, the next replan finds the contradiction (or its absence)
       // after a few operations instead of rebuilding it from the unconstrained optimum.
-      const bool certificate = !s.have_inc && !limit && nodes == 1 && last_rc == GI_INFEASIBLE && s.q < NV;
+      const bool certificate = !s.have_inc && !limit && (nodes == 1 || s.ng_global) && last_rc == GI_INFEASIBLE && s.q < NV;
       if (certificate) {
         SYNC();
         PAR_FOR(k, NV) {
@@ -1157,7 +1202,7 @@ struct Solver {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw, pr[4] = iters;
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
-      pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q;
+      pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q, pr[14] = s.n_nogood, pr[15] = s.ng_skipped;
     }
 #endif
     if (IS_T0) {
