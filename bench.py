@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--mip-gap", type=float, default=0.0, help="hdsm_params.mip_gap (0 = exact, the default; the reference runs "
                     "Gurobi at its default MIPGap 1e-4)")
     ap.add_argument("--time-limit-s", type=float, default=0.0, help="hdsm_params.time_limit_s (0 = none; AC:952 sets 0.08)")
+    ap.add_argument("--device-loop-multi", action="store_true", help="run the device-resident-loop pass with --gpus > 1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the HIP-event pass and the host-buffer pass")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
@@ -274,7 +275,9 @@ def main():
     # hdsm_dswarm_round continues the flight where the set-up left it (round first_round + steps): corridor, reference,
     # replan, commit, publish and the all-gather as one chain of launches per round, no host round trip. A secondary record.
     dloop = None
-    if not args.no_event_pass and (world == 1 or comm is not None):
+    # (with more than one rank only on request: the RCCL exchange inside hdsm_dswarm_round has not run on a multi-GPU box yet,
+    # and a secondary record must not put the line of an N > 1 run at risk)
+    if not args.no_event_pass and (world == 1 or (comm is not None and args.device_loop_multi)):
         dsw = swarm.DeviceSwarm(loop.shard, solver, world_size=world, device=dev.index)
         dsw.upload_plans(loop.plans_all, loop.has_plan)
         for _ in range(2):
