@@ -122,6 +122,16 @@ int hdsm_poly_octa3d_device(int32_t device, int32_t n, const int8_t* world, cons
                             const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
                             int32_t* rc, int32_t* cells, void* scratch, void* hip_stream);
 size_t hdsm_poly_octa3d_scratch_bytes(int32_t n);
+/* The same batch with ONE WAVEFRONT per seed (workspace in LDS, the 64 lanes run the decomposition cooperatively — the form the
+ * device-resident loop uses for one agent's seeds): lower latency per seed, fewer seeds in flight, no scratch; same results. */
+int hdsm_poly_octa3d_batch_wave(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                                const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                                const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                                int32_t* rc, int32_t* cells);
+int hdsm_poly_octa3d_device_wave(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                                 const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                                 const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                                 int32_t* rc, int32_t* cells, void* hip_stream);
 const char* hdsm_corridor_last_error(void);
 
 /* Global paths (path_curr_ of the reference, produced there by the path thread: JPS + DMP + shortening, AC:261-567 — out of

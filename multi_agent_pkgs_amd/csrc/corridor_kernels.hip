@@ -5,8 +5,8 @@
 // independent seeds per replan round (one per agent and new polyhedron). One THREAD runs one decomposition, compiled from the
 // same source as the host entry points, so the rows agree with them bit for bit; its ~45 KB of containers live in a global
 // scratch slab, the polyhedron's voxels in a 4 KB bit overlay around the seed (the shared world grid is never written).
-// Lanes of a wavefront diverge freely — the unit of parallelism is the seed, not the voxel; a wave-cooperative layer growth
-// (ballot over the rim) is the next step once this path is in the loop.
+// Lanes of a wavefront diverge freely — the unit of parallelism is the seed, not the voxel. k_poly_octa3d_wave is the other
+// form: one wavefront per seed, cooperative (what the swarm loop's corridor kernel does for one agent's seeds).
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -71,6 +71,57 @@ __global__ __launch_bounds__(64) void k_poly_octa3d(Batch b) {
   if (b.cells) b.cells[t] = (rc == HDSM_ERR_BAD_ARG) ? 0 : g.count();
 }
 
+// The same batch with ONE WAVEFRONT per seed: workspace, overlay and a 2-bit classification of the world under the overlay in
+// LDS, the decomposition run cooperatively by the 64 lanes (corridor_core.h, Ctx::coop) — the form the device-resident swarm
+// loop uses inside its corridor kernel, where one agent's decompositions are a latency chain. Lower latency per seed, fewer
+// seeds in flight; same rows, bit for bit (tests/test_gpu_configs.py).
+constexpr size_t WORK_BYTES = ((sizeof(Work) + 15) / 16) * 16;
+constexpr size_t SLAB_LDS = WORK_BYTES + WindowGrid::WORDS * 4 + WindowGrid::OCC2_WORDS * 4;
+
+__global__ __launch_bounds__(64) void k_poly_octa3d_wave(Batch b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
+  if (t >= b.n) return;
+  Work& wk = *reinterpret_cast<Work*>(lds);
+  uint32_t* bits = reinterpret_cast<uint32_t*>(lds + WORK_BYTES);
+  uint32_t* occ2 = bits + WindowGrid::WORDS;
+  for (int w = lane; w < WindowGrid::WORDS; w += 64) bits[w] = 0u;
+  const Cell seed{b.seed[3 * t], b.seed[3 * t + 1], b.seed[3 * t + 2]};
+  WindowGrid g{b.world, b.wdim[0], b.wdim[1], b.wdim[2], b.off[3 * t], b.off[3 * t + 1], b.off[3 * t + 2],
+               b.ldim[0], b.ldim[1], b.ldim[2], b.ground[t], -1, seed, bits, occ2};
+  for (int w = lane; w < WindowGrid::OCC2_WORDS; w += 64) {  // the world under the overlay, 16 voxels along x per word
+    const int b0 = w * 16;
+    const int dx0 = b0 & (WindowGrid::OVW - 1), dy = (b0 / WindowGrid::OVW) & (WindowGrid::OVW - 1), dz = b0 / (WindowGrid::OVW * WindowGrid::OVW);
+    uint32_t word = 0;
+    for (int u = 0; u < 16; ++u)
+      word |= WindowGrid::occ2_class(g.world_value(Cell{seed.x + dx0 + u - WindowGrid::OV, seed.y + dy - WindowGrid::OV, seed.z + dz - WindowGrid::OV})) << (2 * u);
+    occ2[w] = word;
+  }
+  __syncthreads();
+  int rc = HDSM_OK, n = 0;
+  if (!g.inside(seed)) {
+    rc = HDSM_ERR_BAD_ARG;
+  } else {
+    int variant = b.variant[t];
+    if (variant < 0) {
+      auto occ = [&](int dx, int dy, int dz) {
+        const Cell c{seed.x + dx, seed.y + dy, seed.z + dz};
+        return g.inside(c) && g.value(c) == kOccupied;
+      };
+      variant = ((occ(-1, 0, 0) && occ(1, 0, 0)) || (occ(0, -1, 0) && occ(0, 1, 0)) || (occ(0, 0, -1) && occ(0, 0, 1))) ? 1 : 0;
+    }
+    const double org[3] = {b.origin[3 * t], b.origin[3 * t + 1], b.origin[3 * t + 2]};
+    const int r = decompose_core(g, wk, variant, seed, b.n_it, b.res, -1, org, b.rows + (size_t)t * b.max_rows * 4, b.max_rows, &n, true, lane);
+    rc = (r == CD_OK) ? HDSM_OK : HDSM_ERR_CAPACITY;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    b.n_rows[t] = n;
+    b.rc[t] = rc;
+    if (b.cells) b.cells[t] = (rc == HDSM_ERR_BAD_ARG) ? 0 : g.count();
+  }
+}
+
 int fail(int code, const std::string& m) {
   g_err = m;
   return code;
@@ -84,13 +135,13 @@ const char* hdsm_corridor_last_error(void) { return g_err.c_str(); }
 
 size_t hdsm_poly_octa3d_scratch_bytes(int32_t n) { return (size_t)(n > 0 ? n : 0) * SLAB; }
 
-int hdsm_poly_octa3d_device(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
-                            const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
-                            const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
-                            int32_t* rc, int32_t* cells, void* scratch, void* hip_stream) {
+static int launch_batch(bool wave, int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                        const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                        const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                        int32_t* rc, int32_t* cells, void* scratch, void* hip_stream) {
   if (n < 0 || !wdim || !ldim || n_it < 0 || !(res > 0) || max_rows < 6) return fail(HDSM_ERR_BAD_ARG, "bad size argument");
   if (n == 0) return HDSM_OK;
-  if (!world || !off || !ground_k || !seed || !variant || !origin || !rows || !n_rows || !rc || !scratch)
+  if (!world || !off || !ground_k || !seed || !variant || !origin || !rows || !n_rows || !rc || (!wave && !scratch))
     return fail(HDSM_ERR_BAD_ARG, "null array argument");
   if (hipSetDevice(device) != hipSuccess) return fail(HDSM_ERR_NO_DEVICE, "hipSetDevice failed");
   Batch b{};
@@ -99,16 +150,33 @@ int hdsm_poly_octa3d_device(int32_t device, int32_t n, const int8_t* world, cons
   b.n = n, b.n_it = n_it, b.max_rows = max_rows, b.res = res;
   b.off = off, b.ground = ground_k, b.seed = seed, b.variant = variant, b.origin = origin;
   b.rows = rows, b.n_rows = n_rows, b.rc = rc, b.cells = cells, b.scratch = static_cast<unsigned char*>(scratch);
-  hipLaunchKernelGGL(k_poly_octa3d, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b);
+  if (wave) hipLaunchKernelGGL(k_poly_octa3d_wave, dim3(n), dim3(64), SLAB_LDS, static_cast<hipStream_t>(hip_stream), b);
+  else hipLaunchKernelGGL(k_poly_octa3d, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(HDSM_ERR_DEVICE, std::string("k_poly_octa3d: ") + hipGetErrorString(e));
   return HDSM_OK;
 }
 
-int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
-                           const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
-                           const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
-                           int32_t* rc, int32_t* cells) {
+int hdsm_poly_octa3d_device(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                            const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                            const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                            int32_t* rc, int32_t* cells, void* scratch, void* hip_stream) {
+  return launch_batch(false, device, n, world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, res, rows, max_rows, n_rows, rc, cells,
+                      scratch, hip_stream);
+}
+
+int hdsm_poly_octa3d_device_wave(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                                 const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                                 const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                                 int32_t* rc, int32_t* cells, void* hip_stream) {
+  return launch_batch(true, device, n, world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, res, rows, max_rows, n_rows, rc, cells,
+                      nullptr, hip_stream);
+}
+
+static int batch_impl(bool wave, int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                      const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                      const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                      int32_t* rc, int32_t* cells) {
   if (n < 0 || !wdim || !ldim) return fail(HDSM_ERR_BAD_ARG, "bad size argument");
   if (n == 0) return HDSM_OK;
   if (!world || !off || !ground_k || !seed || !variant || !origin || !rows || !n_rows || !rc) return fail(HDSM_ERR_BAD_ARG, "null array argument");
@@ -123,7 +191,7 @@ int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const
     if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1);
   };
   al(&d_world, wtot), al(&d_off, N * 12), al(&d_ground, N * 4), al(&d_seed, N * 12), al(&d_var, N * 4), al(&d_org, N * 24);
-  al(&d_rows, N * max_rows * 32), al(&d_nrows, N * 4), al(&d_rc, N * 4), al(&d_cells, N * 4), al(&d_scratch, hdsm_poly_octa3d_scratch_bytes(n));
+  al(&d_rows, N * max_rows * 32), al(&d_nrows, N * 4), al(&d_rc, N * 4), al(&d_cells, N * 4), al(&d_scratch, wave ? 16 : hdsm_poly_octa3d_scratch_bytes(n));
   auto up = [&](void* d, const void* h, size_t bytes) {
     if (e == hipSuccess) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
   };
@@ -131,9 +199,9 @@ int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const
   up(d_org, origin, N * 24);
   int rcall = HDSM_OK;
   if (e == hipSuccess)
-    rcall = hdsm_poly_octa3d_device(device, n, (const int8_t*)d_world, wdim, ldim, (const int32_t*)d_off, (const int32_t*)d_ground,
-                                    (const int32_t*)d_seed, (const int32_t*)d_var, (const double*)d_org, n_it, res, (double*)d_rows, max_rows,
-                                    (int32_t*)d_nrows, (int32_t*)d_rc, (int32_t*)d_cells, d_scratch, nullptr);
+    rcall = launch_batch(wave, device, n, (const int8_t*)d_world, wdim, ldim, (const int32_t*)d_off, (const int32_t*)d_ground,
+                         (const int32_t*)d_seed, (const int32_t*)d_var, (const double*)d_org, n_it, res, (double*)d_rows, max_rows,
+                         (int32_t*)d_nrows, (int32_t*)d_rc, (int32_t*)d_cells, d_scratch, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   auto down = [&](void* h, const void* d, size_t bytes) {
     if (e == hipSuccess && h) e = hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
@@ -144,6 +212,20 @@ int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const
   if (rcall) return rcall;
   if (e != hipSuccess) return fail(HDSM_ERR_DEVICE, std::string("hdsm_poly_octa3d_batch: ") + hipGetErrorString(e));
   return HDSM_OK;
+}
+
+int hdsm_poly_octa3d_batch(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                           const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                           const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                           int32_t* rc, int32_t* cells) {
+  return batch_impl(false, device, n, world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, res, rows, max_rows, n_rows, rc, cells);
+}
+
+int hdsm_poly_octa3d_batch_wave(int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
+                                const int32_t* off, const int32_t* ground_k, const int32_t* seed, const int32_t* variant,
+                                const double* origin, int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows,
+                                int32_t* rc, int32_t* cells) {
+  return batch_impl(true, device, n, world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, res, rows, max_rows, n_rows, rc, cells);
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_creat
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
            "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
            "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new", "hdsm_poly_octa3d_batch",
-           "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_corridor_last_error",
+           "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_poly_octa3d_batch_wave", "hdsm_poly_octa3d_device_wave", "hdsm_corridor_last_error",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
            "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_swarm_record_solve_ms", "hdsm_swarm_shutdown", "hdsm_swarm_prepare_corridor", "hdsm_swarm_vel_cap",
            "hdsm_dswarm_create", "hdsm_dswarm_upload_plans", "hdsm_dswarm_round", "hdsm_dswarm_download", "hdsm_dswarm_destroy", "hdsm_dswarm_last_error",
@@ -277,9 +277,9 @@ def map_preprocess_device(cfg, d_in, d_out, d_scratch, stream=None, device=0):
         raise HdsmError(rc, L.hdsm_map_last_error().decode())
 
 
-def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32, device=0):
+def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32, device=0, wave=False):
     """hdsm_poly_octa3d_batch (row f2 on the device): world int8 [wz][wy][wx]; off/seed [n][3], ground_k/variant [n], origin [n][3].
-    Returns rows [n][max_rows][4], n_rows [n], rc [n], cells [n]."""
+    Returns rows [n][max_rows][4], n_rows [n], rc [n], cells [n]. wave=True: hdsm_poly_octa3d_batch_wave (one wavefront per seed)."""
     L = load()
     world = np.ascontiguousarray(world, dtype=np.int8)
     wdim = np.asarray(world.shape[::-1], dtype=np.int32)
@@ -291,7 +291,7 @@ def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42
     rows = np.zeros((n, max_rows, 4))
     n_rows, rc, cells = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
     i32, d = C.c_int32, C.c_double
-    r = L.hdsm_poly_octa3d_batch(C.c_int32(device), C.c_int32(n), world.ctypes.data_as(C.POINTER(C.c_int8)), _p(wdim, i32), _p(ldim, i32),
+    r = (L.hdsm_poly_octa3d_batch_wave if wave else L.hdsm_poly_octa3d_batch)(C.c_int32(device), C.c_int32(n), world.ctypes.data_as(C.POINTER(C.c_int8)), _p(wdim, i32), _p(ldim, i32),
                                  _p(off, i32), _p(ground_k, i32), _p(seed, i32), _p(variant, i32), _p(origin, d), C.c_int32(n_it),
                                  C.c_double(res), _p(rows, d), C.c_int32(max_rows), _p(n_rows, i32), _p(rc, i32), _p(cells, i32))
     if r:

@@ -32,6 +32,21 @@ lib.poly_octa3d_batch(occ, ldim, off[:64], zero[:64], seed[:64], var[:64], org[:
 t0 = time.perf_counter()
 rows, n_rows, rc, cells = lib.poly_octa3d_batch(occ, ldim, off, zero, seed, var, org)
 t_dev = time.perf_counter() - t0
+# the two device forms on small batches (what one round of a swarm asks for): latency matters there, not seeds in flight
+small = {}
+lib.poly_octa3d_batch(occ, ldim, off[:64], zero[:64], seed[:64], var[:64], org[:64], wave=True)
+for k in (1, 64, 256, 1024, 4096):
+    if k > n:
+        continue
+    rec = {}
+    for name, wave in (("thread_per_seed", False), ("wavefront_per_seed", True)):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lib.poly_octa3d_batch(occ, ldim, off[:k], zero[:k], seed[:k], var[:k], org[:k], wave=wave)
+            ts.append(time.perf_counter() - t0)
+        rec[name + "_ms"] = min(ts) * 1e3
+    small[str(k)] = rec
 m = min(n, 512)
 t0 = time.perf_counter()
 for t in range(m):
@@ -43,4 +58,5 @@ print(json.dumps({"what": "hdsm_poly_octa3d_batch (one thread per seed; includes
                           "one core, per call (includes the Python binding)",
                   "world_voxels": int(occ.size), "seeds": n, "device_batch_s": t_dev, "device_us_per_seed": t_dev / n * 1e6,
                   "host_us_per_seed_one_core": t_host * 1e6, "rows_mean": float(n_rows.mean()), "failed": int((rc != 0).sum()),
-                  "cells_mean": float(cells.mean())}))
+                  "cells_mean": float(cells.mean()),
+                  "small_batches_incl_world_upload_ms": small}))

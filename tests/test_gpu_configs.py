@@ -230,6 +230,12 @@ def test_voxel_decomposition_on_the_device_matches_the_host_bit_for_bit(hdsm):
         off, seed, org = np.array(off, np.int32), np.array(seed, np.int32), np.array(org)
         ground, variant = np.array(ground, np.int32), np.array(variant, np.int32)
         rows, n_rows, rc, cells = hdsm.poly_octa3d_batch(occ2, ldim, off, ground, seed, variant, org, n_it=42, res=0.3, max_rows=32)
+        # the cooperative form (one wavefront per seed, workspace in LDS: what the device loop's corridor kernel runs) gives the
+        # same rows, row counts, return codes and voxel counts, bit for bit
+        w_rows, w_n, w_rc, w_cells = hdsm.poly_octa3d_batch(occ2, ldim, off, ground, seed, variant, org, n_it=42, res=0.3, max_rows=32, wave=True)
+        assert np.array_equal(w_n, n_rows) and np.array_equal(w_rc, rc) and np.array_equal(w_cells, cells), wname
+        valid = np.arange(32)[None, :] < n_rows[:, None]  # (rows beyond n_rows are not written)
+        assert np.array_equal(w_rows[valid], rows[valid]), wname
         aware_cnt = chamfered = 0
         for t in range(n):
             loc = np.zeros((20, 66, 66), np.int8)
