@@ -283,7 +283,8 @@ int hdsm_reset_warm_start(void* handle);
 /* Text of the last error on this thread (HIP error string or argument check that failed).                 */
 const char* hdsm_last_error(void);
 
-/* Library/ABI version: (major << 16) | minor. 1.1: hdsm_params grew the execution knobs and time_limit_s.   */
+/* Library/ABI version: (major << 16) | minor. 1.1: hdsm_params grew the execution knobs and time_limit_s;
+ * 1.2: + hdsm_poly_octa3d_batch_wave / hdsm_poly_octa3d_device_wave (hdsm_swarm.h); nothing removed or changed.   */
 int32_t hdsm_version(void);
 
 #ifdef __cplusplus

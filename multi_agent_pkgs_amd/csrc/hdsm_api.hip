@@ -622,7 +622,7 @@ int check_common(Handle* h, int n_inst, int n_rob) {
 
 extern "C" {
 
-int32_t hdsm_version(void) { return (1 << 16) | 1; }
+int32_t hdsm_version(void) { return (1 << 16) | 2; }  // 1.2: + hdsm_poly_octa3d_batch_wave / _device_wave
 
 const char* hdsm_last_error(void) { return g_err.c_str(); }
 
