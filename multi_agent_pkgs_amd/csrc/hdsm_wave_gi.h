@@ -796,7 +796,7 @@ struct WaveGI {
           s.lam[lane] = (lane < q) ? lk : 0.0;
           if (lane < n) R.xi = xw, s.x[lane] = xw;
         }
-        if (lane == 0) s.f = s.fx0 + 0.5 * bcast64(tt, 0), s.q = q;
+        if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;  // (lane 0's suffix sum is the whole sum)
         wsync();
         PROF(21)
 #ifdef HDSM_DEBUG

@@ -2,7 +2,7 @@
 i.e. the statements the HIP kernel executes for staging rows, verification sweeps and the lazy
 branch-and-bound state machine, checked against the oracle without a GPU. (The device build swaps the inner
 active-set iteration for the register-resident wave version of hdsm_wave_gi.h; that one is covered by the
--m gpu tests.)"""
+-m gpu tests and, on the CPU, by tests/test_wave_emu.py, which runs the device source itself in lockstep fibers.)"""
 import numpy as np
 import pytest
 

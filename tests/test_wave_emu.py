@@ -1,0 +1,101 @@
+"""CPU tests of the DEVICE source of the solver kernel. tests/wave_emu compiles multi_agent_pkgs_amd/csrc/hdsm_core.h +
+hdsm_wave_gi.h in DEVICE mode with g++ against a stand-in for <hip/hip_runtime.h> and runs one workgroup = one wavefront as 64
+fibers in lockstep (every DPP move, v_readlane, v_permlane32_swap, ballot and wsync() is a rendezvous of all lanes, and a
+cross-lane operation reached by only some of the lanes is an error). What the -m gpu tests check on hardware for the
+register-resident active set — split rows, Householder add / drop, warm start and certificates, conflict learning, the
+sweeps on packed positions, the sphere prefilter — is checked here against the oracle without a GPU."""
+import numpy as np
+import pytest
+
+import problems
+from multi_agent_pkgs_amd.params import agile_params, make_params
+
+ARG_KEYS = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+
+
+@pytest.fixture(scope="module")
+def wave():
+    from wave_emu import pywave
+    pywave.lib()
+    return pywave
+
+
+def compare(e, o, tol=1e-8):
+    assert (e["status"] == o["status"]).all(), (e["status"].tolist(), o["status"].tolist())
+    ok = o["status"] != 2
+    if ok.any():
+        assert np.abs(e["traj"] - o["traj"])[ok].max() < tol
+        assert (np.abs(e["obj"] - o["obj"])[ok] / np.maximum(1, np.abs(o["obj"][ok]))).max() < 1e-8
+
+
+CASES = [dict(n_rob=12, seed=1), dict(n_rob=12, seed=2, turn=True), dict(n_rob=12, seed=3, narrow=True, turn=True),
+         dict(n_rob=16, seed=4, spacing=1.0), dict(n_rob=12, seed=5, chamfer=True, narrow=True, turn=True),
+         dict(n_rob=12, seed=6, first_round=True), dict(n_rob=24, seed=8, absent_frac=0.3, spacing=1.5)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_device_source_matches_oracle_h10(wave, oracle, case):
+    """n = 30: the kernel whose rows of J are split over two lanes (NV = 32)."""
+    prm = agile_params(10, max_rows_static=18)
+    case = dict(case)
+    sn = problems.swarm_snapshot(prm, case.pop("n_rob"), case.pop("seed"), **case)
+    args = [sn[k] for k in ARG_KEYS]
+    compare(wave.replan(prm, *args), oracle.replan(prm, *args, n_threads=8))
+
+
+@pytest.mark.parametrize("n_hor,rk4,drag", [(15, False, (0, 0, 0)), (9, True, (0.1, 0.1, 0.3)), (12, True, (0, 0, 0)), (7, False, (0.2, 0.1, 0))])
+def test_device_source_matches_oracle_other_configs(wave, oracle, n_hor, rk4, drag):
+    """Other horizons (n > 30: one lane per row, NV = 48; n < 30: padded factors), RK4 and drag."""
+    prm = make_params(n_hor=n_hor, rk4=rk4, drag=drag, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 10, seed=100 + n_hor, turn=True)
+    args = [sn[k] for k in ARG_KEYS]
+    compare(wave.replan(prm, *args), oracle.replan(prm, *args, n_threads=8))
+
+
+def test_warm_start_and_certificates_do_not_change_the_answer(wave, oracle):
+    """Consecutive replans on one warm-start store (what a handle keeps between launches): the second replan of the SAME
+    inputs is seeded with the first one's working sets — or, for an infeasible instance, with its certificate — and must
+    return the same results with fewer active-set operations; a store filled by a DIFFERENT snapshot (a wrong guess) must
+    not change the results either."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 16, seed=4, spacing=1.0)       # tight: some instances are infeasible
+    args = [sn[k] for k in ARG_KEYS]
+    o = oracle.replan(prm, *args, n_threads=8)
+    assert (o["status"] == 2).any() and (o["status"] == 0).any()
+    store = wave.new_warm_store(16)
+    cold = wave.replan(prm, *args, warm=store)
+    compare(cold, o)
+    assert (store[:, 0] != 0).any()
+    assert ((store[:, 0] & (1 << 30)) != 0).sum() == (o["status"] == 2).sum()   # certificates of the infeasible instances
+    warm = wave.replan(prm, *args, warm=store)
+    compare(warm, o)
+    assert warm["qp_iters"].sum() < cold["qp_iters"].sum()
+    other = problems.swarm_snapshot(prm, 16, seed=2, turn=True)
+    wrong = wave.replan(prm, *[other[k] for k in ARG_KEYS], warm=store)          # store still holds snapshot 4's sets
+    compare(wrong, oracle.replan(prm, *[other[k] for k in ARG_KEYS], n_threads=8))
+
+
+def test_sphere_prefilter_stages_the_same_rows(wave, oracle):
+    """With the sphere records (swarms >= bounds_min agents) the sweeps skip whole neighbours and the automatic pre-sweep is
+    left to the instances whose warm start holds neighbour rows; the answer is that of the step-by-step test."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 40, seed=8, absent_frac=0.2, spacing=1.5)
+    args = [sn[k] for k in ARG_KEYS]
+    plain = wave.replan(prm, *args, bounds_min=10 ** 6)
+    pre = wave.replan(prm, *args, bounds_min=1)
+    compare(pre, oracle.replan(prm, *args, n_threads=8))
+    assert np.array_equal(pre["status"], plain["status"]) and np.abs(pre["traj"] - plain["traj"]).max() < 1e-12
+
+
+def test_branch_and_bound_with_conflict_learning(wave, oracle):
+    """Corridors that force real branching (narrow boxes, turning paths): the device's lazy B&B with conflict learning
+    returns the oracle's optimum (the oracle enumerates depth-first without learning)."""
+    prm = agile_params(10, max_rows_static=18)
+    nodes = 0
+    for seed in (3, 5, 21):
+        sn = problems.swarm_snapshot(prm, 10, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        args = [sn[k] for k in ARG_KEYS]
+        e = wave.replan(prm, *args)
+        compare(e, oracle.replan(prm, *args, n_threads=8))
+        nodes += int(e["nodes"].sum())
+    assert nodes > 3 * 10

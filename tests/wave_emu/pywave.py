@@ -1,0 +1,55 @@
+"""ctypes loader of the CPU execution of the DEVICE kernel source (tests/wave_emu/libhdsm_wave_emu.so). TEST INFRASTRUCTURE."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libhdsm_wave_emu.so")
+_lib = None
+MAXNV = 48
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _lib = C.CDLL(_SO)
+        _lib.wave_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def new_warm_store(n_inst):
+    """The handle's warm-start store: pass the same array to consecutive replans of the same instances."""
+    return np.zeros((n_inst, MAXNV + 2), dtype=np.int32)
+
+
+def replan(prm, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, warm=None, bounds_min=256):
+    N, P = prm.n_hor, prm.poly_hor
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    agent_id, n_poly, n_rows = i32(agent_id), i32(n_poly), i32(n_rows)
+    state, ref, A, b, plans = f64(state), f64(ref), f64(A), f64(b), f64(plans)
+    has_plan = np.ascontiguousarray(has_plan, dtype=np.uint8)
+    n_inst, n_rob = state.shape[0], plans.shape[0]
+    out = dict(traj=np.zeros((n_inst, N + 1, 9)), ctrl=np.zeros((n_inst, N, 3)), used=np.zeros((n_inst, P), dtype=np.uint8),
+               status=np.zeros(n_inst, dtype=np.int32), obj=np.zeros(n_inst), qp_iters=np.zeros(n_inst, dtype=np.int32),
+               nodes=np.zeros(n_inst, dtype=np.int32), sweeps=np.zeros(n_inst, dtype=np.int32), cand=np.zeros(n_inst, dtype=np.int32),
+               flags=np.zeros(n_inst, dtype=np.uint32))
+    d, i, u = C.c_double, C.c_int32, C.c_uint8
+    if warm is not None:
+        assert warm.dtype == np.int32 and warm.flags.c_contiguous and warm.shape == (n_inst, MAXNV + 2)
+    rc = lib().wave_replan(C.byref(prm), n_inst, n_rob, _p(agent_id, i), _p(state, d), _p(ref, d), _p(n_poly, i), _p(n_rows, i),
+                           _p(A, d), _p(b, d), _p(plans, d), _p(has_plan, u), _p(out["traj"], d), _p(out["ctrl"], d),
+                           _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d), _p(out["qp_iters"], i), _p(out["nodes"], i),
+                           _p(out["sweeps"], i), _p(out["cand"], i), _p(out["flags"], C.c_uint32),
+                           _p(warm, i) if warm is not None else None, C.c_int32(bounds_min))
+    if rc == -100:
+        raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
+    assert rc == 0, rc
+    return out

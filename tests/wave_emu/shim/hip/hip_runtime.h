@@ -1,0 +1,211 @@
+// TEST INFRASTRUCTURE — a stand-in for <hip/hip_runtime.h> that lets g++ compile the DEVICE source of the solver kernel
+// (multi_agent_pkgs_amd/csrc/hdsm_core.h + hdsm_wave_gi.h, device mode, NOT the HDSM_EMU logic build) and run it on the CPU:
+// the 64 lanes of one wavefront are 64 fibers (ucontext) executed in lockstep by one host thread; every cross-lane
+// operation (DPP moves, v_readlane, v_permlane32_swap, ballot, shuffles, __syncthreads) is a rendezvous of all lanes on an
+// exchange buffer. One wavefront per workgroup (the product's 64-thread launch, HDSM_THREADS=64). See wave_emu.cpp.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <array>
+#ifdef WEMU_DEBUG
+#include <execinfo.h>
+#endif
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+#define __shared__
+
+namespace wemu {
+struct Dim3 {
+  unsigned x, y, z;
+};
+constexpr int W = 64;
+struct Runtime {
+  int cur = 0;                 // lane whose fiber is running
+  int nlive = 0, arrived = 0;  // rendezvous state
+  unsigned long generation = 0;
+  int tag = -1;                // kind of the operation the current rendezvous belongs to (all lanes must agree)
+  int parity = 0;              // exchange buffer in use
+  int xi[2][W];
+  double xd[2][W];
+  Dim3 tid[W];
+  Dim3 block{W, 1, 1}, grid{1, 1, 1}, bidx{0, 0, 0};
+  long long clock = 0;
+  long ops = 0;
+  int lane_tag[W];             // kind of the operation each lane is waiting at (diagnostics)
+  const char* where[W];
+#ifdef WEMU_DEBUG
+  void* bt[W][12];
+  int nbt[W];
+#endif
+};
+Runtime& rt();
+void yield();                  // back to the scheduler
+[[noreturn]] void fail(const char* what);
+
+// all live lanes meet here; returns the buffer index that was written before the meeting
+inline int rendezvous(int tag) {
+  Runtime& r = rt();
+  r.lane_tag[r.cur] = tag;
+#ifdef WEMU_DEBUG
+  r.nbt[r.cur] = backtrace(r.bt[r.cur], 12);
+#endif
+  if (r.arrived == 0) r.tag = tag;
+  else if (r.tag != tag) {
+    static char msg[160];
+    unsigned long long at_first = 0;
+    for (int l = 0; l < W; ++l) at_first |= (unsigned long long)(r.lane_tag[l] == r.tag && l != r.cur) << l;
+#ifdef WEMU_DEBUG
+    fprintf(stderr, "---- arriving lane %d:\n", r.cur);
+    backtrace_symbols_fd(r.bt[r.cur], r.nbt[r.cur], 2);
+    for (int l = W - 1; l >= 0; --l)
+      if ((at_first >> l) & 1) {
+        fprintf(stderr, "---- waiting lane %d:\n", l);
+        backtrace_symbols_fd(r.bt[l], r.nbt[l], 2);
+        break;
+      }
+#endif
+    snprintf(msg, sizeof msg, "lanes of the wavefront reached DIFFERENT cross-lane operations (kinds %d and %d, %d lanes waiting, mask %llx): divergent use", r.tag, tag, r.arrived, at_first);
+    fail(msg);
+  }
+  const int p = r.parity;
+  const unsigned long gen = r.generation;
+  if (++r.arrived == r.nlive) {
+    r.arrived = 0, ++r.generation, r.parity ^= 1, ++r.ops;
+  } else {
+    while (r.generation == gen) yield();
+  }
+  return p;
+}
+inline int lane() { return rt().cur; }
+inline int xchg_i(int v, int src_lane_of_me(int), int tag);
+}  // namespace wemu
+
+#define threadIdx (wemu::rt().tid[wemu::rt().cur])
+#define blockDim (wemu::rt().block)
+#define gridDim (wemu::rt().grid)
+#define blockIdx (wemu::rt().bidx)
+
+struct alignas(16) double4 {
+  double x, y, z, w;
+};
+
+// ---- scalar helpers ------------------------------------------------------------------------------------------------
+inline int __double2loint(double v) {
+  uint64_t u;
+  memcpy(&u, &v, 8);
+  return (int)(uint32_t)u;
+}
+inline int __double2hiint(double v) {
+  uint64_t u;
+  memcpy(&u, &v, 8);
+  return (int)(uint32_t)(u >> 32);
+}
+inline double __hiloint2double(int hi, int lo) {
+  const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  double v;
+  memcpy(&v, &u, 8);
+  return v;
+}
+inline double __longlong_as_double(long long x) {
+  double v;
+  memcpy(&v, &x, 8);
+  return v;
+}
+inline long long __double_as_longlong(double x) {
+  long long v;
+  memcpy(&v, &x, 8);
+  return v;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline long long clock64() { return ++wemu::rt().clock; }
+inline long long wall_clock64() { return ++wemu::rt().clock; }
+inline int atomicAdd(int* p, int v) {
+  const int old = *p;
+  *p = old + v;
+  return old;
+}
+inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  const unsigned old = *p;
+  *p = old + v;
+  return old;
+}
+
+// ---- cross-lane operations -----------------------------------------------------------------------------------------
+inline void __syncthreads() { (void)wemu::rendezvous(1); }
+inline int wemu_readlane_i(int v, int src) {
+  wemu::Runtime& r = wemu::rt();
+  r.xi[r.parity][r.cur] = v;
+  const int me = r.cur;
+  (void)me;
+  const int p = wemu::rendezvous(2);
+  return wemu::rt().xi[p][src & 63];
+}
+#define __builtin_amdgcn_readlane(v, l) wemu_readlane_i((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) wemu_readlane_i((v), 0)
+inline unsigned long long __ballot(int pred) {
+  wemu::Runtime& r = wemu::rt();
+  r.xi[r.parity][r.cur] = pred ? 1 : 0;
+  const int p = wemu::rendezvous(3);
+  unsigned long long m = 0;
+  for (int l = 0; l < wemu::W; ++l) m |= (unsigned long long)(wemu::rt().xi[p][l] & 1) << l;
+  return m;
+}
+inline int __shfl_xor(int v, int mask, int width = 64) {
+  wemu::Runtime& r = wemu::rt();
+  const int me = r.cur;
+  r.xi[r.parity][me] = v;
+  const int p = wemu::rendezvous(4);
+  const int src = me ^ mask;
+  return (src / width == me / width) ? wemu::rt().xi[p][src] : v;
+}
+inline double __shfl_xor(double v, int mask, int width = 64) {
+  wemu::Runtime& r = wemu::rt();
+  const int me = r.cur;
+  r.xd[r.parity][me] = v;
+  const int p = wemu::rendezvous(5);
+  const int src = me ^ mask;
+  return (src / width == me / width) ? wemu::rt().xd[p][src] : v;
+}
+// DPP moves within 16-lane rows: row_shl:n (0x100 + n) reads lane + n, row_shr:n (0x110 + n) lane - n, row_ror:n (0x120 + n)
+// rotates; a lane without a source keeps `old` (bound_ctrl: the callers pass old = 0 where they want zero fill)
+inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  wemu::Runtime& r = wemu::rt();
+  const int me = r.cur;
+  r.xi[r.parity][me] = src;
+  const int p = wemu::rendezvous(6);
+  const int row = me & ~15, i = me & 15, n = ctrl & 15;
+  int from = -1;
+  if ((ctrl & 0x1f0) == 0x100) from = (i + n < 16) ? i + n : -1;
+  else if ((ctrl & 0x1f0) == 0x110) from = (i - n >= 0) ? i - n : -1;
+  else if ((ctrl & 0x1f0) == 0x120) from = (i - n) & 15;
+  else wemu::fail("DPP control not modelled");
+  (void)row_mask, (void)bank_mask;
+  return from >= 0 ? wemu::rt().xi[p][row + from] : (bound_ctrl ? 0 : old);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+// v_permlane32_swap vdst, vsrc: lanes 32..63 of vdst <-> lanes 0..31 of vsrc; returns {new vdst, new vsrc}
+inline std::array<int, 2> wemu_permlane32_swap(int vdst, int vsrc, bool, bool) {
+  wemu::Runtime& r = wemu::rt();
+  const int me = r.cur;
+  r.xi[r.parity][me] = vdst;
+  const int p1 = wemu::rendezvous(7);
+  const int other_dst = wemu::rt().xi[p1][me ^ 32];
+  wemu::rt().xi[wemu::rt().parity][me] = vsrc;
+  const int p2 = wemu::rendezvous(8);
+  const int other_src = wemu::rt().xi[p2][me ^ 32];
+  return me < 32 ? std::array<int, 2>{vdst, other_dst} : std::array<int, 2>{other_src, vsrc};
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, c, d) wemu_permlane32_swap((a), (b), (c), (d))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)wemu::rendezvous(9))  // wsync(): on the device the lanes are in lockstep anyway
+#define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))

@@ -1,0 +1,168 @@
+// wave_emu.cpp — runs the DEVICE source of the solver kernel on the CPU (TEST INFRASTRUCTURE ONLY).
+//
+// What tests/emu covers is the kernel LOGIC with a textbook active set; the code that actually runs on the GPU — the
+// register-resident, wave-level iteration of hdsm_wave_gi.h with its DPP scans, lane-split rows, Householder add / drop, warm
+// start, certificates, conflict learning, sweeps on the packed positions — was covered by the GPU tests only. Here that very
+// source is compiled by g++ against tests/wave_emu/shim/hip/hip_runtime.h: one workgroup = one wavefront = 64 fibers in
+// lockstep (the product's 64-thread launch), one instance after the other. Never linked into libhdsm.so, not a fallback.
+#include <ucontext.h>
+
+#include <memory>
+#include <vector>
+
+#include "../../multi_agent_pkgs_amd/csrc/hdsm_consts.h"
+#include "../../multi_agent_pkgs_amd/csrc/hdsm_core.h"
+
+namespace wemu {
+namespace {
+Runtime g_rt;
+ucontext_t g_main;
+ucontext_t g_ctx[W];
+bool g_done[W];
+char g_error[256];
+bool g_failed = false;
+constexpr size_t STACK = 512 * 1024;
+std::vector<char> g_stacks;
+void (*g_body)(void*) = nullptr;
+void* g_arg = nullptr;
+
+void trampoline() {
+  g_body(g_arg);
+  Runtime& r = g_rt;
+  g_done[r.cur] = true;
+  --r.nlive;
+  if (r.nlive > 0 && r.arrived == r.nlive) fail("a lane left the kernel while the others wait at a cross-lane operation");
+  swapcontext(&g_ctx[r.cur], &g_main);
+}
+}  // namespace
+
+Runtime& rt() { return g_rt; }
+void yield() { swapcontext(&g_ctx[g_rt.cur], &g_main); }
+void fail(const char* what) {
+  snprintf(g_error, sizeof g_error, "%s (lane %d, operation %ld)", what, g_rt.cur, g_rt.ops);
+  g_failed = true;
+  for (;;) swapcontext(&g_ctx[g_rt.cur], &g_main);  // never resumes: the scheduler stops on g_failed
+}
+
+// one workgroup of 64 threads executing body(arg); false + message on a lockstep violation
+bool run_wave(void (*body)(void*), void* arg, int block_index) {
+  Runtime& r = g_rt;
+  r = Runtime{};
+  r.bidx = {(unsigned)block_index, 0, 0};
+  r.nlive = W;
+  g_body = body, g_arg = arg, g_failed = false;
+  if (g_stacks.size() != STACK * W) g_stacks.assign(STACK * W, 0);
+  for (int l = 0; l < W; ++l) {
+    r.tid[l] = {(unsigned)l, 0, 0};
+    g_done[l] = false;
+    getcontext(&g_ctx[l]);
+    g_ctx[l].uc_stack.ss_sp = g_stacks.data() + STACK * l;
+    g_ctx[l].uc_stack.ss_size = STACK;
+    g_ctx[l].uc_link = &g_main;
+    makecontext(&g_ctx[l], trampoline, 0);
+  }
+  long idle_rounds = 0;
+  while (r.nlive > 0 && !g_failed) {
+    const unsigned long gen = r.generation;
+    const int live = r.nlive;
+    for (int l = 0; l < W && !g_failed; ++l) {
+      if (g_done[l]) continue;
+      r.cur = l;
+      swapcontext(&g_main, &g_ctx[l]);
+    }
+    if (r.generation == gen && r.nlive == live) {
+      if (++idle_rounds > 4) {
+        snprintf(g_error, sizeof g_error, "deadlock: %d of %d lanes wait at a cross-lane operation the others never reach", r.arrived, r.nlive);
+        g_failed = true;
+      }
+    } else {
+      idle_rounds = 0;
+    }
+  }
+  return !g_failed;
+}
+const char* last_error() { return g_error; }
+}  // namespace wemu
+
+namespace {
+template <int NV, int CMAX>
+struct Job {
+  typename hdsm::Solver<NV, CMAX>::S* s;
+  const hdsm::Consts* c;
+  hdsm::Args a;
+  int inst;
+};
+template <int NV, int CMAX>
+void body(void* p) {
+  auto* j = static_cast<Job<NV, CMAX>*>(p);
+  hdsm::Solver<NV, CMAX>::solve_instance(*j->s, *j->c, j->a, j->inst);
+}
+template <int NV, int CMAX>
+int run_all(const hdsm::Consts& c, hdsm::Args& a) {
+  using Sol = hdsm::Solver<NV, CMAX>;
+  a.scratch_stride = (int64_t)Sol::SNAP_STRIDE * hdsm::MAXH;
+  std::vector<double> scratch((size_t)a.scratch_stride);
+  auto shm = std::make_unique<typename Sol::S>();
+  for (int k = 0; k < a.n_inst; ++k) {
+    memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
+    Job<NV, CMAX> job{shm.get(), &c, a, k};
+    job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds inst * stride
+    if (!wemu::run_wave(body<NV, CMAX>, &job, k)) return -100;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" const char* wave_last_error(void) { return wemu::last_error(); }
+
+// Level-2 replan through the device source. `warm` = the handle's warm-start store, [(MAXNV + 2) * n_inst] int32, in/out (zeros:
+// cold; pass the same array again to continue like consecutive launches on one handle); null = warm start off.
+// `bounds_min`: swarms of at least this many agents get the sphere prefilter records, as hdsm_api.hip's launch() does.
+extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id, const double* state_curr,
+                           const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows_static, const double* A_static,
+                           const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
+                           uint8_t* poly_used, int32_t* status, double* obj, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
+                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min) {
+  auto c = std::make_unique<hdsm::Consts>();
+  const char* err = nullptr;
+  int rc = hdsm::build_consts(prm, c.get(), &err);
+  if (rc) return rc;
+  const int N = c->N;
+  // what k_plan_prepass hands to the kernel: packed positions of steps 1..N, and (large swarms) the sphere records
+  std::vector<double> pos((size_t)n_rob * N * 3, 0.0), bounds((size_t)n_rob * 4, 0.0);
+  for (int k = 0; k < n_rob; ++k) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < N; ++i)
+      for (int ax = 0; ax < 3; ++ax) {
+        const double v = has_plan[k] ? plans_all[((size_t)k * (N + 1) + 1 + i) * 9 + ax] : 0.0;
+        pos[((size_t)k * N + i) * 3 + ax] = v;
+        lo[ax] = v < lo[ax] ? v : lo[ax], hi[ax] = v > hi[ax] ? v : hi[ax];
+      }
+    double* b = &bounds[(size_t)k * 4];
+    b[3] = -1.0;
+    if (has_plan[k]) {
+      double r2 = 0;
+      for (int ax = 0; ax < 3; ++ax) b[ax] = 0.5 * (lo[ax] + hi[ax]);
+      for (int i = 0; i < N; ++i) {
+        double d2 = 0;
+        for (int ax = 0; ax < 3; ++ax) {
+          const double u = pos[((size_t)k * N + i) * 3 + ax] - b[ax];
+          d2 += u * u;
+        }
+        r2 = d2 > r2 ? d2 : r2;
+      }
+      b[3] = sqrt(r2) * (1.0 + 1e-9);
+      if (!(b[3] >= 0.0) || !(b[3] < 1e299)) b[3] = 1e300;
+    }
+  }
+  hdsm::Args a{};
+  a.n_inst = n_inst, a.n_rob = n_rob, a.agent_id = agent_id, a.state = state_curr, a.ref = traj_ref;
+  a.n_poly = n_poly, a.n_rows = n_rows_static, a.A = A_static, a.b = b_static, a.plans = plans_all;
+  a.has_plan = has_plan, a.traj = traj_out, a.ctrl = ctrl_out, a.used = poly_used, a.status = status;
+  a.obj = obj, a.st_iters = qp_iters, a.st_nodes = nodes, a.st_sweeps = sweeps, a.st_cand = cand, a.st_flags = flags;
+  a.pos = pos.data();
+  a.bounds = (n_rob >= bounds_min) ? bounds.data() : nullptr;
+  a.warm = (prm->warm_start && warm) ? warm : nullptr;
+  if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a);
+  return run_all<48, 1024>(*c, a);
+}
