@@ -40,6 +40,7 @@ struct Runtime {
   Dim3 block{W, 1, 1}, grid{1, 1, 1}, bidx{0, 0, 0};
   long long clock = 0;
   long ops = 0;
+  long by_kind[12] = {0};      // lockstep points by kind (1 barrier, 2 readlane, 3 ballot, 4/5 shuffle, 6 DPP, 7/8 permlane32_swap, 9 wsync)
   int lane_tag[W];             // kind of the operation each lane is waiting at (diagnostics)
   const char* where[W];
 #ifdef WEMU_DEBUG
@@ -79,7 +80,7 @@ inline int rendezvous(int tag) {
   const int p = r.parity;
   const unsigned long gen = r.generation;
   if (++r.arrived == r.nlive) {
-    r.arrived = 0, ++r.generation, r.parity ^= 1, ++r.ops;
+    r.arrived = 0, ++r.generation, r.parity ^= 1, ++r.ops, ++r.by_kind[tag < 12 ? tag : 0];
   } else {
     while (r.generation == gen) yield();
   }

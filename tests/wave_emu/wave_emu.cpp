@@ -108,7 +108,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a) {
     Job<NV, CMAX> job{shm.get(), &c, a, k};
     job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds inst * stride
     if (!wemu::run_wave(body<NV, CMAX>, &job, k)) return -100;
-    if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points, %d active-set operations\n", k, wemu::rt().ops, a.st_iters ? a.st_iters[k] : -1);
+    if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
   }
   return 0;
 }
