@@ -70,6 +70,11 @@ def test_warm_start_and_certificates_do_not_change_the_answer(wave, oracle):
     warm = wave.replan(prm, *args, warm=store)
     compare(warm, o)
     assert warm["qp_iters"].sum() < cold["qp_iters"].sum()
+    # no pre-staging around a certificate's far-away point: an instance whose (time-shifted) certificate still proves
+    # infeasibility ends without any neighbour sweep; cold, every one of them needed its pre-sweep
+    bad = o["status"] == 2
+    assert (cold["sweeps"][bad] >= 1).all() and (warm["sweeps"][bad] == 0).sum() >= 3
+    assert warm["sweeps"][bad].sum() < cold["sweeps"][bad].sum()
     other = problems.swarm_snapshot(prm, 16, seed=2, turn=True)
     wrong = wave.replan(prm, *[other[k] for k in ARG_KEYS], warm=store)          # store still holds snapshot 4's sets
     compare(wrong, oracle.replan(prm, *[other[k] for k in ARG_KEYS], n_threads=8))
@@ -99,3 +104,20 @@ def test_branch_and_bound_with_conflict_learning(wave, oracle):
         compare(e, oracle.replan(prm, *args, n_threads=8))
         nodes += int(e["nodes"].sum())
     assert nodes > 3 * 10
+
+
+def test_node_budget_is_reported(wave, oracle):
+    """hdsm_params.max_nodes = 1 on corridors that need branching: the instances that would branch come back as HDSM_LIMIT or
+    HDSM_NO_SOLUTION with HDSM_FLAG_NODE_LIMIT, never as a wrong optimum; the others are untouched."""
+    prm = agile_params(10, max_rows_static=18, max_nodes=1)
+    full = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 10, 3, narrow=True, turn=True)
+    args = [sn[k] for k in ARG_KEYS]
+    e, o = wave.replan(prm, *args), oracle.replan(full, *args, n_threads=8)
+    limited = (e["flags"] & 1) != 0
+    assert limited.any()
+    assert (e["status"][limited] != 0).all()
+    same = ~limited
+    assert (e["status"][same] == o["status"][same]).all()
+    ok = same & (o["status"] == 0)
+    assert np.abs(e["traj"][ok] - o["traj"][ok]).max() < 1e-8
