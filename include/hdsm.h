@@ -257,6 +257,12 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
 #define HDSM_FLAG_STAGING_OVERFLOW 8u /* more violated neighbour rows than staging slots: not a search budget   */
 int hdsm_last_sweep_stats(void* handle, int32_t n_inst, int32_t* sphere_records, int32_t* pairs, uint32_t* flags);
 
+/* Duration of the SOLVER KERNEL of the last hdsm_replan[_device] / hdsm_solve on this handle, by HIP events recorded on the
+ * launch stream right before and right after it (i.e. after the pre-pass; measurement aid: bench.py's roofline, which must
+ * agree with the kernel's duration in a rocprofv3 trace). Off by default; hdsm_last_kernel_ms synchronises on the second event. */
+int hdsm_set_kernel_timing(void* handle, int32_t on);
+int hdsm_last_kernel_ms(void* handle, float* ms);
+
 /* ---- multi-GPU: the per-round exchange of the published plans -------------------------------------------------
  * Replaces the DDS all-to-all of the reference (publisher AC:46-48 / 645-677, n_rob - 1 subscriptions AC:610-627,
  * callback AC:629-643) by ONE RCCL all-gather per replan round. Agents are sharded in contiguous id blocks of `per`
@@ -284,7 +290,8 @@ int hdsm_reset_warm_start(void* handle);
 const char* hdsm_last_error(void);
 
 /* Library/ABI version: (major << 16) | minor. 1.1: hdsm_params grew the execution knobs and time_limit_s;
- * 1.2: + hdsm_poly_octa3d_batch_wave / hdsm_poly_octa3d_device_wave (hdsm_swarm.h); nothing removed or changed.   */
+ * 1.2: + hdsm_poly_octa3d_batch_wave / hdsm_poly_octa3d_device_wave (hdsm_swarm.h), hdsm_set_kernel_timing /
+ * hdsm_last_kernel_ms; nothing removed or changed.                                                          */
 int32_t hdsm_version(void);
 
 #ifdef __cplusplus

@@ -480,6 +480,8 @@ struct Handle {
   int order_min = 0;          // batches of at least this many instances are launched most-expensive-first (0 = never)
   uint8_t* d_zero = nullptr;  // n_rob_max zero bytes (has_plan of level 1)
   hipEvent_t ev_done = nullptr;  // recorded after every launch: orders launches that arrive on different streams
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // hdsm_set_kernel_timing: around the solver kernel alone (after the pre-pass)
+  bool time_kernel = false, timed = false;
   bool launched = false;
   struct Buf {                // grow-only device scratch of the host-pointer entry points
     void* p = nullptr;
@@ -568,10 +570,15 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
   int rc;
+  if (h->time_kernel) HIP_TRY(hipEventRecord(h->ev_k0, st));
   if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo(h, a, st);
   else if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
   else rc = h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
   if (rc) return rc;
+  if (h->time_kernel) {
+    HIP_TRY(hipEventRecord(h->ev_k1, st));
+    h->timed = true;
+  }
   HIP_TRY(hipEventRecord(h->ev_done, st));
   h->launched = true;
   return HDSM_OK;
@@ -607,6 +614,8 @@ void free_all(Handle* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+  if (h->ev_k0) (void)hipEventDestroy(h->ev_k0);
+  if (h->ev_k1) (void)hipEventDestroy(h->ev_k1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -622,7 +631,7 @@ int check_common(Handle* h, int n_inst, int n_rob) {
 
 extern "C" {
 
-int32_t hdsm_version(void) { return (1 << 16) | 2; }  // 1.2: + hdsm_poly_octa3d_batch_wave / _device_wave
+int32_t hdsm_version(void) { return (1 << 16) | 2; }  // 1.2: + hdsm_poly_octa3d_batch_wave / _device_wave, hdsm_set_kernel_timing / hdsm_last_kernel_ms
 
 const char* hdsm_last_error(void) { return g_err.c_str(); }
 
@@ -739,6 +748,8 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_k0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_k1);
   if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * I * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(h->d_zero, 0, (size_t)n_rob_max);
   if (e == hipSuccess) e = hipMemset(h->d_plans, 0, (size_t)n_rob_max * (N + 1) * 9 * sizeof(double));
@@ -935,6 +946,24 @@ int hdsm_reset_warm_start(void* handle) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->d_warm, 0, (size_t)(hdsm::MAXNV + 2) * h->max_inst * sizeof(int32_t)));
+  return HDSM_OK;
+}
+
+int hdsm_set_kernel_timing(void* handle, int32_t on) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return set_err(HDSM_ERR_BAD_ARG, "null handle");
+  h->time_kernel = on != 0;
+  if (!h->time_kernel) h->timed = false;
+  return HDSM_OK;
+}
+
+int hdsm_last_kernel_ms(void* handle, float* ms) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h || !ms) return set_err(HDSM_ERR_BAD_ARG, "null argument");
+  if (!h->timed) return set_err(HDSM_ERR_BAD_ARG, "no launch since hdsm_set_kernel_timing(handle, 1)");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(h->ev_k1));
+  HIP_TRY(hipEventElapsedTime(ms, h->ev_k0, h->ev_k1));
   return HDSM_OK;
 }
 

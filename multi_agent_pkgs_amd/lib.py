@@ -20,7 +20,7 @@ HDSM_COMM_ID_BYTES = 128
 
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
-           "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
+           "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_set_kernel_timing", "hdsm_last_kernel_ms", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
            "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new", "hdsm_poly_octa3d_batch",
            "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_poly_octa3d_batch_wave", "hdsm_poly_octa3d_device_wave", "hdsm_corridor_last_error",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
@@ -191,6 +191,14 @@ class Solver:
         _check(self.lib.hdsm_last_sweep_stats(self.h, n_inst, _p(st["sphere_records"], C.c_int32), _p(st["pairs"], C.c_int32),
                                               _p(st["flags"], C.c_uint32)))
         return st
+
+    def set_kernel_timing(self, on=True):
+        _check(self.lib.hdsm_set_kernel_timing(self.h, C.c_int32(1 if on else 0)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0.0)
+        _check(self.lib.hdsm_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def last_stats(self, n_inst):
         st = {k: np.zeros(n_inst, dtype=np.int32) for k in ("qp_iters", "nodes", "sweeps", "cand")}

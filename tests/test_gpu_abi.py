@@ -195,3 +195,25 @@ def test_mip_gap_accepts_what_gurobi_accepts(hdsm, oracle):
         assert (g["obj"][ok] <= exact["obj"][ok] * (1 + gap) + 1e-6).all() and (g["obj"][ok] >= exact["obj"][ok] - 1e-6).all()
         assert (g["nodes"] <= exact["nodes"]).all()
     assert exact["nodes"].max() > 1
+
+
+def test_kernel_timing_measures_the_solver_kernel_alone(hdsm):
+    """hdsm_set_kernel_timing / hdsm_last_kernel_ms: off by default (asking is an error), a positive duration after a launch,
+    below the wall-clock time of the synchronous host-pointer call that contains it."""
+    import time
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 64, seed=5, spacing=1.5)
+    args = [sn[k] for k in ARG_KEYS]
+    sol = hdsm.Solver(prm, 64, 64)
+    sol.replan(*args)
+    with pytest.raises(hdsm.HdsmError):
+        sol.last_kernel_ms()
+    sol.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    sol.replan(*args)
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms = sol.last_kernel_ms()
+    assert 0.0 < ms < wall_ms
+    sol.set_kernel_timing(False)
+    with pytest.raises(hdsm.HdsmError):
+        sol.last_kernel_ms()
