@@ -146,6 +146,14 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
       for (int r = 0; r < 3; ++r) v[r] = vn[r];
     }
   }
+  // p_m = free response + sum_{lag < m} g[ax][0][lag] u: the leading steps whose position no input reaches
+  c->pinned_steps = 0;
+  for (int m = 1; m <= N; ++m) {
+    bool zero = true;
+    for (int ax = 0; ax < 3; ++ax) zero = zero && c->g[ax][0][m - 1] == 0.0;
+    if (!zero) break;
+    c->pinned_steps = m;
+  }
 
   // ---- Hessian of the tracking objective (AC:870-883, AC:2098) in u, its Cholesky factor and inverse
   std::vector<double> H(n * n, 0.0), L(n * n, 0.0);

@@ -354,6 +354,15 @@ struct Solver {
     return tasc_plane_eval(c, cp, op, out);
   }
 
+  // Gridlock test of the first sweep. The positions of the first `pinned_steps` steps do not depend on the inputs (with jerk
+  // inputs and the Euler model p_1 and p_2 are fixed by the current state), so a neighbour row violated there is violated
+  // by EVERY trajectory: the instance is infeasible whatever the polyhedra, and it is known after one sweep instead of the
+  // dozens of active-set operations the dual method needs to run into the contradiction (two thirds of the infeasible
+  // instances of the bench rounds are of this kind: 114 of 178 in round 170, 222 of 222 in round 175). PINNED_TOL is far
+  // above the feasibility tolerance of the method and far below any real gridlock violation. It generalises the test of
+  // the pinned point p_0 (ftol_fixed); the flag is the same.
+  static constexpr double PINNED_TOL = 1e-7;
+
   static HD void sweep(S& s, const Consts& c, const Args& a, int inst, int self, double thresh, bool check_fixed) {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
@@ -388,6 +397,7 @@ struct Solver {
           if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
           continue;
         }
+        if (check_fixed && m <= c.pinned_steps && v > PINNED_TOL) s.fixed_bad = 1;
         if (v > c.tol) s.nviol = 1;  // benign race: every writer stores the same value
         if (-v < thresh) {
 #ifdef HDSM_EMU
@@ -899,26 +909,15 @@ struct Solver {
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
 #ifndef HDSM_EMU
-#ifdef HDSM_PROFILE
-    const long long tw_ = clock64();
-#endif
-    // the guess is an infeasibility certificate (see the hand-over below): its minimiser is a far-away point, staging the
-    // neighbour rows around it means thousands of rows and a retry per radius — the automatic pre-sweep is left out, and a
-    // certificate that still holds ends the instance after a few operations without any sweep
+    // The guess is an infeasibility certificate (see the hand-over below), or the last replan ended on the gridlock test of
+    // its sweep (PINNED_TOL): the neighbourhood was gridlocked. Such an instance sweeps FIRST, at the cold starting point: if
+    // the gridlock persists the test ends it right there; the certificate's own minimiser is a far-away point, so nothing
+    // is pre-staged around it afterwards.
     bool warm_cert = false;
-    if (a.warm != nullptr && np > 0) {
-      warm_cert = (a.warm[(int64_t)inst * (MAXNV + 2)] & WARM_CERT) != 0;
-      if (threadIdx.x < 64) {
-        W::warm_start(s, c, a, R, inst, self, iters);
-        if (threadIdx.x == 0) s.iters_sh = iters;
-      }
-      SYNC();
-      iters = s.iters_sh;
-    }
-#ifdef HDSM_PROFILE
-    t_leaf_ -= 0;
-    const long long t_warm_ = clock64() - tw_;
-    const int it_warm_ = iters;
+    if (a.warm != nullptr && np > 0) warm_cert = (a.warm[(int64_t)inst * (MAXNV + 2)] & WARM_CERT) != 0;
+#if defined(HDSM_PROFILE)
+    long long t_warm_ = 0;
+    int it_warm_ = 0;
 #endif
 #endif
     bool limit = false;
@@ -990,10 +989,30 @@ struct Solver {
         SYNC();
       }
     };
-#ifdef HDSM_EMU
-    const bool warm_cert = false;
+#ifndef HDSM_EMU
+    if (run && warm_cert && c.presweep != 0 && a.l1_rows == nullptr) {
+      if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
+      SYNC();
+      sweep_all(s.ncand, s.ncold);
+      if (s.fixed_bad) run = false;  // still gridlocked: infeasible whatever the choice
+    }
+    if (run && a.warm != nullptr) {
+#ifdef HDSM_PROFILE
+      const long long tw_ = clock64();
 #endif
-    if (run && (c.presweep == 1 || (c.presweep == 2 && !warm_cert && (a.bounds == nullptr || s.ncand > 0)))) {
+      if (threadIdx.x < 64) {
+        W::warm_start(s, c, a, R, inst, self, iters);
+        if (threadIdx.x == 0) s.iters_sh = iters;
+      }
+      SYNC();
+      iters = s.iters_sh;
+#ifdef HDSM_PROFILE
+      t_warm_ = clock64() - tw_;
+      it_warm_ = iters;
+#endif
+    }
+#endif
+    if (run && sweeps == 0 && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
       // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
       // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
       // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
@@ -1192,7 +1211,8 @@ struct Solver {
       }
       const int cnt = s.have_inc ? s.inc_nact : (certificate ? s.q + 1 : 0);
       PAR_FOR(k, NV) if (k < cnt) wp[1 + k] = s.inc_act[k];
-      if (IS_T0) wp[0] = cnt | (certificate ? WARM_CERT : 0);
+      const bool gridlock = s.fixed_bad && !s.have_inc;  // ended on the pinned-position test of a sweep
+      if (IS_T0) wp[0] = cnt | ((certificate || gridlock) ? WARM_CERT : 0);
     }
 #endif
 #if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)

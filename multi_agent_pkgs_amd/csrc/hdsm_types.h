@@ -39,6 +39,9 @@ struct Consts {
   double radius, k2m1, pert;   // drone_radius, (r/h)^2 - 1, plane perturbation
   double Ad[3][3][3], Bd[3][3];  // one-step maps per axis: x+ = Ad x + Bd u   (Euler or RK4, AC:2115-2152)
   double g[3][3][MAXH];          // impulse responses: g[ax][s][lag] = (Ad^lag Bd)[s]
+  int32_t pinned_steps;          // positions p_1 .. p_pinned do not depend on the inputs at all (the impulse response of the
+                                 // position is zero for that many lags: 2 with jerk inputs and the Euler model)
+  int32_t pad_pinned;
   double phi[3][MAXH + 1][3][3]; // Ad^i
   double Hinv[MAXNV * MAXNV];    // inverse Hessian, dense n x n, row-major with stride n
   double J0[MAXNV * MAXNV];      // L^{-T}, H = L L^T

@@ -556,6 +556,7 @@ struct WaveGI {
     const int N = c.N, n_rob = a.n_rob, nt = (int)blockDim.x;  // lane = thread of the WORKGROUP here (all waves sweep)
     PROF_DECL
     const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
+    const int pinned = c.pinned_steps;
     const bool pre = a.bounds != nullptr;
     // Rigorous cull. With p = c + delta:  slack(p) = n_f.(q - p) = |d|/2 - back - n_f.delta  and n_f.n = 1,
     // back <= s_max = max(r, h), |n_f| <= sqrt(1 + (3 pert)^2)  ==>  slack >= |d|/2 - s_max - |n_f| |delta|.
@@ -644,6 +645,7 @@ struct WaveGI {
               if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
               continue;
             }
+            if (check_fixed && m <= pinned && v > 1e-7) s.fixed_bad = 1;  // violated on a position no input can move (Solver::PINNED_TOL)
             if (v > tol) s.nviol = 1;
             if (-v < thresh) {
               const bool hot = -v < hot_tau;

@@ -52,32 +52,53 @@ def test_device_source_matches_oracle_other_configs(wave, oracle, n_hor, rk4, dr
     compare(wave.replan(prm, *args), oracle.replan(prm, *args, n_threads=8))
 
 
-def test_warm_start_and_certificates_do_not_change_the_answer(wave, oracle):
+def test_warm_start_and_gridlock_exit_do_not_change_the_answer(wave, oracle):
     """Consecutive replans on one warm-start store (what a handle keeps between launches): the second replan of the SAME
-    inputs is seeded with the first one's working sets — or, for an infeasible instance, with its certificate — and must
-    return the same results with fewer active-set operations; a store filled by a DIFFERENT snapshot (a wrong guess) must
-    not change the results either."""
+    inputs is seeded with the first one's working sets and must return the same results; a store filled by a DIFFERENT
+    snapshot (a wrong guess) must not change the results either. The infeasible instances of this tight snapshot are all
+    gridlocked — a neighbour's plane cuts off everything p_1 can reach under the jerk limit — and end on the reachability
+    test of their first sweep without a single active-set operation; the store remembers them (certificate bit, no rows) and
+    the next replan sweeps first."""
     prm = agile_params(10, max_rows_static=18)
-    sn = problems.swarm_snapshot(prm, 16, seed=4, spacing=1.0)       # tight: some instances are infeasible
+    sn = problems.swarm_snapshot(prm, 16, seed=4, spacing=1.0)
     args = [sn[k] for k in ARG_KEYS]
     o = oracle.replan(prm, *args, n_threads=8)
-    assert (o["status"] == 2).any() and (o["status"] == 0).any()
+    bad = o["status"] == 2
+    assert bad.any() and (~bad).any()
     store = wave.new_warm_store(16)
     cold = wave.replan(prm, *args, warm=store)
     compare(cold, o)
-    assert (store[:, 0] != 0).any()
-    assert ((store[:, 0] & (1 << 30)) != 0).sum() == (o["status"] == 2).sum()   # certificates of the infeasible instances
+    assert (cold["qp_iters"][bad] == 0).all() and (cold["sweeps"][bad] == 1).all()
+    assert (store[bad, 0] == (1 << 30)).all() and (store[~bad, 0] > 0).all() and (store[~bad, 0] < (1 << 30)).all()
     warm = wave.replan(prm, *args, warm=store)
     compare(warm, o)
-    assert warm["qp_iters"].sum() < cold["qp_iters"].sum()
-    # no pre-staging around a certificate's far-away point: an instance whose (time-shifted) certificate still proves
-    # infeasibility ends without any neighbour sweep; cold, every one of them needed its pre-sweep
-    bad = o["status"] == 2
-    assert (cold["sweeps"][bad] >= 1).all() and (warm["sweeps"][bad] == 0).sum() >= 3
-    assert warm["sweeps"][bad].sum() < cold["sweeps"][bad].sum()
+    assert (warm["qp_iters"][bad] == 0).all() and (warm["sweeps"][bad] == 1).all()
     other = problems.swarm_snapshot(prm, 16, seed=2, turn=True)
     wrong = wave.replan(prm, *[other[k] for k in ARG_KEYS], warm=store)          # store still holds snapshot 4's sets
     compare(wrong, oracle.replan(prm, *[other[k] for k in ARG_KEYS], n_threads=8))
+
+
+def test_infeasibility_certificates_are_handed_over(wave, oracle):
+    """An instance whose ROOT relaxation is infeasible without being gridlocked (here: it starts far above the velocity limit
+    and the jerk limit cannot bring it back inside the state box in time — no neighbour involved) still goes through the dual
+    method; its certificate (working set + the row that could not join it) seeds the next replan, which must come to the
+    same verdict in no more operations."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 1, seed=11)                                # alone: no neighbour rows at all
+    k = 0
+    sn["state"] = sn["state"].copy()
+    sn["state"][k, 3] = 40.0                                                     # v_x far above max_vel
+    args = [sn[key] for key in ARG_KEYS]
+    o = oracle.replan(prm, *args, n_threads=8)
+    assert o["status"][k] == 2
+    store = wave.new_warm_store(1)
+    cold = wave.replan(prm, *args, warm=store)
+    compare(cold, o)
+    assert cold["qp_iters"][k] > 0 and cold["nodes"][k] == 1
+    assert (store[k, 0] & (1 << 30)) != 0 and (store[k, 0] & 0xffff) > 0          # certificate with its rows
+    warm = wave.replan(prm, *args, warm=store)
+    compare(warm, o)
+    assert 0 < warm["qp_iters"][k] <= cold["qp_iters"][k]
 
 
 def test_sphere_prefilter_stages_the_same_rows(wave, oracle):
