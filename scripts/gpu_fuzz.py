@@ -19,6 +19,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(12345)
 K = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
 tot = mism = 0
+kinds = {}
 worst_t = worst_o = 0.0
 lim = 0
 t0 = time.time()
@@ -57,7 +58,10 @@ for case in range(n_cases):
                 print("TRAJ MISMATCH case", case, "rep", rep, "inst", np.where(ok)[0][err].tolist(), dt[err], do[err])
         if bad.any():
             mism += int(bad.sum())
+            for gs, os_ in zip(g["status"][bad].tolist(), o["status"][bad].tolist()):
+                kinds[(gs, os_)] = kinds.get((gs, os_), 0) + 1
             print("STATUS MISMATCH case", case, "rep", rep, dict(n_hor=n_hor, n_rob=n_rob, rk4=rk4, **kw),
                   "inst", np.where(bad)[0].tolist(), "gpu", g["status"][bad].tolist(), "oracle", o["status"][bad].tolist())
+print("status mismatches by (device, oracle) status:", kinds, "| trajectory mismatches:", mism - sum(kinds.values()))
 print(f"fuzz: {tot} instance-solves in {n_cases} cases, mismatches {mism}, LIMIT statuses {lim}, "
       f"worst |dtraj| {worst_t:.2e}, worst rel |dobj| {worst_o:.2e}, {time.time() - t0:.0f} s")
