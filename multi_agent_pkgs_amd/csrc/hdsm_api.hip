@@ -503,23 +503,11 @@ struct Handle {
   hipStream_t last_stream = nullptr;
 };
 
-// LDS behind the instance state goes to branch-and-bound snapshots (hdsm_core.h, snapshot_io): as many levels as fit into
-// `budget` bytes per workgroup
-template <class Sol>
-int snapshot_slots(size_t budget) {
-  const size_t state = Sol::LDS_STATE_BYTES, one = (size_t)Sol::SNAP_STRIDE * sizeof(double);
-  if (budget <= state) return 0;
-  const size_t n = (budget - state) / one;
-  return (int)(n > (size_t)Sol::SNAP_SLOTS_MAX ? (size_t)Sol::SNAP_SLOTS_MAX : n);
-}
-
 template <int NV, int NT>
-int launch_nv(Handle* h, const hdsm::Args& a_in, hipStream_t st) {
+int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
   constexpr int CM = (NV <= 32) ? CMAX30 : CMAX48;
   using Sol = hdsm::Solver<NV, CM>;
-  hdsm::Args a = a_in;
-  a.snap_slots = snapshot_slots<Sol>(158 * 1024);  // one workgroup per CU: what is left of the 160 KB (2 KB spare)
-  const size_t shm = Sol::LDS_STATE_BYTES + (size_t)a.snap_slots * Sol::SNAP_STRIDE * sizeof(double);
+  const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan<NV, CM, NT>;
   static thread_local int attr_dev = -1;
   if (attr_dev != h->device) {
@@ -532,12 +520,10 @@ int launch_nv(Handle* h, const hdsm::Args& a_in, hipStream_t st) {
   return HDSM_OK;
 }
 
-int launch_duo(Handle* h, const hdsm::Args& a_in, hipStream_t st) {
+int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st) {
   using Sol = hdsm::Solver<32, CMAX_DUO>;
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
-  hdsm::Args a = a_in;
-  a.snap_slots = snapshot_slots<Sol>(79 * 1024);  // two workgroups per CU: half of the LDS each
-  const size_t shm = Sol::LDS_STATE_BYTES + (size_t)a.snap_slots * Sol::SNAP_STRIDE * sizeof(double);
+  const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_duo<32, CMAX_DUO, 256>;
   static thread_local int attr_dev = -1;
   if (attr_dev != h->device) {

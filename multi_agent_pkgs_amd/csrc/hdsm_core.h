@@ -122,7 +122,6 @@ struct Shm {
   // makes the QP infeasible together with the rows common to every node — no node containing it needs to be opened
   int32_t inf_id;  // row whose addition proved the last node infeasible (ids as in act[])
   unsigned long long nogood[NOGOODS];
-  int32_t snap_tag[8];  // level held by each LDS snapshot slot (-1: none)
   int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
   int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
   int32_t nviol;  // rows found violated (> tol) by the last sweep
@@ -539,27 +538,8 @@ struct Solver {
   static constexpr int SNAP_STRIDE = W::SNAP_DOUBLES + 2;  // doubles per level
   // The factorisation lives in the registers of wave 0; the other waves of the workgroup (they take part in the
   // sweeps, the set-up and the leaf test) wait at the barrier and pick the outcome up from LDS.
-  // Level L of the tree. The deepest levels are restored over and over (every sibling of a node starts from its parent's state):
-  // next to the copy in the global scratch, as many levels as fit are kept in LDS behind the instance state (slot L % slots,
-  // tagged with its level) and a restore that finds its level there does not wait for global memory.
-  static constexpr int SNAP_SLOTS_MAX = 8;
-  static constexpr size_t LDS_STATE_BYTES = (sizeof(S) + 15) / 16 * 16;
-  static HD void snapshot_io(S& s, const Consts& c, GIState& R, double* buf, bool save, int L, int slots) {
-    double* lds = nullptr;
-    if (slots > 0) lds = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(&s) + LDS_STATE_BYTES) + (size_t)(L % slots) * SNAP_STRIDE;
-    if (threadIdx.x < 64) {
-      const int lane = (int)threadIdx.x;
-      if (save) {
-        W::snapshot(s, R, buf, true, lane);
-        if (lds) {
-          W::snapshot(s, R, lds, true, lane);
-          if (lane == 0) s.snap_tag[L % slots] = L;
-        }
-      } else {
-        const bool hit = lds != nullptr && uni(s.snap_tag[L % slots]) == L;
-        W::snapshot(s, R, hit ? lds : buf, false, lane);
-      }
-    }
+  static HD void snapshot_io(S& s, const Consts& c, GIState& R, double* buf, bool save) {
+    if (threadIdx.x < 64) W::snapshot(s, R, buf, save, (int)threadIdx.x);
     SYNC();
   }
   static HD int gi_run(S& s, const Consts& c, GIState& R, double f_cut, int& iters) {
@@ -576,7 +556,7 @@ struct Solver {
 #else
   struct GIState {};
   static HD int gi_run(S& s, const Consts& c, GIState&, double f_cut, int& iters) { return gi_run(s, c, f_cut, iters); }
-  static HD void snapshot_io(S& s, const Consts& c, GIState&, double* buf, bool save, int, int) { snapshot_io(s, c, buf, save); }
+  static HD void snapshot_io(S& s, const Consts& c, GIState&, double* buf, bool save) { snapshot_io(s, c, buf, save); }
   static constexpr int SNAP_DOUBLES = 2 * NV * LD + 2 * NV + 2;
   static HD void snapshot_io(S& s, const Consts& c, double* buf, bool save) {
     const int n = c.n;
@@ -635,7 +615,7 @@ struct Solver {
         ++nodes;
         const int j = s.br_order[L][pos];
         SYNC();
-        if (pos > 0) snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, false, L, s.args.snap_slots);
+        if (pos > 0) snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, false);
         if (IS_T0) {
           s.br_pos[L] = pos + 1;
           s.assign[s.br_step[L]] = j;
@@ -700,7 +680,6 @@ struct Solver {
       s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
       s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
       s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
-      for (int k = 0; k < 8; ++k) s.snap_tag[k] = -1;
     }
     SYNC();
     // x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at u = 0, the residual
@@ -832,7 +811,6 @@ struct Solver {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
         s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
-        for (int k = 0; k < 8; ++k) s.snap_tag[k] = -1;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -1099,7 +1077,7 @@ struct Solver {
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level;
-          snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, true, L, a.snap_slots);
+          snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, true);
           if (IS_T0) {
             int cnt = 0;
             for (int j = 0; j < np; ++j)

@@ -106,8 +106,6 @@ struct Args {
   int32_t* st_sph;    // sphere records read by the sweeps of this instance
   int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance
   uint32_t* st_flags; // HDSM_FLAG_* bits
-  int32_t snap_slots;   // branch-and-bound snapshots kept in LDS behind the instance state (dynamic shared memory): level L lives in
-  int32_t pad_slots;    // slot L % snap_slots while its tag says so; the global scratch always holds a copy
   int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units + 9 per active row (<= 254), 255 = no solution
 };
 

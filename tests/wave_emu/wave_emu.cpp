@@ -102,14 +102,10 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a) {
   using Sol = hdsm::Solver<NV, CMAX>;
   a.scratch_stride = (int64_t)Sol::SNAP_STRIDE * hdsm::MAXH;
   std::vector<double> scratch((size_t)a.scratch_stride);
-  // the instance state followed by two LDS snapshot slots (hdsm_core.h, snapshot_io), as the launch code lays them out
-  a.snap_slots = 2;
-  const size_t bytes = Sol::LDS_STATE_BYTES + (size_t)a.snap_slots * Sol::SNAP_STRIDE * sizeof(double);
-  std::vector<double> lds(bytes / sizeof(double) + 2);
-  auto* shm = reinterpret_cast<typename Sol::S*>(lds.data());
+  auto shm = std::make_unique<typename Sol::S>();
   for (int k = 0; k < a.n_inst; ++k) {
-    memset(static_cast<void*>(lds.data()), 0, bytes);
-    Job<NV, CMAX> job{shm, &c, a, k};
+    memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
+    Job<NV, CMAX> job{shm.get(), &c, a, k};
     job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds inst * stride
     if (!wemu::run_wave(body<NV, CMAX>, &job, k)) return -100;
     if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
