@@ -142,3 +142,30 @@ def test_node_budget_is_reported(wave, oracle):
     assert (e["status"][same] == o["status"][same]).all()
     ok = same & (o["status"] == 0)
     assert np.abs(e["traj"][ok] - o["traj"][ok]).max() < 1e-8
+
+
+def test_closed_loop_with_a_persistent_warm_start_store(wave, oracle):
+    """Consecutive rounds of a closed loop (host mirror around the solve): the device source, warm-started every round from
+    the store it filled the round before (working sets moved one step towards the present, gridlock / certificate marks),
+    returns what the cold-started oracle returns on the same inputs, round after round."""
+    from multi_agent_pkgs_amd import swarm
+    n = 10
+    prm = agile_params(10, max_rows_static=18)
+    store = wave.new_warm_store(n)
+    seen = []
+
+    def solve(inp, plans, has):
+        args = [inp[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")] + [plans, has]
+        g = wave.replan(prm, *args, warm=store)
+        o = oracle.replan(prm, *args, n_threads=8)
+        compare(g, o, tol=1e-7)
+        seen.append((int(g["qp_iters"].sum()), int((g["status"] == 2).sum())))
+        return g
+
+    loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), n, solve=solve, radius=4.0)   # tight: the ring gridlocks early on
+    for _ in range(20):
+        loop.step()
+    assert len(seen) == 20 and (store[:, 0] != 0).any()
+    assert sum(s[1] for s in seen) >= 8 and seen[-1][1] == 0                              # instances without a solution, then recovery
+    # warm rounds need fewer operations than the cold first one did per agent on a comparable problem
+    assert min(s[0] for s in seen[1:]) < seen[0][0]
