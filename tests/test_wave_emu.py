@@ -169,3 +169,35 @@ def test_closed_loop_with_a_persistent_warm_start_store(wave, oracle):
     assert sum(s[1] for s in seen) >= 8 and seen[-1][1] == 0                              # instances without a solution, then recovery
     # warm rounds need fewer operations than the cold first one did per agent on a comparable problem
     assert min(s[0] for s in seen[1:]) < seen[0][0]
+
+
+@pytest.mark.parametrize("case", [dict(n_rob=12, seed=2, turn=True), dict(n_rob=12, seed=5, chamfer=True, narrow=True, turn=True),
+                                  dict(n_rob=16, seed=4, spacing=1.0)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_four_wavefront_workgroup_matches_oracle(wave, oracle, case):
+    """The product's default launch shape: 256 threads = four wavefronts per instance. Wave 0 iterates, the other three wait at
+    the workgroup barrier and share the set-up, the sweeps and the leaf test (the emulator runs 256 fibers: cross-lane
+    operations meet within a wavefront, __syncthreads() across the workgroup)."""
+    prm = agile_params(10, max_rows_static=18)
+    case = dict(case)
+    sn = problems.swarm_snapshot(prm, case.pop("n_rob"), case.pop("seed"), **case)
+    args = [sn[k] for k in ARG_KEYS]
+    compare(wave.replan(prm, *args, threads=256), oracle.replan(prm, *args, n_threads=8))
+
+
+def test_helper_wavefronts_share_the_staged_row_scan(wave, oracle):
+    """A dense neighbourhood (more than 256 staged rows): wave 0 wakes the three helper wavefronts for every violation scan
+    (select(): `mw`, helper_loop). Same answers as the oracle and as the one-wavefront shape; H = 15 takes the NV = 48 kernel
+    through the same paths."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 100, seed=9, spacing=1.5)
+    sub = np.arange(0, 100, 8)
+    args = [sn[k] if k in ("plans", "has_plan") else sn[k][sub] for k in ARG_KEYS]
+    four, one = wave.replan(prm, *args, threads=256), wave.replan(prm, *args, threads=64)
+    assert four["cand"].max() > 256
+    o = oracle.replan(prm, *args, n_threads=8)
+    compare(four, o)
+    compare(one, o)
+    prm15 = agile_params(15, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm15, 10, seed=115, turn=True)
+    args = [sn[k] for k in ARG_KEYS]
+    compare(wave.replan(prm15, *args, threads=256), oracle.replan(prm15, *args, n_threads=8))

@@ -1,8 +1,8 @@
 // TEST INFRASTRUCTURE — a stand-in for <hip/hip_runtime.h> that lets g++ compile the DEVICE source of the solver kernel
 // (multi_agent_pkgs_amd/csrc/hdsm_core.h + hdsm_wave_gi.h, device mode, NOT the HDSM_EMU logic build) and run it on the CPU:
-// the 64 lanes of one wavefront are 64 fibers (ucontext) executed in lockstep by one host thread; every cross-lane
-// operation (DPP moves, v_readlane, v_permlane32_swap, ballot, shuffles, __syncthreads) is a rendezvous of all lanes on an
-// exchange buffer. One wavefront per workgroup (the product's 64-thread launch, HDSM_THREADS=64). See wave_emu.cpp.
+// the threads of one workgroup (one wavefront of 64, or four: the product's two launch shapes) are fibers (ucontext) run by one
+// host thread; every cross-lane operation (DPP moves, v_readlane, v_permlane32_swap, ballot, shuffles, wsync) is a rendezvous of
+// the lanes of ONE wavefront on its exchange buffer, __syncthreads() a rendezvous of the whole workgroup. See wave_emu.cpp.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -27,67 +27,85 @@ namespace wemu {
 struct Dim3 {
   unsigned x, y, z;
 };
-constexpr int W = 64;
-struct Runtime {
-  int cur = 0;                 // lane whose fiber is running
-  int nlive = 0, arrived = 0;  // rendezvous state
+constexpr int W = 64;        // lanes of a wavefront
+constexpr int MAXT = 256;    // threads of a workgroup (1 or 4 wavefronts)
+struct Wave {                // rendezvous state of one wavefront
+  int nlive = 0, arrived = 0;
   unsigned long generation = 0;
-  int tag = -1;                // kind of the operation the current rendezvous belongs to (all lanes must agree)
-  int parity = 0;              // exchange buffer in use
+  int tag = -1;              // kind of the operation the current rendezvous belongs to (all lanes must agree)
+  int parity = 0;            // exchange buffer in use
   int xi[2][W];
   double xd[2][W];
-  Dim3 tid[W];
+  int lane_tag[W];
+};
+struct Runtime {
+  int cur = 0;               // thread whose fiber is running
+  int nthreads = W;
+  Wave wave[MAXT / W];
+  int b_nlive = 0, b_arrived = 0;   // workgroup barrier
+  unsigned long b_generation = 0;
+  Dim3 tid[MAXT];
   Dim3 block{W, 1, 1}, grid{1, 1, 1}, bidx{0, 0, 0};
   long long clock = 0;
   long ops = 0;
-  long by_kind[12] = {0};      // lockstep points by kind (1 barrier, 2 readlane, 3 ballot, 4/5 shuffle, 6 DPP, 7/8 permlane32_swap, 9 wsync)
-  int lane_tag[W];             // kind of the operation each lane is waiting at (diagnostics)
-  const char* where[W];
+  long by_kind[12] = {0};    // lockstep points by kind (1 barrier, 2 readlane, 3 ballot, 4/5 shuffle, 6 DPP, 7/8 permlane32_swap, 9 wsync)
 #ifdef WEMU_DEBUG
-  void* bt[W][12];
-  int nbt[W];
+  void* bt[MAXT][12];
+  int nbt[MAXT];
 #endif
 };
 Runtime& rt();
 void yield();                  // back to the scheduler
 [[noreturn]] void fail(const char* what);
+inline int lane() { return rt().cur & (W - 1); }
+inline Wave& my_wave() { return rt().wave[rt().cur / W]; }
 
-// all live lanes meet here; returns the buffer index that was written before the meeting
+// all live lanes of the calling lane's WAVEFRONT meet here; returns the buffer index that was written before the meeting
 inline int rendezvous(int tag) {
   Runtime& r = rt();
-  r.lane_tag[r.cur] = tag;
+  Wave& w = my_wave();
+  w.lane_tag[lane()] = tag;
 #ifdef WEMU_DEBUG
   r.nbt[r.cur] = backtrace(r.bt[r.cur], 12);
 #endif
-  if (r.arrived == 0) r.tag = tag;
-  else if (r.tag != tag) {
-    static char msg[160];
+  if (w.arrived == 0) w.tag = tag;
+  else if (w.tag != tag) {
+    static char msg[200];
     unsigned long long at_first = 0;
-    for (int l = 0; l < W; ++l) at_first |= (unsigned long long)(r.lane_tag[l] == r.tag && l != r.cur) << l;
+    for (int l = 0; l < W; ++l) at_first |= (unsigned long long)(w.lane_tag[l] == w.tag && l != lane()) << l;
 #ifdef WEMU_DEBUG
-    fprintf(stderr, "---- arriving lane %d:\n", r.cur);
+    fprintf(stderr, "---- arriving thread %d:\n", r.cur);
     backtrace_symbols_fd(r.bt[r.cur], r.nbt[r.cur], 2);
     for (int l = W - 1; l >= 0; --l)
       if ((at_first >> l) & 1) {
         fprintf(stderr, "---- waiting lane %d:\n", l);
-        backtrace_symbols_fd(r.bt[l], r.nbt[l], 2);
+        backtrace_symbols_fd(r.bt[(r.cur / W) * W + l], r.nbt[(r.cur / W) * W + l], 2);
         break;
       }
 #endif
-    snprintf(msg, sizeof msg, "lanes of the wavefront reached DIFFERENT cross-lane operations (kinds %d and %d, %d lanes waiting, mask %llx): divergent use", r.tag, tag, r.arrived, at_first);
+    snprintf(msg, sizeof msg, "lanes of wavefront %d reached DIFFERENT cross-lane operations (kinds %d and %d, %d lanes waiting, mask %llx): divergent use",
+             r.cur / W, w.tag, tag, w.arrived, at_first);
     fail(msg);
   }
-  const int p = r.parity;
-  const unsigned long gen = r.generation;
-  if (++r.arrived == r.nlive) {
-    r.arrived = 0, ++r.generation, r.parity ^= 1, ++r.ops, ++r.by_kind[tag < 12 ? tag : 0];
+  const int p = w.parity;
+  const unsigned long gen = w.generation;
+  if (++w.arrived == w.nlive) {
+    w.arrived = 0, ++w.generation, w.parity ^= 1, ++r.ops, ++r.by_kind[tag < 12 ? tag : 0];
   } else {
-    while (r.generation == gen) yield();
+    while (w.generation == gen) yield();
   }
   return p;
 }
-inline int lane() { return rt().cur; }
-inline int xchg_i(int v, int src_lane_of_me(int), int tag);
+// __syncthreads(): all live threads of the workgroup
+inline void block_barrier() {
+  Runtime& r = rt();
+  const unsigned long gen = r.b_generation;
+  if (++r.b_arrived == r.b_nlive) {
+    r.b_arrived = 0, ++r.b_generation, ++r.ops, ++r.by_kind[1];
+  } else {
+    while (r.b_generation == gen) yield();
+  }
+}
 }  // namespace wemu
 
 #define threadIdx (wemu::rt().tid[wemu::rt().cur])
@@ -142,47 +160,45 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) {
 }
 
 // ---- cross-lane operations -----------------------------------------------------------------------------------------
-inline void __syncthreads() { (void)wemu::rendezvous(1); }
+inline void __syncthreads() { wemu::block_barrier(); }
 inline int wemu_readlane_i(int v, int src) {
-  wemu::Runtime& r = wemu::rt();
-  r.xi[r.parity][r.cur] = v;
-  const int me = r.cur;
-  (void)me;
+  wemu::Wave& w = wemu::my_wave();
+  w.xi[w.parity][wemu::lane()] = v;
   const int p = wemu::rendezvous(2);
-  return wemu::rt().xi[p][src & 63];
+  return wemu::my_wave().xi[p][src & 63];
 }
 #define __builtin_amdgcn_readlane(v, l) wemu_readlane_i((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) wemu_readlane_i((v), 0)
 inline unsigned long long __ballot(int pred) {
-  wemu::Runtime& r = wemu::rt();
-  r.xi[r.parity][r.cur] = pred ? 1 : 0;
+  wemu::Wave& w = wemu::my_wave();
+  w.xi[w.parity][wemu::lane()] = pred ? 1 : 0;
   const int p = wemu::rendezvous(3);
   unsigned long long m = 0;
-  for (int l = 0; l < wemu::W; ++l) m |= (unsigned long long)(wemu::rt().xi[p][l] & 1) << l;
+  for (int l = 0; l < wemu::W; ++l) m |= (unsigned long long)(wemu::my_wave().xi[p][l] & 1) << l;
   return m;
 }
 inline int __shfl_xor(int v, int mask, int width = 64) {
-  wemu::Runtime& r = wemu::rt();
-  const int me = r.cur;
-  r.xi[r.parity][me] = v;
+  wemu::Wave& w = wemu::my_wave();
+  const int me = wemu::lane();
+  w.xi[w.parity][me] = v;
   const int p = wemu::rendezvous(4);
   const int src = me ^ mask;
-  return (src / width == me / width) ? wemu::rt().xi[p][src] : v;
+  return (src / width == me / width) ? wemu::my_wave().xi[p][src] : v;
 }
 inline double __shfl_xor(double v, int mask, int width = 64) {
-  wemu::Runtime& r = wemu::rt();
-  const int me = r.cur;
-  r.xd[r.parity][me] = v;
+  wemu::Wave& w = wemu::my_wave();
+  const int me = wemu::lane();
+  w.xd[w.parity][me] = v;
   const int p = wemu::rendezvous(5);
   const int src = me ^ mask;
-  return (src / width == me / width) ? wemu::rt().xd[p][src] : v;
+  return (src / width == me / width) ? wemu::my_wave().xd[p][src] : v;
 }
 // DPP moves within 16-lane rows: row_shl:n (0x100 + n) reads lane + n, row_shr:n (0x110 + n) lane - n, row_ror:n (0x120 + n)
 // rotates; a lane without a source keeps `old` (bound_ctrl: the callers pass old = 0 where they want zero fill)
 inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  wemu::Runtime& r = wemu::rt();
-  const int me = r.cur;
-  r.xi[r.parity][me] = src;
+  wemu::Wave& w = wemu::my_wave();
+  const int me = wemu::lane();
+  w.xi[w.parity][me] = src;
   const int p = wemu::rendezvous(6);
   const int row = me & ~15, i = me & 15, n = ctrl & 15;
   int from = -1;
@@ -191,19 +207,18 @@ inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, boo
   else if ((ctrl & 0x1f0) == 0x120) from = (i - n) & 15;
   else wemu::fail("DPP control not modelled");
   (void)row_mask, (void)bank_mask;
-  return from >= 0 ? wemu::rt().xi[p][row + from] : (bound_ctrl ? 0 : old);
+  return from >= 0 ? wemu::my_wave().xi[p][row + from] : (bound_ctrl ? 0 : old);
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 // v_permlane32_swap vdst, vsrc: lanes 32..63 of vdst <-> lanes 0..31 of vsrc; returns {new vdst, new vsrc}
 inline std::array<int, 2> wemu_permlane32_swap(int vdst, int vsrc, bool, bool) {
-  wemu::Runtime& r = wemu::rt();
-  const int me = r.cur;
-  r.xi[r.parity][me] = vdst;
+  const int me = wemu::lane();
+  wemu::my_wave().xi[wemu::my_wave().parity][me] = vdst;
   const int p1 = wemu::rendezvous(7);
-  const int other_dst = wemu::rt().xi[p1][me ^ 32];
-  wemu::rt().xi[wemu::rt().parity][me] = vsrc;
+  const int other_dst = wemu::my_wave().xi[p1][me ^ 32];
+  wemu::my_wave().xi[wemu::my_wave().parity][me] = vsrc;
   const int p2 = wemu::rendezvous(8);
-  const int other_src = wemu::rt().xi[p2][me ^ 32];
+  const int other_src = wemu::my_wave().xi[p2][me ^ 32];
   return me < 32 ? std::array<int, 2>{vdst, other_dst} : std::array<int, 2>{other_src, vsrc};
 }
 #define __builtin_amdgcn_permlane32_swap(a, b, c, d) wemu_permlane32_swap((a), (b), (c), (d))

@@ -4,7 +4,8 @@
 // register-resident, wave-level iteration of hdsm_wave_gi.h with its DPP scans, lane-split rows, Householder add / drop, warm
 // start, certificates, conflict learning, sweeps on the packed positions — was covered by the GPU tests only. Here that very
 // source is compiled by g++ against tests/wave_emu/shim/hip/hip_runtime.h: one workgroup = one wavefront = 64 fibers in
-// lockstep (the product's 64-thread launch), one instance after the other. Never linked into libhdsm.so, not a fallback.
+// lockstep — one wavefront (the product's 64-thread launch) or four (its default: the helper waves share the sweeps, the set-up,
+// the leaf test and the staged-row scans) — one instance after the other. Never linked into libhdsm.so, not a fallback.
 #include <ucontext.h>
 
 #include <memory>
@@ -17,11 +18,11 @@ namespace wemu {
 namespace {
 Runtime g_rt;
 ucontext_t g_main;
-ucontext_t g_ctx[W];
-bool g_done[W];
+ucontext_t g_ctx[MAXT];
+bool g_done[MAXT];
 char g_error[256];
 bool g_failed = false;
-constexpr size_t STACK = 512 * 1024;
+constexpr size_t STACK = 384 * 1024;
 std::vector<char> g_stacks;
 void (*g_body)(void*) = nullptr;
 void* g_arg = nullptr;
@@ -29,9 +30,11 @@ void* g_arg = nullptr;
 void trampoline() {
   g_body(g_arg);
   Runtime& r = g_rt;
+  Wave& w = r.wave[r.cur / W];
   g_done[r.cur] = true;
-  --r.nlive;
-  if (r.nlive > 0 && r.arrived == r.nlive) fail("a lane left the kernel while the others wait at a cross-lane operation");
+  --w.nlive, --r.b_nlive;
+  if (w.nlive > 0 && w.arrived == w.nlive) fail("a lane left the kernel while the others of its wavefront wait at a cross-lane operation");
+  if (r.b_nlive > 0 && r.b_arrived == r.b_nlive) fail("a thread left the kernel while the others wait at __syncthreads()");
   swapcontext(&g_ctx[r.cur], &g_main);
 }
 }  // namespace
@@ -39,20 +42,23 @@ void trampoline() {
 Runtime& rt() { return g_rt; }
 void yield() { swapcontext(&g_ctx[g_rt.cur], &g_main); }
 void fail(const char* what) {
-  snprintf(g_error, sizeof g_error, "%s (lane %d, operation %ld)", what, g_rt.cur, g_rt.ops);
+  snprintf(g_error, sizeof g_error, "%s (thread %d, lockstep point %ld)", what, g_rt.cur, g_rt.ops);
   g_failed = true;
   for (;;) swapcontext(&g_ctx[g_rt.cur], &g_main);  // never resumes: the scheduler stops on g_failed
 }
 
-// one workgroup of 64 threads executing body(arg); false + message on a lockstep violation
-bool run_wave(void (*body)(void*), void* arg, int block_index) {
+// one workgroup of `nthreads` (64 or 256) threads executing body(arg); false + message on a lockstep violation
+bool run_block(void (*body)(void*), void* arg, int block_index, int nthreads) {
   Runtime& r = g_rt;
   r = Runtime{};
+  r.nthreads = nthreads;
+  r.block = {(unsigned)nthreads, 1, 1};
   r.bidx = {(unsigned)block_index, 0, 0};
-  r.nlive = W;
+  r.b_nlive = nthreads;
+  for (int w = 0; w < nthreads / W; ++w) r.wave[w].nlive = W;
   g_body = body, g_arg = arg, g_failed = false;
-  if (g_stacks.size() != STACK * W) g_stacks.assign(STACK * W, 0);
-  for (int l = 0; l < W; ++l) {
+  if (g_stacks.size() != STACK * MAXT) g_stacks.assign(STACK * MAXT, 0);
+  for (int l = 0; l < nthreads; ++l) {
     r.tid[l] = {(unsigned)l, 0, 0};
     g_done[l] = false;
     getcontext(&g_ctx[l]);
@@ -62,17 +68,18 @@ bool run_wave(void (*body)(void*), void* arg, int block_index) {
     makecontext(&g_ctx[l], trampoline, 0);
   }
   long idle_rounds = 0;
-  while (r.nlive > 0 && !g_failed) {
-    const unsigned long gen = r.generation;
-    const int live = r.nlive;
-    for (int l = 0; l < W && !g_failed; ++l) {
+  while (r.b_nlive > 0 && !g_failed) {
+    const long ops = r.ops;
+    const int live = r.b_nlive;
+    for (int l = 0; l < nthreads && !g_failed; ++l) {
       if (g_done[l]) continue;
       r.cur = l;
       swapcontext(&g_main, &g_ctx[l]);
     }
-    if (r.generation == gen && r.nlive == live) {
+    if (r.ops == ops && r.b_nlive == live) {
       if (++idle_rounds > 4) {
-        snprintf(g_error, sizeof g_error, "deadlock: %d of %d lanes wait at a cross-lane operation the others never reach", r.arrived, r.nlive);
+        snprintf(g_error, sizeof g_error, "deadlock: %d of %d threads wait at __syncthreads(), wavefront 0 has %d of %d lanes at a cross-lane operation",
+                 r.b_arrived, r.b_nlive, r.wave[0].arrived, r.wave[0].nlive);
         g_failed = true;
       }
     } else {
@@ -98,7 +105,7 @@ void body(void* p) {
   hdsm::Solver<NV, CMAX>::solve_instance(*j->s, *j->c, j->a, j->inst);
 }
 template <int NV, int CMAX>
-int run_all(const hdsm::Consts& c, hdsm::Args& a) {
+int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   using Sol = hdsm::Solver<NV, CMAX>;
   a.scratch_stride = (int64_t)Sol::SNAP_STRIDE * hdsm::MAXH;
   std::vector<double> scratch((size_t)a.scratch_stride);
@@ -107,7 +114,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a) {
     memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
     Job<NV, CMAX> job{shm.get(), &c, a, k};
     job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds inst * stride
-    if (!wemu::run_wave(body<NV, CMAX>, &job, k)) return -100;
+    if (!wemu::run_block(body<NV, CMAX>, &job, k, nthreads)) return -100;
     if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
   }
   return 0;
@@ -123,7 +130,8 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
                            const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows_static, const double* A_static,
                            const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
                            uint8_t* poly_used, int32_t* status, double* obj, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
-                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min) {
+                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads) {
+  if (threads != 64 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
   int rc = hdsm::build_consts(prm, c.get(), &err);
@@ -164,6 +172,6 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
   a.pos = pos.data();
   a.bounds = (n_rob >= bounds_min) ? bounds.data() : nullptr;
   a.warm = (prm->warm_start && warm) ? warm : nullptr;
-  if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a);
-  return run_all<48, 1024>(*c, a);
+  if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
+  return run_all<48, 1024>(*c, a, threads);
 }
