@@ -201,3 +201,18 @@ def test_helper_wavefronts_share_the_staged_row_scan(wave, oracle):
     sn = problems.swarm_snapshot(prm15, 10, seed=115, turn=True)
     args = [sn[k] for k in ARG_KEYS]
     compare(wave.replan(prm15, *args, threads=256), oracle.replan(prm15, *args, n_threads=8))
+
+
+@pytest.mark.parametrize("kw", [dict(seed=41, narrow=True, turn=True, spacing=1.6), dict(seed=43, chamfer=True, turn=True)])
+def test_level1_through_the_device_source(wave, oracle, kw):
+    """hdsm_solve: the host-side split (common suffix = the planes AddHyperplane appended) + the device source with explicit
+    neighbour rows (no sweeps over plans) vs the oracle's LITERAL level-1 semantics, on both launch shapes."""
+    prm = make_params(n_hor=6, poly_hor=3, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 8, **kw)
+    n_poly, n_rows, A, b = problems.level1_from_snapshot(
+        prm, sn, lambda a: oracle.tasc_planes(prm, a, sn["state"][a], sn["plans"], sn["has_plan"]))
+    o = oracle.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b, n_threads=8)
+    for threads in (64, 256):
+        e = wave.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b, threads=threads)
+        assert e["rc"] == 0
+        compare(e, o, tol=1e-7)

@@ -53,3 +53,22 @@ def replan(prm, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, war
         raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
     assert rc == 0, rc
     return out
+
+
+def solve(prm, state, ref, n_poly, n_rows, A, b, threads=64):
+    """Level 1 through the product's host-side split + the device source."""
+    N, P = prm.n_hor, prm.poly_hor
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    state, ref, A, b, n_poly, n_rows = f64(state), f64(ref), f64(A), f64(b), i32(n_poly), i32(n_rows)
+    n_inst, r_max = state.shape[0], A.shape[3]
+    out = dict(traj=np.zeros((n_inst, N + 1, 9)), ctrl=np.zeros((n_inst, N, 3)), used=np.zeros((n_inst, P), dtype=np.uint8),
+               status=np.zeros(n_inst, dtype=np.int32), obj=np.zeros(n_inst))
+    d, i, u = C.c_double, C.c_int32, C.c_uint8
+    rc = lib().wave_solve(C.byref(prm), n_inst, r_max, _p(state, d), _p(ref, d), _p(n_poly, i), _p(n_rows, i), _p(A, d), _p(b, d),
+                          _p(out["traj"], d), _p(out["ctrl"], d), _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d),
+                          C.c_int32(threads))
+    if rc == -100:
+        raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
+    out["rc"] = rc
+    return out

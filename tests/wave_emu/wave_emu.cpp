@@ -13,6 +13,7 @@
 
 #include "../../multi_agent_pkgs_amd/csrc/hdsm_consts.h"
 #include "../../multi_agent_pkgs_amd/csrc/hdsm_core.h"
+#include "../../multi_agent_pkgs_amd/csrc/hdsm_level1.h"
 
 namespace wemu {
 namespace {
@@ -172,6 +173,30 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
   a.pos = pos.data();
   a.bounds = (n_rob >= bounds_min) ? bounds.data() : nullptr;
   a.warm = (prm->warm_start && warm) ? warm : nullptr;
+  if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
+  return run_all<48, 1024>(*c, a, threads);
+}
+
+// Level 1 (fully formed per-step polyhedra, hdsm_solve) through the product's host-side split and the device source
+extern "C" int wave_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const double* state_curr, const double* traj_ref,
+                          const int32_t* n_poly, const int32_t* n_rows, const double* A, const double* b, double* traj_out,
+                          double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj, int32_t threads) {
+  if (threads != 64 && threads != 256) return -1;
+  auto c = std::make_unique<hdsm::Consts>();
+  const char* err = nullptr;
+  int rc = hdsm::build_consts(prm, c.get(), &err);
+  if (rc) return rc;
+  hdsm::Level1Split sp;
+  rc = hdsm::level1_split(*prm, n_inst, r_max, n_poly, n_rows, A, b, &sp, &err);
+  if (rc) return rc;
+  std::vector<int32_t> ids(n_inst, -1);
+  uint8_t zero = 0;
+  double dummy_plans[16] = {0};
+  hdsm::Args a{};
+  a.n_inst = n_inst, a.n_rob = 0, a.agent_id = ids.data(), a.state = state_curr, a.ref = traj_ref;
+  a.n_poly = sp.n_poly.data(), a.n_rows = sp.n_rows_static.data(), a.A = sp.A_static.data(), a.b = sp.b_static.data();
+  a.plans = dummy_plans, a.has_plan = &zero, a.traj = traj_out, a.ctrl = ctrl_out, a.used = poly_used;
+  a.status = status, a.obj = obj, a.l1_rows = sp.common.data(), a.l1_nrows = sp.n_common.data(), a.l1_rmax = sp.rc_max;
   if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
   return run_all<48, 1024>(*c, a, threads);
 }
