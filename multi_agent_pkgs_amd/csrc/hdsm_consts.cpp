@@ -154,6 +154,11 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
     if (!zero) break;
     c->pinned_steps = m;
   }
+  {  // development switch for A/B runs: HDSM_PINNED_STEPS=0 turns the gridlock test of the sweeps off (never raises the count)
+    int32_t cap = c->pinned_steps;
+    env_int("HDSM_PINNED_STEPS", 0, c->pinned_steps, &cap);
+    c->pinned_steps = cap;
+  }
 
   // ---- Hessian of the tracking objective (AC:870-883, AC:2098) in u, its Cholesky factor and inverse
   std::vector<double> H(n * n, 0.0), L(n * n, 0.0);
