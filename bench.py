@@ -45,6 +45,29 @@ def workload_key(scenario, n_rob, N, world, first, K):
     return f"{scenario}_a{n_rob}_h{N}_g{world}_r{first}_k{K}"
 
 
+def kernel_source_sha16():
+    """Identity of the solver kernel's sources: a committed PMC summary is quoted only for the sources it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("hdsm_core.h", "hdsm_wave_gi.h", "hdsm_api.hip", "hdsm_types.h"):
+        h.update(open(os.path.join(ROOT, "multi_agent_pkgs_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the command line the
+    driver would use) and pass their output through. Rank 0 prints the ONE JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,7 +96,11 @@ def main():
     ap.add_argument("--dist-backend", default="rccl", help="rccl: the product path (hdsm_comm_* / hdsm_exchange_device, "
                     "RCCL linked into libhdsm.so). gloo: testing the multi-rank flow on a box with fewer GPUs than ranks "
                     "(ranks share devices, the all-gather is staged through the host)")
+    ap.add_argument("--no-weak-record", action="store_true", help="N > 1: skip the secondary weak-scaling record (1024 agents "
+                    "per GPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -81,7 +108,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -305,6 +333,73 @@ def main():
                  "what": "hdsm_dswarm_round live: corridor (f2) -> reference (f1) -> replan -> commit -> publish -> exchange, one stream"}
         dsw.close()
 
+    # ---------------------------------------------------------------- N > 1: secondary WEAK-scaling record
+    # The line above shards the SAME 1024 agents over the ranks (strong scaling: a round cannot end before its slowest instance,
+    # so it says little about the exchange). This record fixes the work PER GPU instead: 1024 agents per GPU on a ring of
+    # 1024 N agents (R = n / 2 pi, the same 1 m chord), every rank solving its 1024 instances against all 1024 N published plans,
+    # one RCCL all-gather of the new plans per round. Early rounds of the flight (the squeeze of a ring that large is thousands of
+    # rounds away); same timing contract.
+    weak = None
+    if world > 1 and comm is not None and args.scenario == "circle" and not args.no_weak_record:
+        per_w = 1024
+        n_w = per_w * world
+        first_w = 25
+        solver_w = lib.Solver(prm, per_w, n_w, device=dev.index)
+
+        def solve_w(inp, plans, has):
+            return solver_w.replan(inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has)
+
+        def ref_w(ids, path, n_path, plans, has, vel_cap=None):
+            full, _, pv = solver_w.reference(rcfg, ids, path, n_path, plans, has, vel_cap=vel_cap)
+            return full, pv
+
+        loop_w = swarm.SwarmLoop(prm, cfg, n_w, rank=rank, world=world, solve=solve_w, allgather=allgather_np,
+                                 radius=n_w / (2 * np.pi), reference=ref_w)
+        rec_w = []
+        for r in range(first_w + K):
+            loop_w.step(record=rec_w if r >= first_w - W else None)
+
+        def stack_w(key_, dtype):
+            return torch.from_numpy(np.ascontiguousarray(np.stack([x[key_] for x in rec_w]), dtype=dtype)).to(dev)
+
+        w_agent, w_state, w_ref = stack_w("agent_id", np.int32), stack_w("state", np.float64), stack_w("ref", np.float64)
+        w_npoly, w_nrows = stack_w("n_poly", np.int32), stack_w("n_rows", np.int32)
+        w_A, w_b = stack_w("A", np.float64), stack_w("b", np.float64)
+        w_plans, w_has = stack_w("plans", np.float64), stack_w("has_plan", np.uint8)
+        w_traj = torch.zeros((per_w, N + 1, 9), dtype=torch.float64, device=dev)
+        w_ctrl = torch.zeros((per_w, N, 3), dtype=torch.float64, device=dev)
+        w_used = torch.zeros((per_w, P), dtype=torch.uint8, device=dev)
+        w_status = torch.zeros(per_w, dtype=torch.int32, device=dev)
+        w_obj = torch.zeros(per_w, dtype=torch.float64, device=dev)
+        w_next = torch.zeros((n_w, N + 1, 9), dtype=torch.float64, device=dev)
+        w_next_has = torch.zeros(n_w, dtype=torch.uint8, device=dev)
+
+        def step_w(r):
+            solver_w.replan_device(w_agent[r], w_state[r], w_ref[r], w_npoly[r], w_nrows[r], w_A[r], w_b[r], w_plans[r], w_has[r],
+                                   w_traj, w_ctrl, w_used, w_status, w_obj, stream=stream)
+            comm.exchange_device(w_traj, w_next, w_next_has, stream=stream)
+
+        reps_w = []
+        for _ in range(max(1, args.repeats)):
+            for r in range(0, W):
+                step_w(r)
+            barrier()
+            t0 = time.perf_counter()
+            for r in range(W, W + K):
+                step_w(r)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            reps_w.append(float(t.item()))
+        el_w = sorted(reps_w)[(len(reps_w) - 1) // 2]
+        weak = {"scaling": "weak", "agents": n_w, "agents_per_gpu": per_w, "n_gpus": world, "value": n_w * K / el_w,
+                "unit": "agent-replans/s", "ms_per_step": el_w / K * 1e3, "ms_per_step_repeats": [e / K * 1e3 for e in reps_w],
+                "steps": K, "warmup": W, "rounds": f"{first_w}..{first_w + K - 1}",
+                "exchange_bytes_per_rank_per_round": per_w * (N + 1) * 9 * 8,
+                "what": f"{per_w} agents per GPU on a ring of {n_w} (R = n / 2 pi): every rank solves its {per_w} instances against "
+                        f"all {n_w} plans + ONE RCCL all-gather per round; same barrier / max-over-ranks contract as the line"}
+        solver_w.close()
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -360,11 +455,12 @@ def main():
                      "what": "32 B per sphere record read + 24 B per (neighbour, step) pair that survived the prefilter, "
                              "counted by the kernel over all sweeps, + the per-instance inputs / outputs"}
         traffic, traffic_src = None, None
+        src_sha = kernel_source_sha16()
         pmc = os.path.join(ROOT, "profiles", f"pmc_{key}.json")
-        if os.path.exists(pmc):   # only a PMC summary taken on THIS workload (same agents, rounds, GPUs) is quoted
-            try:
+        if os.path.exists(pmc):   # only a PMC summary taken on THIS workload (same agents, rounds, GPUs) AND on these kernel
+            try:                  # sources is quoted: after a kernel change the figure is null until the counters are re-collected
                 z = json.load(open(pmc))
-                if z.get("workload_key") == key:
+                if z.get("workload_key") == key and z.get("kernel_source_sha16") == src_sha:
                     traffic, traffic_src = z.get("hbm_bytes_per_launch"), os.path.relpath(pmc, ROOT)
             except Exception:
                 traffic = None
@@ -394,6 +490,10 @@ def main():
                 "ms_per_round": host_ms, "agent_replans_per_s": n_rob / (host_ms * 1e-3),
                 "what": "hdsm_replan with host pointers (PCIe-inclusive: H2D inputs, kernel, D2H outputs, sync)"},
             "device_resident_loop": dloop,
+            "rccl_ranks": comm.world if comm is not None else (1 if world == 1 else None),
+            "exchange": ("none (one rank)" if world == 1 else ("RCCL all-gather (hdsm_exchange_device)" if comm is not None
+                                                               else "host-staged gloo all-gather (flow check only)")),
+            "weak_scaling_record": weak,
             "failed_instances_timed_rounds": fails_timed, "failed_instances_recorded": fails,
             "setup_flight_s": t_setup,
             "ms_per_step_repeats": [e / K * 1e3 for e in reps],
@@ -406,7 +506,8 @@ def main():
                                           "staged_rows_max_last_round": int(stats["cand"].max())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_replan": B, "kernel": "k_replan", "after_prefilter": after},
+                         "algorithmic_bytes_per_replan": B, "kernel": "k_replan", "kernel_source_sha16": src_sha,
+                         "after_prefilter": after},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

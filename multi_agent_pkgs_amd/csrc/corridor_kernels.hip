@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64) void k_poly_octa3d(Batch b) {
 // seeds in flight; same rows, bit for bit (tests/test_gpu_configs.py).
 constexpr size_t WORK_BYTES = ((sizeof(Work) + 15) / 16) * 16;
 constexpr size_t SLAB_LDS = WORK_BYTES + WindowGrid::WORDS * 4 + WindowGrid::OCC2_WORDS * 4;
+static_assert(SLAB_LDS + 1024 <= 64 * 1024, "k_poly_octa3d_wave: LDS exceeds the default 64 KB limit of a launch");
 
 __global__ __launch_bounds__(64) void k_poly_octa3d_wave(Batch b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
   __shared__ int cnt_s;
   const int inst = blockIdx.x, tid = threadIdx.x, N = a.N;
   const int self = a.agent_id[inst];
-  const int np = a.n_path[inst];
+  const int np = min(max(a.n_path[inst], 1), a.pmax);  // the host wrapper rejects counts outside [1, pmax]; device callers are clamped
   const bool own_has = self >= 0 && self < a.n_rob && a.has_plan[self];
   // the polyline goes through LDS: the sampling walk below is one thread's chain, and every global read in it was a
   // dependent round trip
@@ -888,10 +888,16 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   a.agent_id = agent_id, a.path = path, a.n_path = n_path, a.vel_cap = vel_cap, a.plans = plans_all;
   a.has_plan = has_plan, a.ref_full = ref_full, a.ref = ref, a.path_vel = path_vel;
   a.rpos = h->d_rpos, a.rsph = h->d_rsph;
-  hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16), dim3(256), 0, static_cast<hipStream_t>(hip_stream), h->N, n_rob, plans_all,
-                     has_plan, h->d_rpos, h->d_rsph);
-  hipLaunchKernelGGL(k_reference, dim3(n_inst), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+  // d_rpos / d_rsph are scratch of the HANDLE: a call that arrives on another stream than the previous launch waits for it
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
+  h->last_stream = st;
+  hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16), dim3(256), 0, st, h->N, n_rob, plans_all, has_plan, h->d_rpos, h->d_rsph);
   HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_reference, dim3(n_inst), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(h->ev_done, st));
+  h->launched = true;
   return HDSM_OK;
 }
 

@@ -37,6 +37,12 @@ struct V3 {
 };
 CD_HD V3 sub(const V3& a, const V3& b) { return {{a[0] - b[0], a[1] - b[1], a[2] - b[2]}}; }
 CD_HD V3 axpy(const V3& a, double s, const V3& b) { return {{a[0] + s * b[0], a[1] + s * b[1], a[2] + s * b[2]}}; }
+// a + s * d / len in the evaluation order of the reference's Eigen expressions (`curr_pt + samp_dist * diff / dist_next`,
+// AC:1320, 1353, 1635; path_tools.cpp:450): (s * d_k) / len per component. The walks accumulate hundreds of these steps and
+// truncate the result to a voxel index or compare it with a strict '<', so the order of the roundings is kept.
+CD_HD V3 step_along(const V3& a, double s, const V3& d, double len) {
+  return {{a[0] + (s * d[0]) / len, a[1] + (s * d[1]) / len, a[2] + (s * d[2]) / len}};
+}
 CD_HD double dot(const V3& a, const V3& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 CD_HD double norm(const V3& a) { return sqrt(dot(a, a)); }
 
@@ -249,7 +255,7 @@ CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
     const V3 diff = sub(next, curr);
     const double dist_next = norm(diff);
     if (dist_next > samp) {
-      curr = axpy(curr, samp / dist_next, diff);
+      curr = step_along(curr, samp, diff, dist_next);
     } else {
       curr = next;
       if (++path_idx == n_path) break;
@@ -276,13 +282,13 @@ CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
           const V3 df = sub(next, curr);
           const double dn = norm(df);
           if (!(dn > samp)) break;
-          curr = axpy(curr, samp / dn, df);
+          curr = step_along(curr, samp, df, dn);
         }
       }
       continue;
     }
     V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
-    if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
+    if (dist_next > 0) seed_pt = step_along(curr, -fmin(samp, dist_next), diff, dist_next);
     int seed[3];
     V3 seed_world;
     for (int ax = 0; ax < 3; ++ax) {
@@ -486,7 +492,7 @@ CD_HD void check_increment(const Cfg& c, AgentS& ag) {
     const V3 diff = sub(target, curr);
     const double dist_next = norm(diff);
     if (dist_next > samp) {
-      curr = axpy(curr, samp / dist_next, diff);
+      curr = step_along(curr, samp, diff, dist_next);
       progress += samp;
     } else {
       curr = target;
@@ -538,7 +544,7 @@ CD_HD double increment_segment_min(const AgentS& ag, int seg, const V3& pt) {
     const V3 diff = sub(target, curr);
     const double dist_next = norm(diff);
     const bool last = !(dist_next > samp);
-    curr = last ? target : axpy(curr, samp / dist_next, diff);
+    curr = last ? target : step_along(curr, samp, diff, dist_next);
     const double d = norm(sub(pt, curr));
     if (d < best) best = d;
     if (last) break;

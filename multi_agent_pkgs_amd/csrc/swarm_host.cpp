@@ -53,7 +53,8 @@ struct Swarm {
     for (int k = 0; k < 3; ++k) c.grid_range[k] = cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
     c.world = has_world ? world.data() : nullptr;
     c.fast_walk = 0;
-    if (const char* e = std::getenv("HDSM_FAST_WALK_HOST")) c.fast_walk = std::atoi(e) != 0;  // test hook: scalar twin of the device shortcut
+    if (const char* e = std::getenv("HDSM_FAST_WALK_HOST"))  // test hook (scalar twin of the device shortcut): "0" or "1", anything else is ignored
+      if ((e[0] == '0' || e[0] == '1') && e[1] == 0) c.fast_walk = e[0] == '1';
     return c;
   }
   // optional occupancy of the world (hdsm_swarm_set_world): voxels of cfg.voxel_size, >= 100 occupied
@@ -126,7 +127,7 @@ std::vector<V3> sample_path(const Swarm& sw, AgentS& ag, const std::vector<V3>& 
     const V3 diff = sub(path[path_idx], curr);
     const double dist_next = norm(diff);
     if (dist_next > limit) {
-      curr = axpy(curr, limit / dist_next, diff);
+      curr = hdsm_sw::step_along(curr, limit, diff, dist_next);
       ref.push_back(curr);
       ++ref_idx;
       limit = std::fmax(0.0, samp_dist - sw.cfg.path_vel_dec * sw.prm.dt);

@@ -47,6 +47,9 @@ constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline ha
 // memory every one of them was a round trip (33 ms per round for 256 agents in the pillar forest).
 constexpr size_t WORK_BYTES = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16;
 constexpr size_t SLAB = WORK_BYTES + hdsm_cd::WindowGrid::WORDS * 4 + hdsm_cd::WindowGrid::OCC2_WORDS * 4;
+// k_corridor also has static __shared__ state (the walk's rows and flags, < 4 KB); together they must stay inside the 64 KB a
+// kernel may use without hipFuncAttributeMaxDynamicSharedMemorySize — a growth of Work / the overlay fails HERE, not at launch
+static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed the default 64 KB limit");
 
 // GenerateSafeCorridor (AC:1236-1447), ONE WAVEFRONT PER AGENT. The walk along the path (steps of voxel / 10: hundreds of
 // them per round) tests every sample against every row of the kept polyhedra; with one thread per agent each test was a chain of
@@ -139,7 +142,7 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
     const V3 diff = sub(next, curr);
     const double dist_next = norm(diff);
     if (dist_next > samp) {
-      curr = axpy(curr, samp / dist_next, diff);
+      curr = step_along(curr, samp, diff, dist_next);
     } else {
       curr = next;
       if (++path_idx == n_path) break;
@@ -181,13 +184,13 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
           const V3 df = sub(next, curr);
           const double dn = norm(df);
           if (!(dn > samp)) break;  // the end of the segment: the regular loop takes over
-          curr = axpy(curr, samp / dn, df);
+          curr = step_along(curr, samp, df, dn);
         }
       }
       continue;
     }
     V3 seed_pt = curr;  // AC:1351-1354: step back to the previous sample
-    if (dist_next > 0) seed_pt = axpy(curr, -fmin(samp, dist_next) / dist_next, diff);
+    if (dist_next > 0) seed_pt = step_along(curr, -fmin(samp, dist_next), diff, dist_next);
     int seed[3];
     V3 seed_world;
     for (int ax = 0; ax < 3; ++ax) {
@@ -435,13 +438,23 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
     delete d;
     return fail(HDSM_ERR_BAD_ARG, "the shard is larger than ceil(n_rob / world_size)");
   }
+  // Layout contract of the device loop (hdsm_swarm.h): the plans buffer holds agent a's record at slot a — the all-gather puts
+  // rank r's block at r * per, a single rank copies its block to slot 0 — and the solver finds an agent's OWN plan (and skips
+  // its own record in the sweeps) by agent id. So the shard must be the block of a rank of the ceil(n_rob / world_size) split.
+  if (d->per > 0 && (d->first % d->per != 0 || (d->n_local < d->per && d->first + d->n_local != d->n_rob) || (world_size == 1 && d->first != 0))) {
+    delete d;
+    return fail(HDSM_ERR_BAD_ARG, "the shard is not a block of the ceil(n_rob / world_size) split: first_id must be rank * per, a short "
+                                  "shard must be the last one (and first_id 0 with world_size 1)");
+  }
   d->rcfg = {d->cfg.path_vel_min, d->cfg.path_vel_max, d->cfg.sens_dist, d->cfg.sens_pot, d->cfg.sens_other_agents, d->cfg.path_vel_dec};
   Cfg& c = d->c;
   c.N = d->prm.n_hor, c.P = d->prm.poly_hor, c.RS = d->prm.max_rows_static, c.step_plan = d->cfg.step_plan;
   c.n_it_decomp = d->cfg.n_it_decomp, c.use_cvx_new = d->cfg.use_cvx_new, c.has_world = hworld ? 1 : 0;
   c.voxel_size = d->cfg.voxel_size, c.grid_z_min = d->cfg.grid_z_min, c.thresh_dist = d->cfg.thresh_dist;
   c.fast_walk = 1;
-  if (const char* e = std::getenv("HDSM_FAST_WALK")) c.fast_walk = std::atoi(e) != 0;
+  if (const char* e = std::getenv("HDSM_FAST_WALK")) {  // development switch (A/B of the walk shortcut): "0" or "1", anything else is ignored
+    if ((e[0] == '0' || e[0] == '1') && e[1] == 0) c.fast_walk = e[0] == '1';
+  }
   for (int k = 0; k < 3; ++k) c.grid_range[k] = d->cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
   if (hipSetDevice(device) != hipSuccess) {
     delete d;
@@ -500,6 +513,12 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   DSwarm* d = static_cast<DSwarm*>(dswarm);
   if (!d) return fail(HDSM_ERR_BAD_ARG, "null dswarm");
   if (d->world > 1 && !comm) return fail(HDSM_ERR_BAD_ARG, "a sharded swarm needs a communicator");
+  if (comm) {  // the communicator must be the one this shard was cut for: its rank's block starts at first
+    int32_t crank = -1, cworld = -1;
+    if (hdsm_comm_info(comm, &crank, &cworld) != HDSM_OK) return fail(HDSM_ERR_COMM, std::string("hdsm_comm_info: ") + hdsm_last_error());
+    if (cworld != d->world || (d->per > 0 && crank != d->first / d->per))
+      return fail(HDSM_ERR_BAD_ARG, "communicator rank / size do not match the shard (first_id / per, world_size)");
+  }
   HIP_TRY(hipSetDevice(d->device));
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;

@@ -492,8 +492,15 @@ typedef struct {
   double inc_f, inc_u[ON], second;
   int inc_assign[MAXH], assign[MAXH];
   int nodes, qp_solves, qp_iters, max_nodes, iter_budget;
+  double cut0; /* verification mode: an upper bound on the optimum known beforehand (INFINITY = none) */
   gi_t gi;
 } bnb_t;
+
+/* objective value at which a node is cut off: the incumbent (minus the exactness margin) or the caller's bound */
+static double bnb_cut(const bnb_t* b) {
+  double c = b->have_inc ? b->inc_f - 1e-9 * fmax(1.0, fabs(b->inc_f)) : INFINITY;
+  return c < b->cut0 ? c : b->cut0;
+}
 
 static void push_con(bnb_t* b, const con_t* c) {
   if (b->ncons == b->cap) {
@@ -595,9 +602,7 @@ static double poly_violation(const bnb_t* b, int i, int j, double st[3][MAXH + 1
 
 static int solve_node(bnb_t* b, double* u, double* f) {
   b->qp_solves++;
-  int rc = gi_solve(&b->gi, b->in, b->cons, b->ncons, b->tol,
-                    b->have_inc ? b->inc_f - 1e-9 * fmax(1.0, fabs(b->inc_f)) : INFINITY,
-                    b->iter_budget - b->qp_iters);
+  int rc = gi_solve(&b->gi, b->in, b->cons, b->ncons, b->tol, bnb_cut(b), b->iter_budget - b->qp_iters);
   b->qp_iters += b->gi.iters;
   if (rc == GI_ITERLIM) b->limit_hit = 1;
   if (rc == GI_CUTOFF && b->gi.f < b->second) b->second = b->gi.f;
@@ -614,7 +619,7 @@ static void bnb_node(bnb_t* b, int depth, const double* u, double f) {
     b->limit_hit = 1;
     return;
   }
-  if (b->have_inc && f >= b->inc_f - 1e-9 * fmax(1.0, fabs(b->inc_f))) {
+  if (f >= bnb_cut(b)) {
     if (f < b->second) b->second = f;
     return;
   }
@@ -646,7 +651,7 @@ static void bnb_node(bnb_t* b, int depth, const double* u, double f) {
     const int j = order[o];
     if (key[j] == INFINITY) continue; /* pinned point outside polyhedron j */
     if (b->limit_hit) return;
-    if (b->have_inc && f >= b->inc_f - 1e-9 * fmax(1.0, fabs(b->inc_f))) return;
+    if (f >= bnb_cut(b)) return;
     b->assign[depth] = j;
     const int mark = b->ncons;
     if (!push_poly(b, depth, j)) {
@@ -665,6 +670,74 @@ static void bnb_node(bnb_t* b, int depth, const double* u, double f) {
   }
 }
 
+/* Second search order (orc_replan_ex, search = 1): a node branches only on a step whose segment lies in NO polyhedron at
+ * the node's own minimiser — the most infeasible such step, children by ascending violation — and a node whose segments
+ * are all contained is a leaf whatever its depth (unassigned steps take the lowest-index containing polyhedron). Exactness
+ * does not depend on the order; this one proves optimality on trees whose step-ordered enumeration exceeds any budget
+ * (many steps with two or three near-equivalent polyhedra). b->assign[i] = -1 marks an unassigned step. */
+static void bnb_lazy(bnb_t* b, const double* u, double f) {
+  const int N = b->prm->n_hor;
+  if (b->limit_hit) return;
+  if (++b->nodes > b->max_nodes) {
+    b->limit_hit = 1;
+    return;
+  }
+  if (f >= bnb_cut(b)) {
+    if (f < b->second) b->second = f;
+    return;
+  }
+  double st[3][MAXH + 1][3];
+  states_from_u(b->in, u, st);
+  int pick = -1, contain[MAXH];
+  double worst = -INFINITY, keys[MAXH][HDSM_MAX_POLY];
+  for (int i = N - 1; i >= 0; i--) {
+    contain[i] = b->assign[i];
+    if (b->assign[i] >= 0) continue;
+    double best = INFINITY;
+    for (int j = 0; j < b->cor->m[i]; j++) {
+      keys[i][j] = poly_violation(b, i, j, st);
+      if (keys[i][j] < best) best = keys[i][j];
+    }
+    for (int j = 0; j < b->cor->m[i]; j++)
+      if (keys[i][j] <= b->tol) {
+        contain[i] = j;
+        break;
+      }
+    if (contain[i] < 0 && best >= worst) worst = best, pick = i; /* ties: the earlier step */
+  }
+  if (pick < 0) {
+    if (b->have_inc && b->inc_f < b->second) b->second = b->inc_f;
+    b->have_inc = 1;
+    b->inc_f = f;
+    memcpy(b->inc_u, u, sizeof(double) * 3 * N);
+    memcpy(b->inc_assign, contain, sizeof(int) * N);
+    return;
+  }
+  const int m = b->cor->m[pick];
+  int order[HDSM_MAX_POLY];
+  for (int j = 0; j < m; j++) order[j] = j;
+  for (int x = 1; x < m; x++)
+    for (int y = x; y > 0 && keys[pick][order[y]] < keys[pick][order[y - 1]]; y--) {
+      int t = order[y];
+      order[y] = order[y - 1];
+      order[y - 1] = t;
+    }
+  for (int o = 0; o < m; o++) {
+    const int j = order[o];
+    if (keys[pick][j] == INFINITY) continue;
+    if (b->limit_hit) break;
+    if (f >= bnb_cut(b)) break;
+    b->assign[pick] = j;
+    const int mark = b->ncons;
+    if (push_poly(b, pick, j)) {
+      double uc[ON], fc;
+      if (solve_node(b, uc, &fc) == GI_OK) bnb_lazy(b, uc, fc);
+    }
+    b->ncons = mark;
+  }
+  b->assign[pick] = -1;
+}
+
 static void finish(const hdsm_params* prm, const double* state, const double* ref, const double* u,
                    double* traj, double* ctrl, double* obj) {
   const int N = prm->n_hor;
@@ -676,7 +749,7 @@ static void finish(const hdsm_params* prm, const double* state, const double* re
 
 static int miqp_shared(const hdsm_params* prm, const shared_t* sh, const double* state, const double* ref,
                        const orc_corridor* cor, double* traj, double* ctrl, uint8_t* used,
-                       orc_result* res) {
+                       orc_result* res, double cut0, int search) {
   const int N = prm->n_hor;
   inst_t in;
   build_inst(prm, sh, state, ref, &in);
@@ -686,7 +759,7 @@ static int miqp_shared(const hdsm_params* prm, const shared_t* sh, const double*
   b->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
   b->max_nodes = prm->max_nodes > 0 ? prm->max_nodes : 100000;
   b->iter_budget = prm->max_qp_iters > 0 ? prm->max_qp_iters : 10000000;
-  b->inc_f = INFINITY, b->second = INFINITY;
+  b->inc_f = INFINITY, b->second = INFINITY, b->cut0 = cut0;
   memset(res, 0, sizeof *res);
   res->status = HDSM_NO_SOLUTION;
   res->runner_up = HDSM_INF;
@@ -694,7 +767,12 @@ static int miqp_shared(const hdsm_params* prm, const shared_t* sh, const double*
   for (int i = 0; i < N; i++) ok &= cor->m[i] > 0;
   if (ok && build_base(b)) {
     double u[ON], f;
-    if (solve_node(b, u, &f) == GI_OK) bnb_node(b, 0, u, f);
+    if (search == 1)
+      for (int i = 0; i < N; i++) b->assign[i] = -1;
+    if (solve_node(b, u, &f) == GI_OK) {
+      if (search == 1) bnb_lazy(b, u, f);
+      else bnb_node(b, 0, u, f);
+    }
   }
   if (b->have_inc) {
     res->status = b->limit_hit ? HDSM_LIMIT : HDSM_OPTIMAL;
@@ -719,7 +797,7 @@ int orc_miqp(const hdsm_params* prm, const double state[9], const double* ref, c
     free(sh);
     return -1;
   }
-  int rc = miqp_shared(prm, sh, state, ref, cor, traj, ctrl, used, res);
+  int rc = miqp_shared(prm, sh, state, ref, cor, traj, ctrl, used, res, INFINITY, 0);
   free(sh);
   return rc;
 }
@@ -836,6 +914,8 @@ typedef struct {
   double *traj, *ctrl, *obj;
   uint8_t* used;
   int32_t *status, *nodes, *qp_iters;
+  const double* obj_hint; /* orc_replan_ex: per-instance upper bound on the optimum (NaN / >= HDSM_INF = none) */
+  int search;             /* orc_replan_ex: 0 steps in order (the default), 1 most infeasible uncontained step (bnb_lazy) */
   int next;
   pthread_mutex_t mtx;
 } batch_t;
@@ -884,7 +964,10 @@ static void run_instance(batch_t* B, int k) {
   orc_result res;
   double traj[(MAXH + 1) * 9], ctrl[MAXH * 3];
   uint8_t used[HDSM_MAX_POLY];
-  miqp_shared(prm, B->sh, B->state + 9 * k, B->ref + (size_t)6 * N * k, &cor, traj, ctrl, used, &res);
+  double cut0 = INFINITY;
+  if (B->obj_hint && B->obj_hint[k] == B->obj_hint[k] && B->obj_hint[k] < HDSM_INF)
+    cut0 = B->obj_hint[k] + 1e-6 * fmax(1.0, fabs(B->obj_hint[k])); /* the hinted optimum itself stays below the cut */
+  miqp_shared(prm, B->sh, B->state + 9 * k, B->ref + (size_t)6 * N * k, &cor, traj, ctrl, used, &res, cut0, B->search);
   B->status[k] = res.status;
   if (B->nodes) B->nodes[k] = res.nodes;
   if (B->qp_iters) B->qp_iters[k] = res.qp_iters;
@@ -945,6 +1028,27 @@ int orc_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int3
   B.state = state_curr, B.ref = traj_ref, B.A = A_static, B.b = b_static, B.plans = plans_all;
   B.has_plan = has_plan, B.traj = traj_out, B.ctrl = ctrl_out, B.obj = obj, B.used = poly_used;
   B.status = status, B.nodes = nodes, B.qp_iters = qp_iters;
+  return run_batch(&B, n_threads);
+}
+
+/* Verification mode of orc_replan. search: 0 = steps in order, 1 = bnb_lazy. obj_hint (may be NULL): obj_hint[k] is an objective value CLAIMED for instance k (e.g. by the device): the
+ * search cuts off every node whose bound exceeds it by more than 1e-6 relative. The claim is never trusted: if it is
+ * right the search ends on the same optimum (status OPTIMAL, outputs comparable as usual); if it is too low nothing is
+ * found (NO_SOLUTION); if it is too high a better point is returned. What the hint buys is pruning from the first node
+ * on, so that trees the step-ordered search cannot finish within its node budget are finished. */
+int orc_replan_ex(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                      const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                      const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                      const double* plans_all, const uint8_t* has_plan, const double* obj_hint, int32_t search,
+                      double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
+                      int32_t* nodes, int32_t* qp_iters, int32_t n_threads) {
+  batch_t B;
+  memset(&B, 0, sizeof B);
+  B.prm = prm, B.level = 2, B.n_inst = n_inst, B.n_rob = n_rob;
+  B.agent_id = agent_id, B.n_poly = n_poly, B.n_rows = n_rows_static;
+  B.state = state_curr, B.ref = traj_ref, B.A = A_static, B.b = b_static, B.plans = plans_all;
+  B.has_plan = has_plan, B.traj = traj_out, B.ctrl = ctrl_out, B.obj = obj, B.used = poly_used;
+  B.status = status, B.nodes = nodes, B.qp_iters = qp_iters, B.obj_hint = obj_hint, B.search = search;
   return run_batch(&B, n_threads);
 }
 

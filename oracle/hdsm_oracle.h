@@ -89,6 +89,16 @@ int orc_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int3
                const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
                uint8_t* poly_used, int32_t* status, double* obj, int32_t* nodes, int32_t* qp_iters,
                int32_t n_threads);
+/* orc_replan with a choice of search order (0 = steps in order, what orc_replan does; 1 = branch on the most infeasible
+ * uncontained step) and, optionally, a claimed objective per instance as an initial cut-off — verification of a claimed
+ * optimum on trees the step-ordered search cannot finish within its budget; the claim is not trusted (hdsm_oracle.c).
+ * obj_hint NULL, or obj_hint[k] NaN / >= HDSM_INF: no hint. */
+int orc_replan_ex(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
+                      const double* state_curr, const double* traj_ref, const int32_t* n_poly,
+                      const int32_t* n_rows_static, const double* A_static, const double* b_static,
+                      const double* plans_all, const uint8_t* has_plan, const double* obj_hint, int32_t search,
+                      double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
+                      int32_t* nodes, int32_t* qp_iters, int32_t n_threads);
 /* Level 1 (fully formed per-step polyhedra, literal: every row is a choice row): restates hdsm_solve.    */
 int orc_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const double* state_curr,
               const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows, const double* A,

@@ -162,8 +162,10 @@ def qp_fixed(prm, state, ref, cor, assign):
 
 
 def replan(prm, agent_id, state, ref, n_poly, n_rows_static, A_static, b_static, plans_all, has_plan,
-           n_threads=1):
-    """Batch level-2 oracle with the array layouts of include/hdsm.h."""
+           n_threads=1, obj_hint=None, search=0):
+    """Batch level-2 oracle with the array layouts of include/hdsm.h. obj_hint [n_inst]: objective values claimed for the
+    instances, used as an initial cut-off (orc_replan_ex: verification of a claim, NaN = none); search: 0 steps in order,
+    1 most infeasible uncontained step first."""
     N, P = prm.n_hor, prm.poly_hor
     agent_id, n_poly, n_rows_static = i32(agent_id), i32(n_poly), i32(n_rows_static)
     state, ref, A_static, b_static = f64(state), f64(ref), f64(A_static), f64(b_static)
@@ -173,10 +175,18 @@ def replan(prm, agent_id, state, ref, n_poly, n_rows_static, A_static, b_static,
                used=np.zeros((n_inst, P), dtype=np.uint8), status=np.zeros(n_inst, dtype=np.int32),
                obj=np.zeros(n_inst), nodes=np.zeros(n_inst, dtype=np.int32),
                qp_iters=np.zeros(n_inst, dtype=np.int32))
-    rc = lib().orc_replan(C.byref(prm), n_inst, n_rob, _ip(agent_id), _dp(state), _dp(ref), _ip(n_poly),
-                          _ip(n_rows_static), _dp(A_static), _dp(b_static), _dp(plans_all), _bp(has_plan),
-                          _dp(out["traj"]), _dp(out["ctrl"]), _bp(out["used"]), _ip(out["status"]),
-                          _dp(out["obj"]), _ip(out["nodes"]), _ip(out["qp_iters"]), int(n_threads))
+    if obj_hint is not None or search:
+        hint = f64(obj_hint) if obj_hint is not None else np.full(n_inst, np.nan)
+        assert hint.shape == (n_inst,)
+        rc = lib().orc_replan_ex(C.byref(prm), n_inst, n_rob, _ip(agent_id), _dp(state), _dp(ref), _ip(n_poly),
+                                 _ip(n_rows_static), _dp(A_static), _dp(b_static), _dp(plans_all), _bp(has_plan),
+                                 _dp(hint), int(search), _dp(out["traj"]), _dp(out["ctrl"]), _bp(out["used"]),
+                                 _ip(out["status"]), _dp(out["obj"]), _ip(out["nodes"]), _ip(out["qp_iters"]), int(n_threads))
+    else:
+        rc = lib().orc_replan(C.byref(prm), n_inst, n_rob, _ip(agent_id), _dp(state), _dp(ref), _ip(n_poly),
+                              _ip(n_rows_static), _dp(A_static), _dp(b_static), _dp(plans_all), _bp(has_plan),
+                              _dp(out["traj"]), _dp(out["ctrl"]), _bp(out["used"]), _ip(out["status"]),
+                              _dp(out["obj"]), _ip(out["nodes"]), _ip(out["qp_iters"]), int(n_threads))
     assert rc == 0
     return out
 

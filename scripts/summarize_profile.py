@@ -19,7 +19,7 @@ lo = seq["setup_flight"] + seq["warmup"]
 hi = lo + seq["timed"]
 key = line["config"]["workload_key"]
 summ = {"tag": tag, "workload_key": key, "command": "python bench.py " + " ".join(sys.argv[2:]) if len(sys.argv) > 2 else None,
-        "kernel": "k_replan", "launch_sequence": seq, "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "ms_per_step", "kernel_ms_mean")}}
+        "kernel": "k_replan", "kernel_source_sha16": line.get("roofline", {}).get("kernel_source_sha16"), "launch_sequence": seq, "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "ms_per_step", "kernel_ms_mean")}}
 
 
 def replan_rows(path, name_col="Kernel_Name"):

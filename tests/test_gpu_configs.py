@@ -1,6 +1,8 @@
-"""GPU tests that FLY BASELINE.json's configurations 3, 4 and 5 in closed loop on the device and check, at selected
+"""GPU tests that FLY BASELINE.json's configurations 2, 3, 4 and 5 in closed loop on the device and check, at selected
 rounds, size-independent properties on EVERY instance plus parity with the CPU oracle on a random subset:
 
+  cfg 2   64 agents, circular exchange with the SHIPPED geometry (R = 22 m around (18, 15),
+          multi_agent_planner_circle.launch.py:25-44), empty world, H = 10; every instance of the checked rounds against the oracle
   cfg 3   256 agents, circular exchange (R = 256 / 2 pi) through a pillar forest, corridors from the voxel decomposition
           (both GetPolyOcta3D and, where a seed is pinched, GetPolyOcta3DNew), H = 10
   cfg 4   1024 agents, circular exchange (R = 1024 / 2 pi), empty world, H = 10, flown THROUGH the rounds in which the
@@ -85,10 +87,10 @@ def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32):
                     inside = True
                     break
             assert inside, (a, i)
-    # oracle parity on a random subset
+    # oracle parity on a random subset (instances the device stopped on a budget are checked by _check_limit_instances)
     sub = rng.choice(n, min(n_parity, n), replace=False)
-    o = oracle.replan(prm, rec["agent_id"][sub], rec["state"][sub], rec["ref"][sub], rec["n_poly"][sub], rec["n_rows"][sub],
-                      rec["A"][sub], rec["b"][sub], rec["plans"], rec["has_plan"], n_threads=8)
+    sub = sub[status[sub] != 1]
+    o = _oracle_proved(oracle, prm, rec, sub)
     assert (status[sub] == o["status"]).all(), (status[sub].tolist(), o["status"].tolist())
     good = o["status"] != 2
     if good.any():
@@ -96,6 +98,73 @@ def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32):
         rel = np.abs(out["obj"][sub] - o["obj"])[good] / np.maximum(1.0, np.abs(o["obj"][good]))
         assert rel.max() < OBJ_RTOL
     return len(ok), int((status == 2).sum())
+
+
+def _oracle_proved(oracle, prm, rec, sub, hint=None, threads=8):
+    """The oracle on instances `sub` of a recorded round, with a PROOF for every one of them: the step-ordered search first
+    (bounded), then — where that ran into its budget — the oracle's other search order (most infeasible step first), which
+    finishes the trees the enumeration in step order cannot. No oracle answer with status LIMIT is ever compared."""
+    keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")
+    bounded = prm.copy()
+    bounded.max_nodes, bounded.max_qp_iters = 100000, 1000000
+    o = oracle.replan(bounded, *[rec[k][sub] for k in keys], rec["plans"], rec["has_plan"], n_threads=threads)
+    again = np.where(o["status"] == 1)[0]
+    if len(again):
+        big = prm.copy()
+        big.max_nodes, big.max_qp_iters = 2000000, 200000000
+        o2 = oracle.replan(big, *[rec[k][sub[again]] for k in keys], rec["plans"], rec["has_plan"], n_threads=threads, search=1,
+                           obj_hint=None if hint is None else hint[again])
+        assert (o2["status"] != 1).all(), "oracle budget exhausted in both search orders"
+        for k in ("traj", "ctrl", "used", "status", "obj", "nodes"):
+            o[k][again] = o2[k]
+    return o
+
+
+def _check_limit_instances(sol, oracle, prm, rec, out):
+    """Instances the device ended on a work budget (status LIMIT: an incumbent without a proof). Their incumbents have passed
+    the property checks of _check_round like every other solution (feasible in every respect); here the oracle finds the true
+    optimum of each and the incumbent's objective must not be BELOW it. Returns [(instance, flags, relative gap)]."""
+    lim = np.where(out["status"] == 1)[0]
+    if len(lim) == 0:
+        return []
+    flags = sol.last_sweep_stats(len(out["status"]))["flags"][lim]
+    o = _oracle_proved(oracle, prm, rec, lim, threads=16)
+    assert (o["status"] == 0).all(), o["status"].tolist()          # an incumbent exists, so the instance is feasible
+    gap = (out["obj"][lim] - o["obj"]) / np.maximum(1.0, np.abs(o["obj"]))
+    assert (gap > -1e-7).all(), gap.tolist()                        # nothing can beat the optimum
+    return [(int(a), int(f), float(g)) for a, f, g in zip(lim, flags, gap)]
+
+
+def test_config_2_64_agents_circle_shipped_geometry(hdsm, oracle):
+    """BASELINE configs[1]: 64 agents, circular exchange, empty environment, H = 10 — the geometry of the reference's own
+    launch file (R = 22 m, centre (18, 15), z = 1.5: chord 2.16 m), flown until the swarm has crossed; EVERY instance of
+    every tenth round is compared with the oracle."""
+    from multi_agent_pkgs_amd import swarm
+    n_rob, N = 64, 10
+    prm = agile_params(N, max_rows_static=18)
+    starts, goals = sc.circle_scenario(n_rob, radius=22.0, cx=18.0, cy=15.0, z=1.5)
+    assert np.allclose(starts[0], [40.0, 15.0, 1.5]) and np.allclose(goals[0], [-4.0, 15.0, 1.5])   # SURVEY 8d known answers
+    sol, loop = _device_loop(hdsm, prm, swarm.default_swarm_config(), n_rob, starts=starts, goals=goals)
+    rng = np.random.default_rng(2)
+    solved = failed = multi = 0
+    dmin = 1e9
+    for r in range(90):
+        rec = []
+        out = loop.step(record=rec)
+        pos, dist, _ = loop.shard.state()
+        d = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=2) + np.eye(n_rob) * 9
+        dmin = min(dmin, float(d.min()))
+        multi += int((out["used"].sum(axis=1) > 1).sum())
+        if r % 10 == 9 or r in (24, 27, 33, 36):                    # + the rounds around the crossing
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, n_rob, rng)
+            assert _check_limit_instances(sol, oracle, prm, rec[0], out) == []
+            solved += n_ok
+            failed += n_bad
+    assert solved > 12 * n_rob * 0.9 and dmin > 0.45                # nobody closer than the drone diameter (0.5 m) - tolerance
+    assert multi > 100                                              # trajectories really span several corridor boxes (MIQP)
+    assert dist.mean() < 0.25 * 44.0, float(dist.mean())            # the swarm has crossed the ring
+    print("cfg2: instance-solves checked against the oracle", solved, "without solution", failed, "closest approach", dmin,
+          "distance to goal mean / max", float(dist.mean()), float(dist.max()))
 
 
 def _pillar_hits(pos, raw, origin, vox=0.3):
@@ -182,7 +251,7 @@ def test_config_5_4096_agents_forest_wall_forest(hdsm, oracle):
     sol, loop = _device_loop(hdsm, prm, cfg, n_rob, starts=starts, goals=goals)
     assert loop.set_world(occ, origin) == 0
     rng = np.random.default_rng(5)
-    rows_max = 0
+    rows_max, limited = 0, []
     for r in range(16):
         rec = []
         out = loop.step(record=rec)
@@ -191,9 +260,12 @@ def test_config_5_4096_agents_forest_wall_forest(hdsm, oracle):
         if r in (3, 15):
             n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 6, rng, plane_chunk=8)
             assert n_ok > 0.9 * n_rob
+        # instances that ended on the node budget: incumbent vs the proven optimum, in EVERY round
+        limited += _check_limit_instances(sol, oracle, prm, rec[0], out) if (out["status"] == 1).any() else []
     pos, _, _ = loop.shard.state()
     assert _pillar_hits(pos, raw, origin) == 0
     assert pos[:, 0].mean() > 3.0 and rows_max > 6                 # moving into the first forest on shaped corridors
+    print("cfg5: instances that ended on a budget (instance, flags, relative gap to the proven optimum):", limited)
 
 
 def test_voxel_decomposition_on_the_device_matches_the_host_bit_for_bit(hdsm):

@@ -490,3 +490,27 @@ def test_map_preprocess_edge_cases(hdsm, oracle):
     with pytest.raises(hdsm.HdsmError) as e:
         hdsm.map_preprocess(default_map_config(potential_dist=3.5), np.zeros((1, 4, 4, 4), np.int8))  # rn = 12 > 9
     assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
+
+
+def test_enumerated_miqp_goldens_on_the_device(hdsm):
+    """tests/golden/miqp_enum.npz — six N = 6 / P = 3 cases with all 729 assignments resolved, three N = 10 / P = 4 cases with every
+    admissible assignment resolved (scipy + KKT certificates + LP infeasibility proofs; planes from refmath, not from the
+    oracle): the device must return the enumerated optimum. Objective to 1e-6 relative, trajectory to 1e-4 (the tolerance
+    BASELINE.json states against the reference solve) where the optimum is unique."""
+    from test_oracle import enum_cases, enum_snapshot
+    import refmath as rm
+    n = 0
+    for k, c in enum_cases():
+        prm, polys, args = enum_snapshot(c)
+        sol = hdsm.Solver(prm, 1, args[7].shape[0])
+        for rep in range(2):   # cold, then warm-started from its own answer
+            g = sol.replan(*args)
+            want = float(c["obj"])
+            assert g["status"][0] == 0 and abs(g["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, rep, g["obj"], want)
+            if float(c["second"]) - want > 1e-3 * max(1.0, abs(want)):
+                assert np.abs(g["traj"][0] - rm.rollout(prm, c["state"], c["u"])).max() < 1e-4, (k, rep)
+            used = set(np.where(g["used"][0])[0].tolist())
+            assert used == set(c["leaf_assign"][0].tolist()) or float(c["second"]) - want <= 1e-3 * max(1.0, abs(want)), (k, used)
+        sol.close()
+        n += 1
+    assert n >= 9

@@ -319,3 +319,95 @@ def test_map_preprocess_unknown_voxels(oracle):
     assert out[5, 7, 7] == -1 and out[7, 9, 7] == -1         # cube neighbours out of the inflation's reach: unknown
     assert out[0, 0, 0] == -1 and out[1, 1, 1] == 0          # border unknown voxel did not spread
     assert out[6, 8, 11] > 0 and out[6, 8, 11] < 100         # known voxel near the obstacle: potential
+
+
+# ------------------------------------------------------------------------------------------- verification mode
+def test_hinted_search_returns_the_same_optimum_and_never_trusts_the_hint(oracle):
+    """orc_replan_hinted (a claimed objective as the initial cut-off): with the TRUE optimum as the claim the answer is the
+    one of the plain search, found with fewer nodes; a claim below the optimum finds nothing; a claim above it is ignored."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 25, seed=35, spacing=1.0, narrow=True, turn=True)
+    args = [sn[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")]
+    plain = oracle.replan(prm, *args, n_threads=4)
+    ok = plain["status"] == 0
+    assert ok.sum() >= 10 and plain["nodes"][ok].max() > 3
+    hint = np.where(ok, plain["obj"], np.nan)
+    hinted = oracle.replan(prm, *args, n_threads=4, obj_hint=hint)
+    assert (hinted["status"] == plain["status"]).all()
+    assert np.abs(hinted["traj"] - plain["traj"])[ok].max() < 1e-9
+    assert (hinted["nodes"] <= plain["nodes"]).all()
+    low = oracle.replan(prm, *args, n_threads=4, obj_hint=np.where(ok, plain["obj"] * (1 - 1e-3) - 1e-3, np.nan))
+    assert (low["status"][ok] == 2).all()
+    high = oracle.replan(prm, *args, n_threads=4, obj_hint=np.where(ok, plain["obj"] * 2 + 1, np.nan))
+    assert (high["status"] == plain["status"]).all() and np.abs(high["traj"] - plain["traj"])[ok].max() < 1e-9
+
+
+def test_both_search_orders_of_the_oracle_agree(oracle):
+    """orc_replan_ex search = 1 (branch on the most infeasible uncontained step, leaves at any depth) against the default
+    step-ordered search on tight snapshots with real trees: same statuses, trajectories, objectives and poly_used."""
+    for prm, n_rob, seed, kw in ((agile_params(10, max_rows_static=18), 25, 35, dict(spacing=1.0, narrow=True, turn=True)),
+                                 (make_params(n_hor=12, rk4=True, drag=(0.1, 0.0, 0.3), max_rows_static=18, poly_hor=3), 16, 7,
+                                  dict(spacing=1.3, narrow=True, turn=True, chamfer=True))):
+        sn = problems.swarm_snapshot(prm, n_rob, seed=seed, **kw)
+        args = [sn[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")]
+        a = oracle.replan(prm, *args, n_threads=4)
+        b = oracle.replan(prm, *args, n_threads=4, search=1)
+        assert (a["status"] == b["status"]).all() and (a["status"] != 1).all()
+        ok = a["status"] == 0
+        assert ok.sum() >= 5 and a["nodes"][ok].max() > 20
+        assert np.abs(a["traj"] - b["traj"])[ok].max() < 1e-8
+        assert (np.abs(a["obj"] - b["obj"])[ok] / np.maximum(1, np.abs(a["obj"][ok]))).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------- enumerated MIQPs (SURVEY 8c-2)
+def enum_cases():
+    path = os.path.join(GOLD, "miqp_enum.npz")
+    g = np.load(path)
+    for k in range(int(g["n_cases"])):
+        yield k, {key[len(f"e{k}_"):]: g[key] for key in g.files if key.startswith(f"e{k}_")}
+
+
+def enum_snapshot(c):
+    """The replan inputs of an enumerated case in the ABI layouts (one instance: the agent the case was built for)."""
+    N, P = int(c["N"]), int(c["P"])
+    prm = make_params(n_hor=N, poly_hor=P, max_rows_static=18)
+    a = int(c["agent"])
+    polys = [(c["polyA"][j], c["polyb"][j]) for j in range(int(c["npoly"]))]
+    n_poly, n_rows, A, b = problems.pack_static([polys], P, prm.max_rows_static)
+    args = (np.array([a], np.int32), c["state"][None], c["ref"][None], n_poly, n_rows, A, b, c["plans"], c["has_plan"])
+    return prm, polys, args
+
+
+def test_enumerated_miqps_pin_the_combinatorial_part(oracle):
+    """tests/golden/miqp_enum.npz: six N = 6 / P = 3 cases with all 729 assignments resolved and three N = 10 / P = 4 cases with
+    every admissible assignment resolved — scipy leaf solutions with KKT certificates, infeasibility by LP proofs, planes from
+    refmath (generator: tests/golden/make_golden.py enum). The oracle's branch and bound (both search orders), its own
+    enumerator, and its fixed-assignment QP on the recorded leaves must reproduce them."""
+    n6 = n10 = 0
+    rng = np.random.default_rng(0)
+    for k, c in enum_cases():
+        prm, polys, args = enum_snapshot(c)
+        N = prm.n_hor
+        total, feasible = int(c["counts"][0]), int(c["counts"][1])
+        assert total == len(polys) ** N and feasible == len(c["leaf_obj"]) and feasible + int(c["counts"][2]) + int(c["counts"][3]) == total
+        want, second = float(c["obj"]), float(c["second"])
+        cor = oracle.Corridor([polys] * N, common_from_table(c["common"], N))
+        r = oracle.miqp(prm, c["state"], c["ref"], cor)
+        assert r["status"] == 0 and abs(r["obj"] - want) < 1e-6 * max(1.0, abs(want)), (k, r["obj"], want)
+        unique = second - want > 1e-3 * max(1.0, abs(want))
+        if unique:
+            assert np.abs(r["traj"] - rm.rollout(prm, c["state"], c["u"])).max() < 1e-4, k
+        for search in (0, 1):   # level 2 from the snapshot: the oracle's own planes this time, both search orders
+            o = oracle.replan(prm, *args, search=search)
+            assert o["status"][0] == 0 and abs(o["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, search)
+        leaves = range(feasible) if N == 6 else rng.choice(feasible, min(feasible, 40), replace=False)
+        for t in leaves:
+            q = oracle.qp_fixed(prm, c["state"], c["ref"], cor, c["leaf_assign"][t].astype(np.int32))
+            assert q["status"] == 0 and abs(q["obj"] - c["leaf_obj"][t]) < 1e-6 * max(1.0, abs(c["leaf_obj"][t])), (k, t)
+        if N == 6:
+            e = oracle.miqp_enum(prm, c["state"], c["ref"], cor)
+            assert e["status"] == 0 and abs(e["obj"] - want) < 1e-6 * max(1.0, abs(want)) and e["nodes"] == total
+            n6 += 1
+        else:
+            n10 += 1
+    assert n6 >= 6 and n10 >= 3

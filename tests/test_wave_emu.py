@@ -216,3 +216,17 @@ def test_level1_through_the_device_source(wave, oracle, kw):
         e = wave.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b, threads=threads)
         assert e["rc"] == 0
         compare(e, o, tol=1e-7)
+
+
+def test_device_source_reproduces_the_enumerated_miqps(wave):
+    """tests/golden/miqp_enum.npz (every admissible assignment resolved by scipy + KKT certificates, see test_oracle.py): the
+    device source's lazy branch and bound on the same snapshots — NV = 32 with n = 18 (padded factor) and n = 30."""
+    from test_oracle import enum_cases, enum_snapshot
+    import refmath as rm
+    for k, c in enum_cases():
+        prm, polys, args = enum_snapshot(c)
+        w = wave.replan(prm, *args)
+        want = float(c["obj"])
+        assert w["status"][0] == 0 and abs(w["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, w["obj"], want)
+        if float(c["second"]) - want > 1e-3 * max(1.0, abs(want)):
+            assert np.abs(w["traj"][0] - rm.rollout(prm, c["state"], c["u"])).max() < 1e-4, k
