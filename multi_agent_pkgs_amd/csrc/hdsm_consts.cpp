@@ -254,7 +254,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
       for (int lane = 0; lane < 64; ++lane) {
         const bool split = n <= SPLIT_N_MAX;
         if (split && j >= 16) continue;
-        const int row = split ? (lane & 31) : lane, col = split ? 16 * (lane >> 5) + j : j;
+        // split kernel (hdsm_wave_gib.h): slot j of lane L holds column ((j ^ L) & 15) + 16 (L >> 5) of row L & 31
+        const int row = split ? (lane & 31) : lane, col = split ? ((j ^ lane) & 15) + 16 * (lane >> 5) : j;
         c->JeqP[(size_t)j * 64 + lane] = (row < n && col < n) ? c->Jeq[(size_t)row * n + col] : (row == col ? 1.0 : 0.0);
       }
     // Set-up map: free response -> gradient at u = 0 -> x0 = -H^{-1} grad -> equality residual -> x_eq, nu, applied

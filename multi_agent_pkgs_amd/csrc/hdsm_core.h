@@ -5,9 +5,8 @@
 // (AC = multi_agent_planner/src/agent_class.cpp). Design notes: DESIGN.md.
 //
 //   * decision vector u = jerk inputs, condensed (states eliminated), n = 3 N, index ax*N + k;
-//   * exact dual active-set QP (Goldfarb-Idnani). Device build: the iteration runs on one wavefront with the
-//     factor in registers (hdsm_wave_gi.h). CPU build (HDSM_EMU): the textbook formulation below with J = L^{-T} Q
-//     and R in plain arrays and Givens sweeps — same pivoting rules, so both builds visit the same vertices;
+//   * exact dual active-set QP (Goldfarb-Idnani): the iteration runs on one wavefront with the factor in registers
+//     (n <= 30: hdsm_wave_gib.h, larger n: hdsm_wave_gi.h);
 //   * everything an instance needs before its first iteration is one linear map of (state, reference), precomputed
 //     by hdsm_create (Consts::KT);
 //   * the n_rob-1 neighbour planes per step are NEVER materialised: a sweep over the all-gathered plans
@@ -20,28 +19,12 @@
 //     only on a step whose segment lies in no polyhedron; children continue the parent's factorisation
 //     (snapshots of the solver state live in a per-instance global scratch, one per depth).
 //
-// The file compiles in two modes:
-//   - device mode (hipcc, gfx950): PAR_FOR distributes a loop over the threads of the workgroup,
-//     SYNC() is __syncthreads();
-//   - HDSM_EMU (g++): the same statements executed sequentially by one host thread. This build exists only
-//     for the CPU test-suite (tests/emu/) to check the kernel LOGIC without a GPU; it is never part of
-//     libhdsm.so and is not a fallback.
+// Device code only (hipcc, gfx950): PAR_FOR distributes a loop over the threads of the workgroup, SYNC() is __syncthreads().
+// The CPU test-suite runs THIS source as lockstep fibers (tests/wave_emu/); there is no second formulation of the algorithm.
 #pragma once
 #include <math.h>
 #include <stdint.h>
 
-#ifdef HDSM_EMU
-#define HD inline
-#define HDN inline
-#define PAR_FOR(i, cnt) for (int i = 0; i < (cnt); ++i)
-#define HDSM_UNROLL
-#define SYNC() ((void)0)
-#define IS_T0 (true)
-#define HDSM_NT 1
-namespace hdsm {
-static inline int atomic_inc_i32(int* p) { return (*p)++; }
-}  // namespace hdsm
-#else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
 #define HDN __device__ __noinline__
@@ -52,7 +35,6 @@ static inline int atomic_inc_i32(int* p) { return (*p)++; }
 namespace hdsm {
 __device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); }
 }  // namespace hdsm
-#endif
 
 #include "hdsm_types.h"
 
@@ -76,13 +58,8 @@ constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered s
 // All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
 template <int NV, int CMAX>
 struct Shm {
-  static constexpr int LD = NV + 1;  // odd leading dimension: row- and column-walks are bank-conflict free
   static constexpr int LDT = (NV <= 32) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
-#ifdef HDSM_EMU
-  double J[NV * LD];
-  double R[NV * LD];
-#else
-  alignas(16) double T[NV * LDT];       // transposition buffer for d = J^T a (J rows live in registers)
+  alignas(16) double T[NV > 32 ? NV * LDT : 2];  // NV = 48: transposition buffer for d = J^T a (J rows live in registers)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
   alignas(16) double dvz[NV + 2];       // d with the working-set columns (j < q) zeroed
@@ -95,8 +72,7 @@ struct Shm {
   long long t_start;                    // constant-rate clock at the start of the instance (time_limit_s)
   long long prof_acc[24];  // 0..7 iteration phases, 8..15 sweeps / set-up, 16..23 inside the warm start
   long long prof_last;
-#endif
-  double x[NV], lam[NV], d[NV], w[NV], z[NV], r[NV], a[NV], suf[NV + 1], gc[NV], gs[NV], grad[NV];
+  double x[NV], lam[NV], w[NV], grad[NV];
   double inc_x[NV];
   double g[3][3][MAXH];
   double fr[3][MAXH + 1][3];
@@ -105,13 +81,11 @@ struct Shm {
   double cprev[MAXH][3];
   double sp[MAXP][MAXRS][4];
   double keys[MAXH][MAXP];
-  double cand[CMAX][4];
+  alignas(16) double cand[CMAX][4];      // staged neighbour rows (n_f, rhs): read as two 16-byte halves by the scans
   double red_v[MAXT];
   double br_f[MAXH];
   double state0[9];
   double f, inc_f, f0;
-  int32_t red_i[MAXT];
-  int32_t red_j[MAXT];
   int32_t cand_m[CMAX];
   int32_t act[NV];
   int32_t sp_rows[MAXP];
@@ -123,7 +97,8 @@ struct Shm {
   int32_t inf_id;  // row whose addition proved the last node infeasible (ids as in act[])
   unsigned long long nogood[NOGOODS];
   int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
-  int32_t ncold;  // device build: rows staged but not scanned every iteration (top of cand[])
+  int32_t ncold;  // rows staged but not scanned every iteration (top of cand[])
+  int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
@@ -166,188 +141,12 @@ HD bool tasc_plane_eval(const Consts& c, const double* cp, const double* op, dou
 
 }  // namespace hdsm
 #include "hdsm_wave_gi.h"
+#include "hdsm_wave_gib.h"
 namespace hdsm {
 
 template <int NV, int CMAX>
 struct Solver {
   using S = Shm<NV, CMAX>;
-  static constexpr int LD = S::LD;
-
-  // ---- block-wide reductions -----------------------------------------------------------------------------
-  // argmax over idx in [0,cnt) of f(idx) -> (value, id); only values > v0 qualify; ties -> lowest idx.
-  template <class F>
-  static HD void block_argmax(S& s, int cnt, double v0, F f, double& vbest, int& ibest) {
-#ifdef HDSM_EMU
-    vbest = v0;
-    ibest = -1;
-    for (int i = 0; i < cnt; ++i) {
-      double v;
-      int id;
-      f(i, v, id);
-      if (v > vbest) vbest = v, ibest = id;
-    }
-#else
-    double v = v0;
-    int bi = -1, bidx = 0x7fffffff;
-    for (int i = (int)threadIdx.x; i < cnt; i += (int)blockDim.x) {
-      double vi;
-      int id;
-      f(i, vi, id);
-      if (vi > v) v = vi, bi = id, bidx = i;
-    }
-    s.red_v[threadIdx.x] = v;
-    s.red_i[threadIdx.x] = bi;
-    s.red_j[threadIdx.x] = bidx;
-    __syncthreads();
-    // tree over the workgroup; equal values resolve to the smallest loop index, i.e. exactly the result
-    // of a sequential scan (keeps the device path and the CPU logic build bit-identical)
-    for (int off = (int)blockDim.x >> 1; off > 0; off >>= 1) {
-      if ((int)threadIdx.x < off) {
-        const double v2 = s.red_v[threadIdx.x + off];
-        const int j2 = s.red_j[threadIdx.x + off];
-        const double v1 = s.red_v[threadIdx.x];
-        if (v2 > v1 || (v2 == v1 && j2 < s.red_j[threadIdx.x])) {
-          s.red_v[threadIdx.x] = v2;
-          s.red_i[threadIdx.x] = s.red_i[threadIdx.x + off];
-          s.red_j[threadIdx.x] = j2;
-        }
-      }
-      __syncthreads();
-    }
-    vbest = s.red_v[0];
-    ibest = s.red_i[0];
-    __syncthreads();
-#endif
-  }
-
-  // ---- trajectory from the current iterate ---------------------------------------------------------------
-  static HD void compute_states(S& s, const Consts& c) {
-    const int N = c.N;
-    PAR_FOR(idx, 9 * N) {
-      const int i = idx / 9 + 1, k = idx % 9, comp = k / 3, ax = k % 3;
-      double v = s.fr[ax][i][comp];
-      const double* gg = s.g[ax][comp];
-      const double* xx = s.x + ax * N;
-      for (int kk = 0; kk < i; ++kk) v += gg[i - 1 - kk] * xx[kk];
-      s.st[i][k] = v;
-    }
-    SYNC();
-  }
-
-  // value - rhs of a constraint (positive = violated); uniform call (all threads, same id)
-  static HD double resid(const S& s, const Consts& c, int id) {
-    const int N = c.N, kind = id_kind(id), p = id_payload(id);
-    if (kind == K_U) {
-      const int var = p >> 1, ax = var / N;
-      return (p & 1) ? (c.lbu[ax] - s.x[var]) : (s.x[var] - c.ubu[ax]);
-    }
-    if (kind == K_S) {
-      const int sg = p & 1, ax = (p >> 1) & 3, comp = (p >> 3) & 3, i = p >> 5;
-      const double v = s.st[i][3 * comp + ax];
-      return sg ? (c.lbs[comp][ax] - v) : (v - c.ubs[comp][ax]);
-    }
-    if (kind == K_E) {
-      const int ax = p % 3, comp = 1 + p / 3;
-      return s.st[N][3 * comp + ax];
-    }
-    if (kind == K_P) {
-      const int r = p & 63, e = (p >> 6) & 1, i = p >> 7;
-      const double* row = s.sp[s.assign[i]][r];
-      const double* pm = s.st[i + e];
-      return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-    }
-    const double* row = s.cand[p];
-    const double* pm = s.st[s.cand_m[p]];
-    return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-  }
-
-  // most violated inequality over: input box, state boxes, rows of assigned polyhedra, staged neighbour rows
-  static HD void select_violated(S& s, const Consts& c, double& vbest, int& ibest) {
-    const int N = c.N, n = c.n, RS = c.RS;
-    const int n_sb = 6 * (N - 1), n_sp = N * 2 * RS, n_c = s.ncand;
-    block_argmax(
-        s, n + n_sb + n_sp + n_c, c.tol,
-        [&](int idx, double& v, int& id) {
-          v = -DINF;
-          id = -1;
-          if (idx < n) {
-            const int ax = idx / N;
-            const double xv = s.x[idx];
-            const double vu = (fabs(c.ubu[ax]) < ABSENT) ? xv - c.ubu[ax] : -DINF;
-            const double vl = (fabs(c.lbu[ax]) < ABSENT) ? c.lbu[ax] - xv : -DINF;
-            if (vu >= vl) v = vu, id = mk_id(K_U, idx << 1);
-            else v = vl, id = mk_id(K_U, (idx << 1) | 1);
-            return;
-          }
-          idx -= n;
-          if (idx < n_sb) {
-            const int i = idx / 6 + 1, k = idx % 6, comp = 1 + k / 3, ax = k % 3;
-            const double sv = s.st[i][3 * comp + ax];
-            const double vu = (fabs(c.ubs[comp][ax]) < ABSENT) ? sv - c.ubs[comp][ax] : -DINF;
-            const double vl = (fabs(c.lbs[comp][ax]) < ABSENT) ? c.lbs[comp][ax] - sv : -DINF;
-            const int base = (i << 5) | (comp << 3) | (ax << 1);
-            if (vu >= vl) v = vu, id = mk_id(K_S, base);
-            else v = vl, id = mk_id(K_S, base | 1);
-            return;
-          }
-          idx -= n_sb;
-          if (idx < n_sp) {
-            const int i = idx / (2 * RS), rem = idx % (2 * RS), e = rem / RS, r = rem % RS;
-            const int j = s.assign[i];
-            if (j < 0 || r >= s.sp_rows[j] || i + e == 0) return;
-            const double* row = s.sp[j][r];
-            const double* pm = s.st[i + e];
-            v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-            id = mk_id(K_P, (i << 7) | (e << 6) | r);
-            return;
-          }
-          idx -= n_sp;
-          const double* row = s.cand[idx];
-          const double* pm = s.st[s.cand_m[idx]];
-          v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-          id = mk_id(K_C, idx);
-        },
-        vbest, ibest);
-  }
-
-  // dense normal a (in u-space) of constraint id:  a . u  (<= | ==)  rhs'
-  static HD void build_normal(S& s, const Consts& c, int id) {
-    const int N = c.N, n = c.n, kind = id_kind(id), p = id_payload(id);
-    int m = 0, comp = 0, cax = -1;
-    double nx = 0, ny = 0, nz = 0, sg = 1;
-    if (kind == K_U) {
-      sg = (p & 1) ? -1.0 : 1.0;
-    } else if (kind == K_S) {
-      sg = (p & 1) ? -1.0 : 1.0;
-      cax = (p >> 1) & 3, comp = (p >> 3) & 3, m = p >> 5;
-    } else if (kind == K_E) {
-      cax = p % 3, comp = 1 + p / 3, m = N;
-    } else if (kind == K_P) {
-      const int r = p & 63, e = (p >> 6) & 1, i = p >> 7;
-      const double* row = s.sp[s.assign[i]][r];
-      nx = row[0], ny = row[1], nz = row[2], m = i + e;
-    } else {
-      const double* row = s.cand[p];
-      nx = row[0], ny = row[1], nz = row[2], m = s.cand_m[p];
-    }
-    PAR_FOR(k, n) {
-      const int ax = k / N, kk = k % N;
-      double v = 0;
-      if (kind == K_U) {
-        v = (k == (p >> 1)) ? sg : 0.0;
-      } else if (kind == K_S || kind == K_E) {
-        if (ax == cax && kk < m) v = sg * s.g[ax][comp][m - 1 - kk];
-      } else if (kk < m) {
-        v = (ax == 0 ? nx : (ax == 1 ? ny : nz)) * s.g[ax][0][m - 1 - kk];
-      }
-      s.a[k] = v;
-    }
-    SYNC();
-  }
-
-#ifdef HDSM_EMU
-#include "hdsm_emu_gi.inc"  // tests/emu: textbook Givens formulation of the active-set loop for the CPU logic build
-#endif  // (the device build uses hdsm_wave_gi.h)
 
   // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
   static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
@@ -363,15 +162,26 @@ struct Solver {
   // the pinned point p_0 (ftol_fixed); the flag is the same.
   static constexpr double PINNED_TOL = 1e-7;
 
+  // After a sweep (one thread): the counters were advanced past the capacity by rows that found no slot. No slot is ever
+  // written twice (a writer checks the other list's counter AFTER its own atomic increment), so the slots below the clamped
+  // counts hold complete rows; the scans must never look beyond them.
+  static HD void clamp_staged(S& s) {
+    if (s.ncand + s.ncold > CMAX) {
+      s.overflow = 1;
+      s.wanted_raw = s.ncand + s.ncold;
+      const int cold = s.ncold < CMAX ? s.ncold : CMAX;
+      if (s.ncand > CMAX - cold) s.ncand = CMAX - cold;
+      s.ncold = cold;
+    }
+  }
+
   static HD void sweep(S& s, const Consts& c, const Args& a, int inst, int self, double thresh, bool check_fixed) {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
-#ifndef HDSM_EMU
     if (!explicit_rows) {  // device build: one thread per (neighbour, step) pair, sphere prefilter (hdsm_wave_gi.h)
       WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, (int)threadIdx.x);
       return;
     }
-#endif
     const int total = explicit_rows ? N * a.l1_rmax : a.n_rob * N;
     PAR_FOR(idx, total) {
       double row[4];
@@ -400,23 +210,16 @@ struct Solver {
         if (check_fixed && m <= c.pinned_steps && v > PINNED_TOL) s.fixed_bad = 1;
         if (v > c.tol) s.nviol = 1;  // benign race: every writer stores the same value
         if (-v < thresh) {
-#ifdef HDSM_EMU
-          const int slot = atomic_inc_i32(&s.ncand);
-          const bool fits = slot < CMAX;
-#else
           // violated (or almost) -> hot list, scanned every iteration; merely close -> cold list at the top of
           // the staging area, scanned only when the hot rows are all satisfied
           const bool hot = -v < c.hot_tau;
           const int slot = hot ? atomic_inc_i32(&s.ncand) : CMAX - 1 - atomic_inc_i32(&s.ncold);
           const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
-#endif
           if (fits && slot >= 0 && slot < CMAX) {
             s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
             s.cand[slot][3] = row[3];
             s.cand_m[slot] = m;
-#ifndef HDSM_EMU
             s.cand_src[slot] = explicit_rows ? -1 : (((idx / N) << 6) | (i << 1) | e);
-#endif
           } else {
             s.overflow = 1;
           }
@@ -425,11 +228,7 @@ struct Solver {
     }
     SYNC();
     if (IS_T0) {
-#ifdef HDSM_EMU
-      if (s.ncand > CMAX) s.ncand = CMAX;
-#else
-      if (s.ncand + s.ncold > CMAX) s.overflow = 1;  // the two lists met: whatever was written may be clobbered
-#endif
+      clamp_staged(s);
     }
     SYNC();
   }
@@ -438,7 +237,7 @@ struct Solver {
   // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if the pinned p_0 is outside.
   static HD int leaf_check(S& s, const Consts& c) {
     const int N = c.N, np = s.n_poly;
-#if !defined(HDSM_EMU) && defined(HDSM_LEAF_MFMA)
+#ifdef HDSM_LEAF_MFMA
     // Opt-in build (-DHDSM_LEAF_MFMA): measured on MI355X it is performance-neutral on every workload tried but costs the
     // two-workgroups-per-CU kernel spilled VGPRs (scratch 24 -> 68 B/lane, HBM writes 3.9 -> 10.4 MB per launch), so the
     // default build keeps the scalar leaf test. Counters of both builds: profiles/r02_mfma_ab.json.
@@ -532,8 +331,16 @@ struct Solver {
   }
 
   // ---- snapshots of the solver state (global scratch), one per branching depth ----------------------------------
-#ifndef HDSM_EMU
-  using W = WaveGI<NV, CMAX>;
+  // n <= 30: rows of J split over two lanes, columns in butterfly order (hdsm_wave_gib.h); larger n: one lane per row
+  template <int NV_, class = void>
+  struct PickW {
+    using type = WaveGI<NV_, CMAX>;
+  };
+  template <class V>
+  struct PickW<32, V> {
+    using type = WaveGIB<CMAX>;
+  };
+  using W = typename PickW<NV>::type;
   using GIState = typename W::Regs;
   static constexpr int SNAP_STRIDE = W::SNAP_DOUBLES + 2;  // doubles per level
   // The factorisation lives in the registers of wave 0; the other waves of the workgroup (they take part in the
@@ -553,32 +360,6 @@ struct Solver {
     iters = s.iters_sh;
     return s.rc;
   }
-#else
-  struct GIState {};
-  static HD int gi_run(S& s, const Consts& c, GIState&, double f_cut, int& iters) { return gi_run(s, c, f_cut, iters); }
-  static HD void snapshot_io(S& s, const Consts& c, GIState&, double* buf, bool save) { snapshot_io(s, c, buf, save); }
-  static constexpr int SNAP_DOUBLES = 2 * NV * LD + 2 * NV + 2;
-  static HD void snapshot_io(S& s, const Consts& c, double* buf, bool save) {
-    const int n = c.n;
-    double* bJ = buf;
-    double* bR = buf + NV * LD;
-    double* bx = bR + NV * LD;
-    double* bl = bx + NV;
-    double* bs = bl + NV;
-    int32_t* bi = (int32_t*)(buf + SNAP_DOUBLES);
-    if (save) {
-      PAR_FOR(k, n * LD) bJ[k] = s.J[k], bR[k] = s.R[k];
-      PAR_FOR(k, n) bx[k] = s.x[k], bl[k] = s.lam[k], bi[k] = s.act[k];
-      if (IS_T0) bs[0] = s.f, bi[NV] = s.q;
-    } else {
-      PAR_FOR(k, n * LD) s.J[k] = bJ[k], s.R[k] = bR[k];
-      PAR_FOR(k, n) s.x[k] = bx[k], s.lam[k] = bl[k], s.act[k] = bi[k];
-      if (IS_T0) s.f = bs[0], s.q = bi[NV];
-    }
-    SYNC();
-  }
-  static constexpr int SNAP_STRIDE = SNAP_DOUBLES + (NV + 2) / 2 + 1;  // doubles per level
-#endif
 
   static HD double cutoff(const S& s, const Consts& c) {
     if (!s.have_inc) return DINF;
@@ -641,10 +422,8 @@ struct Solver {
     const int self = a.agent_id[inst];
     double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
 
-#ifndef HDSM_EMU
     const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
-#endif
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
     if (threadIdx.x < 24) s.prof_acc[threadIdx.x] = 0;
@@ -654,57 +433,6 @@ struct Solver {
 #else
 #define SU_PROF(k)
 #endif
-#ifdef HDSM_EMU
-    // ---- stage the instance in LDS
-    PAR_FOR(k, 9) s.state0[k] = a.state[(int64_t)inst * 9 + k];
-    PAR_FOR(k, 6 * N) s.ref[k / 6][k % 6] = a.ref[(int64_t)inst * 6 * N + k];
-    PAR_FOR(k, 9 * MAXH) s.g[k / (3 * MAXH)][(k / MAXH) % 3][k % MAXH] = c.g[k / (3 * MAXH)][(k / MAXH) % 3][k % MAXH];
-    const int np = min_i(a.n_poly[inst], P);
-    PAR_FOR(k, P) s.sp_rows[k] = (k < np) ? min_i(a.n_rows[(int64_t)inst * P + k], RS) : 0;
-    PAR_FOR(k, P * RS) {
-      const int j = k / RS, r = k % RS;
-      const double* Ar = a.A + (((int64_t)inst * P + j) * RS + r) * 3;
-      s.sp[j][r][0] = Ar[0], s.sp[j][r][1] = Ar[1], s.sp[j][r][2] = Ar[2];
-      s.sp[j][r][3] = a.b[((int64_t)inst * P + j) * RS + r];
-    }
-    PAR_FOR(k, 9 + 6 * N) s.vin[k] = (k < 9) ? a.state[(int64_t)inst * 9 + k] : a.ref[(int64_t)inst * 6 * N + (k - 9)];
-    const bool self_ok = self >= 0 && self < a.n_rob;
-    PAR_FOR(k, 3 * N) {  // both candidates are requested before has_plan[self] is known: one memory latency, not two
-      const int i = k / 3, ax = k % 3;
-      const double from_plan = a.plans[((int64_t)(self_ok ? self : 0) * (N + 1) + (i + 1)) * 9 + ax];
-      const double from_state = a.state[(int64_t)inst * 9 + ax];
-      s.cprev[i][ax] = (self_ok && a.has_plan[self_ok ? self : 0]) ? from_plan : from_state;
-    }
-    PAR_FOR(k, MAXH) s.assign[k] = -1;
-    if (IS_T0) {
-      s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
-      s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
-      s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
-    }
-    SYNC();
-    // x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at u = 0, the residual
-    // of the six terminal equalities at x0 and their multipliers: one dot product each with the precomputed map KT
-    // (hdsm_consts.cpp). The remaining threads build the free response and st[0].
-    const int nk = 3 * n + 12, nvt = 9 + 6 * N;
-    PAR_FOR(idx, nk + 9 * (N + 1)) {
-      if (idx < nk) {
-        double acc = 0;
-        for (int j = 0; j < nvt; ++j) acc += c.KT[j * KROWS + idx] * s.vin[j];
-        if (idx < n) s.x[idx] = acc;
-        else if (idx < 2 * n) s.w[idx - n] = acc;
-        else if (idx < 3 * n) s.grad[idx - 2 * n] = acc;
-        else if (idx < 3 * n + 6) s.red_v[idx - 3 * n] = acc;
-        else s.lam[idx - 3 * n - 6] = acc;
-      } else {
-        const int k = idx - nk;
-        const int i = k / 9, comp = (k % 9) / 3, ax = k % 3;
-        double v = 0;
-        for (int cc = 0; cc < 3; ++cc) v += c.phi[ax][i][comp][cc] * s.state0[3 * cc + ax];
-        s.fr[ax][i][comp] = v;
-        if (i == 0) s.st[0][3 * comp + ax] = s.state0[3 * comp + ax];
-      }
-    }
-#else
     // ---- stage the instance in LDS and apply the set-up map. Every global read of the set-up is REQUESTED before
     // the first one is consumed (memory latency is paid once, or twice for the own plan, whose address needs
     // agent_id[inst]); the generic loops of the CPU build above do the same thing one array at a time.
@@ -844,20 +572,9 @@ struct Solver {
         }
       }
     }
-#endif
     SU_PROF(14)
-#ifdef HDSM_EMU
-    GIState R;
-    PAR_FOR(k, n * n) {
-      const int i = k / n, j = k % n;
-      s.J[i * LD + j] = c.Jeq[k];
-      s.R[i * LD + j] = (i < 6 && j < 6) ? c.Req[i * 6 + j] : 0.0;
-    }
-    PAR_FOR(e, 6) s.act[e] = mk_id(K_E, e);
-#endif
     SYNC();
     // constant term f0, J(x0) = f0 + grad.x0 / 2 and J(x_eq) = J(x0) + resid.nu / 2
-#ifndef HDSM_EMU
     R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
     PAR_FOR(k, NV) s.x0[k] = (k < n) ? s.w[k] : 0.0;
     if (threadIdx.x < 64) {
@@ -883,32 +600,14 @@ struct Solver {
         s.inc_nact = 0;
       }
     }
-#else
-    if (IS_T0) {
-      double f0 = 0;
-      for (int i = 1; i <= N; ++i) {
-        const double* w = (i == N) ? c.wn : c.wx;
-        for (int k = 0; k < 6; ++k) {
-          const double e = s.fr[k % 3][i][k / 3] - s.ref[i - 1][k];
-          f0 += w[k] * e * e;
-        }
-      }
-      double f = f0;
-      for (int k = 0; k < n; ++k) f += 0.5 * s.grad[k] * s.w[k];
-      for (int e = 0; e < 6; ++e) f += 0.5 * s.red_v[e] * s.lam[e];
-      s.f0 = f0;
-      s.f = f;
-    }
-#endif
     SYNC();
     SU_PROF(15)
 
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
     const long long t_setup_ = clock64() - t_begin_;
 #endif
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
-#ifndef HDSM_EMU
     // The guess is an infeasibility certificate (see the hand-over below), or the last replan ended on the gridlock test of
     // its sweep (PINNED_TOL): the neighbourhood was gridlocked. Such an instance sweeps FIRST, at the cold starting point: if
     // the gridlock persists the test ends it right there; the certificate's own minimiser is a far-away point, so nothing
@@ -918,7 +617,6 @@ struct Solver {
 #if defined(HDSM_PROFILE)
     long long t_warm_ = 0;
     int it_warm_ = 0;
-#endif
 #endif
     bool limit = false;
     unsigned flags = 0;
@@ -934,14 +632,6 @@ struct Solver {
         // Verification: rows left unstaged by the staging sweep had slack >= sw_tau at sw_ref; a row's slack moves by
         // at most |n_f| |dp| with |n_f| <= sqrt(1 + (3 pert)^2) (the planes themselves are fixed during an instance).
         // If no trajectory point has moved further than that allows, nothing unstaged can be violated: no sweep.
-#ifdef HDSM_EMU
-        double d2 = 0;
-        for (int m = 0; m <= N; ++m) {
-          const double ux = s.st[m][0] - s.sw_ref[m][0], uy = s.st[m][1] - s.sw_ref[m][1], uz = s.st[m][2] - s.sw_ref[m][2];
-          d2 = d2 > ux * ux + uy * uy + uz * uz ? d2 : ux * ux + uy * uy + uz * uz;
-        }
-        s.sw_d2 = d2;
-#else
         if (threadIdx.x < 64) {
           const int m = (int)threadIdx.x;
           double d2 = 0;
@@ -952,7 +642,6 @@ struct Solver {
           d2 = wave_max64(d2);
           if (m == 0) s.sw_d2 = d2;
         }
-#endif
         SYNC();
         const double nf2 = 1.0 + 9.0 * c.pert * c.pert;
         if (nf2 * s.sw_d2 * (1.0 + 1e-9) <= s.sw_tau * s.sw_tau) {
@@ -965,17 +654,17 @@ struct Solver {
         SYNC();
         if (IS_T0) s.nviol = 0;
         SYNC();
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
         const long long ts_ = clock64();
 #endif
         sweep(s, c, a, inst, self, thresh, sweeps == 0);
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
         t_sweep_ += clock64() - ts_;
 #endif
         ++sweeps;
         if (!s.overflow || thresh <= -c.tol) break;
         SYNC();
-        const int wanted = (s.ncand - before) + (s.ncold - before_cold);  // rows that asked for a slot (counted past the capacity)
+        const int wanted = s.wanted_raw - before - before_cold;  // rows that asked for a slot (counted past the capacity)
         SYNC();
         if (IS_T0) s.ncand = before, s.ncold = before_cold, s.overflow = 0;
         // far more rows than slots (a start point in the middle of a gridlock: thousands of rows): a quarter of the radius
@@ -989,7 +678,6 @@ struct Solver {
         SYNC();
       }
     };
-#ifndef HDSM_EMU
     if (run && warm_cert && c.presweep != 0 && a.l1_rows == nullptr) {
       if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
       SYNC();
@@ -1011,16 +699,11 @@ struct Solver {
       it_warm_ = iters;
 #endif
     }
-#endif
     if (run && sweeps == 0 && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
       // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
       // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
       // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
-#ifdef HDSM_EMU
-      compute_states(s, c);
-#else
       if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
-#endif
       SYNC();
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
@@ -1036,11 +719,11 @@ struct Solver {
         break;
       }
       if (rc == GI_OK) {
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
         const long long tl_ = clock64();
 #endif
         const int bstep = leaf_check(s, c);
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
         t_leaf_ += clock64() - tl_;
 #endif
         if (bstep < 0) {
@@ -1059,7 +742,6 @@ struct Solver {
           }
           PAR_FOR(k, n) s.inc_x[k] = s.x[k];
           PAR_FOR(i, N) s.inc_assign[i] = s.contain[i];
-#ifndef HDSM_EMU
           PAR_FOR(k, NV) {
             int code = 0;
             if (k < s.q) {
@@ -1072,7 +754,6 @@ struct Solver {
             s.inc_act[k] = code;
           }
           if (IS_T0) s.inc_nact = s.q;
-#endif
           if (IS_T0) s.inc_f = s.f, s.have_inc = 1;
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
@@ -1126,7 +807,7 @@ struct Solver {
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
-#if defined(HDSM_PROFILE) && !defined(HDSM_EMU)
+#ifdef HDSM_PROFILE
     if (IS_T0 && a.prof) {
       long long* pr = a.prof + (int64_t)inst * 32;
       for (int k = 0; k < 8; ++k) pr[k] = s.prof_acc[k], pr[16 + k] = s.prof_acc[8 + k], pr[24 + k] = s.prof_acc[16 + k];  // 16..23: inside the sweeps, 24..31: inside the warm start
@@ -1156,7 +837,6 @@ struct Solver {
       }
       SYNC();
       PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
-#ifndef HDSM_EMU
       if (threadIdx.x < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
         const int lane = (int)threadIdx.x;
         double part = (lane < n) ? c.r_u * s.inc_x[lane] * s.inc_x[lane] : 0.0;
@@ -1168,27 +848,13 @@ struct Solver {
         part = wave_sum64(part);
         if (lane == 0) a.obj[inst] = part;
       }
-#endif
       if (IS_T0) {
-#ifdef HDSM_EMU
-        double Jv = 0;
-        for (int k = 0; k < n; ++k) Jv += c.r_u * s.inc_x[k] * s.inc_x[k];
-        for (int i = 1; i <= N; ++i) {
-          const double* w = (i == N) ? c.wn : c.wx;
-          for (int k = 0; k < 6; ++k) {
-            const double e = s.st[i][k] - s.ref[i - 1][k];
-            Jv += w[k] * e * e;
-          }
-        }
-        a.obj[inst] = Jv;
-#endif
         uint8_t* us = a.used + (int64_t)inst * P;
         for (int j = 0; j < P; ++j) us[j] = 0;
         for (int i = 0; i < N; ++i)
           if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
       }
     }
-#ifndef HDSM_EMU
     if (a.warm != nullptr) {  // next replan's guess
       int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
       // No solution because the ROOT relaxation is infeasible (the usual case in a gridlocked neighbourhood, and it
@@ -1214,8 +880,7 @@ struct Solver {
       const bool gridlock = s.fixed_bad && !s.have_inc;  // ended on the pinned-position test of a sweep
       if (IS_T0) wp[0] = cnt | ((certificate || gridlock) ? WARM_CERT : 0);
     }
-#endif
-#if defined(HDSM_TIMELINE) && !defined(HDSM_EMU)
+#ifdef HDSM_TIMELINE
     if (IS_T0 && a.prof) {  // development aid (scripts/gpu_timeline.sh): when and where this instance ran
       long long* pr = a.prof + (int64_t)inst * 32;
       unsigned hw;
@@ -1231,12 +896,9 @@ struct Solver {
       if (a.st_nodes) a.st_nodes[inst] = nodes;
       if (a.st_sweeps) a.st_sweeps[inst] = sweeps;
       if (a.st_cand) a.st_cand[inst] = s.ncand + s.ncold;
-#ifndef HDSM_EMU
       if (a.st_sph) a.st_sph[inst] = s.st_sph;
       if (a.st_pairs) a.st_pairs[inst] = s.st_pairs;
-#endif
       if (a.st_flags) a.st_flags[inst] = flags;
-#ifndef HDSM_EMU
       if (a.st_key) {
         // what the next launch sorts by (hdsm_api.hip, launch_order_block): how long this instance took; an instance without
         // a solution goes first whatever it took — its next replan either ends on the certificate at once or is among the
@@ -1246,7 +908,6 @@ struct Solver {
         const long long ticks = (((long long)wall_clock64() - tl_begin_) >> 6) + 9 * s.q;
         a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
-#endif
     }
     SYNC();
   }

@@ -61,7 +61,8 @@ struct Consts {
   double KTC[KCH * KROWS];
   int32_t kax[KROWS];
   // Jeq (identity beyond n) in the register layout of the kernel that serves this n (hdsm_wave_gi.h):
-  //   n <= 30 (split kernel, NV = 32): JeqP[c * 64 + lane] = Jeq[lane & 31][16 (lane >> 5) + c], c < 16
+  //   n <= 30 (split kernel, NV = 32): JeqP[s * 64 + lane] = Jeq[lane & 31][((s ^ lane) & 15) + 16 (lane >> 5)], s < 16
+  //                                    (the butterfly slot order of hdsm_wave_gib.h)
   //   n  > 30 (NV = 48):               JeqP[j * 64 + lane] = Jeq[lane][j], j < 48
   double JeqP[MAXNV * 64];
 };

@@ -22,7 +22,6 @@
 // Dimension handling: the factors are padded to NV (identity beyond n = 3N), so every loop has a
 // compile-time trip count and unrolls; a padded direction never receives a step (d_k = 0 there).
 #pragma once
-#ifndef HDSM_EMU
 #include <hip/hip_runtime.h>
 
 #include "hdsm_types.h"
@@ -143,8 +142,10 @@ struct WaveGI {
   }
 
   struct Regs {
-    double Jr[NC];  // columns [col0, col0 + NC) of row row_of(lane) of J
+    double Jr[NC];  // columns [col0, col0 + NC) of row row_of(lane) of J (NV = 32: in the slot order of hdsm_wave_gib.h)
     double xi;      // u[lane]
+    double lam;     // NV = 32 (hdsm_wave_gib.h): multiplier and id of working-set position pos_of(lane) while a run is going on
+    int act;
     // per-lane constants of the violation scan (bounds with "absent" mapped to +-DINF), set by init_lane()
     double ub_own, lb_own;      // box of this lane's input
     double sb_ub[2], sb_lb[2];  // boxes of the (up to two) state-bound items scanned by this lane
@@ -675,7 +676,13 @@ struct WaveGI {
       }
     }
     __syncthreads();
-    if (lane == 0 && s.ncand + s.ncold > CMAX) s.overflow = 1;
+    if (lane == 0 && s.ncand + s.ncold > CMAX) {  // rows that found no slot advanced the counters past the capacity: clamp
+      s.overflow = 1;                             // (no slot is written twice, so everything below the clamped counts is complete)
+      s.wanted_raw = s.ncand + s.ncold;
+      const int cold = s.ncold < CMAX ? s.ncold : CMAX;
+      if (s.ncand > CMAX - cold) s.ncand = CMAX - cold;
+      s.ncold = cold;
+    }
     __syncthreads();
     SW_PROF(12)
   }
@@ -1053,4 +1060,3 @@ struct WaveGI {
 };
 
 }  // namespace hdsm
-#endif  // !HDSM_EMU

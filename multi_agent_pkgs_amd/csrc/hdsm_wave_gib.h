@@ -1,0 +1,487 @@
+// hdsm_wave_gib.h — device-only (gfx950): the dual active-set iteration for n <= 30 (NV = 32) with ALL cross-lane traffic of the
+// factor J in registers: no LDS transposition, no dynamically indexed register access.
+//
+// Same mathematics as hdsm_wave_gi.h (Goldfarb-Idnani on J = L^{-T} Q, U = R^{-1}, Householder add / drop); what changes is where
+// the numbers live, chosen so that the two matrix-vector products with J that sit on the dependency chain of every active-set
+// operation — d = J^T a (a reduction over the ROWS of J, i.e. across lanes) and z = J2 d2 (a reduction over the columns, i.e.
+// inside a lane) — need DPP moves only:
+//
+//   * rows: row i of J is split over lanes i (columns 0..15) and i + 32 (columns 16..31), as before ("row layout": per-row
+//     scalars x_i, z_i, a_i live in lanes i and i + 32);
+//   * columns inside a lane are kept in BUTTERFLY ORDER: slot s of lane L holds column  col(L, s) = ((s ^ L) & 15) + 16 (L >> 5).
+//     With that order the sum over the 16 lanes of a DPP row of one value per column ("reduce-scatter") is four stages of
+//     `slot[s] += dpp(slot[partner(s)])` with STATIC slot numbers — row_mirror, row_half_mirror, quad_perm xor 2, quad_perm xor 1 —
+//     15 double additions and 30 v_mov_dpp, no select, and lane L ends up holding column (L & 15) + 16 (L >> 5) in slot 0;
+//     v_permlane16_swap adds the second DPP row of the half. The reverse walk ("all-gather") hands every lane the 16 entries
+//     of a column-distributed vector in exactly the order of its own J slots: 30 v_mov_dpp, no LDS round trip;
+//   * "position layout": what belongs to working-set position / column k — d_k, the multiplier, the constraint id, r_k and
+//     row k of U (LDS, natural column order) — lives in lanes P(k) = (k & 15) + 32 (k >> 4) and P(k) + 16; the lane with bit 4
+//     clear takes columns 0..15 of the U row, its twin columns 16..31, and the two partial dot products meet through
+//     v_permlane16_swap. Multipliers and ids stay in registers during a run (they were an LDS round trip per operation);
+//   * the Householder reflections are applied as J -= (J v) beta v^T with the COMPLETE v (v = d2 - rho e_q, or u_l - sigma e_t
+//     for a drop) gathered from its column-distributed form, so column q (or t) needs no special treatment and no register of
+//     J is ever addressed by a run-time index (the old layout paid a 16-deep select chain per access).
+//
+// Everything that does not touch J's layout (state evaluation, violation scan, helper waves, neighbour sweep, residuals) is
+// inherited from WaveGI<32, CMAX>. NV = 48 (H > 10) keeps the one-lane-per-row code of hdsm_wave_gi.h.
+#pragma once
+#include "hdsm_wave_gi.h"
+
+namespace hdsm {
+
+// v[L] + v[L ^ 16] in every lane (v_permlane16_swap: the two DPP rows of a half)
+__device__ __forceinline__ double row16_sum64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+template <int CMAX>
+struct WaveGIB : WaveGI<32, CMAX> {
+  using Base = WaveGI<32, CMAX>;
+  using S = typename Base::S;
+  using Regs = typename Base::Regs;
+  static constexpr int NV = 32, NC = 16, LDT = S::LDT;
+
+  static __device__ __forceinline__ int pos_of(int lane) { return (lane & 15) + 16 * (lane >> 5); }
+  static __device__ __forceinline__ int lane_of_pos(int k) { return (k & 15) + 32 * (k >> 4); }
+  static __device__ __forceinline__ bool first_copy(int lane) { return (lane & 16) == 0; }
+
+  // sum over the 32 lanes of a half of slot-ordered per-column values: returns, in lane L, the total of column pos_of(L)
+  static __device__ __forceinline__ double reduce_cols(double (&p)[NC]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) p[s] += dpp64<0x140>(p[15 - s]);  // row_mirror: partner L ^ 15
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p[s] += dpp64<0x141>(p[7 - s]);   // row_half_mirror: partner L ^ 7
+#pragma unroll
+    for (int s = 0; s < 2; ++s) p[s] += dpp64<0x4E>(p[s ^ 2]);    // quad_perm [2,3,0,1]: partner L ^ 2
+    p[0] += dpp64<0xB1>(p[1]);                                    // quad_perm [1,0,3,2]: partner L ^ 1
+    return row16_sum64(p[0]);
+  }
+  // v = entry pos_of(L) of a column-distributed vector (both DPP rows of a half hold it) -> g[s] = entry col(L, s)
+  static __device__ __forceinline__ void gather_cols(double v, double (&g)[NC]) {
+    g[0] = v;
+    g[1] = dpp64<0xB1>(g[0]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) g[s ^ 2] = dpp64<0x4E>(g[s]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) g[7 - s] = dpp64<0x141>(g[s]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) g[15 - s] = dpp64<0x140>(g[s]);
+  }
+  // sum over the DISTINCT positions of a position-layout value (every position has two copies)
+  static __device__ __forceinline__ double pos_sum(double v, int lane) { return wave_sum64(first_copy(lane) ? v : 0.0); }
+
+  // multipliers / ids: LDS (between the phases of an instance, position k at index k) <-> registers (inside a run)
+  static __device__ __forceinline__ void load_pos(const S& s, Regs& R, int lane) {
+    R.lam = s.lam[pos_of(lane)], R.act = s.act[pos_of(lane)];
+  }
+  static __device__ __forceinline__ void store_pos(S& s, const Regs& R, int lane) {
+    if (first_copy(lane)) s.lam[pos_of(lane)] = R.lam, s.act[pos_of(lane)] = R.act;
+  }
+
+  // dot product of this lane's half (columns 16 (lane bit 4) ..) of row k = pos_of(lane) of U with s.dvec, both halves summed
+  static __device__ __forceinline__ double u_row_dot(const S& s, int lane) {
+    const int k = pos_of(lane), c0 = (lane & 16);
+    const D2* urow = reinterpret_cast<const D2*>(&s.U[k * LDT + c0]);
+    const D2* dv = reinterpret_cast<const D2*>(&s.dvec[c0]);
+    double r0 = 0, r1 = 0;
+#pragma unroll
+    for (int j = 0; j < NC / 2; ++j) {
+      const D2 u = urow[j], d = dv[j];
+      r0 += u.x * d.x, r1 += u.y * d.y;
+    }
+    return row16_sum64(r0 + r1);
+  }
+
+  // d = J^T(-a) (position layout), ||d||^2, ||d2||^2, d_q, z = J2 d2 (row layout), r = U d1 (position layout), and dz = d with the
+  // working-set columns zeroed (position layout: the source of the Householder vector). `ai` = entry row_of(lane) of the normal.
+  static __device__ __forceinline__ void direction(S& s, const Regs& R, double ai, int q, int lane, double& dj, double& dz,
+                                                   double& dd, double& zz, double& dq, double& zi, double& ri) {
+    double p[NC];
+    const double na = -ai;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) p[k] = R.Jr[k] * na;
+    dj = reduce_cols(p);
+    const int pos = pos_of(lane);
+    if (first_copy(lane)) s.dvec[pos] = dj;  // for r = U d (U has zero columns >= q: no mask needed)
+    dz = (pos >= q) ? dj : 0.0;
+    dd = pos_sum(dj * dj, lane);
+    zz = pos_sum(dz * dz, lane);
+    dq = (q < NV) ? bcast64(dj, lane_of_pos(q < NV ? q : 0)) : 0.0;
+    double g[NC];
+    gather_cols(dz, g);
+    double z0 = 0, z1 = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
+    zi = half_sum64(z0 + z1);
+    wsync();
+    ri = u_row_dot(s, lane);
+  }
+
+  // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q, applied with the complete
+  // vector v = d2 - rho e_q: (J2 v) comes from the same gathered v that the rank-1 update multiplies
+  static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dz, double zz,
+                                                         double dq, double ri) {
+    const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
+    const double beta = 1.0 / (rho * (rho - dq));
+    const int pos = pos_of(lane);
+    double g[NC];
+    gather_cols(pos == q ? dz - rho : dz, g);
+    double w0 = 0, w1 = 0;
+#pragma unroll
+    for (int k = 0; k < NC; k += 2) w0 += R.Jr[k] * g[k], w1 += R.Jr[k + 1] * g[k + 1];
+    const double coef = half_sum64(w0 + w1) * beta;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) R.Jr[k] -= coef * g[k];
+    if (first_copy(lane)) s.U[pos * LDT + q] = (pos < q) ? -ri / rho : ((pos == q) ? 1.0 / rho : 0.0);
+    if (pos == q) R.lam = lam_p, R.act = id;
+    wsync();
+  }
+
+  // working set -= entry at position l: one Householder reflection G with G u_l^T = sigma e_t (u_l = row l of U, t = q - 1).
+  // The rows of U (LDS, natural order) are updated by the lane pair of their position; J through the gathered vector.
+  static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
+    const int t = q - 1, pos = pos_of(lane), c0 = lane & 16;
+    double uv[NC];  // this lane's 16 columns of row l of U
+    {
+      const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT + c0]);
+#pragma unroll
+      for (int j = 0; j < NC; j += 2) {
+        const D2 v2 = rl[j / 2];
+        uv[j] = v2.x, uv[j + 1] = v2.y;
+      }
+    }
+    const double ut = s.U[l * LDT + t];
+    const double ulp = s.U[l * LDT + pos];  // entry pos of u_l: the column-distributed source for J's update
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < NC; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
+    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(row16_sum64(s0 + s1));
+    const double beta = 1.0 / (sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
+    // J (registers): x -= (x . v) beta v with the complete v
+    {
+      double g[NC];
+      gather_cols(pos == t ? ulp - sigma : ulp, g);
+      double w0 = 0, w1 = 0;
+#pragma unroll
+      for (int k = 0; k < NC; k += 2) w0 += R.Jr[k] * g[k], w1 += R.Jr[k + 1] * g[k + 1];
+      const double cj = half_sum64(w0 + w1) * beta;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) R.Jr[k] -= cj * g[k];
+    }
+    // own row of U (row pos): x -= (x . v) beta v; column t belongs to the freed direction and is zeroed below
+    double ur[NC];
+    {
+      const D2* ro = reinterpret_cast<const D2*>(&s.U[pos * LDT + c0]);
+#pragma unroll
+      for (int j = 0; j < NC; j += 2) {
+        const D2 v2 = ro[j / 2];
+        ur[j] = v2.x, ur[j + 1] = v2.y;
+      }
+    }
+    const double urt = s.U[pos * LDT + t];
+    double wu0 = 0, wu1 = 0;
+#pragma unroll
+    for (int j = 0; j < NC; j += 2) wu0 += ur[j] * uv[j], wu1 += ur[j + 1] * uv[j + 1];
+    const double cu = (row16_sum64(wu0 + wu1) - sigma * urt) * beta;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) ur[j] -= cu * uv[j];
+    // multipliers / ids of the positions above l move down by one (through LDS: positions cross the DPP rows)
+    if (first_copy(lane)) s.lam[pos] = R.lam, s.act[pos] = R.act;
+    wsync();  // every lane has read its rows before anybody rewrites a slot
+    if (pos != l && pos < q) {  // rows above l stay, rows l+1..q-1 move up one slot, row l (the dropped entry) disappears
+      D2* dst = reinterpret_cast<D2*>(&s.U[(pos > l ? pos - 1 : pos) * LDT + c0]);
+#pragma unroll
+      for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
+    }
+    if (pos >= l && pos < t) R.lam = s.lam[pos + 1], R.act = s.act[pos + 1];
+    if (pos == t) R.lam = 0.0, R.act = -1;
+    wsync();
+    // structural zeros: column t of every row belongs to the freed direction, slot t is empty again
+    if (first_copy(lane)) s.U[pos * LDT + t] = 0.0;
+    if (pos == t) {
+      D2* dst = reinterpret_cast<D2*>(&s.U[pos * LDT + c0]);
+#pragma unroll
+      for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{0.0, 0.0};
+    }
+    wsync();
+  }
+
+  // ---- warm start (see hdsm_wave_gi.h): the guess is put into the factorisation without taking steps, then the S-pair in
+  // closed form  t = U^T v, lambda = U t, x_W = x0 + J1 t, f_W = f(x0) + |t|^2 / 2
+  static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self, int& iters) {
+    const int lane = (int)threadIdx.x;
+    const int N = c.N, n = c.n;
+    const int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
+    int nw = uni(wp[0]) & ~WARM_CERT;
+    if (nw <= 0) return;
+    if (nw > NV) nw = NV;
+    PROF_DECL
+    int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
+    double my_row[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lane < nw) {
+      const int code = wp[1 + lane];
+      const int kind = id_kind(code), p = id_payload(code);
+      if (kind == K_U) {
+        const int var = p >> 1;
+        if (var % N >= 1) pre = mk_id(K_U, ((var - 1) << 1) | (p & 1));
+      } else if (kind == K_S) {
+        const int i = p >> 5;
+        if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
+      } else if (kind == K_C && a.l1_rows == nullptr) {
+        const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
+        if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
+          const double* op = a.pos + ((int64_t)k * N + i) * 3;
+          if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
+        }
+      }
+    }
+    int q = uni(s.q);
+    const int q_in = q;
+    load_pos(s, R, lane);
+    PROF(16)
+    for (int g = 0; g < nw && q < n; ++g) {
+      int id = __builtin_amdgcn_readlane(pre, g);
+      if (id == -2) {
+        id = -1;
+        const int slot = uni(s.ncand);
+        if (slot < CMAX - uni(s.ncold)) {
+          const double r0 = bcast64(my_row[0], g), r1 = bcast64(my_row[1], g), r2 = bcast64(my_row[2], g), r3 = bcast64(my_row[3], g);
+          const int m = __builtin_amdgcn_readlane(my_m, g), src = __builtin_amdgcn_readlane(my_src, g);
+          if (lane == 0) {
+            s.cand[slot][0] = r0, s.cand[slot][1] = r1, s.cand[slot][2] = r2, s.cand[slot][3] = r3;
+            s.cand_m[slot] = m;
+            s.cand_src[slot] = src;
+            s.ncand = slot + 1;
+          }
+          wsync();
+          id = mk_id(K_C, slot);
+        }
+      }
+      if (id < 0) continue;
+      PROF(17)
+      const double ai = Base::normal_entry(s, R, id, Base::row_of(lane), N, n);
+      PROF(18)
+      double dj, dz, dd, zz, dq, zi, ri;
+      direction(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
+      PROF(19)
+      ++iters;
+      if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
+      householder_add(s, R, id, 0.0, q, lane, dz, zz, dq, ri);
+      PROF(20)
+      ++q;
+    }
+    if (q == q_in) return;  // nothing usable (multipliers / ids in LDS are untouched)
+    // violations of the working-set rows at the unconstrained minimiser x0
+    if (lane < NV) s.x[lane] = s.x0[lane];
+    store_pos(s, R, lane);  // resid() of K_P rows and the hand-over read act[] from LDS
+    wsync();
+    Base::states(s, R, lane, N);
+    const int pos = pos_of(lane), c0 = lane & 16;
+    for (;;) {
+      const double vk = (pos < q) ? Base::resid(s, c, R.act, N) : 0.0;
+      if (first_copy(lane)) s.dvec[pos] = vk;
+      wsync();
+      double tj;  // t = U^T v: column pos of U, this lane's share of the rows (rows >= q of U are zero)
+      {
+        double p0 = 0, p1 = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k += 2) {
+          const D2 vk2 = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
+          p0 += s.U[(c0 + k) * LDT + pos] * vk2.x, p1 += s.U[(c0 + k + 1) * LDT + pos] * vk2.y;
+        }
+        tj = row16_sum64(p0 + p1);
+      }
+      wsync();
+      if (first_copy(lane)) s.dvec[pos] = tj;
+      wsync();
+      const double lk = u_row_dot(s, lane);  // lambda = U t
+      double xw;
+      {
+        double g[NC];
+        gather_cols(tj, g);  // J1 t (t is zero beyond q)
+        double x0 = 0, x1 = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k += 2) x0 += R.Jr[k] * g[k], x1 += R.Jr[k + 1] * g[k + 1];
+        xw = s.x0[Base::row_of(lane)] + half_sum64(x0 + x1);
+      }
+      // most negative multiplier among the inequalities
+      const bool ineq = pos < q && id_kind(R.act) != K_E;
+      const double worst = -wave_max64(ineq ? -lk : -DINF);
+      if (!(worst < -1e-12) || q <= 6) {
+        const double tt = pos_sum(tj * tj, lane);
+        R.lam = (pos < q) ? lk : 0.0;
+        if (lane < n) R.xi = xw, s.x[lane] = xw;
+        else if (lane < 64 && Base::row_of(lane) < n) R.xi = xw;
+        if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;
+        store_pos(s, R, lane);
+        wsync();
+        PROF(21)
+        return;
+      }
+      const int l = pos_of(uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1));
+      PROF(21)
+      drop(s, R, l, q, lane);
+      PROF(22)
+      --q;
+      ++iters;
+    }
+  }
+
+  // Continues from the current (dual feasible) state until no row of the current node is violated.
+  static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
+    const int lane = (int)threadIdx.x;
+    const int n = c.n, N = c.N, max_iters = c.max_iters;
+    const double tol = c.tol;
+    const long long time_ticks = c.time_ticks;  // 0 = no wall-clock budget (the default)
+    double f = s.f;
+    int q = uni(s.q), neq = uni(s.neq_done);
+    int rc = GI_OK;
+    const int pos = pos_of(lane);
+    load_pos(s, R, lane);
+    PROF_DECL
+    for (;;) {
+      Base::states(s, R, lane, N);
+      PROF(0)
+      int ip;
+      double vip;
+      if (neq < 6) {
+        ip = mk_id(K_E, neq);
+        vip = Base::resid(s, c, ip, N);
+      } else {
+        Base::select(s, c, R, lane, tol, N, vip, ip);
+        ip = uni(ip);
+        if (ip < 0) {
+          if (Base::promote_cold(s, lane, tol) > 0) continue;
+          PROF(1)
+          break;
+        }
+        PROF(1)
+      }
+      const bool is_eq = id_kind(ip) == K_E;
+      const double ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
+      double lam_p = 0;
+      bool stop = false;
+      for (;;) {
+        if (iters >= max_iters) {
+          rc = GI_ITERLIM;
+          stop = true;
+          break;
+        }
+        if (time_ticks > 0 && (long long)wall_clock64() - s.t_start > time_ticks) {
+          rc = GI_TIMELIM;
+          stop = true;
+          break;
+        }
+        ++iters;
+        PROF(2)
+        double dj, dz, dd, zz, dq, zi, ri;
+        direction(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
+        PROF(3)
+        const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
+        double t1 = DINF;
+        int l = -1;
+        if (!is_eq) {  // ratio test over the active inequalities (position layout)
+          const bool okk = pos < q && id_kind(R.act) != K_E && ri > 0;
+          const double ratio = okk ? R.lam / ri : DINF;
+          const double m = -wave_max64(-ratio);
+          if (m < DINF) {
+            t1 = m;
+            l = pos_of(uni(__ffsll((long long)__ballot(okk && ratio == m)) - 1));
+          }
+        }
+        PROF(4)
+        if (dependent && l < 0) {
+          rc = GI_INFEASIBLE;
+          if (lane == 0) s.inf_id = ip;  // the row that cannot be satisfied together with the current working set
+          stop = true;
+          break;
+        }
+        if (dependent) {  // dual step only; constraint l leaves
+          if (pos < q) R.lam -= t1 * ri;
+          lam_p += t1;
+          drop(s, R, l, q, lane);
+          --q;
+          PROF(7)
+          continue;
+        }
+        const double t2 = vip / zz;
+        const bool full = is_eq || t2 <= t1;
+        const double t = full ? t2 : t1;
+        R.xi += t * zi;  // (lanes beyond n carry zeros: z is zero on padded rows)
+        if (lane < n) s.x[lane] = R.xi;
+        if (pos < q) R.lam -= t * ri;
+        f += t * zz * (0.5 * t + lam_p);
+        lam_p += t;
+        PROF(5)
+        if (full) {
+          householder_add(s, R, ip, lam_p, q, lane, dz, zz, dq, ri);
+          PROF(6)
+          ++q;
+          if (is_eq) ++neq;
+          break;
+        }
+        drop(s, R, l, q, lane);
+        PROF(7)
+        --q;
+        Base::states(s, R, lane, N);
+        vip = Base::resid(s, c, ip, N);
+        if (f >= f_cut) {
+          rc = GI_CUTOFF;
+          stop = true;
+          break;
+        }
+      }
+      if (stop) break;
+      if (f >= f_cut) {
+        rc = GI_CUTOFF;
+        break;
+      }
+    }
+    store_pos(s, R, lane);
+    wsync();
+    if (lane == 0) s.f = f, s.q = q, s.neq_done = neq, s.cmd = 0;
+    if (blockDim.x > 64) __syncthreads();  // releases the helper waves (they leave on cmd == 0)
+    else wsync();
+    return rc;
+  }
+
+  // snapshots: J slots from registers (layout [slot][lane]), U rows / multipliers / ids / x from LDS
+  static constexpr int SNAP_DOUBLES = Base::SNAP_DOUBLES;
+  static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
+    const int row = Base::row_of(lane), c0 = Base::col0_of(lane);
+    if (save) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) buf[j * 64 + lane] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) R.Jr[j] = buf[j * 64 + lane], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+    }
+    if (lane < NV) {
+      if (save) {
+        buf[2 * NV * NV + lane] = R.xi;
+        buf[(2 * NV + 1) * NV + lane] = s.lam[lane];
+        buf[(2 * NV + 2) * NV + lane] = (double)s.act[lane];
+      } else {
+        s.lam[lane] = buf[(2 * NV + 1) * NV + lane];
+        s.act[lane] = (int)buf[(2 * NV + 2) * NV + lane];
+        s.x[lane] = buf[2 * NV * NV + lane];
+      }
+    }
+    if (!save) R.xi = buf[2 * NV * NV + row];  // both copies of a row
+    if (lane == 0) {
+      if (save) {
+        buf[(2 * NV + 3) * NV] = s.f;
+        buf[(2 * NV + 3) * NV + 1] = (double)s.q;
+      } else {
+        s.f = buf[(2 * NV + 3) * NV];
+        s.q = (int)buf[(2 * NV + 3) * NV + 1];
+      }
+    }
+    wsync();
+  }
+};
+
+}  // namespace hdsm

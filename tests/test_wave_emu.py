@@ -230,3 +230,64 @@ def test_device_source_reproduces_the_enumerated_miqps(wave):
         assert w["status"][0] == 0 and abs(w["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, w["obj"], want)
         if float(c["second"]) - want > 1e-3 * max(1.0, abs(want)):
             assert np.abs(w["traj"][0] - rm.rollout(prm, c["state"], c["u"])).max() < 1e-4, k
+
+
+def test_staging_overflow_is_exact_or_flagged(wave, oracle):
+    """With room for only 16 staged neighbour rows the solver must tighten its staging radius and still return the exact
+    optimum, or report LIMIT / NO_SOLUTION — never a wrong 'optimal'."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 25, seed=9, spacing=1.2)
+    args = [sn[k] for k in ARG_KEYS]
+    e = wave.replan(prm, *args, cmax=16)
+    o = oracle.replan(prm, *args, n_threads=8)
+    exact = e["status"] == 0
+    assert exact.sum() >= 1 and (e["status"] != 0).sum() >= 1   # both outcomes occur with so little room
+    assert (o["status"][exact] == 0).all()
+    assert np.abs(e["traj"] - o["traj"])[exact].max() < 1e-8
+    assert (e["sweeps"] >= 1).all()
+    lim = e["status"] == 1
+    assert ((e["flags"][lim] & 8) != 0).all()                   # HDSM_FLAG_STAGING_OVERFLOW says why
+
+
+def test_lazy_rows_are_verified(wave):
+    """Every accepted solution went through at least one full sweep of the neighbour buffer."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 16, seed=2, turn=True)
+    e = wave.replan(prm, *[sn[k] for k in ARG_KEYS])
+    assert (e["sweeps"][e["status"] == 0] >= 1).all()
+
+
+def test_level1_rejects_step_dependent_static_polyhedra(wave):
+    prm = make_params(n_hor=6, poly_hor=3, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 2, seed=1)
+    n_poly = np.full((2, 6), 2, np.int32)
+    n_rows = np.full((2, 6, 3), 6, np.int32)
+    A = np.zeros((2, 6, 3, 8, 3))
+    b = np.zeros((2, 6, 3, 8))
+    for i in range(6):
+        for j in range(2):
+            Aj, bj = problems.box_rows(np.array([-1.0 - j, -1, 0]), np.array([1.0 + i, 1 + j, 3]))  # grows with the step
+            A[:, i, j, :6], b[:, i, j, :6] = Aj, bj
+    e = wave.solve(prm, sn["state"], sn["ref"], n_poly, n_rows, A, b)
+    assert e["rc"] == -1  # HDSM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("rule", ["0", "1"])
+def test_either_branching_rule_reaches_the_same_optimum(wave, oracle, rule, monkeypatch):
+    """The branching step (first uncontained segment in time / most infeasible one, HDSM_BRANCH_RULE) only shapes the search
+    tree: on corridors that force real branching (narrow boxes, turning paths) both rules must return the oracle's optimum,
+    and the default rule must not need more nodes in total than the other."""
+    monkeypatch.setenv("HDSM_BRANCH_RULE", rule)
+    prm = agile_params(10, max_rows_static=18)
+    nodes = 0
+    for seed in (3, 5, 21, 22):
+        sn = problems.swarm_snapshot(prm, 12, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        args = [sn[k] for k in ARG_KEYS]
+        e = wave.replan(prm, *args)
+        compare(e, oracle.replan(prm, *args, n_threads=8))
+        nodes += int(e["nodes"].sum())
+    assert nodes > 4 * 12                      # the cases do branch
+    seen = test_either_branching_rule_reaches_the_same_optimum.__dict__.setdefault("nodes", {})
+    seen[rule] = nodes
+    if len(seen) == 2:
+        assert seen["1"] <= seen["0"], seen

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE — a stand-in for <hip/hip_runtime.h> that lets g++ compile the DEVICE source of the solver kernel
-// (multi_agent_pkgs_amd/csrc/hdsm_core.h + hdsm_wave_gi.h, device mode, NOT the HDSM_EMU logic build) and run it on the CPU:
+// (multi_agent_pkgs_amd/csrc/hdsm_core.h + hdsm_wave_gi.h + hdsm_wave_gib.h) and run it on the CPU:
 // the threads of one workgroup (one wavefront of 64, or four: the product's two launch shapes) are fibers (ucontext) run by one
 // host thread; every cross-lane operation (DPP moves, v_readlane, v_permlane32_swap, ballot, shuffles, wsync) is a rendezvous of
 // the lanes of ONE wavefront on its exchange buffer, __syncthreads() a rendezvous of the whole workgroup. See wave_emu.cpp.
@@ -193,8 +193,10 @@ inline double __shfl_xor(double v, int mask, int width = 64) {
   const int src = me ^ mask;
   return (src / width == me / width) ? wemu::my_wave().xd[p][src] : v;
 }
-// DPP moves within 16-lane rows: row_shl:n (0x100 + n) reads lane + n, row_shr:n (0x110 + n) lane - n, row_ror:n (0x120 + n)
-// rotates; a lane without a source keeps `old` (bound_ctrl: the callers pass old = 0 where they want zero fill)
+// DPP moves within 16-lane rows: quad_perm (0x00..0xff: lane 4g + k reads lane 4g + sel_k, two bits per k), row_shl:n (0x100 + n)
+// reads lane + n, row_shr:n (0x110 + n) lane - n, row_ror:n (0x120 + n) rotates, row_mirror (0x140) reads lane 15 - i,
+// row_half_mirror (0x141) lane 7 - i within each half row; a lane without a source keeps `old` (bound_ctrl: the callers pass
+// old = 0 where they want zero fill)
 inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   wemu::Wave& w = wemu::my_wave();
   const int me = wemu::lane();
@@ -202,7 +204,10 @@ inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, boo
   const int p = wemu::rendezvous(6);
   const int row = me & ~15, i = me & 15, n = ctrl & 15;
   int from = -1;
-  if ((ctrl & 0x1f0) == 0x100) from = (i + n < 16) ? i + n : -1;
+  if (ctrl >= 0 && ctrl <= 0xff) from = (i & ~3) | ((ctrl >> (2 * (i & 3))) & 3);
+  else if (ctrl == 0x140) from = 15 - i;
+  else if (ctrl == 0x141) from = (i & 8) | (7 - (i & 7));
+  else if ((ctrl & 0x1f0) == 0x100) from = (i + n < 16) ? i + n : -1;
   else if ((ctrl & 0x1f0) == 0x110) from = (i - n >= 0) ? i - n : -1;
   else if ((ctrl & 0x1f0) == 0x120) from = (i - n) & 15;
   else wemu::fail("DPP control not modelled");
@@ -222,6 +227,18 @@ inline std::array<int, 2> wemu_permlane32_swap(int vdst, int vsrc, bool, bool) {
   return me < 32 ? std::array<int, 2>{vdst, other_dst} : std::array<int, 2>{other_src, vsrc};
 }
 #define __builtin_amdgcn_permlane32_swap(a, b, c, d) wemu_permlane32_swap((a), (b), (c), (d))
+// v_permlane16_swap vdst, vsrc: the ODD 16-lane rows of vdst <-> the EVEN rows of vsrc (rows 1 <-> 0 and 3 <-> 2)
+inline std::array<int, 2> wemu_permlane16_swap(int vdst, int vsrc, bool, bool) {
+  const int me = wemu::lane();
+  wemu::my_wave().xi[wemu::my_wave().parity][me] = vdst;
+  const int p1 = wemu::rendezvous(10);
+  const int other_dst = wemu::my_wave().xi[p1][me ^ 16];
+  wemu::my_wave().xi[wemu::my_wave().parity][me] = vsrc;
+  const int p2 = wemu::rendezvous(11);
+  const int other_src = wemu::my_wave().xi[p2][me ^ 16];
+  return (me & 16) == 0 ? std::array<int, 2>{vdst, other_dst} : std::array<int, 2>{other_src, vsrc};
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, c, d) wemu_permlane16_swap((a), (b), (c), (d))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)wemu::rendezvous(9))  // wsync(): on the device the lanes are in lockstep anyway
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))

@@ -1,9 +1,8 @@
 // wave_emu.cpp — runs the DEVICE source of the solver kernel on the CPU (TEST INFRASTRUCTURE ONLY).
 //
-// What tests/emu covers is the kernel LOGIC with a textbook active set; the code that actually runs on the GPU — the
-// register-resident, wave-level iteration of hdsm_wave_gi.h with its DPP scans, lane-split rows, Householder add / drop, warm
-// start, certificates, conflict learning, sweeps on the packed positions — was covered by the GPU tests only. Here that very
-// source is compiled by g++ against tests/wave_emu/shim/hip/hip_runtime.h: one workgroup = one wavefront = 64 fibers in
+// The code that actually runs on the GPU — the register-resident, wave-level iteration of hdsm_wave_gi.h / hdsm_wave_gib.h with
+// its DPP butterflies and scans, lane-split rows, Householder add / drop, warm start, certificates, conflict learning, sweeps on
+// the packed positions — is compiled by g++ against tests/wave_emu/shim/hip/hip_runtime.h: one workgroup = one wavefront = 64 fibers in
 // lockstep — one wavefront (the product's 64-thread launch) or four (its default: the helper waves share the sweeps, the set-up,
 // the leaf test and the staged-row scans) — one instance after the other. Never linked into libhdsm.so, not a fallback.
 #include <ucontext.h>
@@ -127,11 +126,12 @@ extern "C" const char* wave_last_error(void) { return wemu::last_error(); }
 // Level-2 replan through the device source. `warm` = the handle's warm-start store, [(MAXNV + 2) * n_inst] int32, in/out (zeros:
 // cold; pass the same array again to continue like consecutive launches on one handle); null = warm start off.
 // `bounds_min`: swarms of at least this many agents get the sphere prefilter records, as hdsm_api.hip's launch() does.
+// `cmax` in 1..16: a build of the kernel with room for only 16 staged rows (staging-overflow tests); 0 = the product's sizes.
 extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id, const double* state_curr,
                            const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows_static, const double* A_static,
                            const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
                            uint8_t* poly_used, int32_t* status, double* obj, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
-                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads) {
+                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads, int32_t cmax) {
   if (threads != 64 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
@@ -173,6 +173,8 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
   a.pos = pos.data();
   a.bounds = (n_rob >= bounds_min) ? bounds.data() : nullptr;
   a.warm = (prm->warm_start && warm) ? warm : nullptr;
+  if (cmax > 0 && cmax <= 16)  // tiny staging capacity: exercises the overflow path in tests
+    return c->n <= hdsm::SPLIT_N_MAX ? run_all<32, 16>(*c, a, threads) : run_all<48, 16>(*c, a, threads);
   if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
   return run_all<48, 1024>(*c, a, threads);
 }
