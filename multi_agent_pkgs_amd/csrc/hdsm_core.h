@@ -51,6 +51,11 @@ enum { K_U = 0, K_S = 1, K_P = 2, K_C = 3, K_E = 4 };
 HD int mk_id(int kind, int payload) { return (kind << 28) | payload; }
 HD int id_kind(int id) { return (id >> 28) & 7; }
 HD int id_payload(int id) { return id & 0x0fffffff; }
+// staged neighbour rows (K_C): the payload carries the slot in cand[] AND the trajectory point the row acts on, so that the
+// normal of an entering row needs one LDS round trip (row and impulse-response entry together), not two in a chain
+HD int mk_kc(int slot, int m) { return mk_id(K_C, (m << 12) | slot); }
+HD int kc_slot(int payload) { return payload & 0xfff; }
+HD int kc_m(int payload) { return payload >> 12; }
 
 constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered sweep
 
@@ -58,6 +63,7 @@ constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered s
 // All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
 template <int NV, int CMAX>
 struct Shm {
+  static_assert(CMAX <= 4096, "the slot of a staged row must fit the 12 bits kc_slot() reads");
   static constexpr int LDT = (NV <= 32) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
   alignas(16) double T[NV > 32 ? NV * LDT : 2];  // NV = 48: transposition buffer for d = J^T a (J rows live in registers)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
@@ -747,7 +753,7 @@ struct Solver {
             if (k < s.q) {
               code = s.act[k];
               if (id_kind(code) == K_C) {
-                const int src = s.cand_src[id_payload(code)];
+                const int src = s.cand_src[kc_slot(id_payload(code))];
                 code = src >= 0 ? mk_id(K_C, src) : mk_id(K_E, 0);  // explicit rows carry no portable identity
               }
             }
@@ -868,7 +874,7 @@ struct Solver {
           const int code = (k < s.q) ? s.act[k] : (k == s.q ? s.inf_id : 0);
           int portable = code;
           if (k <= s.q && id_kind(code) == K_C) {
-            const int src = s.cand_src[id_payload(code)];
+            const int src = s.cand_src[kc_slot(id_payload(code))];
             portable = src >= 0 ? mk_id(K_C, src) : mk_id(K_E, 0);
           }
           s.inc_act[k] = portable;

@@ -263,7 +263,7 @@ struct WaveGI {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
-        if (idx[u] < hi && vv > v) v = vv, id = mk_id(K_C, idx[u]);
+        if (idx[u] < hi && vv > v) v = vv, id = mk_kc(idx[u], mm[u]);
       }
     }
   }
@@ -402,8 +402,8 @@ struct WaveGI {
       row = s.sp[s.assign[i]][r];
       m = i + e;
     } else {
-      row = s.cand[p];
-      m = s.cand_m[p];
+      row = s.cand[kc_slot(p)];
+      m = kc_m(p);
     }
     return (kk < m) ? row[ax] * s.gz[ax][0][MAXH + m - 1 - kk] : 0.0;
   }
@@ -427,8 +427,8 @@ struct WaveGI {
       row = s.sp[s.assign[i]][r];
       pm = s.st[i + e];
     } else {
-      row = s.cand[p];
-      pm = s.st[s.cand_m[p]];
+      row = s.cand[kc_slot(p)];
+      pm = s.st[kc_m(p)];
     }
     return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
   }
@@ -742,7 +742,7 @@ struct WaveGI {
             s.ncand = slot + 1;
           }
           wsync();
-          id = mk_id(K_C, slot);
+          id = mk_kc(slot, m);
         }
       }
       if (id < 0) continue;

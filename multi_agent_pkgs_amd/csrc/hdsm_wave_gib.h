@@ -257,7 +257,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
             s.ncand = slot + 1;
           }
           wsync();
-          id = mk_id(K_C, slot);
+          id = mk_kc(slot, m);
         }
       }
       if (id < 0) continue;

@@ -62,6 +62,14 @@ class HdsmAgents : public rclcpp::Node {
     timer_ = create_wall_timer(std::chrono::duration<double>(prm_.dt * cfg_.step_plan), [this] { round(); });
     rclcpp::on_shutdown([this] { shutdown(); });
   }
+  // introspection (tests): agents hosted elsewhere whose plan has arrived over traj_full; lock-step rounds done
+  int remote_plans_known() {
+    std::lock_guard<std::mutex> g(mtx_);
+    int cnt = 0;
+    for (int k = 0; k < n_rob_; ++k) cnt += (k < first_ || k >= first_ + n_local_) && has_[k];
+    return cnt;
+  }
+  int rounds() const { return rounds_; }
 
  private:
   void on_other(const Trajectory& msg, int k) {  // TrajectoryOtherAgentsCallback, AC:629-643
@@ -110,6 +118,7 @@ class HdsmAgents : public rclcpp::Node {
       }
       pubs_[k]->publish(msg);
     }
+    ++rounds_;
   }
 
   void shutdown() {  // Agent::OnShutdown, AC:2446-2466, for every hosted agent
@@ -126,7 +135,7 @@ class HdsmAgents : public rclcpp::Node {
   hdsm_params prm_;
   hdsm_swarm_config cfg_;
   void *solver_ = nullptr, *swarm_ = nullptr;
-  int n_rob_, first_, n_local_, n_hor_;
+  int n_rob_, first_, n_local_, n_hor_, rounds_ = 0;
   bool save_stats_;
   std::string topic_;
   std::mutex mtx_;

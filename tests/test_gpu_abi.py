@@ -267,3 +267,21 @@ def test_bench_self_launches_two_ranks_and_reports_rccl_ranks():
     w = z["weak_scaling_record"]
     assert w["scaling"] == "weak" and w["agents_per_gpu"] == 1024 and w["agents"] == 2048 and w["value"] > 0
     assert z["device_resident_loop"]["ms_per_round"] > 0
+
+
+def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
+    """ros/hdsm_agent_node.cpp (compiled against the API-shaped rclcpp of tests/ros_shim): two nodes in one process, each hosting
+    four agents of an eight-agent ring, timers fired in lock step; every plan a node knows about the OTHER node's agents arrived
+    as a multi_agent_planner_msgs/Trajectory on <topic>_<id>/traj_full (AC:46-48, 610-677)."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "ros_shim", "two_nodes")
+    assert os.path.exists(exe), "tests/ros_shim/two_nodes not built (__graft_entry__.build())"
+    r = subprocess.run([exe, "15"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"topics (\d+) published (\d+) delivered (\d+)", r.stdout)
+    topics, pub, dlv = (int(x) for x in m.groups())
+    assert topics == 8 and pub == dlv and pub >= 8 * 14, r.stdout          # one subscriber per topic: the other node
+    assert "node 0: remote plans known 4 of 4, rounds 15" in r.stdout and "node 1: remote plans known 4 of 4, rounds 15" in r.stdout, r.stdout

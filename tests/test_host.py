@@ -493,3 +493,25 @@ def test_voxel_velocity_cap_and_keep_only_free_follow_the_reference_statements()
                     break
             assert np.abs(got[k, :, :3] - pts[:10]).max() < 1e-12, (case, k)
     assert lowered > 10
+
+
+def test_ros_node_type_checks_against_rclcpp_shaped_headers():
+    """Row f3: ros/hdsm_agent_node.cpp compiled (-Wall -Wextra) against tests/ros_shim — rclcpp::Node with declare_parameter /
+    create_publisher / create_subscription / create_wall_timer / now(), multi_agent_planner_msgs::msg::Trajectory with the fields
+    of Trajectory.msg:1-11 and State.msg:1-8 — and linked with libhdsm.so into a program that hosts two nodes. Without a GPU the
+    node's constructor must fail LOUDLY on hdsm_create (no CPU fallback); the exchange itself is a -m gpu test."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = os.path.join(root, "tests", "ros_shim")
+    subprocess.check_call(["make", "-C", shim, "-s", "-B"])
+    r = subprocess.run([os.path.join(shim, "two_nodes"), "3"], capture_output=True, text=True, timeout=120)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:
+        assert r.returncode == 7 and "hdsm_create" in r.stdout and "no HIP device" in r.stdout, r.stdout + r.stderr
