@@ -472,6 +472,7 @@ struct Handle {
   int threads = 256;
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
+  int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
   double* d_bounds = nullptr; // [n_rob_max][4]
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
   double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
@@ -536,6 +537,36 @@ int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st) {
   return HDSM_OK;
 }
 
+// THREE workgroups of 128 threads (two wavefronts: the iterating one and one helper) per CU, for batches that outnumber the
+// resident slots of the two-per-CU kernel. A launch lasts as long as its slowest workgroup CHAIN: with 1024 instances on 512
+// slots an instance that was predicted cheap and turns out long starts late and sets the kernel time (measured: mean span
+// 119 us against 107 us for the slowest instance, profiles/r03_launch_timeline.json); with 768 slots the late starters begin
+// when the first instances without iterations leave (~18 us) and finish inside the slowest instance. The sweeps and the set-up
+// run on half the threads (+2..3 us per instance), the staging area shrinks to 384 rows (three states in 160 KB).
+constexpr int CMAX_TRI = 384;
+template <int NV, int CMAX, int NT>
+__global__ __launch_bounds__(NT, 2) void k_replan_tri(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sol = hdsm::Solver<NV, CMAX>;
+  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
+  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+}
+
+int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st) {
+  using Sol = hdsm::Solver<32, CMAX_TRI>;
+  static_assert(sizeof(typename Sol::S) * 3 <= 160 * 1024, "three instances must fit the LDS of one CU");
+  const size_t shm = sizeof(typename Sol::S);
+  auto kern = k_replan_tri<32, CMAX_TRI, 128>;
+  static thread_local int attr_dev = -1;
+  if (attr_dev != h->device) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_dev = h->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(128), shm, st, h->d_consts, a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
 int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.scratch = h->d_scratch;
   a.scratch_stride = h->scratch_stride;
@@ -571,7 +602,8 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
   int rc;
   if (h->time_kernel) HIP_TRY(hipEventRecord(h->ev_k0, st));
-  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo(h, a, st);
+  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && a.n_inst >= h->tri_min) rc = launch_tri(h, a, st);
+  else if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo(h, a, st);
   else if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
   else rc = h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
   if (rc) return rc;
@@ -702,6 +734,8 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
     h->duo_min = params->duo_min_instances > 0 ? params->duo_min_instances : (params->duo_min_instances < 0 ? 0 : cus + 1);
     env_int("HDSM_DUO_MIN", 0, INT_MAX, &h->duo_min);  // 0 = never
+    h->tri_min = h->duo_min > 0 ? 2 * cus + 1 : 0;     // more instances than the two-per-CU kernel has resident slots
+    env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
     h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
     env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never

@@ -309,8 +309,8 @@ struct WaveGI {
     const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
       if (lane == 0) s.cmd = 1;
-      __syncthreads();                             // helpers start on their share: rows [256 (w), ...) stride 1024
-      scan_rows(s, 0, nc, lane, v, id, 1024);
+      __syncthreads();                             // helpers start on their share: rows [256 w, ...) stride 256 * waves
+      scan_rows(s, 0, nc, lane, v, id, 4 * (int)blockDim.x);
     } else {
       scan_rows(s, 0, nc, lane, v, id);
     }
@@ -323,7 +323,7 @@ struct WaveGI {
     if (mw) {
       __syncthreads();                             // partial results of waves 1..3 are in LDS
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
+      for (int w = 1; w < (int)blockDim.x >> 6; ++w) {
         const double pv = s.part_v[w];
         if (pv > m) m = pv, best = s.part_id[w];
       }
@@ -332,7 +332,7 @@ struct WaveGI {
     ibest = (m > tol) ? best : -1;
   }
 
-  // Waves 1..3 while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
+  // The other waves of the workgroup while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
   static __device__ __forceinline__ void helper_loop(S& s) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
     for (;;) {
@@ -340,7 +340,7 @@ struct WaveGI {
       if (uni(s.cmd) == 0) return;
       double v = -DINF;
       int id = -1;
-      scan_rows(s, 256 * w, uni(s.ncand), lane, v, id, 1024);
+      scan_rows(s, 256 * w, uni(s.ncand), lane, v, id, 4 * (int)blockDim.x);
       const double m = wave_max64(v);
       int best = -1;
       if (m > -DINF) {

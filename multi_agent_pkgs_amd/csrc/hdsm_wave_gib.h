@@ -81,24 +81,38 @@ struct WaveGIB : WaveGI<32, CMAX> {
     if (first_copy(lane)) s.lam[pos_of(lane)] = R.lam, s.act[pos_of(lane)] = R.act;
   }
 
-  // dot product of this lane's half (columns 16 (lane bit 4) ..) of row k = pos_of(lane) of U with s.dvec, both halves summed
-  static __device__ __forceinline__ double u_row_dot(const S& s, int lane) {
-    const int k = pos_of(lane), c0 = (lane & 16);
-    const D2* urow = reinterpret_cast<const D2*>(&s.U[k * LDT + c0]);
-    const D2* dv = reinterpret_cast<const D2*>(&s.dvec[c0]);
+  // this lane's half (columns 16 (lane bit 4) ..) of row k = pos_of(lane) of U: requested EARLY (it does not depend on the
+  // entering row), so that the round trip is hidden behind the butterfly
+  static __device__ __forceinline__ void u_row_load(const S& s, int lane, D2 (&u)[NC / 2]) {
+    const D2* urow = reinterpret_cast<const D2*>(&s.U[pos_of(lane) * LDT + (lane & 16)]);
+#pragma unroll
+    for (int j = 0; j < NC / 2; ++j) u[j] = urow[j];
+  }
+  // ... dotted with s.dvec, both halves summed
+  static __device__ __forceinline__ double u_row_dot(const S& s, int lane, const D2 (&u)[NC / 2]) {
+    const D2* dv = reinterpret_cast<const D2*>(&s.dvec[lane & 16]);
     double r0 = 0, r1 = 0;
 #pragma unroll
     for (int j = 0; j < NC / 2; ++j) {
-      const D2 u = urow[j], d = dv[j];
-      r0 += u.x * d.x, r1 += u.y * d.y;
+      const D2 d = dv[j];
+      r0 += u[j].x * d.x, r1 += u[j].y * d.y;
     }
     return row16_sum64(r0 + r1);
+  }
+  static __device__ __forceinline__ double u_row_dot(const S& s, int lane) {
+    D2 u[NC / 2];
+    u_row_load(s, lane, u);
+    return u_row_dot(s, lane, u);
   }
 
   // d = J^T(-a) (position layout), ||d||^2, ||d2||^2, d_q, z = J2 d2 (row layout), r = U d1 (position layout), and dz = d with the
   // working-set columns zeroed (position layout: the source of the Householder vector). `ai` = entry row_of(lane) of the normal.
+  // WANT_Z = false (warm-start additions: no step is taken): z is not formed (one all-gather and one dot product less).
+  template <bool WANT_Z = true>
   static __device__ __forceinline__ void direction(S& s, const Regs& R, double ai, int q, int lane, double& dj, double& dz,
                                                    double& dd, double& zz, double& dq, double& zi, double& ri) {
+    D2 urow[NC / 2];
+    u_row_load(s, lane, urow);
     double p[NC];
     const double na = -ai;
 #pragma unroll
@@ -110,14 +124,17 @@ struct WaveGIB : WaveGI<32, CMAX> {
     dd = pos_sum(dj * dj, lane);
     zz = pos_sum(dz * dz, lane);
     dq = (q < NV) ? bcast64(dj, lane_of_pos(q < NV ? q : 0)) : 0.0;
-    double g[NC];
-    gather_cols(dz, g);
-    double z0 = 0, z1 = 0;
+    zi = 0.0;
+    if constexpr (WANT_Z) {
+      double g[NC];
+      gather_cols(dz, g);
+      double z0 = 0, z1 = 0;
 #pragma unroll
-    for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
-    zi = half_sum64(z0 + z1);
+      for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
+      zi = half_sum64(z0 + z1);
+    }
     wsync();
-    ri = u_row_dot(s, lane);
+    ri = u_row_dot(s, lane, urow);
   }
 
   // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q, applied with the complete
@@ -265,7 +282,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
       const double ai = Base::normal_entry(s, R, id, Base::row_of(lane), N, n);
       PROF(18)
       double dj, dz, dd, zz, dq, zi, ri;
-      direction(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
+      direction<false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
       PROF(19)
       ++iters;
       if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
@@ -330,6 +347,96 @@ struct WaveGIB : WaveGI<32, CMAX> {
     }
   }
 
+  // The first 256 staged rows (four per lane) are requested BEFORE the state evaluation of an operation — they do not depend
+  // on it — so that the violation scan that follows it pays one LDS round trip (the positions), not two in a chain.
+  struct CandPref {
+    D2 r01[4], r23[4];
+    int mm[4];
+  };
+  static __device__ __forceinline__ void cand_prefetch(const S& s, int lane, CandPref& cp) {
+    const int nc = uni(s.ncand);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = 64 * u + lane, ii = idx < nc ? idx : 0;
+      cp.mm[u] = s.cand_m[ii];
+      cp.r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
+      cp.r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
+    }
+  }
+  // Base::select with the first trip of the staged-row scan taken from the prefetched registers
+  static __device__ __forceinline__ void select_pref(S& s, const Consts& c, const Regs& R, const CandPref& cp, int lane, double tol, int N,
+                                                     double& vbest, int& ibest) {
+    double v = tol;
+    int id = -1;
+    {
+      const double vu = R.xi - R.ub_own, vl = R.lb_own - R.xi;
+      if (vu > v) v = vu, id = mk_id(K_U, lane << 1);
+      if (vl > v) v = vl, id = mk_id(K_U, (lane << 1) | 1);
+    }
+    const double* stf = &s.st[0][0];
+    double sv[2], px[4], py[4], pz[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) sv[e] = stf[R.sb_off[e] >= 0 ? R.sb_off[e] : 0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double* pm = s.st[cp.mm[u]];
+      px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (R.sb_off[e] >= 0) {
+        const double vu = sv[e] - R.sb_ub[e], vl = R.sb_lb[e] - sv[e];
+        if (vu > v) v = vu, id = mk_id(K_S, R.sb_id[e]);
+        if (vl > v) v = vl, id = mk_id(K_S, R.sb_id[e] | 1);
+      }
+    }
+    const int nc = uni(s.ncand);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double vv = cp.r01[u].x * px[u] + cp.r01[u].y * py[u] + cp.r23[u].x * pz[u] - cp.r23[u].y;
+      if (64 * u + lane < nc && vv > v) v = vv, id = mk_kc(64 * u + lane, cp.mm[u]);
+    }
+    if (uni(s.level) > 0) {  // rows of the polyhedra assigned on the current branch (see Base::select)
+      for (int i = 0; i < N; ++i) {
+        const int j = uni(s.assign[i]);
+        if (j < 0) continue;
+        const int rows = uni(s.sp_rows[j]);
+        for (int t = lane; t < 2 * rows; t += 64) {
+          const int e = t >= rows ? 1 : 0, r = t - e * rows;
+          if (i + e == 0) continue;
+          const double* row = s.sp[j][r];
+          const double* pm = s.st[i + e];
+          const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+          if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
+        }
+      }
+    }
+    const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
+    if (mw) {
+      if (lane == 0) s.cmd = 1;
+      __syncthreads();                             // helpers start on their share: rows [256 w, ...) stride 256 * waves
+      Base::scan_rows(s, 4 * (int)blockDim.x, nc, lane, v, id, 4 * (int)blockDim.x);
+    } else if (nc > 256) {
+      Base::scan_rows(s, 256, nc, lane, v, id);
+    }
+    double m = wave_max64(v);
+    int best = -1;
+    if (m > tol) {
+      const unsigned long long mask = __ballot(v == m && id >= 0);
+      best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+    }
+    if (mw) {
+      __syncthreads();                             // partial results of waves 1..3 are in LDS
+#pragma unroll
+      for (int w = 1; w < (int)blockDim.x >> 6; ++w) {
+        const double pv = s.part_v[w];
+        if (pv > m) m = pv, best = s.part_id[w];
+      }
+    }
+    vbest = m;
+    ibest = (m > tol) ? best : -1;
+  }
+
   // Continues from the current (dual feasible) state until no row of the current node is violated.
   static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
     const int lane = (int)threadIdx.x;
@@ -343,6 +450,8 @@ struct WaveGIB : WaveGI<32, CMAX> {
     load_pos(s, R, lane);
     PROF_DECL
     for (;;) {
+      CandPref cp;
+      cand_prefetch(s, lane, cp);
       Base::states(s, R, lane, N);
       PROF(0)
       int ip;
@@ -351,7 +460,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
         ip = mk_id(K_E, neq);
         vip = Base::resid(s, c, ip, N);
       } else {
-        Base::select(s, c, R, lane, tol, N, vip, ip);
+        select_pref(s, c, R, cp, lane, tol, N, vip, ip);
         ip = uni(ip);
         if (ip < 0) {
           if (Base::promote_cold(s, lane, tol) > 0) continue;

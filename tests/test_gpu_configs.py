@@ -135,7 +135,7 @@ def _check_limit_instances(sol, oracle, prm, rec, out, max_check=3):
     if len(lim) == 0:
         return []
     flags = sol.last_sweep_stats(len(out["status"]))["flags"][lim]
-    o = _oracle_proved(oracle, prm, rec, lim, hint=out["obj"][lim] * (1 + 1e-9), threads=16)
+    o = _oracle_proved(oracle, prm, rec, lim, hint=out["obj"][lim] * (1 + 1e-9), threads=16, nodes=20000, iters=4000000)
     res = []
     for t, a in enumerate(lim):
         gap = None
@@ -275,7 +275,7 @@ def test_config_5_4096_agents_forest_wall_forest(hdsm, oracle):
             n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 6, rng, plane_chunk=8)
             assert n_ok > 0.9 * n_rob
         # instances that ended on the node budget: incumbent vs the proven optimum (a few per flight: the proofs are expensive)
-        if (out["status"] == 1).any() and len(limited) < 3:
+        if (out["status"] == 1).any() and len(limited) < 1:
             limited += _check_limit_instances(sol, oracle, prm, rec[0], out, max_check=1)
     pos, _, _ = loop.shard.state()
     assert _pillar_hits(pos, raw, origin) == 0

@@ -193,9 +193,11 @@ def test_helper_wavefronts_share_the_staged_row_scan(wave, oracle):
     sub = np.arange(0, 100, 8)
     args = [sn[k] if k in ("plans", "has_plan") else sn[k][sub] for k in ARG_KEYS]
     four, one = wave.replan(prm, *args, threads=256), wave.replan(prm, *args, threads=64)
+    two = wave.replan(prm, *args, threads=128)   # the three-workgroups-per-CU shape: ONE helper wavefront
     assert four["cand"].max() > 256
     o = oracle.replan(prm, *args, n_threads=8)
     compare(four, o)
+    compare(two, o)
     compare(one, o)
     prm15 = agile_params(15, max_rows_static=18)
     sn = problems.swarm_snapshot(prm15, 10, seed=115, turn=True)

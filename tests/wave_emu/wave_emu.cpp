@@ -132,7 +132,7 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
                            const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
                            uint8_t* poly_used, int32_t* status, double* obj, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
                            int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads, int32_t cmax) {
-  if (threads != 64 && threads != 256) return -1;
+  if (threads != 64 && threads != 128 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
   int rc = hdsm::build_consts(prm, c.get(), &err);
@@ -183,7 +183,7 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
 extern "C" int wave_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const double* state_curr, const double* traj_ref,
                           const int32_t* n_poly, const int32_t* n_rows, const double* A, const double* b, double* traj_out,
                           double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj, int32_t threads) {
-  if (threads != 64 && threads != 256) return -1;
+  if (threads != 64 && threads != 128 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
   int rc = hdsm::build_consts(prm, c.get(), &err);
