@@ -41,12 +41,25 @@ int set_err(int code, const std::string& msg) {
 constexpr int CMAX30 = 1536;  // n <= 30
 constexpr int CMAX48 = 1024;  // n <= 48
 
+// What a workgroup works on. Ordinary launch: block b -> instance order[b] (or b). Pass 2 of a split launch (a.sub_k > 0): block b ->
+// the subtree "polyhedron b % sub_k at the root's branching step" of instance b / sub_k, if pass 1 handed that instance over.
+template <class Sol>
+__device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts& c, const hdsm::Args& a) {
+  if (a.sub_k > 0) {
+    const int inst = (int)blockIdx.x / a.sub_k, sub = (int)blockIdx.x % a.sub_k;
+    if (a.split_info[2 * inst] == 0) return;  // (uniform: the whole workgroup leaves)
+    Sol::solve_instance(s, c, a, inst, (int)blockIdx.x, sub);
+    return;
+  }
+  const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  Sol::solve_instance(s, c, a, inst, inst, -1);
+}
+
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
-  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
 }
 
 // The same solver budgeted for TWO workgroups per CU (registers: 2 waves per SIMD; LDS: a staging area of CMAX_DUO
@@ -58,8 +71,7 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
-  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
 }
 
 // Pre-pass of every level-2 launch, one thread per agent of the swarm:
@@ -469,10 +481,19 @@ struct Handle {
   int device = 0;
   int max_inst = 0, n_rob_max = 0;
   int N = 0, P = 0, RS = 0, n = 0;
-  int threads = 256;
+  int threads = 256, cus = 256;
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
+  // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
+  int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 16 nodes for batches that leave CUs idle, 96 beyond
+  int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
+  int32_t* d_tree_flag = nullptr;
+  int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
+  unsigned long long* d_inc = nullptr;
+  double *d_sub_traj = nullptr, *d_sub_ctrl = nullptr, *d_sub_obj = nullptr, *d_sub_scratch = nullptr;
+  uint8_t* d_sub_used = nullptr;
+  bool sub_ready = false;
   double* d_bounds = nullptr; // [n_rob_max][4]
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
   double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
@@ -505,7 +526,7 @@ struct Handle {
 };
 
 template <int NV, int NT>
-int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
+int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   constexpr int CM = (NV <= 32) ? CMAX30 : CMAX48;
   using Sol = hdsm::Solver<NV, CM>;
   const size_t shm = sizeof(typename Sol::S);
@@ -516,12 +537,12 @@ int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st) {
                                 (int)shm));
     attr_dev = h->device;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(NT), shm, st, h->d_consts, a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
 }
 
-int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st) {
+int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_DUO>;
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
   const size_t shm = sizeof(typename Sol::S);
@@ -532,7 +553,7 @@ int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st) {
                                 (int)shm));
     attr_dev = h->device;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(256), shm, st, h->d_consts, a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
 }
@@ -548,11 +569,36 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 2) void k_replan_tri(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  typename Sol::S& s = *reinterpret_cast<typename Sol::S*>(smem);
-  Sol::solve_instance(s, *cp, a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x);
+  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
 }
 
-int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st) {
+// n > 30 (H up to 16): the factor needs more than 256 registers per lane, so a wavefront must have a SIMD to itself — but a
+// 128-thread workgroup has only two, and TWO such workgroups (four wavefronts, one per SIMD) fit a CU once the staging area is cut
+// to 320 rows (2 x 80.9 KB of LDS). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5: 4096
+// instances, 16 per CU one after the other), and every instance is one latency-bound wavefront: the second one doubles the rate.
+constexpr int CMAX_DUO48 = 320;
+template <int NV, int CMAX, int NT>
+__global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sol = hdsm::Solver<NV, CMAX>;
+  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+}
+int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
+  using Sol = hdsm::Solver<48, CMAX_DUO48>;
+  static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
+  const size_t shm = sizeof(typename Sol::S);
+  auto kern = k_replan_duo48<48, CMAX_DUO48, 128>;
+  static thread_local int attr_dev = -1;
+  if (attr_dev != h->device) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_dev = h->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
+}
+
+int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_TRI>;
   static_assert(sizeof(typename Sol::S) * 3 <= 160 * 1024, "three instances must fit the LDS of one CU");
   const size_t shm = sizeof(typename Sol::S);
@@ -562,10 +608,26 @@ int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     attr_dev = h->device;
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_inst), dim3(128), shm, st, h->d_consts, a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
 }
+
+// ---- subtree splitting: set-up of pass 2, merge, lazily allocated state -------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap) {
+  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (k < n_inst) inc_bits[k] = 0x7ff0000000000000ull;  // +inf
+  if (k == 0) sub_slots[0] = 0, sub_slots[1] = cap;
+  for (int i = k; i < cap; i += n_inst > 0 ? (int)(gridDim.x * blockDim.x) : 1) sub_slots[2 + i] = 0;
+}
+
+// One wavefront per instance that pass 1 handed over: the best answer of its sub-blocks becomes the instance's answer. `a` holds
+// the instance-indexed arrays of the launch, `b` the arrays of pass 2 (index instance * K + subtree).
+__global__ __launch_bounds__(64) void k_split_merge(int N, int K, hdsm::Args a, hdsm::Args b) {
+  hdsm::split_merge(N, K, a, b, (int)blockIdx.x, (int)threadIdx.x, 64);
+}
+
+hipError_t ensure_sub(Handle* h);
 
 int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.scratch = h->d_scratch;
@@ -602,10 +664,67 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
   int rc;
   if (h->time_kernel) HIP_TRY(hipEventRecord(h->ev_k0, st));
-  if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && a.n_inst >= h->tri_min) rc = launch_tri(h, a, st);
-  else if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo(h, a, st);
-  else if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, a, st) : launch_nv<32, 256>(h, a, st);
-  else rc = h->threads == 64 ? launch_nv<48, 64>(h, a, st) : launch_nv<48, 256>(h, a, st);
+  auto solve = [&](const hdsm::Args& x, int blocks) -> int {  // the kernel shape that suits `blocks` workgroups
+    hdsm::Args y = x;
+    y.n_inst = x.n_inst;
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && blocks >= h->tri_min) return launch_tri(h, y, st, blocks);
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo(h, y, st, blocks);
+    if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, y, st, blocks) : launch_nv<32, 256>(h, y, st, blocks);
+    if (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo48(h, y, st, blocks);
+    return h->threads == 64 ? launch_nv<48, 64>(h, y, st, blocks) : launch_nv<48, 256>(h, y, st, blocks);
+  };
+  a.warm_out = a.warm;
+  a.tree_flag = h->d_tree_flag;
+  // nodes after which an instance is handed over: small batches leave most CUs idle, so sub-blocks are free; in a batch that
+  // fills the GPU every handed-over instance costs poly_hor set-ups and sweeps on busy CUs, so only the deep trees go
+  const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 16 : 96);
+  a.tree_mark = budget;
+  // Subtree splitting. A launch lasts as long as its slowest instance, and in obstacle worlds that is one agent between pillars
+  // whose branch and bound needs hundreds of nodes while the other workgroups have been idle for milliseconds. When the last
+  // launch met such a tree (tree_flag), this one runs in three kernels: (1) the ordinary solve with a small node budget — an
+  // instance that exceeds it stops without outputs and records the step its root branched on; (2) poly_hor workgroups per
+  // handed-over instance, workgroup j searching the subtree "polyhedron j at that step" (a partition of the search space that
+  // does not depend on numerical noise), pruning against the best objective any of them has found (one atomicMin per
+  // incumbent); (3) a merge that keeps the best answer. Same answers as the one-kernel form: the search is exact either way.
+  bool split = h->split_mode == 1;
+  if (h->split_mode == 2 && h->h_tree_flag != nullptr) {
+    // The word is raised by kernels that may still be running when the next launch is enqueued (callers queue rounds back to
+    // back), so a sighting keeps the split form on for the next few launches; deep trees persist over rounds anyway.
+    if (*h->h_tree_flag != 0) *h->h_tree_flag = 0, h->split_ttl = 8;
+    if (h->split_ttl > 0) split = true, --h->split_ttl;
+  }
+  if (split && !h->sub_ready) split = ensure_sub(h) == hipSuccess;
+  if (!split) {
+    rc = solve(a, a.n_inst);
+  } else {
+    const int K = h->P, G = a.n_inst * K, I = h->max_inst;
+    a.split_budget = budget, a.split_info = h->d_split, a.tree_mark = 0;
+    rc = solve(a, a.n_inst);
+    if (rc) return rc;
+    hdsm::Args b = a;
+    b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = h->d_inc, b.sub_slots = h->d_sub_slots, b.tree_flag = nullptr;
+    {  // the node budget is the INSTANCE's: what pass 1 left of it is shared by the sub-blocks
+      const int total = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
+      const int left = total - budget;
+      b.node_cap = left > K ? (left + K - 1) / K : 1;
+    }
+    b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
+    b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr;
+    int32_t* ss = h->d_sub_stats;
+    const size_t GI = (size_t)I * K;
+    b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
+    b.st_flags = reinterpret_cast<uint32_t*>(ss + 6 * GI), b.st_key = ss + 7 * GI;
+    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap);
+    HIP_TRY(hipGetLastError());
+    // (most of the G blocks leave at once — only the sub-blocks of handed-over instances work — so the kernel shape is chosen for
+    // few, long-running workgroups: one per CU with the large staging area, whatever G is)
+    if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, b, st, G) : launch_nv<32, 256>(h, b, st, G);
+    else if (h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo48(h, b, st, G);  // (large batches hand over hundreds of instances)
+    else rc = h->threads == 64 ? launch_nv<48, 64>(h, b, st, G) : launch_nv<48, 256>(h, b, st, G);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, K, a, b);
+    HIP_TRY(hipGetLastError());
+  }
   if (rc) return rc;
   if (h->time_kernel) {
     HIP_TRY(hipEventRecord(h->ev_k1, st));
@@ -638,7 +757,30 @@ int64_t scratch_stride_for(int n) {
                  : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
 }
 
+// state of the split launches, allocated on the first one: outputs / statistics / guesses per sub-block (max_inst x poly_hor), a
+// pool of snapshot scratch for the sub-blocks that really work (at most 2048 at a time)
+hipError_t ensure_sub(Handle* h) {
+  const size_t G = (size_t)h->max_inst * h->P, N = (size_t)h->N;
+  h->sub_cap = (int)(G < 2048 ? G : 2048);
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_sub_slots, 2 + (size_t)h->sub_cap));
+  ok(dmalloc(&h->d_sub_stats, 8 * G)), ok(dmalloc(&h->d_sub_warm, (hdsm::MAXNV + 2) * G)), ok(dmalloc(&h->d_sub_status, G));
+  ok(dmalloc(&h->d_sub_traj, G * (N + 1) * 9)), ok(dmalloc(&h->d_sub_ctrl, G * N * 3)), ok(dmalloc(&h->d_sub_obj, G)), ok(dmalloc(&h->d_sub_used, G * h->P));
+  ok(dmalloc(&h->d_sub_scratch, (size_t)h->sub_cap * (size_t)h->scratch_stride));
+  if (e == hipSuccess) e = hipMemset(h->d_split, 0, 2 * (size_t)h->max_inst * sizeof(int32_t));
+  h->sub_ready = e == hipSuccess;
+  return e;
+}
+
 void free_all(Handle* h) {
+  void* sub[] = {h->d_split, h->d_inc, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
+                 h->d_sub_used, h->d_sub_scratch};
+  for (void* p : sub)
+    if (p) (void)hipFree(p);
+  if (h->h_tree_flag) (void)hipHostFree(h->h_tree_flag);
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_rpos,  h->d_rsph,  h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
@@ -732,10 +874,13 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   {
     hipDeviceProp_t prop;
     const int cus = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    h->cus = cus;
     h->duo_min = params->duo_min_instances > 0 ? params->duo_min_instances : (params->duo_min_instances < 0 ? 0 : cus + 1);
     env_int("HDSM_DUO_MIN", 0, INT_MAX, &h->duo_min);  // 0 = never
     h->tri_min = h->duo_min > 0 ? 2 * cus + 1 : 0;     // more instances than the two-per-CU kernel has resident slots
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
+    env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
+    env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
     h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
     env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never
@@ -779,6 +924,11 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_obj, I));
   ok(dmalloc(&h->d_has, (size_t)n_rob_max));
   ok(dmalloc(&h->d_used, I * P));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->h_tree_flag), sizeof(int32_t), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *h->h_tree_flag = 0;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_tree_flag), h->h_tree_flag, 0);
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming);

@@ -104,6 +104,7 @@ struct Shm {
   unsigned long long nogood[NOGOODS];
   int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
   int32_t ncold;  // rows staged but not scanned every iteration (top of cand[])
+  double inc_shared;   // split launches: best objective found by ANY sub-block of this instance (DINF: none / ordinary launch)
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
@@ -368,14 +369,25 @@ struct Solver {
   }
 
   static HD double cutoff(const S& s, const Consts& c) {
-    if (!s.have_inc) return DINF;
-    const double exact = 1e-9 * fmax(1.0, fabs(s.inc_f)), gap = c.mip_gap * fabs(s.inc_f);  // hdsm_params.mip_gap (Gurobi MIPGap)
-    return s.inc_f - (gap > exact ? gap : exact);
+    // the incumbent of this workgroup, or — pass 2 of a split launch — the best one of all sub-blocks of the instance
+    // (s.inc_shared: refreshed from global memory by thread 0 at every node, see select_child)
+    const double inc = s.have_inc ? (s.inc_f < s.inc_shared ? s.inc_f : s.inc_shared) : s.inc_shared;
+    if (!(inc < DINF)) return DINF;
+    const double exact = 1e-9 * fmax(1.0, fabs(inc)), gap = c.mip_gap * fabs(inc);  // hdsm_params.mip_gap (Gurobi MIPGap)
+    return inc - (gap > exact ? gap : exact);
   }
 
   // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
   // assigns the child's polyhedron. Returns false when the tree is exhausted (or the node budget is).
-  static HD bool select_child(S& s, const Consts& c, GIState& R, double* snap, int& nodes, bool& limit) {
+  static HD bool select_child(S& s, const Consts& c, GIState& R, double* snap, int& nodes, bool& limit, int inst, bool& handed_over) {
+    if (s.args.inc_bits != nullptr) {  // pass 2 of a split launch: what the other sub-blocks of this instance have found
+      SYNC();
+      if (IS_T0) {
+        const unsigned long long bits = __hip_atomic_load(&s.args.inc_bits[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.inc_shared = __longlong_as_double((long long)bits);
+      }
+      SYNC();
+    }
     for (;;) {
       const int level = s.level;
       if (level == 0) return false;
@@ -395,7 +407,11 @@ struct Solver {
             continue;
           }
         }
-        if (nodes >= c.max_nodes) {
+        if (s.args.split_budget > 0 && nodes >= s.args.split_budget) {  // pass 1 of a split launch: hand the tree over
+          handed_over = true;
+          return false;
+        }
+        if (nodes >= (s.args.node_cap > 0 ? s.args.node_cap : c.max_nodes)) {
           limit = true;
           return false;
         }
@@ -420,13 +436,35 @@ struct Solver {
   }
 
   // ---- one instance, start to finish ------------------------------------------------------------------------
-  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst) {
+  // `inst`: the instance (inputs, warm-start guess); `out`: where its outputs, statistics and scratch live — `inst` itself, or,
+  // in pass 2 of a split launch, the slot of this sub-block; `sub`: the polyhedron this sub-block fixes at the root's
+  // branching step (-1: ordinary solve).
+  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub) {
     if (IS_T0) s.args = a_in;
     SYNC();
     const Args& a = s.args;
     const int N = c.N, n = c.n, P = c.P, RS = c.RS;
     const int self = a.agent_id[inst];
-    double* snap = a.scratch + (int64_t)inst * a.scratch_stride;
+    double* snap = a.scratch + (int64_t)out * a.scratch_stride;
+    bool no_slot = false;
+    int my_slot = -1;
+    if (sub >= 0) {  // pass 2: snapshot scratch comes from a pool of slots, taken for the lifetime of the workgroup (the pool is
+      SYNC();        // larger than the number of workgroups that can be resident at once, so a free slot always exists)
+      if (IS_T0) {
+        const int cap = a.sub_slots[1];
+        int got = -1;
+        for (int probe = 0; probe < cap && got < 0; ++probe) {
+          const int i = (int)(((unsigned)blockIdx.x * 7u + (unsigned)probe) % (unsigned)cap);
+          if (atomicCAS(&a.sub_slots[2 + i], 0, 1) == 0) got = i;
+        }
+        s.iters_sh = got;
+      }
+      SYNC();
+      my_slot = s.iters_sh;
+      no_slot = my_slot < 0;
+      snap = a.scratch + (int64_t)(no_slot ? 0 : my_slot) * a.scratch_stride;
+      SYNC();
+    }
 
     const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
 #ifdef HDSM_PROFILE
@@ -544,7 +582,7 @@ struct Solver {
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
-        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.inc_shared = DINF;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -624,10 +662,23 @@ struct Solver {
     long long t_warm_ = 0;
     int it_warm_ = 0;
 #endif
-    bool limit = false;
+    bool limit = false, handed_over = false;
     unsigned flags = 0;
     bool run = np > 0;
     if (IS_T0) s.sw_tau = 0.0;
+    if (sub >= 0) {  // pass 2 of a split launch: this workgroup owns the subtree "polyhedron `sub` at the root's branching step"
+      const int step = a.split_info[2 * inst + 1];
+      bool admissible = sub < np && step >= 0 && step < N;
+      if (admissible && step == 0)  // rows on the pinned p_0 only gate the choice (leaf_check: keys = DINF)
+        for (int r = 0; r < s.sp_rows[sub]; ++r) {
+          const double* row = s.sp[sub][r];
+          admissible = admissible && !(row[0] * s.st[0][0] + row[1] * s.st[0][1] + row[2] * s.st[0][2] - row[3] > c.ftol_fixed);
+        }
+      run = run && admissible;
+      if (run && no_slot) run = false, limit = true, flags |= FLAG_NODE_LIMIT;  // (pool exhausted: reported like a node budget)
+      SYNC();
+      if (IS_T0 && run) s.assign[step] = sub, s.level = 1, s.br_step[0] = step, s.br_cnt[0] = 0, s.br_pos[0] = 0, s.br_f[0] = 0.0;
+    }
     SYNC();
     // all neighbour rows near (first call) or violated at (later calls) the current point -> staging area; a staging
     // radius that overflows the LDS slots is tightened (it only decides what is pre-staged: exactness comes from the
@@ -760,7 +811,11 @@ struct Solver {
             s.inc_act[k] = code;
           }
           if (IS_T0) s.inc_nact = s.q;
-          if (IS_T0) s.inc_f = s.f, s.have_inc = 1;
+          if (IS_T0) {
+            s.inc_f = s.f, s.have_inc = 1;
+            // split launches: the other sub-blocks of this instance prune against it (objectives are >= 0: the bit patterns order)
+            if (a.inc_bits != nullptr && s.f >= 0.0) atomicMin(&a.inc_bits[inst], (unsigned long long)__double_as_longlong(s.f));
+          }
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level;
@@ -809,7 +864,7 @@ struct Solver {
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
       const bool lim_before = limit;
-      run = select_child(s, c, R, snap, nodes, limit);
+      run = select_child(s, c, R, snap, nodes, limit, inst, handed_over);
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
@@ -822,10 +877,19 @@ struct Solver {
     }
 #endif
     // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective
+    // (an instance handed over to pass 2 of a split launch leaves without outputs: the merge kernel writes them)
+    if (handed_over) {
+      SYNC();
+      if (IS_T0) s.have_inc = 0;
+      SYNC();
+      limit = true;
+    }
+    if (IS_T0 && a.split_budget > 0) a.split_info[2 * inst] = handed_over ? 1 : 0, a.split_info[2 * inst + 1] = handed_over ? s.br_step[0] : -1;
+    if (IS_T0 && a.tree_flag != nullptr && (handed_over || (a.tree_mark > 0 && nodes >= a.tree_mark))) *a.tree_flag = 1;
     const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
     if (s.have_inc) {
-      double* tr = a.traj + (int64_t)inst * 9 * (N + 1);
-      double* cu = a.ctrl + (int64_t)inst * 3 * N;
+      double* tr = a.traj + (int64_t)out * 9 * (N + 1);
+      double* cu = a.ctrl + (int64_t)out * 3 * N;
       PAR_FOR(k, 3 * N) cu[k] = s.inc_x[(k % 3) * N + k / 3];
       PAR_FOR(ax, 3) {
         double xs[3] = {s.state0[ax], s.state0[3 + ax], s.state0[6 + ax]};
@@ -852,22 +916,22 @@ struct Solver {
           part += ((i == N) ? c.wn[k] : c.wx[k]) * e * e;
         }
         part = wave_sum64(part);
-        if (lane == 0) a.obj[inst] = part;
+        if (lane == 0) a.obj[out] = part;
       }
       if (IS_T0) {
-        uint8_t* us = a.used + (int64_t)inst * P;
+        uint8_t* us = a.used + (int64_t)out * P;
         for (int j = 0; j < P; ++j) us[j] = 0;
         for (int i = 0; i < N; ++i)
           if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
       }
     }
-    if (a.warm != nullptr) {  // next replan's guess
-      int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
+    if (a.warm != nullptr && !handed_over) {  // next replan's guess
+      int32_t* wp = a.warm_out + (int64_t)out * (MAXNV + 2);
       // No solution because the ROOT relaxation is infeasible (the usual case in a gridlocked neighbourhood, and it
       // tends to persist for several rounds): hand over the certificate — the working set at the moment of the proof
       // and the row that could not join it. Seeded with it, the next replan finds the contradiction (or its absence)
       // after a few operations instead of rebuilding it from the unconstrained optimum.
-      const bool certificate = !s.have_inc && !limit && (nodes == 1 || s.ng_global) && last_rc == GI_INFEASIBLE && s.q < NV;
+      const bool certificate = !s.have_inc && !limit && (sub < 0 ? (nodes == 1 || s.ng_global) : s.ng_global != 0) && last_rc == GI_INFEASIBLE && s.q < NV;
       if (certificate) {
         SYNC();
         PAR_FOR(k, NV) {
@@ -897,14 +961,14 @@ struct Solver {
     }
 #endif
     if (IS_T0) {
-      a.status[inst] = status;
-      if (a.st_iters) a.st_iters[inst] = iters;
-      if (a.st_nodes) a.st_nodes[inst] = nodes;
-      if (a.st_sweeps) a.st_sweeps[inst] = sweeps;
-      if (a.st_cand) a.st_cand[inst] = s.ncand + s.ncold;
-      if (a.st_sph) a.st_sph[inst] = s.st_sph;
-      if (a.st_pairs) a.st_pairs[inst] = s.st_pairs;
-      if (a.st_flags) a.st_flags[inst] = flags;
+      a.status[out] = status;
+      if (a.st_iters) a.st_iters[out] = iters;
+      if (a.st_nodes) a.st_nodes[out] = nodes;
+      if (a.st_sweeps) a.st_sweeps[out] = sweeps;
+      if (a.st_cand) a.st_cand[out] = s.ncand + s.ncold;
+      if (a.st_sph) a.st_sph[out] = s.st_sph;
+      if (a.st_pairs) a.st_pairs[out] = s.st_pairs;
+      if (a.st_flags) a.st_flags[out] = flags;
       if (a.st_key) {
         // what the next launch sorts by (hdsm_api.hip, launch_order_block): how long this instance took; an instance without
         // a solution goes first whatever it took — its next replan either ends on the certificate at once or is among the
@@ -912,8 +976,9 @@ struct Solver {
         // (+ 9 units per row of the final working set: next to the duration, the size of the active set is what predicts the
         // next replan's length best on the crossing rounds — list-scheduling replay of recorded launches, profiles/README.md)
         const long long ticks = (((long long)wall_clock64() - tl_begin_) >> 6) + 9 * s.q;
-        a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
+        a.st_key[out] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
+      if (my_slot >= 0) atomicExch(&a.sub_slots[2 + my_slot], 0);  // (all snapshot traffic of this workgroup is behind it)
     }
     SYNC();
   }
@@ -921,5 +986,44 @@ struct Solver {
   static HD int min_i(int x, int y) { return x < y ? x : y; }
   static HD int max_i(int x, int y) { return x > y ? x : y; }
 };
+
+// Split launches, last step (k_split_merge: one wavefront per instance; `lane` of `lanes`): the best answer of the sub-blocks of an
+// instance that pass 1 handed over becomes the instance's answer. `a` holds the instance-indexed arrays of the launch, `b` the
+// arrays of pass 2 (index instance * K + subtree).
+HD void split_merge(int N, int K, const Args& a, const Args& b, int inst, int lane, int lanes) {
+  if (inst >= a.n_inst || a.split_info[2 * inst] == 0) return;
+  int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = 0, sph = 0, pairs = 0;
+  unsigned flags = 0;
+  double obj = DINF;
+  for (int k = 0; k < K; ++k) {
+    const int g = inst * K + k;
+    const int st = b.status[g];
+    iters += b.st_iters[g], nodes += b.st_nodes[g], sweeps += b.st_sweeps[g];
+    if (b.st_sph) sph += b.st_sph[g], pairs += b.st_pairs[g];
+    cand = b.st_cand[g] > cand ? b.st_cand[g] : cand;
+    flags |= b.st_flags[g];
+    lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
+    if (st != ST_NO_SOLUTION && b.obj[g] < obj) obj = b.obj[g], best = g;
+  }
+  const int status = best < 0 ? ST_NO_SOLUTION : (lim ? ST_LIMIT : ST_OPTIMAL);
+  if (best >= 0) {
+    for (int e = lane; e < (N + 1) * 9; e += lanes) a.traj[(int64_t)inst * (N + 1) * 9 + e] = b.traj[(int64_t)best * (N + 1) * 9 + e];
+    for (int e = lane; e < N * 3; e += lanes) a.ctrl[(int64_t)inst * N * 3 + e] = b.ctrl[(int64_t)best * N * 3 + e];
+    for (int e = lane; e < K; e += lanes) a.used[(int64_t)inst * K + e] = b.used[(int64_t)best * K + e];
+  }
+  if (a.warm != nullptr) {  // next replan's guess: the best sub-block's working set (none: start cold)
+    int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
+    const int32_t* src = b.warm_out + (int64_t)(best >= 0 ? best : inst * K) * (MAXNV + 2);
+    for (int e = lane; e < MAXNV + 2; e += lanes) wp[e] = best >= 0 ? src[e] : 0;
+  }
+  if (lane == 0) {
+    if (best >= 0) a.obj[inst] = obj;
+    a.status[inst] = status;
+    a.st_iters[inst] = iters, a.st_nodes[inst] = nodes, a.st_sweeps[inst] = sweeps, a.st_cand[inst] = cand;
+    if (a.st_sph) a.st_sph[inst] = sph, a.st_pairs[inst] = pairs;
+    a.st_flags[inst] = flags;
+    if (a.st_key) a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : 254;  // a deep tree: launch it first next time
+  }
+}
 
 }  // namespace hdsm

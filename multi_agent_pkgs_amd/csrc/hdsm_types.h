@@ -107,6 +107,20 @@ struct Args {
   int32_t* st_sph;    // sphere records read by the sweeps of this instance
   int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance
   uint32_t* st_flags; // HDSM_FLAG_* bits
+  // ---- subtree splitting (hdsm_api.hip, launch_split): a launch in three kernels for batches with deep branch-and-bound trees
+  int32_t split_budget;   // pass 1: an instance whose tree is not finished after this many nodes stops WITHOUT outputs and
+                          // records the step its root branched on in split_info (0 = ordinary launch)
+  int32_t sub_k;          // pass 2: block b continues instance b / sub_k inside the subtree "root step = polyhedron b % sub_k";
+                          // instances that were not handed over leave at once (0 = ordinary launch)
+  int32_t* split_info;    // [n_inst][2]: handed over (0 / 1), root branching step
+  unsigned long long* inc_bits;  // [n_inst]: best objective any sub-block has found so far (bits of a non-negative double,
+                                 // +inf at the start): the sub-blocks of an instance prune against each other's incumbents
+  int32_t node_cap;       // pass 2: node budget of ONE sub-block (the instance's budget is shared by its sub-blocks; 0 = Consts::max_nodes)
+  int32_t* sub_slots;     // pass 2: pool of snapshot-scratch slots: [1] = capacity, [2 + i] = slot i taken (0 / 1)
+  int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree outgrew split_budget (ordinary launch) or that was
+                          // handed over (pass 1) — the handle switches the NEXT launch to the split form when it sees it
+  int32_t tree_mark;      // ordinary launches: node count from which an instance raises tree_flag (0 = never)
+  int32_t* warm_out;      // where the NEXT replan's guess is written: warm itself, or the per-sub-block copy of pass 2
   int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units + 9 per active row (<= 254), 255 = no solution
 };
 

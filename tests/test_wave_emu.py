@@ -202,7 +202,9 @@ def test_helper_wavefronts_share_the_staged_row_scan(wave, oracle):
     prm15 = agile_params(15, max_rows_static=18)
     sn = problems.swarm_snapshot(prm15, 10, seed=115, turn=True)
     args = [sn[k] for k in ARG_KEYS]
-    compare(wave.replan(prm15, *args, threads=256), oracle.replan(prm15, *args, n_threads=8))
+    o15 = oracle.replan(prm15, *args, n_threads=8)
+    compare(wave.replan(prm15, *args, threads=256), o15)
+    compare(wave.replan(prm15, *args, threads=128), o15)   # the two-per-CU shape of the H > 10 kernel
 
 
 @pytest.mark.parametrize("kw", [dict(seed=41, narrow=True, turn=True, spacing=1.6), dict(seed=43, chamfer=True, turn=True)])

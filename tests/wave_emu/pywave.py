@@ -29,7 +29,7 @@ def new_warm_store(n_inst):
     return np.zeros((n_inst, MAXNV + 2), dtype=np.int32)
 
 
-def replan(prm, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, warm=None, bounds_min=256, threads=64, cmax=0):
+def replan(prm, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, warm=None, bounds_min=256, threads=64, cmax=0, split_budget=0):
     N, P = prm.n_hor, prm.poly_hor
     f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
@@ -48,7 +48,7 @@ def replan(prm, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, war
                            _p(A, d), _p(b, d), _p(plans, d), _p(has_plan, u), _p(out["traj"], d), _p(out["ctrl"], d),
                            _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d), _p(out["qp_iters"], i), _p(out["nodes"], i),
                            _p(out["sweeps"], i), _p(out["cand"], i), _p(out["flags"], C.c_uint32),
-                           _p(warm, i) if warm is not None else None, C.c_int32(bounds_min), C.c_int32(threads), C.c_int32(cmax))
+                           _p(warm, i) if warm is not None else None, C.c_int32(bounds_min), C.c_int32(threads), C.c_int32(cmax), C.c_int32(split_budget))
     if rc == -100:
         raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
     assert rc == 0, rc

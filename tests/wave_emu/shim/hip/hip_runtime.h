@@ -153,6 +153,24 @@ inline int atomicAdd(int* p, int v) {
   *p = old + v;
   return old;
 }
+inline int atomicCAS(int* p, int cmp, int val) {
+  const int old = *p;
+  if (old == cmp) *p = val;
+  return old;
+}
+inline int atomicExch(int* p, int v) {
+  const int old = *p;
+  *p = v;
+  return old;
+}
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
+  const unsigned long long old = *p;
+  if (v < old) *p = v;
+  return old;
+}
+#define __ATOMIC_RELAXED_SHIM 0
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(ptr, order, scope) (*(ptr))
 inline unsigned atomicAdd(unsigned* p, unsigned v) {
   const unsigned old = *p;
   *p = old + v;

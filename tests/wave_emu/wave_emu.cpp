@@ -97,12 +97,12 @@ struct Job {
   typename hdsm::Solver<NV, CMAX>::S* s;
   const hdsm::Consts* c;
   hdsm::Args a;
-  int inst;
+  int inst, out, sub;
 };
 template <int NV, int CMAX>
 void body(void* p) {
   auto* j = static_cast<Job<NV, CMAX>*>(p);
-  hdsm::Solver<NV, CMAX>::solve_instance(*j->s, *j->c, j->a, j->inst);
+  hdsm::Solver<NV, CMAX>::solve_instance(*j->s, *j->c, j->a, j->inst, j->out, j->sub);
 }
 template <int NV, int CMAX>
 int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
@@ -110,12 +110,49 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   a.scratch_stride = (int64_t)Sol::SNAP_STRIDE * hdsm::MAXH;
   std::vector<double> scratch((size_t)a.scratch_stride);
   auto shm = std::make_unique<typename Sol::S>();
+  if (a.warm_out == nullptr) a.warm_out = a.warm;
+  // split_budget > 0: the three steps of hdsm_api.hip's split launch, one workgroup after the other — pass 1 with the node
+  // budget, then for every instance it handed over one sub-block per polyhedron (own outputs, shared incumbent word), then
+  // the merge (hdsm::split_merge, the body of k_split_merge)
+  const int K = c.P;
+  std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, sub_slots(2 + 4, 0);
+  std::vector<unsigned long long> inc_bits;
+  std::vector<double> sub_traj, sub_ctrl, sub_obj;
+  std::vector<uint8_t> sub_used;
+  if (a.split_budget > 0) {
+    split_info.assign((size_t)2 * a.n_inst, 0);
+    a.split_info = split_info.data();
+  }
   for (int k = 0; k < a.n_inst; ++k) {
     memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
-    Job<NV, CMAX> job{shm.get(), &c, a, k};
-    job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds inst * stride
+    Job<NV, CMAX> job{shm.get(), &c, a, k, k, -1};
+    job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds out * stride
     if (!wemu::run_block(body<NV, CMAX>, &job, k, nthreads)) return -100;
     if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
+  }
+  if (a.split_budget > 0) {
+    const size_t G = (size_t)a.n_inst * K, N = (size_t)c.N;
+    hdsm::Args b = a;
+    sub_status.assign(G, hdsm::ST_NO_SOLUTION), sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
+    inc_bits.assign(a.n_inst, 0x7ff0000000000000ull);
+    sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * K, 0);
+    sub_slots[0] = 0, sub_slots[1] = 4;
+    b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = inc_bits.data(), b.sub_slots = sub_slots.data();
+    b.traj = sub_traj.data(), b.ctrl = sub_ctrl.data(), b.used = sub_used.data(), b.status = sub_status.data(), b.obj = sub_obj.data();
+    b.warm_out = sub_warm.data();
+    b.st_iters = sub_stats.data(), b.st_nodes = sub_stats.data() + G, b.st_sweeps = sub_stats.data() + 2 * G, b.st_cand = sub_stats.data() + 3 * G;
+    b.st_sph = nullptr, b.st_pairs = nullptr, b.st_flags = reinterpret_cast<uint32_t*>(sub_stats.data() + 6 * G), b.st_key = nullptr;
+    for (int g = 0; g < (int)G; ++g) {
+      const int inst = g / K;
+      if (split_info[2 * inst] == 0) continue;
+      memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
+      Job<NV, CMAX> job{shm.get(), &c, b, inst, g, g % K};
+      std::vector<double> sub_scratch;  // (the sub-blocks run one after the other: every one gets a slot of the 4-slot pool)
+      sub_scratch.resize((size_t)a.scratch_stride * 4);
+      job.a.scratch = sub_scratch.data();
+      if (!wemu::run_block(body<NV, CMAX>, &job, g, nthreads)) return -100;
+    }
+    for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, K, a, b, inst, 0, 1);
   }
   return 0;
 }
@@ -131,7 +168,8 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
                            const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows_static, const double* A_static,
                            const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
                            uint8_t* poly_used, int32_t* status, double* obj, int32_t* qp_iters, int32_t* nodes, int32_t* sweeps,
-                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads, int32_t cmax) {
+                           int32_t* cand, uint32_t* flags, int32_t* warm, int32_t bounds_min, int32_t threads, int32_t cmax,
+                           int32_t split_budget) {
   if (threads != 64 && threads != 128 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
@@ -173,6 +211,7 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
   a.pos = pos.data();
   a.bounds = (n_rob >= bounds_min) ? bounds.data() : nullptr;
   a.warm = (prm->warm_start && warm) ? warm : nullptr;
+  a.split_budget = split_budget;
   if (cmax > 0 && cmax <= 16)  // tiny staging capacity: exercises the overflow path in tests
     return c->n <= hdsm::SPLIT_N_MAX ? run_all<32, 16>(*c, a, threads) : run_all<48, 16>(*c, a, threads);
   if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
