@@ -268,6 +268,29 @@ struct WaveGI {
     }
   }
 
+  // Rows of the polyhedra assigned on the current branch: lane t < rows tests row t at p_i, lane rows + t at p_{i+1}, one
+  // assigned step per trip. The assignment and the row counts are fetched ONCE (lane i holds assign[i], lane j the row count
+  // of polyhedron j) and handed round with v_readlane, so a trip is one LDS round trip — row and point together — instead
+  // of the three in a chain (assign[i] -> sp_rows[j] -> row) the step-by-step loop paid in every node of a tree.
+  static __device__ __forceinline__ void scan_assigned(const S& s, int lane, int N, double& v, int& id) {
+    const int aj = lane < N ? s.assign[lane] : -1;
+    const int nr = lane < MAXP ? s.sp_rows[lane] : 0;
+    unsigned long long am = __ballot(aj >= 0);
+    while (am != 0ull) {
+      const int i = __ffsll((long long)am) - 1;
+      am &= am - 1ull;
+      const int j = __builtin_amdgcn_readlane(aj, i), rows = __builtin_amdgcn_readlane(nr, j);
+      for (int t = lane; t < 2 * rows; t += 64) {
+        const int e = t >= rows ? 1 : 0, r = t - e * rows;
+        if (i + e == 0) continue;
+        const double* row = s.sp[j][r];
+        const double* pm = s.st[i + e];
+        const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+        if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
+      }
+    }
+  }
+
   // most violated row among: input / state boxes, rows of assigned polyhedra, HOT staged rows
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
                                                 double& vbest, int& ibest) {
@@ -288,23 +311,7 @@ struct WaveGI {
         if (vl > v) v = vl, id = mk_id(K_S, R.sb_id[e] | 1);
       }
     }
-    if (uni(s.level) > 0) {  // rows of the polyhedra assigned on the current branch
-      // step by step, assigned steps only (wave-uniform skip): lane t < rows tests the row at p_i, lane rows + t at p_{i+1}.
-      // (One flat loop over [N][2][RS] with its runtime divisions cost 4 k cycles per operation in branch-and-bound nodes.)
-      for (int i = 0; i < N; ++i) {
-        const int j = uni(s.assign[i]);
-        if (j < 0) continue;
-        const int rows = uni(s.sp_rows[j]);
-        for (int t = lane; t < 2 * rows; t += 64) {
-          const int e = t >= rows ? 1 : 0, r = t - e * rows;
-          if (i + e == 0) continue;
-          const double* row = s.sp[j][r];
-          const double* pm = s.st[i + e];
-          const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-          if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
-        }
-      }
-    }
+    if (uni(s.level) > 0) scan_assigned(s, lane, N, v, id);  // rows of the polyhedra assigned on the current branch
     const int nc = uni(s.ncand);
     const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {

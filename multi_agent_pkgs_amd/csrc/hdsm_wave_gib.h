@@ -396,21 +396,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
       const double vv = cp.r01[u].x * px[u] + cp.r01[u].y * py[u] + cp.r23[u].x * pz[u] - cp.r23[u].y;
       if (64 * u + lane < nc && vv > v) v = vv, id = mk_kc(64 * u + lane, cp.mm[u]);
     }
-    if (uni(s.level) > 0) {  // rows of the polyhedra assigned on the current branch (see Base::select)
-      for (int i = 0; i < N; ++i) {
-        const int j = uni(s.assign[i]);
-        if (j < 0) continue;
-        const int rows = uni(s.sp_rows[j]);
-        for (int t = lane; t < 2 * rows; t += 64) {
-          const int e = t >= rows ? 1 : 0, r = t - e * rows;
-          if (i + e == 0) continue;
-          const double* row = s.sp[j][r];
-          const double* pm = s.st[i + e];
-          const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-          if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
-        }
-      }
-    }
+    if (uni(s.level) > 0) Base::scan_assigned(s, lane, N, v, id);  // rows of the polyhedra assigned on the current branch
     const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
       if (lane == 0) s.cmd = 1;

@@ -43,6 +43,19 @@ CD_HD V3 axpy(const V3& a, double s, const V3& b) { return {{a[0] + s * b[0], a[
 CD_HD V3 step_along(const V3& a, double s, const V3& d, double len) {
   return {{a[0] + (s * d[0]) / len, a[1] + (s * d[1]) / len, a[2] + (s * d[2]) / len}};
 }
+// The walk's shortcut (corridor_step): `n_safe` samples ahead of `curr` on the way to `next` are known to lie inside the kept
+// polyhedron the current sample is in, so they need neither a test nor — being equally spaced on a straight line — a step each:
+// the walk moves k samp along the segment in ONE step, k = the samples that fit before the segment's last one (the regular
+// loop handles the end of a segment itself). The position differs from k single steps by their accumulated rounding (~k ulp);
+// the shortcut's margin (three samples and kWalkTol of slack in every row) is orders of magnitude above that.
+CD_HD void walk_jump(V3& curr, const V3& next, double samp, int n_safe) {
+  const V3 df = {{next[0] - curr[0], next[1] - curr[1], next[2] - curr[2]}};
+  const double dn = sqrt((df[0] * df[0] + df[1] * df[1]) + df[2] * df[2]);
+  const double fit = (dn - samp) / samp;  // steps after which more than one sample of the segment is still ahead
+  int k = fit > 1e6 ? 1000000 : (fit > 0 ? (int)fit : 0);
+  if (k > n_safe) k = n_safe;
+  if (k > 0) curr = step_along(curr, k * samp, df, dn);
+}
 CD_HD double dot(const V3& a, const V3& b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 CD_HD double norm(const V3& a) { return sqrt(dot(a, a)); }
 
@@ -278,10 +291,18 @@ CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {
         }
         const double cap = t_exit / samp - 3.0;
         int n_safe = cap > 1e6 ? 1000000 : (cap > 0 ? (int)cap : 0);
+        if (!c.has_world) {
+          // free space: the skipped samples are not even generated one by one (walk_jump). Only where the polyhedra are the
+          // large boxes of an empty grid: next to obstacles a routed path slides along faces, the outcome of the first
+          // TESTED sample after the shortcut can hang on the last bit of the position, and the sample-by-sample form below
+          // keeps that bit what the reference's loop produces.
+          if (n_safe > 0) walk_jump(curr, next, samp, n_safe);
+          n_safe = 0;
+        }
         for (; n_safe > 0; --n_safe) {
           const V3 df = sub(next, curr);
           const double dn = norm(df);
-          if (!(dn > samp)) break;
+          if (!(dn > samp)) break;  // the end of the segment: the regular loop takes over
           curr = step_along(curr, samp, df, dn);
         }
       }

@@ -52,7 +52,7 @@ struct Swarm {
     c.voxel_size = cfg.voxel_size, c.grid_z_min = cfg.grid_z_min, c.thresh_dist = cfg.thresh_dist;
     for (int k = 0; k < 3; ++k) c.grid_range[k] = cfg.grid_range[k], c.wdim[k] = wdim[k], c.worigin[k] = worigin[k];
     c.world = has_world ? world.data() : nullptr;
-    c.fast_walk = 0;
+    c.fast_walk = 1;  // the same walk as the device loop (shortcut past samples provably inside a kept polyhedron); 0 = every sample generated and tested
     if (const char* e = std::getenv("HDSM_FAST_WALK_HOST"))  // test hook (scalar twin of the device shortcut): "0" or "1", anything else is ignored
       if ((e[0] == '0' || e[0] == '1') && e[1] == 0) c.fast_walk = e[0] == '1';
     return c;

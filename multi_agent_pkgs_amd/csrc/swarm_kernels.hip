@@ -123,13 +123,10 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       rv[h] = j < n_poly && r < ag.polys[j].rows;
       for (int q = 0; q < 3; ++q) ra[h][q] = rv[h] ? ag.polys[j].A[r][q] : 0.0;
       ra[h][3] = rv[h] ? ag.polys[j].b[r] : 0.0;
-      for (int jj = 0; jj < hdsm::MAXP; ++jj) {
-        unsigned long long m = 0;
-        for (int bit = 0; bit < 64; ++bit) {
-          const int l2 = bit + 64 * h;
-          if (l2 / RS == jj) m |= 1ull << bit;
-        }
-        pm[h][jj] = m;
+      for (int jj = 0; jj < hdsm::MAXP; ++jj) {  // bits of the rows [jj RS, (jj + 1) RS) that fall into this half's 64 rows
+        const int lo = jj * RS - 64 * h, hi = lo + RS;
+        const int a0 = lo < 0 ? 0 : lo, a1 = hi > 64 ? 64 : hi;
+        pm[h][jj] = a1 > a0 ? ((a1 - a0 == 64 ? ~0ull : ((1ull << (a1 - a0)) - 1ull)) << a0) : 0ull;
       }
     }
   };
@@ -180,6 +177,14 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
         for (int off = 32; off > 0; off >>= 1) t_exit = fmin(t_exit, __shfl_xor(t_exit, off));
         const double cap = t_exit / samp - 3.0;
         int n_safe = cap > 1e6 ? 1000000 : (cap > 0 ? (int)cap : 0);
+        if (!c.has_world) {
+          // free space: the skipped samples are not even generated one by one (walk_jump). Only where the polyhedra are the
+          // large boxes of an empty grid: next to obstacles a routed path slides along faces, the outcome of the first
+          // TESTED sample after the shortcut can hang on the last bit of the position, and the sample-by-sample form below
+          // keeps that bit what the reference's loop produces.
+          if (n_safe > 0) walk_jump(curr, next, samp, n_safe);
+          n_safe = 0;
+        }
         for (; n_safe > 0; --n_safe) {
           const V3 df = sub(next, curr);
           const double dn = norm(df);

@@ -141,3 +141,37 @@ def test_walk_shortcut_leaves_the_corridor_unchanged(oracle, monkeypatch):
     for r in range(rounds):
         for k in plain[r]:
             assert np.array_equal(plain[r][k], fast[r][k]), (r, k)
+
+
+def test_walk_jump_in_free_space_leaves_the_corridor_unchanged(oracle, monkeypatch):
+    """Empty world: the shortcut does not even generate the skipped samples one by one (swarm_core.h walk_jump: k samples along
+    the segment in one step). The position then differs from the sample-by-sample walk by accumulated rounding only, far
+    below the shortcut's margin: the boxes the corridor generator produces — seeds are voxel indices — must be identical.
+    (23 agents: no path is parallel to a grid axis. On an axis-parallel path that starts on the voxel lattice EVERY tenth
+    sample lies exactly on a voxel face, and which side it is counted on hangs on the last bit of the accumulated position in
+    any implementation, the reference's included; such a path is not a test of anything.)"""
+    from oracle import pyoracle as orc
+    n, rounds = 23, 60
+    prm = agile_params(10, max_rows_static=18)
+
+    def cpu(inp, plans, has):
+        return orc.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    def fly(mode):
+        monkeypatch.setenv("HDSM_FAST_WALK_HOST", mode)
+        loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), n, solve=cpu, radius=12.0)
+        out = []
+        for _ in range(rounds):
+            rec = []
+            loop.step(record=rec)
+            out.append({k: rec[0][k].copy() for k in ("n_poly", "n_rows", "A", "b")})
+        return out
+
+    plain, fast = fly("0"), fly("1")
+    new_boxes = 0
+    for r in range(rounds):
+        for k in plain[r]:
+            assert np.array_equal(plain[r][k], fast[r][k]), (r, k)
+        if r:
+            new_boxes += int((plain[r]["b"] != plain[r - 1]["b"]).any(axis=(1, 2)).sum())
+    assert new_boxes > n          # the corridors really moved on during the flight
