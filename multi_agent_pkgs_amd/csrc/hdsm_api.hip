@@ -45,14 +45,14 @@ constexpr int CMAX48 = 1024;  // n <= 48
 // the subtree "polyhedron b % sub_k at the root's branching step" of instance b / sub_k, if pass 1 handed that instance over.
 template <class Sol>
 __device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts& c, const hdsm::Args& a) {
+  int inst, out, sub = -1;  // (ONE call site below: the solver is a single inlined body of ~17 k instructions)
   if (a.sub_k > 0) {
-    const int inst = (int)blockIdx.x / a.sub_k, sub = (int)blockIdx.x % a.sub_k;
+    inst = (int)blockIdx.x / a.sub_k, sub = (int)blockIdx.x % a.sub_k, out = (int)blockIdx.x;
     if (a.split_info[2 * inst] == 0) return;  // (uniform: the whole workgroup leaves)
-    Sol::solve_instance(s, c, a, inst, (int)blockIdx.x, sub);
-    return;
+  } else {
+    inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, out = inst;
   }
-  const int inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-  Sol::solve_instance(s, c, a, inst, inst, -1);
+  Sol::solve_instance(s, c, a, inst, out, sub);
 }
 
 template <int NV, int CMAX, int NT>

@@ -111,8 +111,6 @@ struct WaveGIB : WaveGI<32, CMAX> {
   template <bool WANT_Z = true>
   static __device__ __forceinline__ void direction(S& s, const Regs& R, double ai, int q, int lane, double& dj, double& dz,
                                                    double& dd, double& zz, double& dq, double& zi, double& ri) {
-    D2 urow[NC / 2];
-    u_row_load(s, lane, urow);
     double p[NC];
     const double na = -ai;
 #pragma unroll
@@ -134,7 +132,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
       zi = half_sum64(z0 + z1);
     }
     wsync();
-    ri = u_row_dot(s, lane, urow);
+    ri = u_row_dot(s, lane);
   }
 
   // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q, applied with the complete
@@ -347,82 +345,6 @@ struct WaveGIB : WaveGI<32, CMAX> {
     }
   }
 
-  // The first 256 staged rows (four per lane) are requested BEFORE the state evaluation of an operation — they do not depend
-  // on it — so that the violation scan that follows it pays one LDS round trip (the positions), not two in a chain.
-  struct CandPref {
-    D2 r01[4], r23[4];
-    int mm[4];
-  };
-  static __device__ __forceinline__ void cand_prefetch(const S& s, int lane, CandPref& cp) {
-    const int nc = uni(s.ncand);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = 64 * u + lane, ii = idx < nc ? idx : 0;
-      cp.mm[u] = s.cand_m[ii];
-      cp.r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
-      cp.r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
-    }
-  }
-  // Base::select with the first trip of the staged-row scan taken from the prefetched registers
-  static __device__ __forceinline__ void select_pref(S& s, const Consts& c, const Regs& R, const CandPref& cp, int lane, double tol, int N,
-                                                     double& vbest, int& ibest) {
-    double v = tol;
-    int id = -1;
-    {
-      const double vu = R.xi - R.ub_own, vl = R.lb_own - R.xi;
-      if (vu > v) v = vu, id = mk_id(K_U, lane << 1);
-      if (vl > v) v = vl, id = mk_id(K_U, (lane << 1) | 1);
-    }
-    const double* stf = &s.st[0][0];
-    double sv[2], px[4], py[4], pz[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) sv[e] = stf[R.sb_off[e] >= 0 ? R.sb_off[e] : 0];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double* pm = s.st[cp.mm[u]];
-      px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      if (R.sb_off[e] >= 0) {
-        const double vu = sv[e] - R.sb_ub[e], vl = R.sb_lb[e] - sv[e];
-        if (vu > v) v = vu, id = mk_id(K_S, R.sb_id[e]);
-        if (vl > v) v = vl, id = mk_id(K_S, R.sb_id[e] | 1);
-      }
-    }
-    const int nc = uni(s.ncand);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double vv = cp.r01[u].x * px[u] + cp.r01[u].y * py[u] + cp.r23[u].x * pz[u] - cp.r23[u].y;
-      if (64 * u + lane < nc && vv > v) v = vv, id = mk_kc(64 * u + lane, cp.mm[u]);
-    }
-    if (uni(s.level) > 0) Base::scan_assigned(s, lane, N, v, id);  // rows of the polyhedra assigned on the current branch
-    const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
-    if (mw) {
-      if (lane == 0) s.cmd = 1;
-      __syncthreads();                             // helpers start on their share: rows [256 w, ...) stride 256 * waves
-      Base::scan_rows(s, 4 * (int)blockDim.x, nc, lane, v, id, 4 * (int)blockDim.x);
-    } else if (nc > 256) {
-      Base::scan_rows(s, 256, nc, lane, v, id);
-    }
-    double m = wave_max64(v);
-    int best = -1;
-    if (m > tol) {
-      const unsigned long long mask = __ballot(v == m && id >= 0);
-      best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
-    }
-    if (mw) {
-      __syncthreads();                             // partial results of waves 1..3 are in LDS
-#pragma unroll
-      for (int w = 1; w < (int)blockDim.x >> 6; ++w) {
-        const double pv = s.part_v[w];
-        if (pv > m) m = pv, best = s.part_id[w];
-      }
-    }
-    vbest = m;
-    ibest = (m > tol) ? best : -1;
-  }
-
   // Continues from the current (dual feasible) state until no row of the current node is violated.
   static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
     const int lane = (int)threadIdx.x;
@@ -436,8 +358,6 @@ struct WaveGIB : WaveGI<32, CMAX> {
     load_pos(s, R, lane);
     PROF_DECL
     for (;;) {
-      CandPref cp;
-      cand_prefetch(s, lane, cp);
       Base::states(s, R, lane, N);
       PROF(0)
       int ip;
@@ -446,7 +366,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
         ip = mk_id(K_E, neq);
         vip = Base::resid(s, c, ip, N);
       } else {
-        select_pref(s, c, R, cp, lane, tol, N, vip, ip);
+        Base::select(s, c, R, lane, tol, N, vip, ip);
         ip = uni(ip);
         if (ip < 0) {
           if (Base::promote_cold(s, lane, tol) > 0) continue;

@@ -8,6 +8,8 @@ bash scripts/gpu_profile_bench.sh $TAG > gpurun_out/$TAG/profile.log 2>&1; tail 
 run() { t=$1; shift; timeout 900 python bench.py --no-cpu-baseline "$@" > gpurun_out/$TAG/bench_$t.json 2> gpurun_out/$TAG/bench_$t.err; echo "$t rc=$?"; cut -c1-240 gpurun_out/$TAG/bench_$t.json; }
 run cfg2_circle64 --agents 64 --first-round 35 --steps 50 --warmup 10
 run cfg3_forest256 --scenario forest --agents 256 --first-round 60
+HDSM_SPLIT=0 run cfg3_forest256_unsplit --scenario forest --agents 256 --first-round 60 --no-event-pass
+HDSM_SPLIT=0 run cfg5_fwf4096_h15_unsplit --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2 --no-event-pass
 run cfg5_fwf4096_h15 --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2
 run circle4096_h15 --agents 4096 --horizon 15 --first-round 20 --steps 8 --warmup 2
 BENCH_ARGS="" bash scripts/gpu_prof_bench.sh > gpurun_out/$TAG/phases.log 2>&1; cp gpurun_out/prof_bench.log gpurun_out/$TAG/prof_bench.log; tail -3 gpurun_out/$TAG/phases.log | cut -c1-400
