@@ -286,24 +286,36 @@ struct Solver {
       SYNC();
     } else
 #endif
-    PAR_FOR(idx, N * np) {
-      const int i = idx / np, j = idx % np;
-      double vmax = -DINF;
-      if (s.assign[i] < 0) {
-        for (int r = 0; r < s.sp_rows[j]; ++r) {
-          const double* row = s.sp[j][r];
-          for (int e = 0; e < 2; ++e) {
-            const double* pm = s.st[i + e];
-            const double v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
+    {
+      // One item = (step i, polyhedron j, end point e, half of the rows): up to 4 N np items of a handful of rows each — the
+      // loop over all rows at both points used to sit in N np threads (2.2 us per leaf test). Partial maxima go through
+      // red_v (MAXT entries: with more than 4 polyhedra the rows are not halved).
+      const int K = (N * np * 4 <= MAXT) ? 4 : 2, halves = K / 2;
+      PAR_FOR(idx, N * np * K) {
+        const int t = idx % K, e = t & 1, rc = t >> 1, ij = idx / K, i = ij / np, j = ij % np;
+        double vmax = -DINF;
+        if (s.assign[i] < 0) {
+          const int rows = s.sp_rows[j], per = (rows + halves - 1) / halves, r0 = rc * per, r1 = r0 + per < rows ? r0 + per : rows;
+          const double* pm = s.st[i + e];
+          const double px = pm[0], py = pm[1], pz = pm[2];
+          for (int r = r0; r < r1; ++r) {
+            const double* row = s.sp[j][r];
+            const double v = row[0] * px + row[1] * py + row[2] * pz - row[3];
             if (i + e == 0) {
-              if (v > c.ftol_fixed) vmax = DINF;
+              if (v > c.ftol_fixed) vmax = DINF;  // rows on the pinned p_0 only gate the choice
             } else if (v > vmax) {
               vmax = v;
             }
           }
         }
+        s.red_v[idx] = vmax;
       }
-      s.keys[i][j] = vmax;
+      SYNC();
+      PAR_FOR(ij, N * np) {
+        double vmax = s.red_v[K * ij];
+        for (int t = 1; t < K; ++t) vmax = s.red_v[K * ij + t] > vmax ? s.red_v[K * ij + t] : vmax;
+        s.keys[ij / np][ij % np] = vmax;
+      }
     }
     SYNC();
     PAR_FOR(i, N) {  // one thread per step: lowest-index polyhedron containing the segment

@@ -256,28 +256,41 @@ struct WaveGIB : WaveGI<32, CMAX> {
     int q = uni(s.q);
     const int q_in = q;
     load_pos(s, R, lane);
+    {  // the neighbour rows of the guess go into the staging area in ONE step: every lane that holds one takes the next free slot
+      const unsigned long long want = __ballot(pre == -2);
+      if (want != 0ull) {
+        const int base = uni(s.ncand), room = CMAX - uni(s.ncold) - base;
+        const int rank = __popcll(want & ((1ull << lane) - 1ull));
+        if (pre == -2) {
+          if (rank < room) {
+            const int slot = base + rank;
+            s.cand[slot][0] = my_row[0], s.cand[slot][1] = my_row[1], s.cand[slot][2] = my_row[2], s.cand[slot][3] = my_row[3];
+            s.cand_m[slot] = my_m;
+            s.cand_src[slot] = my_src;
+            pre = mk_kc(slot, my_m);
+          } else {
+            pre = -1;
+          }
+        }
+        const int cnt = __popcll(want);
+        if (lane == 0) s.ncand = base + (cnt < room ? cnt : (room > 0 ? room : 0));
+        wsync();
+      }
+    }
     PROF(16)
     for (int g = 0; g < nw && q < n; ++g) {
-      int id = __builtin_amdgcn_readlane(pre, g);
-      if (id == -2) {
-        id = -1;
-        const int slot = uni(s.ncand);
-        if (slot < CMAX - uni(s.ncold)) {
-          const double r0 = bcast64(my_row[0], g), r1 = bcast64(my_row[1], g), r2 = bcast64(my_row[2], g), r3 = bcast64(my_row[3], g);
-          const int m = __builtin_amdgcn_readlane(my_m, g), src = __builtin_amdgcn_readlane(my_src, g);
-          if (lane == 0) {
-            s.cand[slot][0] = r0, s.cand[slot][1] = r1, s.cand[slot][2] = r2, s.cand[slot][3] = r3;
-            s.cand_m[slot] = m;
-            s.cand_src[slot] = src;
-            s.ncand = slot + 1;
-          }
-          wsync();
-          id = mk_kc(slot, m);
-        }
-      }
+      const int id = __builtin_amdgcn_readlane(pre, g);
       if (id < 0) continue;
       PROF(17)
-      const double ai = Base::normal_entry(s, R, id, Base::row_of(lane), N, n);
+      double ai;
+      if (id_kind(id) == K_C) {  // the row is in lane g's registers: its normal needs one LDS read (the impulse response), not two in a chain
+        const double nx = bcast64(my_row[0], g), ny = bcast64(my_row[1], g), nz = bcast64(my_row[2], g);
+        const int m = kc_m(id_payload(id)), var = Base::row_of(lane);
+        const double nax = R.ax == 0 ? nx : (R.ax == 1 ? ny : nz);
+        ai = (var < n && R.kk < m) ? nax * s.gz[R.ax][0][MAXH + m - 1 - R.kk] : 0.0;
+      } else {
+        ai = Base::normal_entry(s, R, id, Base::row_of(lane), N, n);
+      }
       PROF(18)
       double dj, dz, dd, zz, dq, zi, ri;
       direction<false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
