@@ -494,6 +494,8 @@ struct Handle {
   double *d_sub_traj = nullptr, *d_sub_ctrl = nullptr, *d_sub_obj = nullptr, *d_sub_scratch = nullptr;
   uint8_t* d_sub_used = nullptr;
   bool sub_ready = false;
+  void* h_out = nullptr;      // pinned staging of hdsm_replan's outputs (grow-only)
+  size_t h_out_cap = 0;
   double* d_bounds = nullptr; // [n_rob_max][4]
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
   double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
@@ -781,6 +783,7 @@ void free_all(Handle* h) {
   for (void* p : sub)
     if (p) (void)hipFree(p);
   if (h->h_tree_flag) (void)hipHostFree(h->h_tree_flag);
+  if (h->h_out) (void)hipHostFree(h->h_out);
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_rpos,  h->d_rsph,  h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
@@ -1005,22 +1008,40 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   HIP_TRY(hipMemcpyAsync(h->d_b, b_static, I * P * RS * 8, H2D, st));
   HIP_TRY(hipMemcpyAsync(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, H2D, st));
   HIP_TRY(hipMemcpyAsync(h->d_has, has_plan, (size_t)n_rob, H2D, st));
-  // outputs are "left untouched" for instances without a solution: seed the device copies with the
-  // caller's current contents
-  HIP_TRY(hipMemcpyAsync(h->d_traj, traj_out, I * (N + 1) * 9 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_ctrl, ctrl_out, I * N * 3 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_used, poly_used, I * P, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_obj, obj, I * 8, H2D, st));
   int rc = hdsm_replan_device(handle, n_inst, n_rob, h->d_agent, h->d_state, h->d_ref, h->d_npoly, h->d_nrows,
                               h->d_A, h->d_b, h->d_plans, h->d_has, h->d_traj, h->d_ctrl, h->d_used,
                               h->d_status, h->d_obj, st);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(traj_out, h->d_traj, I * (N + 1) * 9 * 8, D2H, st));
-  HIP_TRY(hipMemcpyAsync(ctrl_out, h->d_ctrl, I * N * 3 * 8, D2H, st));
-  HIP_TRY(hipMemcpyAsync(poly_used, h->d_used, I * P, D2H, st));
-  HIP_TRY(hipMemcpyAsync(status, h->d_status, I * 4, D2H, st));
-  HIP_TRY(hipMemcpyAsync(obj, h->d_obj, I * 8, D2H, st));
+  // Outputs are "left untouched" for instances without a solution. The caller's arrays are not uploaded to seed the device
+  // copies (a megabyte each way per 1024 agents): the results come back into a pinned staging block of the handle and only
+  // the instances that HAVE a solution are copied into the caller's arrays.
+  const size_t trj = (N + 1) * 9, ctl = N * 3;
+  const size_t need = I * (trj * 8 + ctl * 8 + 8 + 4 + P);
+  if (need > h->h_out_cap) {
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    h->h_out = nullptr, h->h_out_cap = 0;
+    HIP_TRY(hipHostMalloc(&h->h_out, need, hipHostMallocDefault));
+    h->h_out_cap = need;
+  }
+  double* o_traj = static_cast<double*>(h->h_out);
+  double* o_ctrl = o_traj + I * trj;
+  double* o_obj = o_ctrl + I * ctl;
+  int32_t* o_status = reinterpret_cast<int32_t*>(o_obj + I);
+  uint8_t* o_used = reinterpret_cast<uint8_t*>(o_status + I);
+  HIP_TRY(hipMemcpyAsync(o_traj, h->d_traj, I * trj * 8, D2H, st));
+  HIP_TRY(hipMemcpyAsync(o_ctrl, h->d_ctrl, I * ctl * 8, D2H, st));
+  HIP_TRY(hipMemcpyAsync(o_obj, h->d_obj, I * 8, D2H, st));
+  HIP_TRY(hipMemcpyAsync(o_status, h->d_status, I * 4, D2H, st));
+  HIP_TRY(hipMemcpyAsync(o_used, h->d_used, I * P, D2H, st));
   HIP_TRY(hipStreamSynchronize(st));
+  for (size_t k = 0; k < I; ++k) {
+    status[k] = o_status[k];
+    if (o_status[k] == HDSM_NO_SOLUTION) continue;
+    std::memcpy(traj_out + k * trj, o_traj + k * trj, trj * 8);
+    std::memcpy(ctrl_out + k * ctl, o_ctrl + k * ctl, ctl * 8);
+    std::memcpy(poly_used + k * P, o_used + k * P, P);
+    obj[k] = o_obj[k];
+  }
   return HDSM_OK;
 }
 
