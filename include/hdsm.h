@@ -97,8 +97,9 @@ typedef struct hdsm_params {
   int32_t threads_per_instance; /* 256 (default) or 64 threads per agent-replan                      HDSM_THREADS      */
   int32_t prefilter_min_agents; /* swarms of at least this many agents get the sphere prefilter
                                    (default 256; negative = never)                                  HDSM_BOUNDS_MIN   */
-  int32_t duo_min_instances;    /* batches of at least this many instances run two workgroups per CU
-                                   (default: compute units + 1; negative = never)                   HDSM_DUO_MIN      */
+  int32_t duo_min_instances;    /* batches of at least this many instances run several workgroups per CU: two from this
+                                   count on (default: compute units + 1; negative = never), and for n_hor <= 10 three
+                                   128-thread ones from 2 x compute units + 1 on (HDSM_TRI_MIN)     HDSM_DUO_MIN      */
   int32_t presweep;             /* neighbour rows staged before the first active-set run: 0 automatic,
                                    1 never, 2 always                                                HDSM_PRESWEEP     */
   int32_t branch_rule;          /* branch on: 0 the most infeasible segment (default), 1 the first in time HDSM_BRANCH_RULE */
@@ -106,6 +107,10 @@ typedef struct hdsm_params {
                                    the previous launch (needs warm_start; default 2 x compute units + 1; negative = never)
                                                                                                     HDSM_ORDER_MIN    */
   double stage_radius;          /* [m] slack below which a neighbour row is staged (default 0.6)     HDSM_CAND_TAU     */
+  /* (Environment only, for A/B scripts: HDSM_SPLIT 0 / 1 / 2 = never / always / automatically (default) run a launch whose
+   * predecessor met a deep branch-and-bound tree as three kernels — budgeted solve, one workgroup per polyhedron of the root's
+   * branching step for the instances that exceeded the budget, merge; HDSM_SPLIT_BUDGET = that budget in nodes. The answers
+   * do not depend on it; max_nodes stays the budget of an INSTANCE, shared by its sub-searches.)                  */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and
    * returns the incumbent (HDSM_LIMIT) or HDSM_NO_SOLUTION — what Gurobi does, and just as irreproducible. 0 = none
