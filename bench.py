@@ -49,7 +49,7 @@ def kernel_source_sha16():
     """Identity of the solver kernel's sources: a committed PMC summary is quoted only for the sources it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("hdsm_core.h", "hdsm_wave_gi.h", "hdsm_api.hip", "hdsm_types.h"):
+    for f in ("hdsm_core.h", "hdsm_wave_gi.h", "hdsm_wave_gib.h", "hdsm_api.hip", "hdsm_types.h"):
         h.update(open(os.path.join(ROOT, "multi_agent_pkgs_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <fstream>
 #include <new>
+#include <numeric>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -24,22 +25,26 @@ struct Stats {
 
 const char* kNames[6] = {"comp_time_sc_", "comp_time_tasc_", "comp_time_opt_", "comp_time_tot_", "comp_time_tot_wall_", "comp_time_path_"};
 
-// SaveAndDisplayCompTime, AC:1943-1971
+// The three figures the reference prints per timing series (SaveAndDisplayCompTime, AC:1943-1971): its running max starts at 0 and its
+// running min at 1e10, which shows in the printout of an empty or an all-negative series, so the same clamps are applied here.
+struct Summary {
+  double mean, hi, lo;
+  explicit Summary(const std::vector<double>& v)
+      : mean(std::accumulate(v.begin(), v.end(), 0.0) / v.size()),
+        hi(v.empty() ? 0.0 : std::max(0.0, *std::max_element(v.begin(), v.end()))),
+        lo(v.empty() ? 1e10 : std::min(1e10, *std::min_element(v.begin(), v.end()))) {}
+};
+
+void write_csv_row(const std::vector<double>& v, const std::string& path) {
+  std::ofstream f(path);
+  f << std::fixed;
+  for (double x : v) f << x << ",";
+}
+
 void comp_time(const std::vector<double>& v, const std::string& dir, const std::string& filename, bool save, std::ostream& out) {
-  if (save) {
-    std::ofstream f(dir + filename);
-    for (double x : v) f << std::fixed << x << ",";
-  }
-  out << filename << ": ";
-  double max_t = 0, min_t = 1e10, sum_t = 0;
-  for (double x : v) {
-    if (x > max_t) max_t = x;
-    if (x < min_t) min_t = x;
-    sum_t += x;
-  }
-  out << std::endl << "mean: " << sum_t / v.size();
-  out << std::endl << "max: " << max_t;
-  out << std::endl << "min: " << min_t << std::endl;
+  if (save) write_csv_row(v, dir + filename);
+  const Summary m(v);
+  out << filename << ": \nmean: " << m.mean << "\nmax: " << m.hi << "\nmin: " << m.lo << std::endl;
 }
 
 }  // namespace
