@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--time-limit-s", type=float, default=0.0, help="hdsm_params.time_limit_s (0 = none; AC:952 sets 0.08)")
     ap.add_argument("--device-loop-multi", action="store_true", help="run the device-resident-loop pass with --gpus > 1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold-start", action="store_true", help="development: hdsm_params.warm_start = 0 (every replan starts from the "
+                    "unconstrained optimum; the default line carries the working sets over)")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the HIP-event pass and the host-buffer pass")
     ap.add_argument("--host-reference", action="store_true", help="generate the reference trajectories of the set-up "
                     "flight on the host (csrc/swarm_host.cpp) instead of with the f1 device kernel (hdsm_reference)")
@@ -127,7 +129,7 @@ def main():
     from multi_agent_pkgs_amd.params import agile_params, agile_ref_config
 
     N = args.horizon
-    prm = agile_params(N, max_rows_static=18, mip_gap=args.mip_gap, time_limit_s=args.time_limit_s)
+    prm = agile_params(N, max_rows_static=18, mip_gap=args.mip_gap, time_limit_s=args.time_limit_s, warm_start=not args.cold_start)
     P, RS = prm.poly_hor, prm.max_rows_static
     n_rob = args.agents
     radius = args.radius if args.radius > 0 else max(22.0, n_rob / (2 * np.pi))

@@ -91,6 +91,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->hot_tau = 1e30;  // [m] staged rows closer than this are scanned every iteration ("hot"); the rest only at
                       // convergence. Measured on MI355X: any finite radius costs more iterations than it saves.
   env_real("HDSM_HOT_TAU", 1e-3, 1e30, &c->hot_tau);
+  c->pick_rule = 1;
+  env_int("HDSM_PICK_RULE", 0, 1, &c->pick_rule);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);
@@ -258,6 +260,30 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
         const int row = split ? (lane & 31) : lane, col = split ? ((j ^ lane) & 15) + 16 * (lane >> 5) : j;
         c->JeqP[(size_t)j * 64 + lane] = (row < n && col < n) ? c->Jeq[(size_t)row * n + col] : (row == col ? 1.0 : 0.0);
       }
+    {  // pick-rule weights: Z = J2 J2^T (the inverse Hessian on the null space of the terminal equalities), a^T Z a per row family
+      std::vector<double> Z((size_t)n * n, 0.0);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          double sacc = 0;
+          for (int k = 6; k < n; ++k) sacc += c->Jeq[(size_t)i * n + k] * c->Jeq[(size_t)j * n + k];
+          Z[(size_t)i * n + j] = sacc;
+        }
+      auto quad = [&](int ax, int comp, int m) {  // a = impulse response of component comp of axis ax at step m
+        double sacc = 0;
+        for (int k = 0; k < m; ++k)
+          for (int l = 0; l < m; ++l) sacc += c->g[ax][comp][m - 1 - k] * Z[(size_t)(ax * N + k) * n + ax * N + l] * c->g[ax][comp][m - 1 - l];
+        return sacc;
+      };
+      for (int k = 0; k < MAXNV; ++k) c->wu[k] = (k < n && Z[(size_t)k * n + k] > 1e-300) ? 1.0 / std::sqrt(Z[(size_t)k * n + k]) : 1.0;
+      for (int ax = 0; ax < 3; ++ax)
+        for (int comp = 0; comp < 3; ++comp)
+          for (int m = 0; m <= MAXH; ++m) {
+            const double dd = (m >= 1 && m <= N) ? quad(ax, comp, m) : 0.0;
+            c->ws[ax][comp][m] = dd > 1e-300 ? 1.0 / std::sqrt(dd) : 1.0;
+          }
+      for (int m = 0; m <= MAXH; ++m)
+        for (int ax = 0; ax < 3; ++ax) c->kap[m][ax] = (m >= 1 && m <= N) ? quad(ax, 0, m) : 0.0;
+    }
     // Set-up map: free response -> gradient at u = 0 -> x0 = -H^{-1} grad -> equality residual -> x_eq, nu, applied
     // to the unit vectors of v = (state_curr, traj_ref). The tracking cost pairs x_i with ref_{i-1} (AC:870-883).
     const int nv = 9 + 6 * N;

@@ -61,6 +61,17 @@ constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered s
 
 // ---------------------------------------------------------------------------------------------------------
 // All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
+// step m of a staged row and the weight 1 / sqrt(a^T Z a) of its normal (Consts::pick_rule; single precision: it only orders picks)
+struct alignas(8) MW {
+  int32_t m;
+  float w;
+};
+HD MW mk_mw(const double (*kap)[4], double nx, double ny, double nz, int m) {
+  const double q = nx * nx * kap[m][0] + ny * ny * kap[m][1] + nz * nz * kap[m][2];
+  // (a row on a pinned position cannot be moved at all: if it is violated it goes first and ends the instance)
+  return MW{m, q > 1e-60 ? (float)(1.0 / sqrt(q)) : 1e30f};
+}
+
 template <int NV, int CMAX>
 struct Shm {
   static_assert(CMAX <= 4096, "the slot of a staged row must fit the 12 bits kc_slot() reads");
@@ -76,8 +87,10 @@ struct Shm {
   int32_t inc_act[NV], inc_nact;        // working set of the incumbent (portable ids) -> next replan's guess
   int32_t st_sph, st_pairs;             // sweep counters: sphere records read, (neighbour, step) positions loaded
   long long t_start;                    // constant-rate clock at the start of the instance (time_limit_s)
+#ifdef HDSM_PROFILE
   long long prof_acc[24];  // 0..7 iteration phases, 8..15 sweeps / set-up, 16..23 inside the warm start
   long long prof_last;
+#endif
   double x[NV], lam[NV], w[NV], grad[NV];
   double inc_x[NV];
   double g[3][3][MAXH];
@@ -92,7 +105,7 @@ struct Shm {
   double br_f[MAXH];
   double state0[9];
   double f, inc_f, f0;
-  int32_t cand_m[CMAX];
+  MW cand_mw[CMAX];      // step of each staged row + its pick-rule weight (one 8-byte read in the scan)
   int32_t act[NV];
   int32_t sp_rows[MAXP];
   int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
@@ -116,9 +129,16 @@ struct Shm {
   double sw_tau;               // had slack >= sw_tau there, so it cannot be violated while |p - sw_ref| |n_f| <= sw_tau
   double sw_d2;                // max_m |st[m] - sw_ref[m]|^2 (scratch of the displacement test)
   double bnd[24];        // device build: lbu[3], ubu[3], lbs[3][3], ubs[3][3] (read by resid() inside the iteration)
-  double vin[KCOLS + 8];  // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded
-  double part_v[4];      // per-wave partial maxima of the staged-row scan
+  // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded. It lives in red_v[16 ...): the set-up itself
+  // uses red_v[0..5] (residuals of the terminal equalities), the leaf test comes later
+  static_assert(MAXT >= 16 + KCOLS + 8, "the reduction scratch doubles as the set-up's input vector");
+  HD double* vin() { return &red_v[16]; }
+  double part_v[4];      // per-wave partial results of the staged-row scan: violation, key and id of the wave's pick
+  double part_key[4];
+  double part_tol;       // ... and what wave 0 tells the helpers: the tolerance and the pick rule of this scan
   int32_t part_id[4];
+  int32_t part_norm;
+  double kap[MAXH + 1][4];  // Consts::kap (pick-rule factors of the position rows)
   Args args;  // launch arguments, copied once so that the kernarg SGPRs are dead after the prologue
 };
 
@@ -225,7 +245,7 @@ struct Solver {
           if (fits && slot >= 0 && slot < CMAX) {
             s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
             s.cand[slot][3] = row[3];
-            s.cand_m[slot] = m;
+            s.cand_mw[slot] = mk_mw(s.kap, row[0], row[1], row[2], m);
             s.cand_src[slot] = explicit_rows ? -1 : (((idx / N) << 6) | (i << 1) | e);
           } else {
             s.overflow = 1;
@@ -524,7 +544,7 @@ struct Solver {
       // while all the others are already in flight; the kernel arguments are used straight from the SGPRs here.
       const Args& g = a_in;
       struct Req {
-        double v_in, v_g, a0, a1, a2, a3, p0, p1, p2, q0, q1, q2, v_u, v_b;
+        double v_in, v_g, a0, a1, a2, a3, p0, p1, p2, q0, q1, q2, v_u, v_b, v_k;
         int nr, sj, sr, fi, fcomp, fax;
       };
       auto request = [&](int vt) {
@@ -543,10 +563,11 @@ struct Solver {
         r.v_u = (ui < 6 && uj < 6) ? c.Ueq[ui * 6 + uj] : 0.0;
         r.v_b = (vt < 3) ? c.lbu[vt] : (vt < 6) ? c.ubu[vt - 3] : (vt < 15) ? (&c.lbs[0][0])[vt - 6]
                                                                 : (&c.ubs[0][0])[vt < 24 ? vt - 15 : 0];
+        r.v_k = (&c.kap[0][0])[vt < 4 * (MAXH + 1) ? vt : 0];
         return r;
       };
       auto commit = [&](int vt, const Req& r) {
-        if (vt < KCOLS + 8) s.vin[vt] = r.v_in;  // zero beyond 9 + 6N: padded coefficients (N < NV / 3) meet finite numbers
+        if (vt < KCOLS + 8) s.vin()[vt] = r.v_in;  // zero beyond 9 + 6N: padded coefficients (N < NV / 3) meet finite numbers
         if (vt < nvt) {
           if (vt < 9) s.state0[vt] = r.v_in;
           else (&s.ref[0][0])[vt - 9] = r.v_in;
@@ -571,6 +592,7 @@ struct Solver {
         }
         if (vt < MAXH) s.assign[vt] = -1;
         if (vt < 24) s.bnd[vt] = r.v_b;
+        if (vt < 4 * (MAXH + 1)) (&s.kap[0][0])[vt] = r.v_k;
       };
       ST_PROF(8)
       const Req r0 = request(tid);
@@ -602,6 +624,7 @@ struct Solver {
       SU_PROF(13)
       // the set-up map: x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at
       // u = 0, the residual of the six terminal equalities at x0 and their multipliers
+      const double* vin = s.vin();
       auto store = [&](int row, double acc) {
         if (row < n) s.x[row] = acc;
         else if (row < 2 * n) s.w[row - n] = acc;
@@ -612,13 +635,13 @@ struct Solver {
       if (tid < ((nk + 63) & ~63)) {
         double acc = 0;
         HDSM_UNROLL
-        for (int u = 0; u < KH; ++u) acc += kv[u] * s.vin[kbase + 3 * u];
+        for (int u = 0; u < KH; ++u) acc += kv[u] * vin[kbase + 3 * u];
         if (k_on) store(tid, acc);
       }
       for (int row = tid + nt; row < nk; row += nt) {  // 64-thread launches
         const int base = c.kax[row];
         double acc = 0;
-        for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * s.vin[base + 3 * u];
+        for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * vin[base + 3 * u];
         store(row, acc);
       }
       if constexpr (NV > 32) {

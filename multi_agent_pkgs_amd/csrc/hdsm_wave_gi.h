@@ -151,6 +151,7 @@ struct WaveGI {
     double sb_ub[2], sb_lb[2];  // boxes of the (up to two) state-bound items scanned by this lane
     int sb_off[2], sb_id[2];    // their offset in st[][] (as a flat index) and id base; -1 = no item
     int ax, kk;                 // variable row_of(lane) = jerk of axis ax at step kk (runtime divisions done once)
+    float wu, sb_w[2];          // pick-rule weights of this lane's input box and state-bound items
   };
 
   static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane) {
@@ -170,6 +171,7 @@ struct WaveGI {
     R.ax = row_of(lane) / N, R.kk = row_of(lane) % N;
     R.ub_own = (lane < n && fabs(ubu) < ABSENT) ? ubu : DINF;
     R.lb_own = (lane < n && fabs(lbu) < ABSENT) ? lbu : -DINF;
+    R.wu = (float)c.wu[lane < n ? lane : 0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool on = lane + 64 * e < n_sb;
@@ -177,6 +179,7 @@ struct WaveGI {
       R.sb_id[e] = on ? ((ii[e] << 5) | (comp[e] << 3) | (axs[e] << 1)) : 0;
       R.sb_ub[e] = (on && fabs(ubs[e]) < ABSENT) ? ubs[e] : DINF;
       R.sb_lb[e] = (on && fabs(lbs[e]) < ABSENT) ? lbs[e] : -DINF;
+      R.sb_w[e] = (float)c.ws[axs[e]][comp[e]][on ? ii[e] : 0];
     }
   }
 
@@ -240,30 +243,42 @@ struct WaveGI {
     wsync();
   }
 
-  // violation of staged rows [lo, hi) -> running (v, id); four rows per trip, loads issued before first use
-  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double& v, int& id,
+  // The rule that picks the next row (Consts::pick_rule): every violated row (violation above `tol`) competes with the key
+  // violation * weight, weight = 1 / sqrt(a^T Z a) of its normal (1 with pick_rule 0). (key, v, id) = the running best of a lane.
+  struct Pick {
+    double key, v;
+    int id;
+  };
+  static __device__ __forceinline__ double plane_weight(const S& s, double nx, double ny, double nz, int m) {
+    return (double)mk_mw(s.kap, nx, ny, nz, m).w;
+  }
+
+  // violation of staged rows [lo, hi) -> running pick; four rows per trip, loads issued before first use
+  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double tol, bool norm, Pick& pk,
                                                    int stride = 256) {
     for (int base = lo; base < hi; base += stride) {
-      int idx[4], mm[4];
+      int idx[4];
+      MW mw[4];
       D2 r01[4], r23[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         idx[u] = base + 64 * u + lane;
         const int ii = idx[u] < hi ? idx[u] : lo;
-        mm[u] = s.cand_m[ii];
+        mw[u] = s.cand_mw[ii];
         r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
         r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
       }
       double px[4], py[4], pz[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double* pm = s.st[mm[u]];
+        const double* pm = s.st[mw[u].m];
         px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
-        if (idx[u] < hi && vv > v) v = vv, id = mk_kc(idx[u], mm[u]);
+        const double key = norm ? vv * (double)mw[u].w : vv;
+        if (idx[u] < hi && vv > tol && key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_kc(idx[u], mw[u].m);
       }
     }
   }
@@ -272,7 +287,7 @@ struct WaveGI {
   // assigned step per trip. The assignment and the row counts are fetched ONCE (lane i holds assign[i], lane j the row count
   // of polyhedron j) and handed round with v_readlane, so a trip is one LDS round trip — row and point together — instead
   // of the three in a chain (assign[i] -> sp_rows[j] -> row) the step-by-step loop paid in every node of a tree.
-  static __device__ __forceinline__ void scan_assigned(const S& s, int lane, int N, double& v, int& id) {
+  static __device__ __forceinline__ void scan_assigned(const S& s, int lane, int N, double tol, bool norm, Pick& pk) {
     const int aj = lane < N ? s.assign[lane] : -1;
     const int nr = lane < MAXP ? s.sp_rows[lane] : 0;
     unsigned long long am = __ballot(aj >= 0);
@@ -286,57 +301,64 @@ struct WaveGI {
         const double* row = s.sp[j][r];
         const double* pm = s.st[i + e];
         const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-        if (vv > v) v = vv, id = mk_id(K_P, (i << 7) | (e << 6) | r);
+        if (vv > tol) {
+          const double key = norm ? vv * plane_weight(s, row[0], row[1], row[2], i + e) : vv;
+          if (key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_id(K_P, (i << 7) | (e << 6) | r);
+        }
       }
     }
   }
 
-  // most violated row among: input / state boxes, rows of assigned polyhedra, HOT staged rows
+  // the row that enters next among: input / state boxes, rows of assigned polyhedra, HOT staged rows (-1: nothing is violated)
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
                                                 double& vbest, int& ibest) {
-    double v = tol;
-    int id = -1;
-    {
-      const double vu = R.xi - R.ub_own, vl = R.lb_own - R.xi;
-      if (vu > v) v = vu, id = mk_id(K_U, lane << 1);
-      if (vl > v) v = vl, id = mk_id(K_U, (lane << 1) | 1);
-    }
+    const bool norm = c.pick_rule != 0;
+    Pick pk{0.0, 0.0, -1};
+    auto offer = [&](double vv, float w, int id) {
+      if (vv > tol) {
+        const double key = norm ? vv * (double)w : vv;
+        if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
+      }
+    };
+    offer(R.xi - R.ub_own, R.wu, mk_id(K_U, lane << 1));
+    offer(R.lb_own - R.xi, R.wu, mk_id(K_U, (lane << 1) | 1));
     const double* stf = &s.st[0][0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (R.sb_off[e] >= 0) {
         const double sv = stf[R.sb_off[e]];
-        const double vu = sv - R.sb_ub[e], vl = R.sb_lb[e] - sv;
-        if (vu > v) v = vu, id = mk_id(K_S, R.sb_id[e]);
-        if (vl > v) v = vl, id = mk_id(K_S, R.sb_id[e] | 1);
+        offer(sv - R.sb_ub[e], R.sb_w[e], mk_id(K_S, R.sb_id[e]));
+        offer(R.sb_lb[e] - sv, R.sb_w[e], mk_id(K_S, R.sb_id[e] | 1));
       }
     }
-    if (uni(s.level) > 0) scan_assigned(s, lane, N, v, id);  // rows of the polyhedra assigned on the current branch
+    if (uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
     const int nc = uni(s.ncand);
     const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
-      if (lane == 0) s.cmd = 1;
+      if (lane == 0) s.cmd = 1, s.part_tol = tol, s.part_norm = norm ? 1 : 0;
       __syncthreads();                             // helpers start on their share: rows [256 w, ...) stride 256 * waves
-      scan_rows(s, 0, nc, lane, v, id, 4 * (int)blockDim.x);
+      scan_rows(s, 0, nc, lane, tol, norm, pk, 4 * (int)blockDim.x);
     } else {
-      scan_rows(s, 0, nc, lane, v, id);
+      scan_rows(s, 0, nc, lane, tol, norm, pk);
     }
-    double m = wave_max64(v);
+    double m = wave_max64(pk.key);
+    double mv = 0.0;
     int best = -1;
-    if (m > tol) {
-      const unsigned long long mask = __ballot(v == m && id >= 0);
-      best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+    if (m > 0.0) {
+      const int src = __ffsll((long long)__ballot(pk.key == m && pk.id >= 0)) - 1;
+      best = __builtin_amdgcn_readlane(pk.id, src);
+      mv = bcast64(pk.v, src);
     }
     if (mw) {
       __syncthreads();                             // partial results of waves 1..3 are in LDS
 #pragma unroll
       for (int w = 1; w < (int)blockDim.x >> 6; ++w) {
-        const double pv = s.part_v[w];
-        if (pv > m) m = pv, best = s.part_id[w];
+        const double pkey = s.part_key[w];
+        if (pkey > m) m = pkey, mv = s.part_v[w], best = s.part_id[w];
       }
     }
-    vbest = m;
-    ibest = (m > tol) ? best : -1;
+    vbest = mv;
+    ibest = (m > 0.0) ? best : -1;
   }
 
   // The other waves of the workgroup while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
@@ -345,16 +367,17 @@ struct WaveGI {
     for (;;) {
       __syncthreads();
       if (uni(s.cmd) == 0) return;
-      double v = -DINF;
-      int id = -1;
-      scan_rows(s, 256 * w, uni(s.ncand), lane, v, id, 4 * (int)blockDim.x);
-      const double m = wave_max64(v);
+      Pick pk{0.0, 0.0, -1};
+      scan_rows(s, 256 * w, uni(s.ncand), lane, s.part_tol, s.part_norm != 0, pk, 4 * (int)blockDim.x);
+      const double m = wave_max64(pk.key);
       int best = -1;
-      if (m > -DINF) {
-        const unsigned long long mask = __ballot(v == m && id >= 0);
-        best = __builtin_amdgcn_readlane(id, __ffsll((long long)mask) - 1);
+      double mv = 0.0;
+      if (m > 0.0) {
+        const int src = __ffsll((long long)__ballot(pk.key == m && pk.id >= 0)) - 1;
+        best = __builtin_amdgcn_readlane(pk.id, src);
+        mv = bcast64(pk.v, src);
       }
-      if (lane == 0) s.part_v[w] = m, s.part_id[w] = best;
+      if (lane == 0) s.part_key[w] = m, s.part_v[w] = mv, s.part_id[w] = best;
       __syncthreads();
     }
   }
@@ -367,13 +390,13 @@ struct WaveGI {
     const int before = uni(s.ncand);
     for (int idx = CMAX - ncold + lane; idx < CMAX; idx += 64) {
       const double* row = s.cand[idx];
-      const double* pm = s.st[s.cand_m[idx]];
+      const double* pm = s.st[s.cand_mw[idx].m];
       const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
       if (vv > tol) {
         const int slot = atomicAdd(&s.ncand, 1);
         if (slot < CMAX - ncold) {
           s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2], s.cand[slot][3] = row[3];
-          s.cand_m[slot] = s.cand_m[idx];
+          s.cand_mw[slot] = s.cand_mw[idx];
           s.cand[idx][3] = DINF;  // neutralise the cold copy: it can never be violated again
         } else {
           s.overflow = 1;
@@ -666,7 +689,7 @@ struct WaveGI {
               const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
               if (fits && slot >= 0 && slot < CMAX) {
                 s.cand[slot][0] = fx, s.cand[slot][1] = fy, s.cand[slot][2] = fz, s.cand[slot][3] = rhs;
-                s.cand_m[slot] = m;
+                s.cand_mw[slot] = mk_mw(s.kap, fx, fy, fz, m);
                 s.cand_src[slot] = (k << 6) | (i << 1) | e;
               } else {
                 s.overflow = 1;
@@ -744,7 +767,7 @@ struct WaveGI {
           const int m = __builtin_amdgcn_readlane(my_m, g), src = __builtin_amdgcn_readlane(my_src, g);
           if (lane == 0) {
             s.cand[slot][0] = r0, s.cand[slot][1] = r1, s.cand[slot][2] = r2, s.cand[slot][3] = r3;
-            s.cand_m[slot] = m;
+            s.cand_mw[slot] = mk_mw(s.kap, r0, r1, r2, m);
             s.cand_src[slot] = src;
             s.ncand = slot + 1;
           }

@@ -257,7 +257,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
           if (rank < room) {
             const int slot = base + rank;
             s.cand[slot][0] = my_row[0], s.cand[slot][1] = my_row[1], s.cand[slot][2] = my_row[2], s.cand[slot][3] = my_row[3];
-            s.cand_m[slot] = my_m;
+            s.cand_mw[slot] = mk_mw(s.kap, my_row[0], my_row[1], my_row[2], my_m);
             s.cand_src[slot] = my_src;
             pre = mk_kc(slot, my_m);
           } else {
@@ -381,6 +381,13 @@ struct WaveGIB : WaveGI<32, CMAX> {
         PROF(1)
       }
       const bool is_eq = id_kind(ip) == K_E;
+#ifdef HDSM_TRACE_GI
+      if (lane == 0) {
+        const int kd = id_kind(ip), pl = id_payload(ip);
+        if (kd == K_C) printf("  pick C m=%d src(k=%d,i=%d,e=%d) v=%.3e q=%d f=%.6g\n", kc_m(pl), s.cand_src[kc_slot(pl)] >> 6, (s.cand_src[kc_slot(pl)] >> 1) & 31, s.cand_src[kc_slot(pl)] & 1, vip, q, f);
+        else printf("  pick kind=%d payload=%d v=%.3e q=%d f=%.6g\n", kd, pl, vip, q, f);
+      }
+#endif
       const double ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
       double lam_p = 0;
       bool stop = false;
@@ -413,6 +420,9 @@ struct WaveGIB : WaveGI<32, CMAX> {
           }
         }
         PROF(4)
+#ifdef HDSM_TRACE_GI
+        if (lane == 0) printf("    step dep=%d t1=%.3e t2=%.3e l=%d zz=%.3e dd=%.3e\n", (int)dependent, t1, dependent ? 0.0 : vip / zz, l, zz, dd);
+#endif
         if (dependent && l < 0) {
           rc = GI_INFEASIBLE;
           if (lane == 0) s.inf_id = ip;  // the row that cannot be satisfied together with the current working set
