@@ -120,6 +120,7 @@ struct Shm {
   double inc_shared;   // split launches: best objective found by ANY sub-block of this instance (DINF: none / ordinary launch)
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
+  int32_t leaf_pick;  // result of the one-wavefront leaf test
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
@@ -306,6 +307,61 @@ struct Solver {
       SYNC();
     } else
 #endif
+    if (N * np <= 64) {
+      // The usual shape (N np <= 64): ONE wavefront, lane = (step i, polyhedron j), both end points of the segment against every
+      // row of j, then the containing polyhedron per step from a ballot and the step to branch on from one wave reduction — no
+      // workgroup barrier inside (the version below spends four, and two runtime divisions per item: 2.7 us per leaf test on
+      // the bench rounds against 0.4 us for this one). The other wavefronts wait at the barrier that publishes the result.
+      if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        const bool on = lane < N * np;
+        // (N np <= 64: the quotient by a small runtime np is exact in single precision)
+        const int i = on ? (int)(((float)lane + 0.5f) * (1.0f / (float)np)) : 0, j = on ? lane - i * np : 0;
+        const int ai = s.assign[i];
+        double vmax = -DINF;
+        if (on && ai < 0) {
+          const int rows = s.sp_rows[j];
+          const double* p0 = s.st[i];
+          const double* p1 = s.st[i + 1];
+          const double ax_ = p0[0], ay_ = p0[1], az_ = p0[2], bx_ = p1[0], by_ = p1[1], bz_ = p1[2];
+          double v0max = -DINF, v1max = -DINF;
+          for (int r = 0; r < rows; ++r) {
+            const double* row = s.sp[j][r];
+            const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            const double v0 = r0 * ax_ + r1 * ay_ + r2 * az_ - r3, v1 = r0 * bx_ + r1 * by_ + r2 * bz_ - r3;
+            v0max = v0 > v0max ? v0 : v0max, v1max = v1 > v1max ? v1 : v1max;
+          }
+          if (i == 0) vmax = (v0max > c.ftol_fixed) ? DINF : v1max;  // rows on the pinned p_0 only gate the choice
+          else vmax = v0max > v1max ? v0max : v1max;
+        }
+        if (on) s.keys[i][j] = vmax;
+        const unsigned long long inside = __ballot(on && vmax <= c.tol);
+        // lane i < N: its step
+        const int my_a = lane < N ? s.assign[lane] : 0;
+        const unsigned fits = lane < N ? (unsigned)((inside >> (lane * np)) & ((1ull << np) - 1ull)) : 1u;
+        const int cont = (lane < N) ? (my_a >= 0 ? my_a : (fits != 0u ? __ffsll((long long)fits) - 1 : -1)) : 0;
+        if (lane < N) s.contain[lane] = cont;
+        wsync();
+        double best = -DINF;  // smallest violation among the polyhedra of an uncontained step (-DINF: contained / no step)
+        if (lane < N && cont < 0) {
+          best = DINF;
+          for (int jj = 0; jj < np; ++jj) best = s.keys[lane][jj] < best ? s.keys[lane][jj] : best;
+        }
+        const unsigned long long open = __ballot(lane < N && cont < 0);
+        int pick = -1;
+        if (open != 0ull) {
+          if (c.branch_rule == 0) {
+            pick = __ffsll((long long)open) - 1;  // the first in time
+          } else {
+            const double worst = wave_max64(best);  // the most infeasible one; ties: the earlier step
+            pick = __ffsll((long long)__ballot(lane < N && cont < 0 && best == worst)) - 1;
+          }
+        }
+        if (lane == 0) s.leaf_pick = pick;
+      }
+      SYNC();
+      return s.leaf_pick;
+    }
     {
       // One item = (step i, polyhedron j, end point e, half of the rows): up to 4 N np items of a handful of rows each — the
       // loop over all rows at both points used to sit in N np threads (2.2 us per leaf test). Partial maxima go through
