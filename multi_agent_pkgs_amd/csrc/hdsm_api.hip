@@ -486,6 +486,7 @@ struct Handle {
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
+  int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
   int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 16 nodes for batches that leave CUs idle, 96 beyond
   int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
   int32_t* d_tree_flag = nullptr;
@@ -625,8 +626,8 @@ __global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long lo
 
 // One wavefront per instance that pass 1 handed over: the best answer of its sub-blocks becomes the instance's answer. `a` holds
 // the instance-indexed arrays of the launch, `b` the arrays of pass 2 (index instance * K + subtree).
-__global__ __launch_bounds__(64) void k_split_merge(int N, int K, hdsm::Args a, hdsm::Args b) {
-  hdsm::split_merge(N, K, a, b, (int)blockIdx.x, (int)threadIdx.x, 64);
+__global__ __launch_bounds__(64) void k_split_merge(int N, int P, int K, hdsm::Args a, hdsm::Args b) {
+  hdsm::split_merge(N, P, K, a, b, (int)blockIdx.x, (int)threadIdx.x, 64);
 }
 
 hipError_t ensure_sub(Handle* h);
@@ -699,7 +700,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   if (!split) {
     rc = solve(a, a.n_inst);
   } else {
-    const int K = h->P, G = a.n_inst * K, I = h->max_inst;
+    const int K = h->sub_k, G = a.n_inst * K, I = h->max_inst;
     a.split_budget = budget, a.split_info = h->d_split, a.tree_mark = 0;
     rc = solve(a, a.n_inst);
     if (rc) return rc;
@@ -720,11 +721,13 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     // (most of the G blocks leave at once — only the sub-blocks of handed-over instances work — so the kernel shape is chosen for
     // few, long-running workgroups: one per CU with the large staging area, whatever G is)
-    if (h->n <= hdsm::SPLIT_N_MAX) rc = h->threads == 64 ? launch_nv<32, 64>(h, b, st, G) : launch_nv<32, 256>(h, b, st, G);
-    else if (h->threads == 256 && h->duo_min > 0 && a.n_inst >= h->duo_min) rc = launch_duo48(h, b, st, G);  // (large batches hand over hundreds of instances)
+    // (two split levels: up to poly_hor^2 workgroups per handed-over instance — two per CU, as for a large batch)
+    const bool many = h->threads == 256 && h->duo_min > 0 && (a.n_inst >= h->duo_min || K > h->P);
+    if (h->n <= hdsm::SPLIT_N_MAX) rc = many ? launch_duo(h, b, st, G) : (h->threads == 64 ? launch_nv<32, 64>(h, b, st, G) : launch_nv<32, 256>(h, b, st, G));
+    else if (many) rc = launch_duo48(h, b, st, G);  // (large batches hand over hundreds of instances)
     else rc = h->threads == 64 ? launch_nv<48, 64>(h, b, st, G) : launch_nv<48, 256>(h, b, st, G);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, K, a, b);
+    hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, h->P, K, a, b);
     HIP_TRY(hipGetLastError());
   }
   if (rc) return rc;
@@ -762,7 +765,7 @@ int64_t scratch_stride_for(int n) {
 // state of the split launches, allocated on the first one: outputs / statistics / guesses per sub-block (max_inst x poly_hor), a
 // pool of snapshot scratch for the sub-blocks that really work (at most 2048 at a time)
 hipError_t ensure_sub(Handle* h) {
-  const size_t G = (size_t)h->max_inst * h->P, N = (size_t)h->N;
+  const size_t G = (size_t)h->max_inst * h->sub_k, N = (size_t)h->N;
   h->sub_cap = (int)(G < 2048 ? G : 2048);
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) {
@@ -884,6 +887,10 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
+    int depth = 3;
+    env_int("HDSM_SPLIT_DEPTH", 1, 3, &depth);
+    h->sub_k = h->P;
+    for (int l = 1; l < depth; ++l) h->sub_k *= h->P;
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
     h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
     env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never

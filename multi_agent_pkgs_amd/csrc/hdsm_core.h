@@ -527,7 +527,7 @@ struct Solver {
   // `inst`: the instance (inputs, warm-start guess); `out`: where its outputs, statistics and scratch live — `inst` itself, or,
   // in pass 2 of a split launch, the slot of this sub-block; `sub`: the polyhedron this sub-block fixes at the root's
   // branching step (-1: ordinary solve).
-  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub) {
+  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub_in) {
     if (IS_T0) s.args = a_in;
     SYNC();
     const Args& a = s.args;
@@ -536,7 +536,7 @@ struct Solver {
     double* snap = a.scratch + (int64_t)out * a.scratch_stride;
     bool no_slot = false;
     int my_slot = -1;
-    if (sub >= 0) {  // pass 2: snapshot scratch comes from a pool of slots, taken for the lifetime of the workgroup (the pool is
+    if (sub_in >= 0) {  // pass 2: snapshot scratch comes from a pool of slots, taken for the lifetime of the workgroup (the pool is
       SYNC();        // larger than the number of workgroups that can be resident at once, so a free slot always exists)
       if (IS_T0) {
         const int cap = a.sub_slots[1];
@@ -757,7 +757,18 @@ struct Solver {
     unsigned flags = 0;
     bool run = np > 0;
     if (IS_T0) s.sw_tau = 0.0;
-    if (sub >= 0) {  // pass 2 of a split launch: this workgroup owns the subtree "polyhedron `sub` at the root's branching step"
+    // pass 2 of a split launch: this workgroup owns the subtree "polyhedron `sub` at the root's branching step" — or, with D
+    // split levels (sub_k = poly_hor^D), the part of it that the further digits of its index select: digit l = the polyhedron
+    // at the step the node of depth l branches on (the workgroups that share a prefix all solve the nodes of that prefix: a
+    // few nodes of redundant work buy a partition poly_hor times finer per level)
+    int sub = sub_in, sub_depth = sub_in >= 0 ? 1 : 0, sub_rest = 0;  // sub_rest: digits 1 .. D-1, the first one lowest
+    if (sub_in >= 0)
+      for (int k = a.sub_k; k > P; k /= P) {
+        sub_rest = sub_rest * P + sub % P;
+        sub /= P;
+        ++sub_depth;
+      }
+    if (sub >= 0) {
       const int step = a.split_info[2 * inst + 1];
       bool admissible = sub < np && step >= 0 && step < N;
       if (admissible && step == 0)  // rows on the pinned p_0 only gate the choice (leaf_check: keys = DINF)
@@ -921,6 +932,14 @@ struct Solver {
                 s.br_order[L][y] = s.br_order[L][y - 1];
                 s.br_order[L][y - 1] = t;
               }
+            if (L >= 1 && L < sub_depth) {  // a further split level: of the children of this node the workgroup owns one
+              int digit = sub_rest;
+              for (int x1 = 1; x1 < L; ++x1) digit /= P;
+              digit %= P;
+              bool mine = false;
+              for (int x1 = 0; x1 < cnt; ++x1) mine = mine || s.br_order[L][x1] == digit;
+              s.br_order[L][0] = digit, cnt = mine ? 1 : 0;
+            }
             s.br_cnt[L] = cnt, s.br_pos[L] = 0, s.br_step[L] = bstep, s.br_f[L] = s.f;
             s.level = L + 1;
           }
@@ -1080,8 +1099,8 @@ struct Solver {
 
 // Split launches, last step (k_split_merge: one wavefront per instance; `lane` of `lanes`): the best answer of the sub-blocks of an
 // instance that pass 1 handed over becomes the instance's answer. `a` holds the instance-indexed arrays of the launch, `b` the
-// arrays of pass 2 (index instance * K + subtree).
-HD void split_merge(int N, int K, const Args& a, const Args& b, int inst, int lane, int lanes) {
+// arrays of pass 2 (index instance * K + subtree, K = P or P^2 sub-blocks per instance).
+HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst, int lane, int lanes) {
   if (inst >= a.n_inst || a.split_info[2 * inst] == 0) return;
   int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = 0, sph = 0, pairs = 0;
   unsigned flags = 0;
@@ -1100,7 +1119,7 @@ HD void split_merge(int N, int K, const Args& a, const Args& b, int inst, int la
   if (best >= 0) {
     for (int e = lane; e < (N + 1) * 9; e += lanes) a.traj[(int64_t)inst * (N + 1) * 9 + e] = b.traj[(int64_t)best * (N + 1) * 9 + e];
     for (int e = lane; e < N * 3; e += lanes) a.ctrl[(int64_t)inst * N * 3 + e] = b.ctrl[(int64_t)best * N * 3 + e];
-    for (int e = lane; e < K; e += lanes) a.used[(int64_t)inst * K + e] = b.used[(int64_t)best * K + e];
+    for (int e = lane; e < P; e += lanes) a.used[(int64_t)inst * P + e] = b.used[(int64_t)best * P + e];
   }
   if (a.warm != nullptr) {  // next replan's guess: the best sub-block's working set (none: start cold)
     int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);

@@ -518,3 +518,35 @@ def test_enumerated_miqp_goldens_on_the_device(hdsm):
         sol.close()
         n += 1
     assert n >= 9
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_subtree_splitting_gives_the_unsplit_answer(hdsm, oracle, depth, monkeypatch):
+    """The split launch forced on (HDSM_SPLIT=1) with a two-node budget: every instance that branches is handed over to
+    poly_hor^depth sub-blocks (shared incumbent, merge kernel). Same answers as the one-kernel launch and as the oracle, on
+    corridors that force real branching and on the enumerated MIQP goldens (where the optimum is certified independently)."""
+    from test_oracle import enum_cases, enum_snapshot
+    prm = agile_params(10, max_rows_static=18)
+    plain_sol = hdsm.Solver(prm, 10, 10)
+    monkeypatch.setenv("HDSM_SPLIT", "1")
+    monkeypatch.setenv("HDSM_SPLIT_BUDGET", "2")
+    monkeypatch.setenv("HDSM_SPLIT_DEPTH", str(depth))
+    sol = hdsm.Solver(prm, 10, 10)
+    handed = 0
+    for seed in (3, 5, 21):
+        sn = problems.swarm_snapshot(prm, 10, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        args = [sn[k] for k in ARG_KEYS]
+        for rep in range(2):   # cold, then warm-started
+            g, p = sol.replan(*args), plain_sol.replan(*args)
+            compare(g, oracle.replan(prm, *args, n_threads=8))
+            assert np.array_equal(g["status"], p["status"]) and np.abs(g["traj"] - p["traj"]).max() < 1e-9
+        handed += int((p["nodes"] > 2).sum())
+    assert handed >= 3
+    sol.close()
+    for k, c in enum_cases():
+        eprm, polys, args = enum_snapshot(c)
+        es = hdsm.Solver(eprm, 1, args[7].shape[0])
+        g = es.replan(*args)
+        want = float(c["obj"])
+        assert g["status"][0] == 0 and abs(g["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, g["obj"], want, g["nodes"])
+        es.close()

@@ -128,6 +128,25 @@ def test_branch_and_bound_with_conflict_learning(wave, oracle):
     assert nodes > 3 * 10
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_subtree_splitting_gives_the_unsplit_answer(wave, oracle, depth, monkeypatch):
+    """The split launch of hdsm_api.hip (pass 1 with a node budget, poly_hor^depth sub-blocks per handed-over instance that
+    prune against a shared incumbent, merge), run here one workgroup after the other on the device source: with a budget
+    of two nodes every instance that branches at all is handed over, and the answer is the oracle's whatever the depth."""
+    monkeypatch.setenv("WEMU_SPLIT_DEPTH", str(depth))
+    prm = agile_params(10, max_rows_static=18)
+    handed = 0
+    for seed in (3, 5):
+        sn = problems.swarm_snapshot(prm, 10, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        args = [sn[k] for k in ARG_KEYS]
+        plain = wave.replan(prm, *args)
+        e = wave.replan(prm, *args, split_budget=2)
+        compare(e, oracle.replan(prm, *args, n_threads=8))
+        assert np.array_equal(e["status"], plain["status"]) and np.abs(e["traj"] - plain["traj"]).max() < 1e-9
+        handed += int((plain["nodes"] > 2).sum())
+    assert handed >= 3
+
+
 def test_node_budget_is_reported(wave, oracle):
     """hdsm_params.max_nodes = 1 on corridors that need branching: the instances that would branch come back as HDSM_LIMIT or
     HDSM_NO_SOLUTION with HDSM_FLAG_NODE_LIMIT, never as a wrong optimum; the others are untouched."""

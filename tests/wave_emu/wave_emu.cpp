@@ -114,7 +114,8 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   // split_budget > 0: the three steps of hdsm_api.hip's split launch, one workgroup after the other — pass 1 with the node
   // budget, then for every instance it handed over one sub-block per polyhedron (own outputs, shared incumbent word), then
   // the merge (hdsm::split_merge, the body of k_split_merge)
-  const int K = c.P;
+  int K = c.P;  // sub-blocks per instance: poly_hor^D (hdsm_api.hip: HDSM_SPLIT_DEPTH, default 3)
+  for (int l = 1, d = getenv("WEMU_SPLIT_DEPTH") ? atoi(getenv("WEMU_SPLIT_DEPTH")) : 3; l < d && l < 3; ++l) K *= c.P;
   std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, sub_slots(2 + 4, 0);
   std::vector<unsigned long long> inc_bits;
   std::vector<double> sub_traj, sub_ctrl, sub_obj;
@@ -135,7 +136,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
     hdsm::Args b = a;
     sub_status.assign(G, hdsm::ST_NO_SOLUTION), sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
     inc_bits.assign(a.n_inst, 0x7ff0000000000000ull);
-    sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * K, 0);
+    sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * c.P, 0);
     sub_slots[0] = 0, sub_slots[1] = 4;
     b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = inc_bits.data(), b.sub_slots = sub_slots.data();
     b.traj = sub_traj.data(), b.ctrl = sub_ctrl.data(), b.used = sub_used.data(), b.status = sub_status.data(), b.obj = sub_obj.data();
@@ -152,7 +153,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
       job.a.scratch = sub_scratch.data();
       if (!wemu::run_block(body<NV, CMAX>, &job, g, nthreads)) return -100;
     }
-    for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, K, a, b, inst, 0, 1);
+    for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, c.P, K, a, b, inst, 0, 1);
   }
   return 0;
 }
