@@ -487,7 +487,7 @@ struct Handle {
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
-  int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 16 nodes for batches that leave CUs idle, 96 beyond
+  int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 8 nodes for batches that leave CUs idle, 96 beyond
   int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
   int32_t* d_tree_flag = nullptr;
   int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
@@ -680,7 +680,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.tree_flag = h->d_tree_flag;
   // nodes after which an instance is handed over: small batches leave most CUs idle, so sub-blocks are free; in a batch that
   // fills the GPU every handed-over instance costs poly_hor set-ups and sweeps on busy CUs, so only the deep trees go
-  const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 16 : 96);
+  const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 8 : 96);
   a.tree_mark = budget;
   // Subtree splitting. A launch lasts as long as its slowest instance, and in obstacle worlds that is one agent between pillars
   // whose branch and bound needs hundreds of nodes while the other workgroups have been idle for milliseconds. When the last

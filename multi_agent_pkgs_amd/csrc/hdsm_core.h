@@ -591,10 +591,6 @@ struct Solver {
           for (int j = 0; j < W::NC; ++j) R.Jr[j] = c.JeqP[j * 64 + tid];
         }
       }
-      W::init_lane(R, c, tid);
-      const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
-      fw0 = (tid < 64) ? ((fi0 == N) ? c.wn[fk0] : c.wx[fk0]) : 0.0;
-      fw1 = (tid < 64) ? ((fi1 == N) ? c.wn[fk1] : c.wx[fk1]) : 0.0;
       // Everything else is staged in "virtual thread" slots: slot vt takes item vt of every array. Round 0 (vt = tid)
       // is split into requests and LDS writes so that the two reads that need agent_id[inst] (the own plan) go out
       // while all the others are already in flight; the kernel arguments are used straight from the SGPRs here.
@@ -651,7 +647,11 @@ struct Solver {
         if (vt < 4 * (MAXH + 1)) (&s.kap[0][0])[vt] = r.v_k;
       };
       ST_PROF(8)
+      const typename W::LaneReq lane_req = W::init_lane_request(c, tid);
+      const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
+      const double wn0 = c.wn[fk0], wx0 = c.wx[fk0], wn1 = c.wn[fk1], wx1 = c.wx[fk1];
       const Req r0 = request(tid);
+
       ST_PROF(9)
       // the own plan (or, before the first plan exists, the current position at every step)
       const bool self_ok = self >= 0 && self < g.n_rob;
@@ -666,6 +666,10 @@ struct Solver {
       ST_PROF(10)
       commit(tid, r0);
       ST_PROF(11)
+      // (per-lane constants of the iteration: their loads use what they fetch at once, so they come after the staging requests)
+      W::init_lane(R, c, tid, lane_req);
+      fw0 = (tid < 64) ? ((fi0 == N) ? wn0 : wx0) : 0.0;
+      fw1 = (tid < 64) ? ((fi1 == N) ? wn1 : wx1) : 0.0;
       const int items = max_i(max_i(P * RS, 6 * S::LDT), max_i(9 * MAXH, 9 * (N + 1)));
       for (int vt = tid + nt; vt < items; vt += nt) commit(vt, request(vt));
       for (int k = 6 * S::LDT + tid; k < NV * S::LDT; k += nt) s.U[k] = 0.0;

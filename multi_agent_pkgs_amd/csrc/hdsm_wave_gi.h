@@ -154,32 +154,42 @@ struct WaveGI {
     float wu, sb_w[2];          // pick-rule weights of this lane's input box and state-bound items
   };
 
-  static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane) {
-    const int N = c.N, n = c.n;
-    const int n_sb = 6 * (N - 1);
-    // all bounds are requested first and selected afterwards (no wait between the loads)
-    const int ax0 = (lane < n) ? lane / N : 0;
-    const double ubu = c.ubu[ax0], lbu = c.lbu[ax0];
-    double ubs[2], lbs[2];
+  // per-lane constants of the iteration in two steps: the loads (issued with the staging requests of the set-up, so that
+  // their latency is not a round trip of its own) and, once those have been consumed, the registers
+  struct LaneReq {
+    double ubu, lbu, ubs[2], lbs[2], wu, sb_w[2];
     int comp[2], axs[2], ii[2];
+  };
+  static __device__ __forceinline__ LaneReq init_lane_request(const Consts& c, int lane) {
+    const int N = c.N, n = c.n;
+    LaneReq q;
+    const int ax0 = (lane < n) ? lane / N : 0;
+    q.ubu = c.ubu[ax0], q.lbu = c.lbu[ax0];
+    q.wu = c.wu[lane < n ? lane : 0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int idx = lane + 64 * e, k = idx % 6;
-      ii[e] = idx / 6 + 1, comp[e] = 1 + k / 3, axs[e] = k % 3;
-      ubs[e] = c.ubs[comp[e]][axs[e]], lbs[e] = c.lbs[comp[e]][axs[e]];
+      q.ii[e] = idx / 6 + 1, q.comp[e] = 1 + k / 3, q.axs[e] = k % 3;
+      q.ubs[e] = c.ubs[q.comp[e]][q.axs[e]], q.lbs[e] = c.lbs[q.comp[e]][q.axs[e]];
+      q.sb_w[e] = c.ws[q.axs[e]][q.comp[e]][q.ii[e] <= MAXH ? q.ii[e] : 0];
     }
+    return q;
+  }
+  static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane, const LaneReq& q) {
+    const int N = c.N, n = c.n;
+    const int n_sb = 6 * (N - 1);
     R.ax = row_of(lane) / N, R.kk = row_of(lane) % N;
-    R.ub_own = (lane < n && fabs(ubu) < ABSENT) ? ubu : DINF;
-    R.lb_own = (lane < n && fabs(lbu) < ABSENT) ? lbu : -DINF;
-    R.wu = (float)c.wu[lane < n ? lane : 0];
+    R.ub_own = (lane < n && fabs(q.ubu) < ABSENT) ? q.ubu : DINF;
+    R.lb_own = (lane < n && fabs(q.lbu) < ABSENT) ? q.lbu : -DINF;
+    R.wu = (float)q.wu;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool on = lane + 64 * e < n_sb;
-      R.sb_off[e] = on ? ii[e] * 9 + 3 * comp[e] + axs[e] : -1;
-      R.sb_id[e] = on ? ((ii[e] << 5) | (comp[e] << 3) | (axs[e] << 1)) : 0;
-      R.sb_ub[e] = (on && fabs(ubs[e]) < ABSENT) ? ubs[e] : DINF;
-      R.sb_lb[e] = (on && fabs(lbs[e]) < ABSENT) ? lbs[e] : -DINF;
-      R.sb_w[e] = (float)c.ws[axs[e]][comp[e]][on ? ii[e] : 0];
+      R.sb_off[e] = on ? q.ii[e] * 9 + 3 * q.comp[e] + q.axs[e] : -1;
+      R.sb_id[e] = on ? ((q.ii[e] << 5) | (q.comp[e] << 3) | (q.axs[e] << 1)) : 0;
+      R.sb_ub[e] = (on && fabs(q.ubs[e]) < ABSENT) ? q.ubs[e] : DINF;
+      R.sb_lb[e] = (on && fabs(q.lbs[e]) < ABSENT) ? q.lbs[e] : -DINF;
+      R.sb_w[e] = (float)q.sb_w[e];
     }
   }
 
