@@ -318,19 +318,19 @@ struct WaveGIB : WaveGI<32, CMAX> {
       if (first_copy(lane)) s.dvec[pos] = tj;
       wsync();
       const double lk = u_row_dot(s, lane);  // lambda = U t
-      double xw;
-      {
-        double g[NC];
-        gather_cols(tj, g);  // J1 t (t is zero beyond q)
-        double x0 = 0, x1 = 0;
-#pragma unroll
-        for (int k = 0; k < NC; k += 2) x0 += R.Jr[k] * g[k], x1 += R.Jr[k + 1] * g[k + 1];
-        xw = s.x0[Base::row_of(lane)] + half_sum64(x0 + x1);
-      }
       // most negative multiplier among the inequalities
       const bool ineq = pos < q && id_kind(R.act) != K_E;
       const double worst = -wave_max64(ineq ? -lk : -DINF);
       if (!(worst < -1e-12) || q <= 6) {
+        double xw;  // x_W = x0 + J1 t (t is zero beyond q): only the pair that is kept needs it
+        {
+          double g[NC];
+          gather_cols(tj, g);
+          double x0 = 0, x1 = 0;
+#pragma unroll
+          for (int k = 0; k < NC; k += 2) x0 += R.Jr[k] * g[k], x1 += R.Jr[k + 1] * g[k + 1];
+          xw = s.x0[Base::row_of(lane)] + half_sum64(x0 + x1);
+        }
         const double tt = pos_sum(tj * tj, lane);
         R.lam = (pos < q) ? lk : 0.0;
         if (lane < n) R.xi = xw, s.x[lane] = xw;
