@@ -98,7 +98,7 @@ struct Shm {
   double ref[MAXH][6];
   double st[MAXH + 1][9];
   double cprev[MAXH][3];
-  double sp[MAXP][MAXRS][4];
+  alignas(16) double sp[MAXP][MAXRS][4];  // rows of the instance's polyhedra (A, b): read as two 16-byte halves by scan_assigned
   double keys[MAXH][MAXP];
   alignas(16) double cand[CMAX][4];      // staged neighbour rows (n_f, rhs): read as two 16-byte halves by the scans
   double red_v[MAXT];
