@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--time-limit-s", type=float, default=0.0, help="hdsm_params.time_limit_s (0 = none; AC:952 sets 0.08)")
     ap.add_argument("--device-loop-multi", action="store_true", help="run the device-resident-loop pass with --gpus > 1 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--save-recording", default="", help="development: write the recorded rounds (solver inputs) to this .npz")
+    ap.add_argument("--load-recording", default="", help="development: replay the rounds of a --save-recording file instead of flying "
+                    "the set-up flight (A/B of execution knobs on IDENTICAL inputs; implies --no-event-pass)")
     ap.add_argument("--cold-start", action="store_true", help="development: hdsm_params.warm_start = 0 (every replan starts from the "
                     "unconstrained optimum; the default line carries the working sets over)")
     ap.add_argument("--no-event-pass", action="store_true", help="skip the HIP-event pass and the host-buffer pass")
@@ -194,21 +197,32 @@ def main():
         raw, world_origin = sc.forest_wall_forest(int(np.ceil((10 + 2.01 * n_y) / 30)), int(np.ceil((9 + 2.01 * n_y) / 15)), seed=0)
         world_occ = sc.inflate(raw)
         cfg.grid_range[2], cfg.grid_z_min = 12.0, -6.0
-    loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
-                           allgather=allgather_np if world > 1 else None, radius=radius,
-                           reference=None if args.host_reference else ref_dev, starts=starts, goals=goals)
-    if world_occ is not None:
-        unrouted = loop.set_world(world_occ, world_origin, route=args.scenario != "lanes")
-        assert unrouted == 0
-    rec, fails, fails_timed = [], 0, 0
-    t_setup = time.perf_counter()
-    for r in range(rec_to):
-        out = loop.step(record=rec if r >= rec_from else None)
-        if r >= rec_from:
-            fails += int((out["status"] == 2).sum())
-        if r >= first_round:
-            fails_timed += int((out["status"] == 2).sum())
-    t_setup = time.perf_counter() - t_setup
+    rec_keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+    if args.load_recording:
+        assert world == 1
+        args.no_event_pass = True
+        z = np.load(args.load_recording)
+        rec = [{k: z[k][i] for k in rec_keys} for i in range(z["agent_id"].shape[0])]
+        assert len(rec) == rec_to - rec_from, "the recording was made with other --steps / --warmup / --first-round"
+        fails, fails_timed, t_setup = int(z["fails"]), int(z["fails_timed"]), 0.0
+    else:
+        loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=solve_np,
+                               allgather=allgather_np if world > 1 else None, radius=radius,
+                               reference=None if args.host_reference else ref_dev, starts=starts, goals=goals)
+        if world_occ is not None:
+            unrouted = loop.set_world(world_occ, world_origin, route=args.scenario != "lanes")
+            assert unrouted == 0
+        rec, fails, fails_timed = [], 0, 0
+        t_setup = time.perf_counter()
+        for r in range(rec_to):
+            out = loop.step(record=rec if r >= rec_from else None)
+            if r >= rec_from:
+                fails += int((out["status"] == 2).sum())
+            if r >= first_round:
+                fails_timed += int((out["status"] == 2).sum())
+        t_setup = time.perf_counter() - t_setup
+        if args.save_recording:
+            np.savez(args.save_recording, fails=fails, fails_timed=fails_timed, **{k: np.stack([x[k] for x in rec]) for k in rec_keys})
     if world > 1:
         cnt = torch.tensor([fails_timed, fails], dtype=torch.int64)
         dist.all_reduce(cnt)

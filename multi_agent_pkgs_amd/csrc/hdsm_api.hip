@@ -691,9 +691,10 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // incumbent); (3) a merge that keeps the best answer. Same answers as the one-kernel form: the search is exact either way.
   bool split = h->split_mode == 1;
   if (h->split_mode == 2 && h->h_tree_flag != nullptr) {
-    // The word is raised by kernels that may still be running when the next launch is enqueued (callers queue rounds back to
-    // back), so a sighting keeps the split form on for the next few launches; deep trees persist over rounds anyway.
-    if (*h->h_tree_flag != 0) *h->h_tree_flag = 0, h->split_ttl = 8;
+    // The word is raised by kernels that may still be running when the next launch is enqueued (callers that queue dozens of
+    // rounds back to back see it dozens of launches late), so a sighting keeps the split form on for the next 256 launches:
+    // deep trees persist over rounds, and a split launch in which nothing is handed over costs three near-empty kernels.
+    if (*h->h_tree_flag != 0) *h->h_tree_flag = 0, h->split_ttl = 256;
     if (h->split_ttl > 0) split = true, --h->split_ttl;
   }
   if (split && !h->sub_ready) split = ensure_sub(h) == hipSuccess;

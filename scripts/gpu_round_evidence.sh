@@ -11,6 +11,12 @@ run cfg3_forest256 --scenario forest --agents 256 --first-round 60
 HDSM_SPLIT=0 run cfg3_forest256_unsplit --scenario forest --agents 256 --first-round 60 --no-event-pass
 HDSM_SPLIT=0 run cfg5_fwf4096_h15_unsplit --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2 --no-event-pass
 run cfg5_fwf4096_h15 --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2
+run cfg5_fwf4096_h15_deep --scenario fwf --agents 4096 --horizon 15 --first-round 30 --steps 6 --warmup 2 --no-event-pass
+HDSM_SPLIT_DEPTH=1 run cfg5_fwf4096_h15_deep_depth1 --scenario fwf --agents 4096 --horizon 15 --first-round 30 --steps 6 --warmup 2 --no-event-pass
+HDSM_SPLIT_DEPTH=1 run cfg3_forest256_depth1 --scenario forest --agents 256 --first-round 60 --no-event-pass
+HDSM_PICK_RULE=0 run circle1024_raw_pick_rule --no-event-pass
+HDSM_PICK_RULE=0 run cfg3_forest256_raw_pick_rule --scenario forest --agents 256 --first-round 60 --no-event-pass
+run circle1024_cold_start --cold-start --no-event-pass
 run circle4096_h15 --agents 4096 --horizon 15 --first-round 20 --steps 8 --warmup 2
 BENCH_ARGS="" bash scripts/gpu_prof_bench.sh > gpurun_out/$TAG/phases.log 2>&1; cp gpurun_out/prof_bench.log gpurun_out/$TAG/prof_bench.log; tail -3 gpurun_out/$TAG/phases.log | cut -c1-400
 timeout 300 python scripts/bench_corridor.py > gpurun_out/$TAG/f2_corridor.json 2> gpurun_out/$TAG/f2_corridor.err; cat gpurun_out/$TAG/f2_corridor.json
