@@ -681,7 +681,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // nodes after which an instance is handed over: small batches leave most CUs idle, so sub-blocks are free; in a batch that
   // fills the GPU every handed-over instance costs poly_hor set-ups and sweeps on busy CUs, so only the deep trees go
   const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 8 : 96);
-  a.tree_mark = budget;
+  a.tree_mark = budget > hdsm::TREE_MARK ? budget : hdsm::TREE_MARK;
   // Subtree splitting. A launch lasts as long as its slowest instance, and in obstacle worlds that is one agent between pillars
   // whose branch and bound needs hundreds of nodes while the other workgroups have been idle for milliseconds. When the last
   // launch met such a tree (tree_flag), this one runs in three kernels: (1) the ordinary solve with a small node budget — an
@@ -702,7 +702,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     rc = solve(a, a.n_inst);
   } else {
     const int K = h->sub_k, G = a.n_inst * K, I = h->max_inst;
-    a.split_budget = budget, a.split_info = h->d_split, a.tree_mark = 0;
+    a.split_budget = budget, a.split_info = h->d_split, a.tree_mark = 0;  // (a.tree_flag stays: k_split_merge raises it for trees that are still deep)
     rc = solve(a, a.n_inst);
     if (rc) return rc;
     hdsm::Args b = a;

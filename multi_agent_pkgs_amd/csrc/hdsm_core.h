@@ -42,6 +42,7 @@ namespace hdsm {
 
 enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
 constexpr int NOGOODS = 48;      // conflicts kept per instance (branch and bound)
+constexpr int TREE_MARK = 32;       // nodes from which a tree counts as deep (the split form of a launch pays from about there)
 constexpr int WARM_CERT = 1 << 30;  // bit of the stored working-set size: the set is an infeasibility certificate
 enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
 enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
@@ -999,7 +1000,7 @@ struct Solver {
       limit = true;
     }
     if (IS_T0 && a.split_budget > 0) a.split_info[2 * inst] = handed_over ? 1 : 0, a.split_info[2 * inst + 1] = handed_over ? s.br_step[0] : -1;
-    if (IS_T0 && a.tree_flag != nullptr && (handed_over || (a.tree_mark > 0 && nodes >= a.tree_mark))) *a.tree_flag = 1;
+    if (IS_T0 && a.tree_flag != nullptr && a.tree_mark > 0 && nodes >= a.tree_mark) *a.tree_flag = 1;  // (split launches: the merge raises it)
     const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
     if (s.have_inc) {
       double* tr = a.traj + (int64_t)out * 9 * (N + 1);
@@ -1131,6 +1132,7 @@ HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst,
     for (int e = lane; e < MAXNV + 2; e += lanes) wp[e] = best >= 0 ? src[e] : 0;
   }
   if (lane == 0) {
+    if (a.tree_flag != nullptr && nodes >= TREE_MARK) *a.tree_flag = 1;  // still a deep tree: the next launches stay in the split form
     if (best >= 0) a.obj[inst] = obj;
     a.status[inst] = status;
     a.st_iters[inst] = iters, a.st_nodes[inst] = nodes, a.st_sweeps[inst] = sweeps, a.st_cand[inst] = cand;

@@ -125,8 +125,9 @@ struct Args {
                                  // +inf at the start): the sub-blocks of an instance prune against each other's incumbents
   int32_t node_cap;       // pass 2: node budget of ONE sub-block (the instance's budget is shared by its sub-blocks; 0 = Consts::max_nodes)
   int32_t* sub_slots;     // pass 2: pool of snapshot-scratch slots: [1] = capacity, [2 + i] = slot i taken (0 / 1)
-  int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree outgrew split_budget (ordinary launch) or that was
-                          // handed over (pass 1) — the handle switches the NEXT launch to the split form when it sees it
+  int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree reached tree_mark nodes (ordinary launch) or, in a
+                          // split launch, by the merge for a handed-over instance with a deep tree (TREE_MARK nodes over all its
+                          // sub-blocks) — the handle keeps the NEXT launches in the split form while it sees it
   int32_t tree_mark;      // ordinary launches: node count from which an instance raises tree_flag (0 = never)
   int32_t* warm_out;      // where the NEXT replan's guess is written: warm itself, or the per-sub-block copy of pass 2
   int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units + 9 per active row (<= 254), 255 = no solution

@@ -25,7 +25,7 @@ while i < len(raw):
     blocks.append(raw[i + 2:i + 2 + n * 16].reshape(n, 16))  # begin, end (10 ns ticks), block, hw id, iters, nodes, sweeps, staged, flags, cold, status, pairs, spheres, q
     i += 2 + n * 16
 ev = blocks[-rounds - 1:]
-SLOTS = 512
+SLOTS = int(os.environ.get("SLOTS", "768"))  # resident workgroups: 3 per CU (k_replan_tri), 2 per CU = 512 (k_replan_duo)
 
 
 def makespan(order, dur):
