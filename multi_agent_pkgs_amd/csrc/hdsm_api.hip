@@ -492,6 +492,7 @@ struct Handle {
   int32_t* d_tree_flag = nullptr;
   int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
   unsigned long long* d_inc = nullptr;
+  int32_t* d_node_pool = nullptr;  // [max_inst] nodes the sub-blocks of an instance may still open (Args::node_pool)
   double *d_sub_traj = nullptr, *d_sub_ctrl = nullptr, *d_sub_obj = nullptr, *d_sub_scratch = nullptr;
   uint8_t* d_sub_used = nullptr;
   bool sub_ready = false;
@@ -617,9 +618,9 @@ int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 }
 
 // ---- subtree splitting: set-up of pass 2, merge, lazily allocated state -------------------------------------------------
-__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap) {
+__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap, int32_t* node_pool, int nodes_left) {
   const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k < n_inst) inc_bits[k] = 0x7ff0000000000000ull;  // +inf
+  if (k < n_inst) inc_bits[k] = 0x7ff0000000000000ull, node_pool[k] = nodes_left;  // +inf; the budget pass 1 left
   if (k == 0) sub_slots[0] = 0, sub_slots[1] = cap;
   for (int i = k; i < cap; i += n_inst > 0 ? (int)(gridDim.x * blockDim.x) : 1) sub_slots[2 + i] = 0;
 }
@@ -707,18 +708,20 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     if (rc) return rc;
     hdsm::Args b = a;
     b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = h->d_inc, b.sub_slots = h->d_sub_slots, b.tree_flag = nullptr;
-    {  // the node budget is the INSTANCE's: what pass 1 left of it is shared by the sub-blocks
-      const int total = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
-      const int left = total - budget;
-      b.node_cap = left > K ? (left + K - 1) / K : 1;
-    }
+    // the node budget is the INSTANCE's: every sub-block starts with an equal share of what pass 1 left of it and hands the
+    // unused part back to the instance's pool when it finishes; a sub-block that has used its share draws from that pool
+    const int total_nodes = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
+    const int left_nodes = total_nodes - budget > K ? total_nodes - budget : K;
+    b.node_cap = left_nodes / K;
+    const int nodes_left = left_nodes - b.node_cap * K;  // (the remainder of the division starts in the pool)
+    b.node_pool = h->d_node_pool;
     b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
     b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr;
     int32_t* ss = h->d_sub_stats;
     const size_t GI = (size_t)I * K;
     b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
     b.st_flags = reinterpret_cast<uint32_t*>(ss + 6 * GI), b.st_key = ss + 7 * GI;
-    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap);
+    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap, h->d_node_pool, nodes_left);
     HIP_TRY(hipGetLastError());
     // (most of the G blocks leave at once — only the sub-blocks of handed-over instances work — so the kernel shape is chosen for
     // few, long-running workgroups: one per CU with the large staging area, whatever G is)
@@ -772,7 +775,7 @@ hipError_t ensure_sub(Handle* h) {
   auto ok = [&](hipError_t r) {
     if (e == hipSuccess) e = r;
   };
-  ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_sub_slots, 2 + (size_t)h->sub_cap));
+  ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_node_pool, (size_t)h->max_inst)), ok(dmalloc(&h->d_sub_slots, 2 + (size_t)h->sub_cap));
   ok(dmalloc(&h->d_sub_stats, 8 * G)), ok(dmalloc(&h->d_sub_warm, (hdsm::MAXNV + 2) * G)), ok(dmalloc(&h->d_sub_status, G));
   ok(dmalloc(&h->d_sub_traj, G * (N + 1) * 9)), ok(dmalloc(&h->d_sub_ctrl, G * N * 3)), ok(dmalloc(&h->d_sub_obj, G)), ok(dmalloc(&h->d_sub_used, G * h->P));
   ok(dmalloc(&h->d_sub_scratch, (size_t)h->sub_cap * (size_t)h->scratch_stride));
@@ -782,7 +785,7 @@ hipError_t ensure_sub(Handle* h) {
 }
 
 void free_all(Handle* h) {
-  void* sub[] = {h->d_split, h->d_inc, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
+  void* sub[] = {h->d_split, h->d_inc, h->d_node_pool, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
                  h->d_sub_used, h->d_sub_scratch};
   for (void* p : sub)
     if (p) (void)hipFree(p);

@@ -42,6 +42,7 @@ namespace hdsm {
 
 enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
 constexpr int NOGOODS = 48;      // conflicts kept per instance (branch and bound)
+constexpr int NODE_CHUNK = 4;       // nodes a sub-block of a split launch takes from its instance's pool at a time
 constexpr int TREE_MARK = 32;       // nodes from which a tree counts as deep (the split form of a launch pays from about there)
 constexpr int WARM_CERT = 1 << 30;  // bit of the stored working-set size: the set is an infeasibility certificate
 enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
@@ -122,6 +123,7 @@ struct Shm {
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t leaf_pick;  // result of the one-wavefront leaf test
+  int32_t node_res;   // pass 2 of a split launch: nodes drawn from the instance's pool and not yet opened
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
@@ -130,7 +132,7 @@ struct Shm {
   double sw_ref[MAXH + 1][3];  // positions at the last STAGING sweep and its radius (0 = none): every row not staged then
   double sw_tau;               // had slack >= sw_tau there, so it cannot be violated while |p - sw_ref| |n_f| <= sw_tau
   double sw_d2;                // max_m |st[m] - sw_ref[m]|^2 (scratch of the displacement test)
-  double bnd[24];        // device build: lbu[3], ubu[3], lbs[3][3], ubs[3][3] (read by resid() inside the iteration)
+  double bnd[24];        // lbu[3], ubu[3], lbs[3][3], ubs[3][3], absent = -+DINF (read by select() and resid() inside the iteration)
   // set-up: v = (state_curr, traj_ref) flat, the input of the map KT, zero-padded. It lives in red_v[16 ...): the set-up itself
   // uses red_v[0..5] (residuals of the terminal equalities), the leaf test comes later
   static_assert(MAXT >= 16 + KCOLS + 8, "the reduction scratch doubles as the set-up's input vector");
@@ -500,7 +502,20 @@ struct Solver {
           handed_over = true;
           return false;
         }
-        if (nodes >= (s.args.node_cap > 0 ? s.args.node_cap : c.max_nodes)) {
+        if (s.args.node_pool != nullptr) {  // pass 2 of a split launch: own share first, then what finished sub-blocks handed back
+          SYNC();
+          if (IS_T0 && s.node_res == 0) {
+            const int old = atomicAdd(&s.args.node_pool[inst], -NODE_CHUNK);
+            s.node_res = old >= NODE_CHUNK ? NODE_CHUNK : (old > 0 ? old : 0);
+          }
+          SYNC();
+          if (s.node_res == 0) {
+            limit = true;
+            return false;
+          }
+          SYNC();
+          if (IS_T0) --s.node_res;
+        } else if (nodes >= c.max_nodes) {
           limit = true;
           return false;
         }
@@ -644,7 +659,10 @@ struct Solver {
           if (vt >= n) s.x[vt] = 0.0;
         }
         if (vt < MAXH) s.assign[vt] = -1;
-        if (vt < 24) s.bnd[vt] = r.v_b;
+        if (vt < 24) {  // lbu[3], ubu[3], lbs[3][3], ubs[3][3]; an absent bound can never be violated
+          const bool lower = vt < 3 || (vt >= 6 && vt < 15);
+          s.bnd[vt] = fabs(r.v_b) < ABSENT ? r.v_b : (lower ? -DINF : DINF);
+        }
         if (vt < 4 * (MAXH + 1)) (&s.kap[0][0])[vt] = r.v_k;
       };
       ST_PROF(8)
@@ -677,7 +695,7 @@ struct Solver {
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
-        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.inc_shared = DINF;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.inc_shared = DINF, s.node_res = sub_in >= 0 ? a_in.node_cap : 0;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -1094,6 +1112,7 @@ struct Solver {
         a.st_key[out] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
       if (my_slot >= 0) atomicExch(&a.sub_slots[2 + my_slot], 0);  // (all snapshot traffic of this workgroup is behind it)
+      if (a.node_pool != nullptr && s.node_res > 0) atomicAdd(&a.node_pool[inst], s.node_res);  // the unused part of the share: to the instance's pool
     }
     SYNC();
   }

@@ -123,7 +123,10 @@ struct Args {
   int32_t* split_info;    // [n_inst][2]: handed over (0 / 1), root branching step
   unsigned long long* inc_bits;  // [n_inst]: best objective any sub-block has found so far (bits of a non-negative double,
                                  // +inf at the start): the sub-blocks of an instance prune against each other's incumbents
-  int32_t node_cap;       // pass 2: node budget of ONE sub-block (the instance's budget is shared by its sub-blocks; 0 = Consts::max_nodes)
+  int32_t node_cap;       // pass 2: share of the instance's node budget (what pass 1 left of Consts::max_nodes) every sub-block starts with
+  int32_t* node_pool;     // pass 2: [n_inst] nodes handed back by sub-blocks that finished below their share; a sub-block that has used
+                          // its share draws from here in chunks — the budget stays the instance's wherever in the tree the work is,
+                          // and a tree that overruns it stops all its sub-blocks at about the same time
   int32_t* sub_slots;     // pass 2: pool of snapshot-scratch slots: [1] = capacity, [2 + i] = slot i taken (0 / 1)
   int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree reached tree_mark nodes (ordinary launch) or, in a
                           // split launch, by the merge for a handed-over instance with a deep tree (TREE_MARK nodes over all its

@@ -101,6 +101,15 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// an integer the optimiser must treat as recomputed here (no effect on the value): stops it from hoisting what depends on it
+__device__ __forceinline__ void keep_in_loop(int& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
 struct alignas(16) D2 {
   double x, y;
 };
@@ -146,10 +155,10 @@ struct WaveGI {
     double xi;      // u[lane]
     double lam;     // NV = 32 (hdsm_wave_gib.h): multiplier and id of working-set position pos_of(lane) while a run is going on
     int act;
-    // per-lane constants of the violation scan (bounds with "absent" mapped to +-DINF), set by init_lane()
-    double ub_own, lb_own;      // box of this lane's input
-    double sb_ub[2], sb_lb[2];  // boxes of the (up to two) state-bound items scanned by this lane
-    int sb_off[2], sb_id[2];    // their offset in st[][] (as a flat index) and id base; -1 = no item
+    // per-lane constants of the violation scan, set by init_lane(). The bounds themselves are read from LDS (Shm::bnd, "absent"
+    // mapped to +-DINF): six doubles per lane held in registers across the whole instance were spilled to scratch and reloaded
+    // INSIDE every scan.
+    int sb_id[2];               // id base (step << 5 | comp << 3 | axis << 1) of the (up to two) state-bound items of this lane, -1 = none
     int ax, kk;                 // variable row_of(lane) = jerk of axis ax at step kk (runtime divisions done once)
     float wu, sb_w[2];          // pick-rule weights of this lane's input box and state-bound items
   };
@@ -157,38 +166,30 @@ struct WaveGI {
   // per-lane constants of the iteration in two steps: the loads (issued with the staging requests of the set-up, so that
   // their latency is not a round trip of its own) and, once those have been consumed, the registers
   struct LaneReq {
-    double ubu, lbu, ubs[2], lbs[2], wu, sb_w[2];
+    double wu, sb_w[2];
     int comp[2], axs[2], ii[2];
   };
   static __device__ __forceinline__ LaneReq init_lane_request(const Consts& c, int lane) {
-    const int N = c.N, n = c.n;
+    const int n = c.n;
     LaneReq q;
-    const int ax0 = (lane < n) ? lane / N : 0;
-    q.ubu = c.ubu[ax0], q.lbu = c.lbu[ax0];
     q.wu = c.wu[lane < n ? lane : 0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int idx = lane + 64 * e, k = idx % 6;
       q.ii[e] = idx / 6 + 1, q.comp[e] = 1 + k / 3, q.axs[e] = k % 3;
-      q.ubs[e] = c.ubs[q.comp[e]][q.axs[e]], q.lbs[e] = c.lbs[q.comp[e]][q.axs[e]];
       q.sb_w[e] = c.ws[q.axs[e]][q.comp[e]][q.ii[e] <= MAXH ? q.ii[e] : 0];
     }
     return q;
   }
   static __device__ __forceinline__ void init_lane(Regs& R, const Consts& c, int lane, const LaneReq& q) {
-    const int N = c.N, n = c.n;
+    const int N = c.N;
     const int n_sb = 6 * (N - 1);
     R.ax = row_of(lane) / N, R.kk = row_of(lane) % N;
-    R.ub_own = (lane < n && fabs(q.ubu) < ABSENT) ? q.ubu : DINF;
-    R.lb_own = (lane < n && fabs(q.lbu) < ABSENT) ? q.lbu : -DINF;
     R.wu = (float)q.wu;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const bool on = lane + 64 * e < n_sb;
-      R.sb_off[e] = on ? q.ii[e] * 9 + 3 * q.comp[e] + q.axs[e] : -1;
-      R.sb_id[e] = on ? ((q.ii[e] << 5) | (q.comp[e] << 3) | (q.axs[e] << 1)) : 0;
-      R.sb_ub[e] = (on && fabs(q.ubs[e]) < ABSENT) ? q.ubs[e] : DINF;
-      R.sb_lb[e] = (on && fabs(q.lbs[e]) < ABSENT) ? q.lbs[e] : -DINF;
+      R.sb_id[e] = on ? ((q.ii[e] << 5) | (q.comp[e] << 3) | (q.axs[e] << 1)) : -1;
       R.sb_w[e] = (float)q.sb_w[e];
     }
   }
@@ -259,8 +260,8 @@ struct WaveGI {
     double key, v;
     int id;
   };
-  static __device__ __forceinline__ double plane_weight(const S& s, double nx, double ny, double nz, int m) {
-    return (double)mk_mw(s.kap, nx, ny, nz, m).w;
+  static __device__ __forceinline__ float plane_weight(const S& s, double nx, double ny, double nz, int m) {
+    return mk_mw(s.kap, nx, ny, nz, m).w;
   }
 
   // violation of staged rows [lo, hi) -> running pick; four rows per trip, loads issued before first use
@@ -287,7 +288,7 @@ struct WaveGI {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
-        const double key = norm ? vv * (double)mw[u].w : vv;
+        const double key = norm ? (double)((float)vv * mw[u].w) : vv;
         if (idx[u] < hi && vv > tol && key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_kc(idx[u], mw[u].m);
       }
     }
@@ -312,7 +313,7 @@ struct WaveGI {
         const double* pm = s.st[i + e];
         const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
         if (vv > tol) {
-          const double key = norm ? vv * plane_weight(s, row[0], row[1], row[2], i + e) : vv;
+          const double key = norm ? (double)((float)vv * plane_weight(s, row[0], row[1], row[2], i + e)) : vv;
           if (key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_id(K_P, (i << 7) | (e << 6) | r);
         }
       }
@@ -326,19 +327,23 @@ struct WaveGI {
     Pick pk{0.0, 0.0, -1};
     auto offer = [&](double vv, float w, int id) {
       if (vv > tol) {
-        const double key = norm ? vv * (double)w : vv;
+        const double key = norm ? (double)((float)vv * w) : vv;  // (single precision: a double copy of w, hoisted out of the loop, went to scratch)
         if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
       }
     };
-    offer(R.xi - R.ub_own, R.wu, mk_id(K_U, lane << 1));
-    offer(R.lb_own - R.xi, R.wu, mk_id(K_U, (lane << 1) | 1));
-    const double* stf = &s.st[0][0];
+    if (lane < c.n) {  // box of this lane's input (lane = variable; its axis is R.ax)
+      offer(R.xi - s.bnd[3 + R.ax], R.wu, mk_id(K_U, lane << 1));
+      offer(s.bnd[R.ax] - R.xi, R.wu, mk_id(K_U, (lane << 1) | 1));
+    }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (R.sb_off[e] >= 0) {
-        const double sv = stf[R.sb_off[e]];
-        offer(sv - R.sb_ub[e], R.sb_w[e], mk_id(K_S, R.sb_id[e]));
-        offer(R.sb_lb[e] - sv, R.sb_w[e], mk_id(K_S, R.sb_id[e] | 1));
+      int sid = R.sb_id[e];
+      keep_in_loop(sid);  // (the three LDS addresses below: hoisted out of the iteration loop they were spilled to scratch)
+      if (sid >= 0) {
+        const int ca = ((sid >> 3) & 3) * 3 + ((sid >> 1) & 3);  // 3 comp + axis
+        const double sv = s.st[sid >> 5][ca];
+        offer(sv - s.bnd[15 + ca], R.sb_w[e], mk_id(K_S, sid));
+        offer(s.bnd[6 + ca] - sv, R.sb_w[e], mk_id(K_S, sid | 1));
       }
     }
     if (uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch

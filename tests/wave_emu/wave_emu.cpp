@@ -136,6 +136,10 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
     hdsm::Args b = a;
     sub_status.assign(G, hdsm::ST_NO_SOLUTION), sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
     inc_bits.assign(a.n_inst, 0x7ff0000000000000ull);
+    const int left_nodes = c.max_nodes - a.split_budget > K ? c.max_nodes - a.split_budget : K;
+    std::vector<int32_t> node_pool((size_t)a.n_inst, left_nodes - (left_nodes / K) * K);
+    b.node_cap = left_nodes / K;
+    b.node_pool = node_pool.data();
     sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * c.P, 0);
     sub_slots[0] = 0, sub_slots[1] = 4;
     b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = inc_bits.data(), b.sub_slots = sub_slots.data();
