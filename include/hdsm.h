@@ -107,10 +107,14 @@ typedef struct hdsm_params {
                                    the previous launch (needs warm_start; default 2 x compute units + 1; negative = never)
                                                                                                     HDSM_ORDER_MIN    */
   double stage_radius;          /* [m] slack below which a neighbour row is staged (default 0.6)     HDSM_CAND_TAU     */
-  /* (Environment only, for A/B scripts: HDSM_SPLIT 0 / 1 / 2 = never / always / automatically (default) run a launch whose
-   * predecessor met a deep branch-and-bound tree as three kernels — budgeted solve, one workgroup per polyhedron of the root's
-   * branching step for the instances that exceeded the budget, merge; HDSM_SPLIT_BUDGET = that budget in nodes. The answers
-   * do not depend on it; max_nodes stays the budget of an INSTANCE, shared by its sub-searches.)                  */
+  /* (Environment only, for A/B scripts. HDSM_SPLIT 0 / 1 / 2 = never / always / automatically (default) run a launch whose
+   * predecessors met a deep branch-and-bound tree (32 nodes) as three kernels — budgeted solve; poly_hor^D workgroups for
+   * every instance that exceeded the budget, each searching the subtree its index selects at the first D branching levels;
+   * merge. HDSM_SPLIT_BUDGET = that budget in nodes (default 8 for batches that leave CUs idle, 96 beyond),
+   * HDSM_SPLIT_DEPTH = D (1 .. 3, default 3). max_nodes stays the budget of an INSTANCE: its sub-searches start with equal
+   * shares and pass what they do not use on to the others. HDSM_PICK_RULE 1 (default) / 0: the row that enters the working
+   * set next is the most violated one in the metric of the problem (violation / sqrt(a' Z a)) / the most violated one.
+   * None of these changes an answer that is HDSM_OPTIMAL.)                                                       */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and
    * returns the incumbent (HDSM_LIMIT) or HDSM_NO_SOLUTION — what Gurobi does, and just as irreproducible. 0 = none
