@@ -550,3 +550,28 @@ def test_subtree_splitting_gives_the_unsplit_answer(hdsm, oracle, depth, monkeyp
         want = float(c["obj"])
         assert g["status"][0] == 0 and abs(g["obj"][0] - want) < 1e-6 * max(1.0, abs(want)), (k, g["obj"], want, g["nodes"])
         es.close()
+
+
+def test_pick_rule_changes_the_path_not_the_answer(hdsm, oracle, monkeypatch):
+    """HDSM_PICK_RULE = 0 (most violated row first) and 1 (most violated in the metric of the problem, the default): two paths of
+    the dual method to the same optimum — same statuses, same trajectories, on plain, turning and branching corridors and on an
+    infeasible batch (agents far above the velocity limit); the default needs no more operations in total."""
+    prm = agile_params(10, max_rows_static=18)
+    monkeypatch.setenv("HDSM_PICK_RULE", "0")
+    raw = hdsm.Solver(prm, 25, 25)
+    monkeypatch.setenv("HDSM_PICK_RULE", "1")
+    nrm = hdsm.Solver(prm, 25, 25)
+    ops = [0, 0]
+    for seed, kw in [(71, dict(spacing=1.2)), (72, dict(turn=True, spacing=1.0)), (73, dict(narrow=True, turn=True)), (74, dict(spacing=0.8))]:
+        sn = problems.swarm_snapshot(prm, 25, seed, **kw)
+        if seed == 74:
+            sn["state"] = sn["state"].copy()
+            sn["state"][::3, 3] = 40.0
+        args = [sn[k] for k in ARG_KEYS]
+        o = oracle.replan(prm, *args, n_threads=8)
+        for k, sol in enumerate((raw, nrm)):
+            g = sol.replan(*args)
+            compare(g, o)
+            ops[k] += int(g["qp_iters"].sum())
+    print("operations, raw rule vs normalised rule:", ops)
+    assert ops[1] <= ops[0]
