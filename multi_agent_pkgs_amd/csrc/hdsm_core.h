@@ -1088,7 +1088,9 @@ struct Solver {
       long long* pr = a.prof + (int64_t)inst * 32;
       unsigned hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw, pr[4] = iters;
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw | ((long long)(xcc & 15u) << 32), pr[4] = iters;
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
       pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q, pr[14] = s.n_nogood, pr[15] = s.ng_skipped;
     }
