@@ -263,7 +263,11 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
 #define HDSM_FLAG_NODE_LIMIT 1u       /* max_nodes spent                                                        */
 #define HDSM_FLAG_ITER_LIMIT 2u       /* max_qp_iters spent                                                     */
 #define HDSM_FLAG_TIME_LIMIT 4u       /* time_limit_s spent                                                     */
-#define HDSM_FLAG_STAGING_OVERFLOW 8u /* more violated neighbour rows than staging slots: not a search budget   */
+#define HDSM_FLAG_STAGING_OVERFLOW 8u /* more violated neighbour rows than staging slots: not a search budget. The kernels that
+                                       * share a compute unit (large batches) have fewer slots than the one-per-CU kernel;
+                                       * hdsm_replan solves an instance that overflowed them again at once with the large
+                                       * area, hdsm_replan_device reports the flag on the first launch and adds that rescue
+                                       * pass to the launches that follow (the handle keeps it on for 256 launches)        */
 int hdsm_last_sweep_stats(void* handle, int32_t n_inst, int32_t* sphere_records, int32_t* pairs, uint32_t* flags);
 
 /* Duration of the SOLVER KERNEL of the last hdsm_replan[_device] / hdsm_solve on this handle, by HIP events recorded on the

@@ -51,6 +51,7 @@ __device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts
     if (a.split_info[2 * inst] == 0) return;  // (uniform: the whole workgroup leaves)
   } else {
     inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, out = inst;
+    if (a.rescue && !(a.st_flags[inst] & hdsm::FLAG_STAGING_OVERFLOW)) return;  // (uniform)
   }
   Sol::solve_instance(s, c, a, inst, out, sub);
 }
@@ -488,6 +489,11 @@ struct Handle {
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
   int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 8 nodes for batches that leave CUs idle, 96 beyond
+  int32_t* h_ovf_flag = nullptr;    // pinned host word: an instance ended on a staging overflow (Args::ovf_flag), and its device alias
+  int32_t* d_ovf_flag = nullptr;
+  int rescue_ttl = 0;               // launches left that carry the rescue pass
+  bool last_small = false;          // the last launch used a kernel shape with a reduced staging area
+  hdsm::Args last_args;             // ... and its arguments (the host-buffer path adds the rescue pass at once)
   int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
   int32_t* d_tree_flag = nullptr;
   int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
@@ -633,6 +639,15 @@ __global__ __launch_bounds__(64) void k_split_merge(int N, int P, int K, hdsm::A
 
 hipError_t ensure_sub(Handle* h);
 
+// the one-per-CU kernel (largest staging area) over the batch of `a`; only instances flagged HDSM_FLAG_STAGING_OVERFLOW work
+int launch_rescue(Handle* h, const hdsm::Args& a, hipStream_t st) {
+  hdsm::Args r = a;
+  r.rescue = 1, r.order = nullptr, r.split_budget = 0, r.sub_k = 0, r.split_info = nullptr, r.inc_bits = nullptr, r.node_pool = nullptr;
+  r.sub_slots = nullptr, r.tree_flag = nullptr, r.tree_mark = 0, r.warm_out = r.warm, r.ovf_flag = nullptr;
+  if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, r, st, r.n_inst) : launch_nv<32, 256>(h, r, st, r.n_inst);
+  return h->threads == 64 ? launch_nv<48, 64>(h, r, st, r.n_inst) : launch_nv<48, 256>(h, r, st, r.n_inst);
+}
+
 int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.scratch = h->d_scratch;
   a.scratch_stride = h->scratch_stride;
@@ -668,9 +683,11 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // with 256 threads the other three waves of the CU share the sweeps, the set-up and the leaf test.
   int rc;
   if (h->time_kernel) HIP_TRY(hipEventRecord(h->ev_k0, st));
+  bool small = false;  // a kernel shape with a reduced staging area was used (two or three workgroups per CU)
   auto solve = [&](const hdsm::Args& x, int blocks) -> int {  // the kernel shape that suits `blocks` workgroups
     hdsm::Args y = x;
     y.n_inst = x.n_inst;
+    small = small || (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min);
     if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && blocks >= h->tri_min) return launch_tri(h, y, st, blocks);
     if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo(h, y, st, blocks);
     if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, y, st, blocks) : launch_nv<32, 256>(h, y, st, blocks);
@@ -679,6 +696,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   };
   a.warm_out = a.warm;
   a.tree_flag = h->d_tree_flag;
+  a.ovf_flag = h->d_ovf_flag, a.rescue = 0;
   // nodes after which an instance is handed over: small batches leave most CUs idle, so sub-blocks are free; in a batch that
   // fills the GPU every handed-over instance costs poly_hor set-ups and sweeps on busy CUs, so only the deep trees go
   const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 8 : 96);
@@ -727,6 +745,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     // few, long-running workgroups: one per CU with the large staging area, whatever G is)
     // (two split levels: up to poly_hor^2 workgroups per handed-over instance — two per CU, as for a large batch)
     const bool many = h->threads == 256 && h->duo_min > 0 && (a.n_inst >= h->duo_min || K > h->P);
+    small = small || many;
     if (h->n <= hdsm::SPLIT_N_MAX) rc = many ? launch_duo(h, b, st, G) : (h->threads == 64 ? launch_nv<32, 64>(h, b, st, G) : launch_nv<32, 256>(h, b, st, G));
     else if (many) rc = launch_duo48(h, b, st, G);  // (large batches hand over hundreds of instances)
     else rc = h->threads == 64 ? launch_nv<48, 64>(h, b, st, G) : launch_nv<48, 256>(h, b, st, G);
@@ -735,6 +754,20 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     HIP_TRY(hipGetLastError());
   }
   if (rc) return rc;
+  // Staging overflow. The kernels that share a CU have a fraction of the staging rows of the one-per-CU kernel (384 / 768 / 320
+  // against 1536 / 1024); an instance in a very dense neighbourhood can fill them with VIOLATED rows alone and then ends with
+  // HDSM_FLAG_STAGING_OVERFLOW. It raises a word in pinned host memory; while the handle has seen that word in the last 256
+  // launches, every launch that used such a kernel is followed by a rescue pass — the one-per-CU kernel over the batch, in
+  // which only the instances that carry the flag are solved again (the host-buffer entry point adds it at once, see hdsm_replan).
+  h->last_small = small, h->last_args = a;
+  if (small && h->h_ovf_flag != nullptr) {
+    if (*h->h_ovf_flag != 0) *h->h_ovf_flag = 0, h->rescue_ttl = 256;
+    if (h->rescue_ttl > 0) {
+      --h->rescue_ttl;
+      rc = launch_rescue(h, a, st);
+      if (rc) return rc;
+    }
+  }
   if (h->time_kernel) {
     HIP_TRY(hipEventRecord(h->ev_k1, st));
     h->timed = true;
@@ -790,6 +823,7 @@ void free_all(Handle* h) {
   for (void* p : sub)
     if (p) (void)hipFree(p);
   if (h->h_tree_flag) (void)hipHostFree(h->h_tree_flag);
+  if (h->h_ovf_flag) (void)hipHostFree(h->h_ovf_flag);
   if (h->h_out) (void)hipHostFree(h->h_out);
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
                   h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
@@ -938,6 +972,11 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_obj, I));
   ok(dmalloc(&h->d_has, (size_t)n_rob_max));
   ok(dmalloc(&h->d_used, I * P));
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->h_ovf_flag), sizeof(int32_t), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *h->h_ovf_flag = 0;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_ovf_flag), h->h_ovf_flag, 0);
+  }
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->h_tree_flag), sizeof(int32_t), hipHostMallocMapped);
   if (e == hipSuccess) {
     *h->h_tree_flag = 0;
@@ -1023,6 +1062,14 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
                               h->d_A, h->d_b, h->d_plans, h->d_has, h->d_traj, h->d_ctrl, h->d_used,
                               h->d_status, h->d_obj, st);
   if (rc) return rc;
+  if (h->last_small && h->h_ovf_flag != nullptr && h->rescue_ttl == 0) {  // (a launch that already carried the rescue pass needs no second one)
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*h->h_ovf_flag != 0) {  // an instance ran out of staging rows in a shared-CU kernel: solve it again now, with the large area
+      *h->h_ovf_flag = 0, h->rescue_ttl = 256;
+      rc = launch_rescue(h, h->last_args, st);
+      if (rc) return rc;
+    }
+  }
   // Outputs are "left untouched" for instances without a solution. The caller's arrays are not uploaded to seed the device
   // copies (a megabyte each way per 1024 agents): the results come back into a pinned staging block of the handle and only
   // the instances that HAVE a solution are copied into the caller's arrays.

@@ -1113,6 +1113,7 @@ struct Solver {
         const long long ticks = (((long long)wall_clock64() - tl_begin_) >> 6) + 9 * s.q;
         a.st_key[out] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
+      if (a.ovf_flag != nullptr && (flags & FLAG_STAGING_OVERFLOW)) *a.ovf_flag = 1;
       if (my_slot >= 0) atomicExch(&a.sub_slots[2 + my_slot], 0);  // (all snapshot traffic of this workgroup is behind it)
       if (a.node_pool != nullptr && s.node_res > 0) atomicAdd(&a.node_pool[inst], s.node_res);  // the unused part of the share: to the instance's pool
     }

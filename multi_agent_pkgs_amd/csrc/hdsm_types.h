@@ -132,6 +132,9 @@ struct Args {
                           // split launch, by the merge for a handed-over instance with a deep tree (TREE_MARK nodes over all its
                           // sub-blocks) — the handle keeps the NEXT launches in the split form while it sees it
   int32_t tree_mark;      // ordinary launches: node count from which an instance raises tree_flag (0 = never)
+  int32_t rescue;         // 1: this launch only re-solves the instances whose last answer carries HDSM_FLAG_STAGING_OVERFLOW (st_flags), with the
+                          // large staging area of the one-per-CU kernel; the others leave at once
+  int32_t* ovf_flag;      // host-visible word an instance raises when it ends on a staging overflow (the handle then adds the rescue pass)
   int32_t* warm_out;      // where the NEXT replan's guess is written: warm itself, or the per-sub-block copy of pass 2
   int32_t* st_key;    // launch-order key for the NEXT launch: duration of this instance in 0.64-us units + 9 per active row (<= 254), 255 = no solution
 };

@@ -285,3 +285,50 @@ def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
     topics, pub, dlv = (int(x) for x in m.groups())
     assert topics == 8 and pub == dlv and pub >= 8 * 14, r.stdout          # one subscriber per topic: the other node
     assert "node 0: remote plans known 4 of 4, rounds 15" in r.stdout and "node 1: remote plans known 4 of 4, rounds 15" in r.stdout, r.stdout
+
+
+def test_staging_overflow_in_a_shared_cu_kernel_is_rescued(hdsm, oracle, monkeypatch):
+    """The kernels that share a CU have a fraction of the staging rows of the one-per-CU kernel. A dense H = 15 neighbourhood
+    (36 agents 1.3 m apart, all within reach over the horizon) fills the 320 rows of the two-per-CU kernel with violated rows
+    alone. Host buffers (hdsm_replan): the instances that overflowed are solved again at once with the large staging area —
+    the oracle's answers come back. Device pointers (hdsm_replan_device, nothing to wait for): the first launch reports
+    them honestly (HDSM_FLAG_STAGING_OVERFLOW, never a wrong optimum); once the handle has seen the flag the following
+    launches carry the rescue pass."""
+    import torch
+    from test_gpu_fuzz import _case, K
+    rng = np.random.default_rng(12345)
+    for case in range(12):
+        prm, n_rob, kw, sn = _case(rng, case)
+    assert prm.n_hor == 15 and n_rob == 36          # case 11 of the fuzz sequence
+    args = [sn[k] for k in K]
+    big = prm.copy()
+    big.max_nodes, big.max_qp_iters = 500000, 100000000
+    o = oracle.replan(big, *args, n_threads=32, search=1)
+    monkeypatch.setenv("HDSM_DUO_MIN", "1")
+    sol = hdsm.Solver(prm, n_rob, n_rob)
+    sol_dev = hdsm.Solver(prm, n_rob, n_rob)
+    monkeypatch.delenv("HDSM_DUO_MIN")
+    g = sol.replan(*args)
+    assert (g["status"] == o["status"]).all() and (sol.last_sweep_stats(n_rob)["flags"] & 8 == 0).all()
+    ok = o["status"] == 0
+    assert np.abs(g["traj"] - o["traj"])[ok].max() < 1e-6
+    # the asynchronous entry point
+    dev = torch.device("cuda", 0)
+    dt = dict(agent_id=torch.int32, state=torch.float64, ref=torch.float64, n_poly=torch.int32, n_rows=torch.int32,
+              A=torch.float64, b=torch.float64, plans=torch.float64, has_plan=torch.uint8)
+    d = {k: torch.from_numpy(np.ascontiguousarray(sn[k])).to(dev).to(dt[k]).contiguous() for k in K}
+    N, P = prm.n_hor, prm.poly_hor
+    out = dict(traj=torch.zeros((n_rob, N + 1, 9), dtype=torch.float64, device=dev), ctrl=torch.zeros((n_rob, N, 3), dtype=torch.float64, device=dev),
+               used=torch.zeros((n_rob, P), dtype=torch.uint8, device=dev), status=torch.zeros(n_rob, dtype=torch.int32, device=dev),
+               obj=torch.zeros(n_rob, dtype=torch.float64, device=dev))
+    flagged = []
+    for call in range(2):
+        sol_dev.replan_device(*[d[k] for k in K], out["traj"], out["ctrl"], out["used"], out["status"], out["obj"])
+        torch.cuda.synchronize()
+        st, fl = out["status"].cpu().numpy(), sol_dev.last_sweep_stats(n_rob)["flags"]
+        flagged.append(int((fl & 8 != 0).sum()))
+        wrong = (st != o["status"]) & (fl & 8 == 0)
+        assert not wrong.any(), (call, np.where(wrong)[0].tolist())             # an answer without the flag is the oracle's
+        same = (st == 0) & (o["status"] == 0) & (fl & 8 == 0)
+        assert np.abs(out["traj"].cpu().numpy() - o["traj"])[same].max() < 1e-6
+    assert flagged[0] > 0 and flagged[1] == 0 and (st == o["status"]).all(), flagged

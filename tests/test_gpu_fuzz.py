@@ -4,7 +4,9 @@ neighbours — each solved twice on one handle (cold, then warm-started from its
 instance with the oracle. EVERY device answer is verified: up to H = 10 by the oracle's step-ordered search and, where
 that runs into its budget, by its second search order (most infeasible step first, orc_replan_ex); beyond H = 10 by the
 second order directly (the enumeration in step order needs minutes per instance there). An oracle answer with status
-LIMIT is never accepted as a verdict."""
+LIMIT is never accepted as a verdict. Every case also goes through the OTHER launch forms the handle would pick for large
+batches or deep trees — the kernels that share a CU (reduced staging area, with the rescue pass for instances that overflow
+it) and the three-kernel subtree split with a two-node budget — forced here by the HDSM_* environment knobs."""
 import numpy as np
 import pytest
 
@@ -30,7 +32,12 @@ def _case(rng, case):
     return prm, n_rob, kw, problems.swarm_snapshot(prm, n_rob, seed=1000 + case, **kw)
 
 
-def test_fuzz_every_device_answer_is_verified_by_the_oracle(oracle):
+FORMS = [dict(),                                                              # what the handle picks for the batch by itself
+         dict(HDSM_DUO_MIN="1", HDSM_TRI_MIN="1"),                            # shared-CU kernels (three / two workgroups per CU)
+         dict(HDSM_SPLIT="1", HDSM_SPLIT_BUDGET="2")]                         # subtree split, poly_hor^3 sub-blocks per tree
+
+
+def test_fuzz_every_device_answer_is_verified_by_the_oracle(oracle, monkeypatch):
     from multi_agent_pkgs_amd import lib
     rng = np.random.default_rng(12345)
     tot = n15 = reproved = limits = 0
@@ -54,25 +61,30 @@ def test_fuzz_every_device_answer_is_verified_by_the_oracle(oracle):
         else:                 # long horizons: the step-ordered enumeration needs minutes per instance, the other order milliseconds
             o = oracle.replan(big, *args, n_threads=THREADS, search=1)
         assert (o["status"] != 1).all(), (case, np.where(o["status"] == 1)[0].tolist())
-        sol = lib.Solver(prm, n_rob, n_rob)   # fresh handle: cold start; the second call exercises the warm start
-        for rep in range(2):
-            g = sol.replan(*args)
-            tot += n_rob
-            n15 += n_rob * (prm.n_hor == 15)
-            limits += int((g["status"] == 1).sum())
-            assert (g["status"] == o["status"]).all(), (case, rep, kw, np.where(g["status"] != o["status"])[0].tolist(),
-                                                        g["status"].tolist(), o["status"].tolist())
-            ok = o["status"] == 0
-            if ok.any():
-                dt = np.abs(g["traj"] - o["traj"])[ok].reshape(ok.sum(), -1).max(1)
-                do = np.abs(g["obj"] - o["obj"])[ok] / np.maximum(1, np.abs(o["obj"][ok]))
-                assert do.max() < 1e-6, (case, rep, float(do.max()))
-                # a different but equally good optimum (objective equal to 1e-9) is a tie of the MIQP, not an error
-                tie = (dt > 1e-6) & (do < 1e-9)
-                assert ((dt < 1e-6) | tie).all(), (case, rep, np.where(ok)[0][(dt >= 1e-6) & ~tie].tolist(), dt.max())
-                worst_t = max(worst_t, float(dt[~tie].max()) if (~tie).any() else 0.0)
-                worst_o = max(worst_o, float(do.max()))
-        sol.close()
+        for form in FORMS:
+            for k_, v_ in form.items():
+                monkeypatch.setenv(k_, v_)
+            sol = lib.Solver(prm, n_rob, n_rob)   # fresh handle: cold start; the second call exercises the warm start
+            for k_ in form:
+                monkeypatch.delenv(k_)
+            for rep in range(2):
+                g = sol.replan(*args)
+                tot += n_rob
+                n15 += n_rob * (prm.n_hor == 15)
+                limits += int((g["status"] == 1).sum())
+                assert (g["status"] == o["status"]).all(), (case, form, rep, kw, np.where(g["status"] != o["status"])[0].tolist(),
+                                                            g["status"].tolist(), o["status"].tolist())
+                ok = o["status"] == 0
+                if ok.any():
+                    dt = np.abs(g["traj"] - o["traj"])[ok].reshape(ok.sum(), -1).max(1)
+                    do = np.abs(g["obj"] - o["obj"])[ok] / np.maximum(1, np.abs(o["obj"][ok]))
+                    assert do.max() < 1e-6, (case, form, rep, float(do.max()))
+                    # a different but equally good optimum (objective equal to 1e-9) is a tie of the MIQP, not an error
+                    tie = (dt > 1e-6) & (do < 1e-9)
+                    assert ((dt < 1e-6) | tie).all(), (case, form, rep, np.where(ok)[0][(dt >= 1e-6) & ~tie].tolist(), dt.max())
+                    worst_t = max(worst_t, float(dt[~tie].max()) if (~tie).any() else 0.0)
+                    worst_o = max(worst_o, float(do.max()))
+            sol.close()
     assert limits == 0 and n15 > 0
-    print(f"fuzz: {tot} instance-solves in {N_CASES} cases ({n15} at H = 15), all verified; {reproved} instances needed the "
+    print(f"fuzz: {tot} instance-solves in {N_CASES} cases x {len(FORMS)} launch forms ({n15} at H = 15), all verified; {reproved} instances needed the "
           f"oracle's second search order; worst |dtraj| {worst_t:.2e}, worst rel |dobj| {worst_o:.2e}")
