@@ -33,7 +33,8 @@ def _case(rng, case):
 
 
 FORMS = [dict(),                                                              # what the handle picks for the batch by itself
-         dict(HDSM_DUO_MIN="1", HDSM_TRI_MIN="1"),                            # shared-CU kernels (three / two workgroups per CU)
+         dict(HDSM_DUO_MIN="1", HDSM_TRI_MIN="1", HDSM_ORDER_MIN="1", HDSM_BOUNDS_MIN="1"),  # what a large batch gets: shared-CU
+                                                                              # kernels, launch order, sphere prefilter
          dict(HDSM_SPLIT="1", HDSM_SPLIT_BUDGET="2")]                         # subtree split, poly_hor^3 sub-blocks per tree
 
 
