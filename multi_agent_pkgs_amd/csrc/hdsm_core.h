@@ -28,7 +28,7 @@
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
 #define HDN __device__ __noinline__
-#define PAR_FOR(i, cnt) for (int i = (int)threadIdx.x; i < (cnt); i += (int)blockDim.x)
+#define PAR_FOR(i, cnt) for (int i = tid_here(); i < (cnt); i += (int)blockDim.x)  // (tid_here: hdsm_wave_gi.h)
 #define HDSM_UNROLL _Pragma("unroll")
 #define SYNC() __syncthreads()
 #define IS_T0 (threadIdx.x == 0)
@@ -123,6 +123,7 @@ struct Shm {
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t leaf_pick;  // result of the one-wavefront leaf test
+  double* snap;       // this workgroup's snapshot scratch (global memory; kept here, not in a register pair across the active-set run)
   int32_t node_res;   // pass 2 of a split launch: nodes drawn from the instance's pool and not yet opened
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
@@ -210,7 +211,7 @@ struct Solver {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
     if (!explicit_rows) {  // device build: one thread per (neighbour, step) pair, sphere prefilter (hdsm_wave_gi.h)
-      WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, (int)threadIdx.x);
+      WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, tid_here());
       return;
     }
     const int total = explicit_rows ? N * a.l1_rmax : a.n_rob * N;
@@ -316,7 +317,7 @@ struct Solver {
       // workgroup barrier inside (the version below spends four, and two runtime divisions per item: 2.7 us per leaf test on
       // the bench rounds against 0.4 us for this one). The other wavefronts wait at the barrier that publishes the result.
       if (threadIdx.x < 64) {
-        const int lane = (int)threadIdx.x;
+        const int lane = tid_here();
         const bool on = lane < N * np;
         // (N np <= 64: the quotient by a small runtime np is exact in single precision)
         const int i = on ? (int)(((float)lane + 0.5f) * (1.0f / (float)np)) : 0, j = on ? lane - i * np : 0;
@@ -342,7 +343,7 @@ struct Solver {
         // lane i < N: its step
         const int my_a = lane < N ? s.assign[lane] : 0;
         const unsigned fits = lane < N ? (unsigned)((inside >> (lane * np)) & ((1ull << np) - 1ull)) : 1u;
-        const int cont = (lane < N) ? (my_a >= 0 ? my_a : (fits != 0u ? __ffsll((long long)fits) - 1 : -1)) : 0;
+        const int cont = (lane < N) ? (my_a >= 0 ? my_a : (fits != 0u ? __builtin_ffs((int)fits) - 1 : -1)) : 0;
         if (lane < N) s.contain[lane] = cont;
         wsync();
         double best = -DINF;  // smallest violation among the polyhedra of an uncontained step (-DINF: contained / no step)
@@ -444,7 +445,10 @@ struct Solver {
   // The factorisation lives in the registers of wave 0; the other waves of the workgroup (they take part in the
   // sweeps, the set-up and the leaf test) wait at the barrier and pick the outcome up from LDS.
   static HD void snapshot_io(S& s, const Consts& c, GIState& R, double* buf, bool save) {
-    if (threadIdx.x < 64) W::snapshot(s, R, buf, save, (int)threadIdx.x);
+    // (the per-lane addresses of a snapshot are formed here, when one is taken: hoisted out of the branch-and-bound loop they
+    // were kept alive across the whole active-set run — 37 dwords per lane spilled to scratch by EVERY instance, tree or not)
+    buf = keep_in_loop(buf);
+    if (threadIdx.x < 64) W::snapshot(s, R, buf, save, tid_here());
     SYNC();
   }
   static HD int gi_run(S& s, const Consts& c, GIState& R, double f_cut, int& iters) {
@@ -470,7 +474,7 @@ struct Solver {
 
   // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
   // assigns the child's polyhedron. Returns false when the tree is exhausted (or the node budget is).
-  static HD bool select_child(S& s, const Consts& c, GIState& R, double* snap, int& nodes, bool& limit, int inst, bool& handed_over) {
+  static HD bool select_child(S& s, const Consts& c, GIState& R, int& nodes, bool& limit, int inst, bool& handed_over) {
     if (s.args.inc_bits != nullptr) {  // pass 2 of a split launch: what the other sub-blocks of this instance have found
       SYNC();
       if (IS_T0) {
@@ -522,7 +526,7 @@ struct Solver {
         ++nodes;
         const int j = s.br_order[L][pos];
         SYNC();
-        if (pos > 0) snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, false);
+        if (pos > 0) snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, false);
         if (IS_T0) {
           s.br_pos[L] = pos + 1;
           s.assign[s.br_step[L]] = j;
@@ -569,6 +573,7 @@ struct Solver {
       snap = a.scratch + (int64_t)(no_slot ? 0 : my_slot) * a.scratch_stride;
       SYNC();
     }
+    if (IS_T0) s.snap = snap;  // (read back at the few places a snapshot is taken or restored; published by the set-up's barriers)
 
     const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
 #ifdef HDSM_PROFILE
@@ -815,7 +820,7 @@ struct Solver {
         // at most |n_f| |dp| with |n_f| <= sqrt(1 + (3 pert)^2) (the planes themselves are fixed during an instance).
         // If no trajectory point has moved further than that allows, nothing unstaged can be violated: no sweep.
         if (threadIdx.x < 64) {
-          const int m = (int)threadIdx.x;
+          const int m = tid_here();
           double d2 = 0;
           if (m <= N) {
             const double ux = s.st[m][0] - s.sw_ref[m][0], uy = s.st[m][1] - s.sw_ref[m][1], uz = s.st[m][2] - s.sw_ref[m][2];
@@ -861,7 +866,7 @@ struct Solver {
       }
     };
     if (run && warm_cert && c.presweep != 0 && a.l1_rows == nullptr) {
-      if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
+      if (threadIdx.x < 64) W::states(s, R, tid_here(), N);
       SYNC();
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // still gridlocked: infeasible whatever the choice
@@ -885,7 +890,7 @@ struct Solver {
       // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
       // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
       // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
-      if (threadIdx.x < 64) W::states(s, R, (int)threadIdx.x, N);
+      if (threadIdx.x < 64) W::states(s, R, tid_here(), N);
       SYNC();
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
@@ -944,7 +949,7 @@ struct Solver {
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level;
-          snapshot_io(s, c, R, snap + (int64_t)L * SNAP_STRIDE, true);
+          snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, true);
           if (IS_T0) {
             int cnt = 0;
             for (int j = 0; j < np; ++j)
@@ -997,7 +1002,7 @@ struct Solver {
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
       const bool lim_before = limit;
-      run = select_child(s, c, R, snap, nodes, limit, inst, handed_over);
+      run = select_child(s, c, R, nodes, limit, inst, handed_over);
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
@@ -1041,7 +1046,7 @@ struct Solver {
       SYNC();
       PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
       if (threadIdx.x < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
-        const int lane = (int)threadIdx.x;
+        const int lane = tid_here();
         double part = (lane < n) ? c.r_u * s.inc_x[lane] * s.inc_x[lane] : 0.0;
         for (int idx = lane; idx < 6 * N; idx += 64) {
           const int i = idx / 6 + 1, k = idx % 6;

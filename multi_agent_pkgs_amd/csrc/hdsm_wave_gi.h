@@ -110,6 +110,23 @@ __device__ __forceinline__ void keep_in_loop(int& v) {
 #endif
 }
 
+// threadIdx.x as a value formed HERE: the thread-indexed LDS addresses of the all-thread loops (PAR_FOR) are then computed where
+// they are used; hoisted out of the branch-and-bound loop they stayed alive across the active-set run and were spilled
+__device__ __forceinline__ int tid_here() {
+  int t = (int)threadIdx.x;
+  keep_in_loop(t);
+  return t;
+}
+
+// ... and the same for a pointer
+template <class T>
+__device__ __forceinline__ T* keep_in_loop(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(p));
+#endif
+  return p;
+}
+
 struct alignas(16) D2 {
   double x, y;
 };
@@ -1067,6 +1084,7 @@ struct WaveGI {
   // snapshots: J rows from registers, U rows / multipliers / ids / x from LDS; layout [row j][lane]
   static constexpr int SNAP_DOUBLES = (2 * NV + 3) * NV + 2;
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
+    keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
     const int row = row_of(lane), c0 = col0_of(lane);
     if (row_ok(lane)) {
       if (save) {

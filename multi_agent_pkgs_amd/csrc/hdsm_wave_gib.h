@@ -481,6 +481,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
   // snapshots: J slots from registers (layout [slot][lane]), U rows / multipliers / ids / x from LDS
   static constexpr int SNAP_DOUBLES = Base::SNAP_DOUBLES;
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
+    keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
     const int row = Base::row_of(lane), c0 = Base::col0_of(lane);
     if (save) {
 #pragma unroll
