@@ -363,7 +363,11 @@ struct WaveGIB : WaveGI<32, CMAX> {
     load_pos(s, R, lane);
     PROF_DECL
     for (;;) {
-      Base::states(s, R, lane, N);
+      // (the lane masks and addresses of the state evaluation and the scan are formed here, per operation: hoisted out of
+      // the loop they sat in spilled SGPR pairs and came back through v_readlane, 18 per operation)
+      int ln = lane;
+      keep_in_loop(ln);
+      Base::states(s, R, ln, N);
       PROF(0)
       int ip;
       double vip;
@@ -371,7 +375,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
         ip = mk_id(K_E, neq);
         vip = Base::resid(s, c, ip, N);
       } else {
-        Base::select(s, c, R, lane, tol, N, vip, ip);
+        Base::select(s, c, R, ln, tol, N, vip, ip);
         ip = uni(ip);
         if (ip < 0) {
           if (Base::promote_cold(s, lane, tol) > 0) continue;
