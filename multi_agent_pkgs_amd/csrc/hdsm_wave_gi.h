@@ -972,7 +972,9 @@ struct WaveGI {
     int rc = GI_OK;
     PROF_DECL
     for (;;) {
-      states(s, R, lane, N);
+      int ln = lane;  // (lane masks and addresses of the state evaluation and the scan: formed per operation, see hdsm_wave_gib.h)
+      keep_in_loop(ln);
+      states(s, R, ln, N);
       PROF(0)
       int ip;
       double vip;
@@ -980,7 +982,7 @@ struct WaveGI {
         ip = mk_id(K_E, neq);
         vip = resid(s, c, ip, N);
       } else {
-        select(s, c, R, lane, tol, N, vip, ip);
+        select(s, c, R, ln, tol, N, vip, ip);
         ip = uni(ip);
         if (ip < 0) {
           if (promote_cold(s, lane, tol) > 0) continue;
