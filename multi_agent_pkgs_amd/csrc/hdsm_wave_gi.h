@@ -31,8 +31,10 @@ namespace hdsm {
 template <int CTRL>
 __device__ __forceinline__ double dpp64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // (every control used with dpp64 is a permutation inside the row: each lane receives a value, so there is no "old" value to keep —
+  // with update_dpp(x, x, ...) the compiler copied x first: one v_mov_b32 per v_mov_b32_dpp, 170 of them per active-set operation)
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double bcast64(double v, int lane) {  // lane must be wave-uniform
@@ -58,8 +60,8 @@ __device__ __forceinline__ double wave_sum64(double v) {  // every lane gets the
 template <int CTRL>
 __device__ __forceinline__ double dpp64z(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);  // (bound_ctrl: a lane that reads from outside its row gets 0)
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 // suffix sum over the wave: out[i] = sum_{k >= i} v[k]   (row_shl scans + row totals through v_readlane)

@@ -233,6 +233,7 @@ inline int wemu_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, boo
   return from >= 0 ? wemu::my_wave().xi[p][row + from] : (bound_ctrl ? 0 : old);
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wemu_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_mov_dpp(src, ctrl, rm, bm, bc) wemu_dpp(0, (src), (ctrl), (rm), (bm), (bc))  // (no `old`: undefined where no lane is read)
 // v_permlane32_swap vdst, vsrc: lanes 32..63 of vdst <-> lanes 0..31 of vsrc; returns {new vdst, new vsrc}
 inline std::array<int, 2> wemu_permlane32_swap(int vdst, int vsrc, bool, bool) {
   const int me = wemu::lane();
