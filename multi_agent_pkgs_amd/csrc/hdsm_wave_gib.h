@@ -131,8 +131,9 @@ struct WaveGIB : WaveGI<32, CMAX> {
   // vector v = d2 - rho e_q: (J2 v) comes from the same gathered v that the rank-1 update multiplies
   static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dz, double zz,
                                                          double dq, double ri) {
-    const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
-    const double beta = 1.0 / (rho * (rho - dq));
+    const double inv_rho_abs = rsq_nr(zz);  // (zz > 0: the caller has tested it against ||d||^2)
+    const double rho = (dq > 0 ? -1.0 : 1.0) * (zz * inv_rho_abs), inv_rho = (dq > 0 ? -1.0 : 1.0) * inv_rho_abs;
+    const double beta = rcp_nr(rho * (rho - dq));
     const int pos = pos_of(lane);
     double g[NC];
     gather_cols(pos == q ? dz - rho : dz, g);
@@ -142,7 +143,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
     const double coef = half_sum64(w0 + w1) * beta;
 #pragma unroll
     for (int k = 0; k < NC; ++k) R.Jr[k] -= coef * g[k];
-    if (first_copy(lane)) s.U[pos * LDT + q] = (pos < q) ? -ri / rho : ((pos == q) ? 1.0 / rho : 0.0);
+    if (first_copy(lane)) s.U[pos * LDT + q] = (pos < q) ? -ri * inv_rho : ((pos == q) ? inv_rho : 0.0);
     if (pos == q) R.lam = lam_p, R.act = id;
     wsync();
   }
@@ -165,8 +166,9 @@ struct WaveGIB : WaveGI<32, CMAX> {
     double s0 = 0, s1 = 0;
 #pragma unroll
     for (int j = 0; j < NC; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
-    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(row16_sum64(s0 + s1));
-    const double beta = 1.0 / (sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
+    const double ss = row16_sum64(s0 + s1);  // |u_l|^2 > 0: u_l is a row of the inverse of a regular triangular factor
+    const double sigma = (ut > 0 ? -1.0 : 1.0) * (ss * rsq_nr(ss));
+    const double beta = rcp_nr(sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
     // J (registers): x -= (x . v) beta v with the complete v
     {
       double g[NC];
@@ -441,7 +443,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
           PROF(7)
           continue;
         }
-        const double t2 = vip / zz;
+        const double t2 = vip * rcp_nr(zz);  // (not dependent: zz > 1e-20 ||d||^2 > 0)
         const bool full = is_eq || t2 <= t1;
         const double t = full ? t2 : t1;
         R.xi += t * zi;  // (lanes beyond n carry zeros: z is zero on padded rows)

@@ -261,3 +261,4 @@ inline std::array<int, 2> wemu_permlane16_swap(int vdst, int vsrc, bool, bool) {
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)wemu::rendezvous(9))  // wsync(): on the device the lanes are in lockstep anyway
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))
+#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
