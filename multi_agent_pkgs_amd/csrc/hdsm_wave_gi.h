@@ -300,33 +300,43 @@ struct WaveGI {
   }
 
   // violation of staged rows [lo, hi) -> running pick; four rows per trip, loads issued before first use
-  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double tol, bool norm, Pick& pk,
-                                                   int stride = 256) {
+  // UN rows per lane and trip (64 UN rows per trip of the wavefront), loads issued before first use
+  template <int UN>
+  static __device__ __forceinline__ void scan_rows_n(const S& s, int lo, int hi, int lane, double tol, bool norm, Pick& pk, int stride) {
     for (int base = lo; base < hi; base += stride) {
-      int idx[4];
-      MW mw[4];
-      D2 r01[4], r23[4];
+      int idx[UN];
+      MW mw[UN];
+      D2 r01[UN], r23[UN];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UN; ++u) {
         idx[u] = base + 64 * u + lane;
         const int ii = idx[u] < hi ? idx[u] : lo;
         mw[u] = s.cand_mw[ii];
         r01[u] = *reinterpret_cast<const D2*>(&s.cand[ii][0]);
         r23[u] = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
       }
-      double px[4], py[4], pz[4];
+      double px[UN], py[UN], pz[UN];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UN; ++u) {
         const double* pm = s.st[mw[u].m];
         px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UN; ++u) {
         const double vv = r01[u].x * px[u] + r01[u].y * py[u] + r23[u].x * pz[u] - r23[u].y;
         const double key = norm ? (double)((float)vv * mw[u].w) : vv;
         if (idx[u] < hi && vv > tol && key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_kc(idx[u], mw[u].m);
       }
     }
+  }
+  // violation of staged rows [lo, hi) -> running pick. The operation is bound by the instructions its wavefront issues, and the
+  // usual staging area holds 90-180 rows: one, two or four rows per lane, whatever covers [lo, hi) in one trip
+  static __device__ __forceinline__ void scan_rows(const S& s, int lo, int hi, int lane, double tol, bool norm, Pick& pk,
+                                                   int stride = 256) {
+    const int cnt = hi - lo;
+    if (stride == 256 && cnt <= 64) scan_rows_n<1>(s, lo, hi, lane, tol, norm, pk, 64);
+    else if (stride == 256 && cnt <= 128) scan_rows_n<2>(s, lo, hi, lane, tol, norm, pk, 128);
+    else scan_rows_n<4>(s, lo, hi, lane, tol, norm, pk, stride);
   }
 
   // Rows of the polyhedra assigned on the current branch: lane t < rows tests row t at p_i, lane rows + t at p_{i+1}, one
