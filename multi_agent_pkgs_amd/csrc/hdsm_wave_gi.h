@@ -376,9 +376,10 @@ struct WaveGI {
         if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
       }
     };
+    // (a box: at most one side is violated, and with the same weight the larger violation wins anyway — ONE candidate per box)
     if (lane < c.n) {  // box of this lane's input (lane = variable; its axis is R.ax)
-      offer(R.xi - s.bnd[3 + R.ax], R.wu, mk_id(K_U, lane << 1));
-      offer(s.bnd[R.ax] - R.xi, R.wu, mk_id(K_U, (lane << 1) | 1));
+      const double vu = R.xi - s.bnd[3 + R.ax], vl = s.bnd[R.ax] - R.xi;
+      offer(vl > vu ? vl : vu, R.wu, mk_id(K_U, (lane << 1) | (vl > vu ? 1 : 0)));
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -387,8 +388,8 @@ struct WaveGI {
       if (sid >= 0) {
         const int ca = ((sid >> 3) & 3) * 3 + ((sid >> 1) & 3);  // 3 comp + axis
         const double sv = s.st[sid >> 5][ca];
-        offer(sv - s.bnd[15 + ca], R.sb_w[e], mk_id(K_S, sid));
-        offer(s.bnd[6 + ca] - sv, R.sb_w[e], mk_id(K_S, sid | 1));
+        const double vu = sv - s.bnd[15 + ca], vl = s.bnd[6 + ca] - sv;
+        offer(vl > vu ? vl : vu, R.sb_w[e], mk_id(K_S, sid | (vl > vu ? 1 : 0)));
       }
     }
     if (uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
