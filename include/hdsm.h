@@ -114,6 +114,8 @@ typedef struct hdsm_params {
    * HDSM_SPLIT_DEPTH = D (1 .. 3, default 3). max_nodes stays the budget of an INSTANCE: its sub-searches start with equal
    * shares and pass what they do not use on to the others. HDSM_PICK_RULE 1 (default) / 0: the row that enters the working
    * set next is the most violated one in the metric of the problem (violation / sqrt(a' Z a)) / the most violated one.
+   * HDSM_BOX_CUT 1 (default) / 0: a dual objective above the largest objective any point of the input box can have ends an
+   * active-set run as infeasible / only the formal proof does.
    * None of these changes an answer that is HDSM_OPTIMAL.)                                                       */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and

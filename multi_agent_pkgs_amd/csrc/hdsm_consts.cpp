@@ -93,6 +93,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   env_real("HDSM_HOT_TAU", 1e-3, 1e30, &c->hot_tau);
   c->pick_rule = 1;
   env_int("HDSM_PICK_RULE", 0, 1, &c->pick_rule);
+  c->box_cut = 1;
+  env_int("HDSM_BOX_CUT", 0, 1, &c->box_cut);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);
@@ -175,6 +177,11 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
         }
         H[(ax * N + k) * n + ax * N + l] = h;
       }
+  for (int j = 0; j < MAXNV; ++j) {  // row sums of |H| (bound of the objective over the input box), rounded up
+    double r = 0;
+    for (int k = 0; j < n && k < n; ++k) r += std::fabs(H[j * n + k]);
+    c->hrow1[j] = r * (1.0 + 1e-12);
+  }
   for (int j = 0; j < n; ++j) {
     double d = H[j * n + j];
     for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];

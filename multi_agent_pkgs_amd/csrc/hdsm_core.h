@@ -119,6 +119,7 @@ struct Shm {
   unsigned long long nogood[NOGOODS];
   int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
   int32_t ncold;  // rows staged but not scanned every iteration (top of cand[])
+  double f_box;        // upper bound of the objective over the input box (DINF: no box / Consts::box_cut off)
   double inc_shared;   // split launches: best objective found by ANY sub-block of this instance (DINF: none / ordinary launch)
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
@@ -451,10 +452,22 @@ struct Solver {
     if (threadIdx.x < 64) W::snapshot(s, R, buf, save, tid_here());
     SYNC();
   }
+  // No point of the input box has an objective above f_box (set-up), and the dual method's f only grows: once it passes f_box the
+  // working set together with the row on its way in cannot be satisfied inside the box — infeasible, proven without driving the
+  // multipliers to the formal dependency (the longest proofs of the bench rounds spend their last five operations there). The
+  // run sees one cut-off, min(incumbent bound, f_box); which of the two it was is sorted out here.
   static HD int gi_run(S& s, const Consts& c, GIState& R, double f_cut, int& iters) {
+    const double f_box = s.f_box, f_eff = f_cut < f_box ? f_cut : f_box;
+    if (s.f >= f_eff) {  // (a warm start can arrive above the bound: its guess was a certificate)
+      const int rc0 = s.f >= f_cut ? GI_CUTOFF : GI_INFEASIBLE;
+      SYNC();
+      if (IS_T0 && rc0 == GI_INFEASIBLE) s.inf_id = s.act[s.q - 1];
+      SYNC();
+      return rc0;
+    }
     if (threadIdx.x < 64) {
-      const int rc = W::run(s, c, R, f_cut, iters);
-      if (threadIdx.x == 0) s.rc = rc, s.iters_sh = iters;
+      const int rc = W::run(s, c, R, f_eff, iters);
+      if (threadIdx.x == 0) s.rc = (rc == GI_CUTOFF && !(s.f >= f_cut)) ? GI_INFEASIBLE : rc, s.iters_sh = iters;
     } else {
       W::helper_loop(s);  // waves 1..3: share the staged-row scans of wave 0's iteration
     }
@@ -592,6 +605,7 @@ struct Solver {
     GIState R;
     const int nk = 3 * n + 12, nvt = 9 + 6 * N;
     double fw0, fw1;  // weights of the (at most two) tracking residuals this lane of wave 0 squares for the constant term
+    double hrow_own;  // Consts::hrow1 of this lane's variable (the box bound of the objective, below)
     const int np = min_i(a.n_poly[inst], P);
     {
       const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
@@ -692,6 +706,7 @@ struct Solver {
       ST_PROF(11)
       // (per-lane constants of the iteration: their loads use what they fetch at once, so they come after the staging requests)
       W::init_lane(R, c, tid, lane_req);
+      hrow_own = lane_req.hrow;
       fw0 = (tid < 64) ? ((fi0 == N) ? wn0 : wx0) : 0.0;
       fw1 = (tid < 64) ? ((fi1 == N) ? wn1 : wx1) : 0.0;
       const int items = max_i(max_i(P * RS, 6 * S::LDT), max_i(9 * MAXH, 9 * (N + 1)));
@@ -756,7 +771,13 @@ struct Solver {
       t0 = wave_sum64(t0);
       const double t1 = wave_sum64(lane < n ? s.grad[lane] * s.w[lane] : 0.0);
       const double t2 = wave_sum64(lane < 6 ? s.red_v[lane] * s.lam[lane] : 0.0);
+      // the largest objective inside the input box, bounded from above: J(u) = J(x0) + (u - x0)^T H (u - x0) / 2 and
+      // w^T H w <= sum_j (sum_k |H_jk|) w_j^2, |w_j| <= the distance from x0_j to the farther end of its interval (no box: no bound)
+      double wm = 0.0;
+      if (lane < n) wm = fmax(fabs(s.bnd[3 + lane / N] - s.w[lane]), fabs(s.bnd[lane / N] - s.w[lane]));
+      const double t3 = wave_sum64(lane < n ? hrow_own * wm * wm : 0.0);
       if (lane == 0) {
+        s.f_box = c.box_cut != 0 ? (t0 + 0.5 * t1 + 0.5 * t3) * (1.0 + 1e-9) + 1e-9 : DINF;
         s.f0 = t0;
         s.fx0 = t0 + 0.5 * t1;
         s.f = s.fx0 + 0.5 * t2;

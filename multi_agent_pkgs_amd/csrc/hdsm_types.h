@@ -33,7 +33,8 @@ struct Consts {
   int32_t pick_rule;    // row that enters the working set next: 0 the most violated one, 1 (default) the most violated one in the
                         // metric of the problem, violation / sqrt(a^T Z a) with Z = H^-1 projected on the terminal equalities
                         // (HDSM_PICK_RULE): a jerk bound (tens of m/s^3) and a separating plane (centimetres) become comparable
-  int32_t pad_pick;
+  int32_t box_cut;      // 1 (default): a dual objective above the largest objective any point of the input box can have ends an
+                        // active-set run as infeasible (HDSM_BOX_CUT); 0: only the formal proof (dependent row, no multiplier to give way)
   double tol, ftol_fixed, cand_tau, hot_tau;
   double mip_gap;  // relative gap at which a node is cut off against the incumbent (0 = exact)
   long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)
@@ -70,6 +71,7 @@ struct Consts {
   //   n  > 30 (NV = 48):               JeqP[j * 64 + lane] = Jeq[lane][j], j < 48
   double JeqP[MAXNV * 64];
   // weights of the pick rule, 1 / sqrt(a^T Z a) of the constant rows and the per-axis factors of the position rows:
+  double hrow1[MAXNV];            // sum_k |H_jk|, rounded up (the bound of the objective over the input box, Shm::f_box)
   double wu[MAXNV];               // input box of variable k
   double ws[3][3][MAXH + 1];      // state box [ax][comp][step]
   double kap[MAXH + 1][4];        // a row n . p_m <= b has a^T Z a = sum_ax n_ax^2 kap[m][ax]

@@ -201,6 +201,7 @@ struct WaveGI {
   // per-lane constants of the iteration in two steps: the loads (issued with the staging requests of the set-up, so that
   // their latency is not a round trip of its own) and, once those have been consumed, the registers
   struct LaneReq {
+    double hrow;  // Consts::hrow1 of this lane's variable (used once, by the set-up)
     double wu, sb_w[2];
     int comp[2], axs[2], ii[2];
   };
@@ -208,6 +209,7 @@ struct WaveGI {
     const int n = c.n;
     LaneReq q;
     q.wu = c.wu[lane < n ? lane : 0];
+    q.hrow = c.hrow1[lane < n ? lane : 0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int idx = lane + 64 * e, k = idx % 6;
@@ -1095,6 +1097,7 @@ struct WaveGI {
         vip = resid(s, c, ip, N);
         if (f >= f_cut) {
           rc = GI_CUTOFF;
+          if (lane == 0) s.inf_id = ip;  // (gi_run turns a cut on the box bound into a proof of infeasibility: the row on its way in)
           stop = true;
           break;
         }
@@ -1102,6 +1105,7 @@ struct WaveGI {
       if (stop) break;
       if (f >= f_cut) {
         rc = GI_CUTOFF;
+        if (lane == 0) s.inf_id = ip;
         break;
       }
     }

@@ -466,6 +466,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
         vip = Base::resid(s, c, ip, N);
         if (f >= f_cut) {
           rc = GI_CUTOFF;
+          if (lane == 0) s.inf_id = ip;  // (gi_run turns a cut on the box bound into a proof of infeasibility: the row on its way in)
           stop = true;
           break;
         }
@@ -473,6 +474,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
       if (stop) break;
       if (f >= f_cut) {
         rc = GI_CUTOFF;
+        if (lane == 0) s.inf_id = ip;
         break;
       }
     }
