@@ -244,13 +244,19 @@ struct WaveGI {
   }
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
+  // PART (n <= 30 only): 0 = positions, velocities and accelerations; 1 = positions only; 2 = velocities and accelerations only
+  template <int PART = 0>
   static __device__ __forceinline__ void states(S& s, const Regs& R, int lane, int N) {
     if constexpr (SPLIT) {  // both halves of the wave work: each sums half of the impulse-response taps
+      constexpr bool P0 = PART != 2, VA = PART != 1;
       const int row = lane & 31, h = lane >> 5;
       const bool on = row < 3 * N;
       const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
       double acc0 = 0, acc1 = 0, acc2 = 0;
-      if (h == 0) acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
+      if (h == 0) {
+        if constexpr (P0) acc0 = s.fr[ax][m][0];
+        if constexpr (VA) acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
+      }
       const double* xx = s.x + ax * N;
       const double* g0 = &s.gz[ax][0][MAXH + m - 1];
       const double* g1 = &s.gz[ax][1][MAXH + m - 1];
@@ -261,12 +267,15 @@ struct WaveGI {
       for (int k = 0; k < HH; ++k) {
         const int kk = h * HH + k;
         const double xk = xx[kk];
-        acc0 += g0[-kk] * xk;
-        acc1 += g1[-kk] * xk;
-        acc2 += g2[-kk] * xk;
+        if constexpr (P0) acc0 += g0[-kk] * xk;
+        if constexpr (VA) acc1 += g1[-kk] * xk, acc2 += g2[-kk] * xk;
       }
-      acc0 = half_sum64(acc0), acc1 = half_sum64(acc1), acc2 = half_sum64(acc2);
-      if (on && h == 0) s.st[m][ax] = acc0, s.st[m][3 + ax] = acc1, s.st[m][6 + ax] = acc2;
+      if constexpr (P0) acc0 = half_sum64(acc0);
+      if constexpr (VA) acc1 = half_sum64(acc1), acc2 = half_sum64(acc2);
+      if (on && h == 0) {
+        if constexpr (P0) s.st[m][ax] = acc0;
+        if constexpr (VA) s.st[m][3 + ax] = acc1, s.st[m][6 + ax] = acc2;
+      }
       wsync();
       return;
     }
@@ -368,6 +377,9 @@ struct WaveGI {
   }
 
   // the row that enters next among: input / state boxes, rows of assigned polyhedra, HOT staged rows (-1: nothing is violated)
+  // MODE 0: all row families; 1: all but the state boxes; 2: the state boxes only (hdsm_wave_gib.h looks at those — and
+  // evaluates the velocities and accelerations they bound — only when nothing else is violated)
+  template <int MODE = 0>
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
                                                 double& vbest, int& ibest) {
     const bool norm = c.pick_rule != 0;
@@ -379,12 +391,12 @@ struct WaveGI {
       }
     };
     // (a box: at most one side is violated, and with the same weight the larger violation wins anyway — ONE candidate per box)
-    if (lane < c.n) {  // box of this lane's input (lane = variable; its axis is R.ax)
+    if (MODE != 2 && lane < c.n) {  // box of this lane's input (lane = variable; its axis is R.ax)
       const double vu = R.xi - s.bnd[3 + R.ax], vl = s.bnd[R.ax] - R.xi;
       offer(vl > vu ? vl : vu, R.wu, mk_id(K_U, (lane << 1) | (vl > vu ? 1 : 0)));
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < (MODE != 1 ? 2 : 0); ++e) {
       int sid = R.sb_id[e];
       keep_in_loop(sid);  // (the three LDS addresses below: hoisted out of the iteration loop they were spilled to scratch)
       if (sid >= 0) {
@@ -394,8 +406,8 @@ struct WaveGI {
         offer(vl > vu ? vl : vu, R.sb_w[e], mk_id(K_S, sid | (vl > vu ? 1 : 0)));
       }
     }
-    if (uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
-    const int nc = uni(s.ncand);
+    if (MODE != 2 && uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
+    const int nc = MODE != 2 ? uni(s.ncand) : 0;
     const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
       if (lane == 0) s.cmd = 1, s.part_tol = tol, s.part_norm = norm ? 1 : 0;
