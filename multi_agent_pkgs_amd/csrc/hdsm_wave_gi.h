@@ -244,7 +244,7 @@ struct WaveGI {
   }
 
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
-  // PART (n <= 30 only): 0 = positions, velocities and accelerations; 1 = positions only; 2 = velocities and accelerations only
+  // PART: 0 = positions, velocities and accelerations; 1 = positions only; 2 = velocities and accelerations only
   template <int PART = 0>
   static __device__ __forceinline__ void states(S& s, const Regs& R, int lane, int N) {
     if constexpr (SPLIT) {  // both halves of the wave work: each sums half of the impulse-response taps
@@ -280,8 +280,11 @@ struct WaveGI {
       return;
     }
     if (lane < 3 * N) {
+      constexpr bool P0 = PART != 2, VA = PART != 1;
       const int ax = R.ax, m = R.kk + 1;
-      double acc0 = s.fr[ax][m][0], acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
+      double acc0 = 0, acc1 = 0, acc2 = 0;
+      if constexpr (P0) acc0 = s.fr[ax][m][0];
+      if constexpr (VA) acc1 = s.fr[ax][m][1], acc2 = s.fr[ax][m][2];
       const double* xx = s.x + ax * N;
       const double* g0 = &s.gz[ax][0][MAXH + m - 1];
       const double* g1 = &s.gz[ax][1][MAXH + m - 1];
@@ -289,13 +292,11 @@ struct WaveGI {
 #pragma unroll
       for (int k = 0; k < HT; ++k) {
         const double xk = xx[k];
-        acc0 += g0[-k] * xk;
-        acc1 += g1[-k] * xk;
-        acc2 += g2[-k] * xk;
+        if constexpr (P0) acc0 += g0[-k] * xk;
+        if constexpr (VA) acc1 += g1[-k] * xk, acc2 += g2[-k] * xk;
       }
-      s.st[m][ax] = acc0;
-      s.st[m][3 + ax] = acc1;
-      s.st[m][6 + ax] = acc2;
+      if constexpr (P0) s.st[m][ax] = acc0;
+      if constexpr (VA) s.st[m][3 + ax] = acc1, s.st[m][6 + ax] = acc2;
     }
     wsync();
   }
@@ -1017,16 +1018,23 @@ struct WaveGI {
     for (;;) {
       int ln = lane;  // (lane masks and addresses of the state evaluation and the scan: formed per operation, see hdsm_wave_gib.h)
       keep_in_loop(ln);
-      states(s, R, ln, N);
-      PROF(0)
       int ip;
       double vip;
       if (neq < 6) {
+        states(s, R, ln, N);
+        PROF(0)
         ip = mk_id(K_E, neq);
         vip = resid(s, c, ip, N);
-      } else {
-        select(s, c, R, ln, tol, N, vip, ip);
+      } else {  // (state boxes last, as in hdsm_wave_gib.h)
+        states<1>(s, R, ln, N);
+        PROF(0)
+        select<1>(s, c, R, ln, tol, N, vip, ip);
         ip = uni(ip);
+        if (ip < 0) {
+          states<2>(s, R, ln, N);
+          select<2>(s, c, R, ln, tol, N, vip, ip);
+          ip = uni(ip);
+        }
         if (ip < 0) {
           if (promote_cold(s, lane, tol) > 0) continue;
           PROF(1)
