@@ -382,7 +382,7 @@ struct WaveGI {
   // evaluates the velocities and accelerations they bound — only when nothing else is violated)
   template <int MODE = 0>
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
-                                                double& vbest, int& ibest) {
+                                                double& vbest, int& ibest, double* kbest = nullptr) {
     const bool norm = c.pick_rule != 0;
     Pick pk{0.0, 0.0, -1};
     auto offer = [&](double vv, float w, int id) {
@@ -435,6 +435,7 @@ struct WaveGI {
     }
     vbest = mv;
     ibest = (m > 0.0) ? best : -1;
+    if (kbest != nullptr) *kbest = m;  // the winner's key: violation / sqrt(a^T Z a) with the normalised rule
   }
 
   // The other waves of the workgroup while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.

@@ -100,7 +100,9 @@ struct WaveGIB : WaveGI<32, CMAX> {
   // d = J^T(-a) (position layout), ||d||^2, ||d2||^2, d_q, z = J2 d2 (row layout), r = U d1 (position layout), and dz = d with the
   // working-set columns zeroed (position layout: the source of the Householder vector). `ai` = entry row_of(lane) of the normal.
   // WANT_Z = false (warm-start additions: no step is taken): z is not formed (one all-gather and one dot product less).
-  template <bool WANT_Z = true>
+  // WANT_DD = false: ||d||^2 is not formed (a wave sum less; the regular loop then tests the dependency of the entering row against
+  // a^T Z a, which the pick rule hands over with the row — see run()).
+  template <bool WANT_Z = true, bool WANT_DD = true>
   static __device__ __forceinline__ void direction(S& s, const Regs& R, double ai, int q, int lane, double& dj, double& dz,
                                                    double& dd, double& zz, double& dq, double& zi, double& ri) {
     double p[NC];
@@ -111,7 +113,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
     const int pos = pos_of(lane);
     if (first_copy(lane)) s.dvec[pos] = dj;  // for r = U d (U has zero columns >= q: no mask needed)
     dz = (pos >= q) ? dj : 0.0;
-    dd = pos_sum(dj * dj, lane);
+    dd = WANT_DD ? pos_sum(dj * dj, lane) : 0.0;
     zz = pos_sum(dz * dz, lane);
     dq = (q < NV) ? bcast64(dj, lane_of_pos(q < NV ? q : 0)) : 0.0;
     zi = 0.0;
@@ -358,6 +360,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
     const int n = c.n, N = c.N, max_iters = c.max_iters;
     const double tol = c.tol;
     const long long time_ticks = c.time_ticks;  // 0 = no wall-clock budget (the default)
+    const bool norm_pick = c.pick_rule != 0;
     double f = s.f;
     int q = uni(s.q), neq = uni(s.neq_done);
     int rc = GI_OK;
@@ -370,7 +373,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
       int ln = lane;
       keep_in_loop(ln);
       int ip;
-      double vip;
+      double vip, kip = 0.0;  // kip: the pick's key = vip / sqrt(a^T Z a) (normalised rule)
       if (neq < 6) {
         Base::states(s, R, ln, N);
         PROF(0)
@@ -381,11 +384,11 @@ struct WaveGIB : WaveGI<32, CMAX> {
         // input box and no plane is violated: a third of the instructions of evaluation + scan, spared in most operations
         Base::template states<1>(s, R, ln, N);
         PROF(0)
-        Base::template select<1>(s, c, R, ln, tol, N, vip, ip);
+        Base::template select<1>(s, c, R, ln, tol, N, vip, ip, &kip);
         ip = uni(ip);
         if (ip < 0) {
           Base::template states<2>(s, R, ln, N);
-          Base::template select<2>(s, c, R, ln, tol, N, vip, ip);
+          Base::template select<2>(s, c, R, ln, tol, N, vip, ip, &kip);
           ip = uni(ip);
         }
         if (ip < 0) {
@@ -396,6 +399,12 @@ struct WaveGIB : WaveGI<32, CMAX> {
         PROF(1)
       }
       const bool is_eq = id_kind(ip) == K_E;
+      // 1e-20 a^T Z a of the entering row, from the key of its pick (normalised rule: kip = vip / sqrt(a^T Z a)); < 0: not available
+      double dep_thr = -1.0;
+      if (norm_pick && kip > 0.0) {
+        const double root = vip * rcp_nr(kip);
+        dep_thr = 1e-20 * root * root;
+      }
 #ifdef HDSM_TRACE_GI
       if (lane == 0) {
         const int kd = id_kind(ip), pl = id_payload(ip);
@@ -420,14 +429,23 @@ struct WaveGIB : WaveGI<32, CMAX> {
         ++iters;
         PROF(2)
         double dj, dz, dd, zz, dq, zi, ri;
-        direction(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
+        // Dependency of the entering row on the working set: ||d_2||^2 against ||d||^2 = a^T H^-1 a. With the normalised pick rule the
+        // row arrives with a^T Z a = (vip / kip)^2 at the moment of the pick (dep_thr), and ||d_2||^2 <= a^T Z a <= a^T H^-1 a: the test
+        // against a^T Z a differs only where ||d_2||^2 is 1e-20 of either — far below rounding — and spares the wave sum of ||d||^2.
+        bool dependent;
+        direction<true, false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);  // (one call site: the body is inlined)
+        if (dep_thr >= 0.0) {
+          dependent = !(zz > dep_thr) || q >= NV;
+        } else {
+          dd = pos_sum(dj * dj, lane);
+          dependent = !(zz > 1e-20 * dd) || q >= NV;
+        }
         PROF(3)
-        const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
         double t1 = DINF;
         int l = -1;
         if (!is_eq) {  // ratio test over the active inequalities (position layout)
-          const bool okk = pos < q && id_kind(R.act) != K_E && ri > 0;
-          const double ratio = okk ? R.lam / ri : DINF;
+          const bool okk = pos < q && id_kind(R.act) != K_E && ri > 1e-250;  // (1e-250: the Newton reciprocal wants a normal number)
+          const double ratio = okk ? R.lam * rcp_nr(okk ? ri : 1.0) : DINF;
           const double m = -wave_max64(-ratio);
           if (m < DINF) {
             t1 = m;
