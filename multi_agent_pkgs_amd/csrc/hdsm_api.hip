@@ -1260,9 +1260,9 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
     for (int k = 0; k < n_inst; ++k) late += pr[(size_t)k * 32] - t0 > 200;  // started more than 2 us after the first
     if (const char* path = std::getenv("HDSM_TIMELINE_DUMP")) {  // raw rows for offline analysis, one block per launch
       if (FILE* f = std::fopen(path, "ab")) {
-        const long long head[2] = {0x54494d454c494e45LL, n_inst};
+        const long long head[2] = {0x54494d454c494e32LL, n_inst};  // ("TIMELIN2": 24 entries per instance)
         std::fwrite(head, sizeof(long long), 2, f);
-        for (int k = 0; k < n_inst; ++k) std::fwrite(&pr[(size_t)k * 32], sizeof(long long), 16, f);
+        for (int k = 0; k < n_inst; ++k) std::fwrite(&pr[(size_t)k * 32], sizeof(long long), 24, f);
         std::fclose(f);
       }
     }
@@ -1289,6 +1289,11 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
                                  "leaf", "TOTAL", "iters", "sweeps", "warm_ops", "warm_cycles", "sw_cull", "sw_filter",
                                  "sw_load", "sw_body", "sw_tail", "su_stage", "su_grad", "su_fact",
                                  "w_prep", "w_fetch", "w_normal", "w_dir", "w_add", "w_pair", "w_drop", "w_7"};
+#ifdef HDSM_PROF_OP  // record 16..31 = slots 8..23: the inside of a regular operation (OP_PROF in hdsm_wave_gi.h / hdsm_wave_gib.h)
+    static const char* op_nm[16] = {"sel_boxes", "sel_rows", "op10", "normal_entry", "d_reduce", "d_sums", "d_gather_z", "d_urow", "add_scalars", "add_gather",
+                                    "add_update", "probe_a", "probe_cost", "op21", "op22", "op23"};
+    for (int j = 0; j < 16; ++j) nm[16 + j] = op_nm[j];
+#endif
     std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);
     for (int j = 0; j < 32; ++j) std::fprintf(stderr, " %s=%lld", nm[j], pr[(size_t)worst * 32 + j]);
     std::fprintf(stderr, "\nHDSM_PROFILE mean:");

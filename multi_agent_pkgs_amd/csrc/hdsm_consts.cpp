@@ -95,6 +95,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   env_int("HDSM_PICK_RULE", 0, 1, &c->pick_rule);
   c->box_cut = 1;
   env_int("HDSM_BOX_CUT", 0, 1, &c->box_cut);
+  c->scanner = 1;
+  env_int("HDSM_SCANNER", 0, 1, &c->scanner);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);

@@ -469,7 +469,7 @@ struct Solver {
       const int rc = W::run(s, c, R, f_eff, iters);
       if (threadIdx.x == 0) s.rc = (rc == GI_CUTOFF && !(s.f >= f_cut)) ? GI_INFEASIBLE : rc, s.iters_sh = iters;
     } else {
-      W::helper_loop(s);  // waves 1..3: share the staged-row scans of wave 0's iteration
+      W::helper_loop(s, c, R);  // n <= 30: wave 1 evaluates and picks while wave 0 updates; larger n: waves 1..3 share long scans
     }
     SYNC();
     iters = s.iters_sh;
@@ -595,7 +595,11 @@ struct Solver {
     if (threadIdx.x < 24) s.prof_acc[threadIdx.x] = 0;
     SYNC();
     PROF_DECL
+#ifdef HDSM_PROF_OP
+#define SU_PROF(k)
+#else
 #define SU_PROF(k) PROF(k)
+#endif
 #else
 #define SU_PROF(k)
 #endif
@@ -685,7 +689,7 @@ struct Solver {
         if (vt < 4 * (MAXH + 1)) (&s.kap[0][0])[vt] = r.v_k;
       };
       ST_PROF(8)
-      const typename W::LaneReq lane_req = W::init_lane_request(c, tid);
+      const typename W::LaneReq lane_req = W::init_lane_request(c, tid & 63);  // (every wave: wave 1 scans with its own copy)
       const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
       const double wn0 = c.wn[fk0], wx0 = c.wx[fk0], wn1 = c.wn[fk1], wx1 = c.wx[fk1];
       const Req r0 = request(tid);
@@ -705,7 +709,7 @@ struct Solver {
       commit(tid, r0);
       ST_PROF(11)
       // (per-lane constants of the iteration: their loads use what they fetch at once, so they come after the staging requests)
-      W::init_lane(R, c, tid, lane_req);
+      W::init_lane(R, c, tid & 63, lane_req);
       hrow_own = lane_req.hrow;
       fw0 = (tid < 64) ? ((fi0 == N) ? wn0 : wx0) : 0.0;
       fw1 = (tid < 64) ? ((fi1 == N) ? wn1 : wx1) : 0.0;
@@ -790,6 +794,16 @@ struct Solver {
 #ifdef HDSM_PROFILE
     const long long t_setup_ = clock64() - t_begin_;
 #endif
+#ifdef HDSM_TIMELINE
+    const long long tl_setup_ = (long long)wall_clock64();  // (10-ns ticks; phases of the instance for scripts/timeline_fit.py)
+    long long tl_warm_ = 0, tl_sweep_ = 0, tl_run_ = 0, tl_leaf_ = 0;
+    int tl_warm_it_ = 0, tl_runs_ = 0;
+#define TL_T0 const long long tl_t0_ = (long long)wall_clock64();
+#define TL_ADD(acc) acc += (long long)wall_clock64() - tl_t0_;
+#else
+#define TL_T0
+#define TL_ADD(acc)
+#endif
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
     // The guess is an infeasibility certificate (see the hand-over below), or the last replan ended on the gridlock test of
@@ -865,7 +879,9 @@ struct Solver {
 #ifdef HDSM_PROFILE
         const long long ts_ = clock64();
 #endif
+        TL_T0
         sweep(s, c, a, inst, self, thresh, sweeps == 0);
+        TL_ADD(tl_sweep_)
 #ifdef HDSM_PROFILE
         t_sweep_ += clock64() - ts_;
 #endif
@@ -896,12 +912,17 @@ struct Solver {
 #ifdef HDSM_PROFILE
       const long long tw_ = clock64();
 #endif
+      TL_T0
       if (threadIdx.x < 64) {
         W::warm_start(s, c, a, R, inst, self, iters);
         if (threadIdx.x == 0) s.iters_sh = iters;
       }
       SYNC();
       iters = s.iters_sh;
+      TL_ADD(tl_warm_)
+#ifdef HDSM_TIMELINE
+      tl_warm_it_ = iters;
+#endif
 #ifdef HDSM_PROFILE
       t_warm_ = clock64() - tw_;
       it_warm_ = iters;
@@ -919,7 +940,15 @@ struct Solver {
     int last_rc = GI_OK;
     (void)last_rc;  // (read by the warm-start hand-over of the device build only)
     while (run) {
-      const int rc = gi_run(s, c, R, cutoff(s, c), iters);
+      int rc;
+      {
+        TL_T0
+        rc = gi_run(s, c, R, cutoff(s, c), iters);
+        TL_ADD(tl_run_)
+#ifdef HDSM_TIMELINE
+        ++tl_runs_;
+#endif
+      }
       last_rc = rc;
       if (rc == GI_ITERLIM || rc == GI_TIMELIM) {
         limit = true;
@@ -930,7 +959,12 @@ struct Solver {
 #ifdef HDSM_PROFILE
         const long long tl_ = clock64();
 #endif
-        const int bstep = leaf_check(s, c);
+        int bstep;
+        {
+          TL_T0
+          bstep = leaf_check(s, c);
+          TL_ADD(tl_leaf_)
+        }
 #ifdef HDSM_PROFILE
         t_leaf_ += clock64() - tl_;
 #endif
@@ -1119,6 +1153,7 @@ struct Solver {
       pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw | ((long long)(xcc & 15u) << 32), pr[4] = iters;
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
       pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q, pr[14] = s.n_nogood, pr[15] = s.ng_skipped;
+      pr[16] = tl_setup_ - tl_begin_, pr[17] = tl_warm_, pr[18] = tl_warm_it_, pr[19] = tl_sweep_, pr[20] = tl_run_, pr[21] = tl_runs_, pr[22] = tl_leaf_, pr[23] = 0;
     }
 #endif
     if (IS_T0) {

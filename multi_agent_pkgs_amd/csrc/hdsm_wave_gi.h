@@ -153,17 +153,32 @@ struct alignas(16) D2 {
 // cycle counters accumulated in LDS by lane 0 (keeps them out of the SGPR file)
 #define PROF_DECL if (threadIdx.x == 0) s.prof_last = clock64();
 #define PROF(k) if (threadIdx.x == 0) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last; s.prof_last = now_; }
+#elif defined(HDSM_ISA_MARKS)
+// ISA study build (hipcc -S -DHDSM_ISA_MARKS): the phase boundaries show up as comments in the listing
+#define PROF_DECL
+#define PROF(k) asm volatile("; ISA_MARK " #k);
 #else
 #define PROF_DECL
 #define PROF(k)
 #endif
 // -DHDSM_PROF_STAGE (with -DHDSM_PROFILE): slots 16..20 time the steps of the staging phase instead of the sweeps
-#if defined(HDSM_PROFILE) && defined(HDSM_PROF_STAGE)
+// -DHDSM_PROF_OP (with -DHDSM_PROFILE): slots 8..23 time the inside of a regular active-set operation (OP_PROF) instead of the
+// sweeps, the set-up and the warm start
+#if defined(HDSM_PROFILE) && defined(HDSM_PROF_OP)
+#define SW_PROF(k)
+#define ST_PROF(k)
+#define WS_PROF(k)
+#define OP_PROF(k) PROF(k)
+#elif defined(HDSM_PROFILE) && defined(HDSM_PROF_STAGE)
 #define SW_PROF(k)
 #define ST_PROF(k) PROF(k)
+#define WS_PROF(k) PROF(k)
+#define OP_PROF(k)
 #else
 #define SW_PROF(k) PROF(k)
 #define ST_PROF(k)
+#define WS_PROF(k) PROF(k)
+#define OP_PROF(k)
 #endif
 
 template <int NV, int CMAX>
@@ -380,7 +395,8 @@ struct WaveGI {
   // the row that enters next among: input / state boxes, rows of assigned polyhedra, HOT staged rows (-1: nothing is violated)
   // MODE 0: all row families; 1: all but the state boxes; 2: the state boxes only (hdsm_wave_gib.h looks at those — and
   // evaluates the velocities and accelerations they bound — only when nothing else is violated)
-  template <int MODE = 0>
+  // SHARE: a long staging area is shared with the helper waves (two workgroup barriers; helper_loop below)
+  template <int MODE = 0, bool SHARE = true>
   static __device__ __forceinline__ void select(S& s, const Consts& c, const Regs& R, int lane, double tol, int N,
                                                 double& vbest, int& ibest, double* kbest = nullptr) {
     const bool norm = c.pick_rule != 0;
@@ -407,9 +423,10 @@ struct WaveGI {
         offer(vl > vu ? vl : vu, R.sb_w[e], mk_id(K_S, sid | (vl > vu ? 1 : 0)));
       }
     }
+    OP_PROF(8)
     if (MODE != 2 && uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
     const int nc = MODE != 2 ? uni(s.ncand) : 0;
-    const bool mw = blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
+    const bool mw = SHARE && blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
       if (lane == 0) s.cmd = 1, s.part_tol = tol, s.part_norm = norm ? 1 : 0;
       __syncthreads();                             // helpers start on their share: rows [256 w, ...) stride 256 * waves
@@ -417,6 +434,7 @@ struct WaveGI {
     } else {
       scan_rows(s, 0, nc, lane, tol, norm, pk);
     }
+    OP_PROF(9)
     double m = wave_max64(pk.key);
     double mv = 0.0;
     int best = -1;
@@ -439,7 +457,7 @@ struct WaveGI {
   }
 
   // The other waves of the workgroup while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
-  static __device__ __forceinline__ void helper_loop(S& s) {
+  static __device__ __forceinline__ void helper_loop(S& s, const Consts&, Regs&) {
     const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
     for (;;) {
       __syncthreads();
@@ -832,7 +850,7 @@ struct WaveGI {
       }
     }
     int q = uni(s.q);
-    PROF(16)
+    WS_PROF(16)
     for (int g = 0; g < nw && q < n; ++g) {
       int id = __builtin_amdgcn_readlane(pre, g);
       if (id == -2) {
@@ -853,16 +871,16 @@ struct WaveGI {
         }
       }
       if (id < 0) continue;
-      PROF(17)
+      WS_PROF(17)
       const double ai = normal_entry(s, R, id, row_of(lane), N, n);
-      PROF(18)
+      WS_PROF(18)
       double dv[NC], dd, zz, dq, zi, ri;
       direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
-      PROF(19)
+      WS_PROF(19)
       ++iters;
       if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
       householder_add(s, R, id, 0.0, q, lane, dv, zz, dq, zi, ri);
-      PROF(20)
+      WS_PROF(20)
       ++q;
     }
     if (q == uni(s.q)) return;  // nothing usable
@@ -919,7 +937,7 @@ struct WaveGI {
         }
         if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;  // (lane 0's suffix sum is the whole sum)
         wsync();
-        PROF(21)
+        WS_PROF(21)
 #ifdef HDSM_DEBUG
         states(s, R, lane, N);
         if (blockIdx.x == 2 && lane < q)
@@ -929,9 +947,9 @@ struct WaveGI {
         return;
       }
       const int l = uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1);
-      PROF(21)
+      WS_PROF(21)
       drop(s, R, l, q, lane);
-      PROF(22)
+      WS_PROF(22)
       --q;
       ++iters;
     }

@@ -110,6 +110,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
 #pragma unroll
     for (int k = 0; k < NC; ++k) p[k] = R.Jr[k] * na;
     dj = reduce_cols(p);
+    if constexpr (WANT_Z) { OP_PROF(12) }
     const int pos = pos_of(lane);
     if (first_copy(lane)) s.dvec[pos] = dj;  // for r = U d (U has zero columns >= q: no mask needed)
     dz = (pos >= q) ? dj : 0.0;
@@ -118,19 +119,23 @@ struct WaveGIB : WaveGI<32, CMAX> {
     dq = (q < NV) ? bcast64(dj, lane_of_pos(q < NV ? q : 0)) : 0.0;
     zi = 0.0;
     if constexpr (WANT_Z) {
+      OP_PROF(13)
       double g[NC];
       gather_cols(dz, g);
       double z0 = 0, z1 = 0;
 #pragma unroll
       for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
       zi = half_sum64(z0 + z1);
+      OP_PROF(14)
     }
     wsync();
     ri = u_row_dot(s, lane);
+    if constexpr (WANT_Z) { OP_PROF(15) }
   }
 
   // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q, applied with the complete
   // vector v = d2 - rho e_q: (J2 v) comes from the same gathered v that the rank-1 update multiplies
+  template <bool PROBE = false>  // (PROBE: the call of the regular loop, timed by the -DHDSM_PROF_OP build)
   static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dz, double zz,
                                                          double dq, double ri) {
     const double inv_rho_abs = rsq_nr(zz);  // (zz > 0: the caller has tested it against ||d||^2)
@@ -138,13 +143,16 @@ struct WaveGIB : WaveGI<32, CMAX> {
     const double beta = rcp_nr(rho * (rho - dq));
     const int pos = pos_of(lane);
     double g[NC];
+    if constexpr (PROBE) { OP_PROF(16) }
     gather_cols(pos == q ? dz - rho : dz, g);
+    if constexpr (PROBE) { OP_PROF(17) }
     double w0 = 0, w1 = 0;
 #pragma unroll
     for (int k = 0; k < NC; k += 2) w0 += R.Jr[k] * g[k], w1 += R.Jr[k + 1] * g[k + 1];
     const double coef = half_sum64(w0 + w1) * beta;
 #pragma unroll
     for (int k = 0; k < NC; ++k) R.Jr[k] -= coef * g[k];
+    if constexpr (PROBE) { OP_PROF(18) }
     if (first_copy(lane)) s.U[pos * LDT + q] = (pos < q) ? -ri * inv_rho : ((pos == q) ? inv_rho : 0.0);
     if (pos == q) R.lam = lam_p, R.act = id;
     wsync();
@@ -273,11 +281,11 @@ struct WaveGIB : WaveGI<32, CMAX> {
         wsync();
       }
     }
-    PROF(16)
+    WS_PROF(16)
     for (int g = 0; g < nw && q < n; ++g) {
       const int id = __builtin_amdgcn_readlane(pre, g);
       if (id < 0) continue;
-      PROF(17)
+      WS_PROF(17)
       double ai;
       if (id_kind(id) == K_C) {  // the row is in lane g's registers: its normal needs one LDS read (the impulse response), not two in a chain
         const double nx = bcast64(my_row[0], g), ny = bcast64(my_row[1], g), nz = bcast64(my_row[2], g);
@@ -287,14 +295,14 @@ struct WaveGIB : WaveGI<32, CMAX> {
       } else {
         ai = Base::normal_entry(s, R, id, Base::row_of(lane), N, n);
       }
-      PROF(18)
+      WS_PROF(18)
       double dj, dz, dd, zz, dq, zi, ri;
       direction<false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);
-      PROF(19)
+      WS_PROF(19)
       ++iters;
       if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
       householder_add(s, R, id, 0.0, q, lane, dz, zz, dq, ri);
-      PROF(20)
+      WS_PROF(20)
       ++q;
     }
     if (q == q_in) return;  // nothing usable (multipliers / ids in LDS are untouched)
@@ -342,13 +350,13 @@ struct WaveGIB : WaveGI<32, CMAX> {
         if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;
         store_pos(s, R, lane);
         wsync();
-        PROF(21)
+        WS_PROF(21)
         return;
       }
       const int l = pos_of(uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1));
-      PROF(21)
+      WS_PROF(21)
       drop(s, R, l, q, lane);
-      PROF(22)
+      WS_PROF(22)
       --q;
       ++iters;
     }
@@ -366,6 +374,12 @@ struct WaveGIB : WaveGI<32, CMAX> {
     int rc = GI_OK;
     const int pos = pos_of(lane);
     load_pos(s, R, lane);
+    // Workgroups of more than one wavefront: wave 1 is the SCANNER (scanner_loop below). Evaluating the trajectory at the new
+    // iterate and picking the row that enters next reads nothing the Householder update writes, so the scanner does both while
+    // this wave applies the update of the operation before (two workgroup barriers per operation: "go" after the step, "done"
+    // before the next direction); the normal of the picked row comes back through LDS with the pick.
+    const bool duo = blockDim.x > 64 && c.scanner != 0;
+    bool pending = false;  // a scan is under way (posted after the last step): its result is behind the next barrier
     PROF_DECL
     for (;;) {
       // (the lane masks and addresses of the state evaluation and the scan are formed here, per operation: hoisted out of
@@ -374,21 +388,35 @@ struct WaveGIB : WaveGI<32, CMAX> {
       keep_in_loop(ln);
       int ip;
       double vip, kip = 0.0;  // kip: the pick's key = vip / sqrt(a^T Z a) (normalised rule)
+      double ai;
       if (neq < 6) {
         Base::states(s, R, ln, N);
         PROF(0)
         ip = mk_id(K_E, neq);
         vip = Base::resid(s, c, ip, N);
+        ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
+      } else if (duo) {
+        if (!pending) {
+          if (lane == 0) s.cmd = CMD_PICK;
+          __syncthreads();  // go
+        }
+        __syncthreads();    // done
+        pending = false;
+        ip = uni(s.part_id[1]);
+        PROF(1)
+        if (ip < 0) break;
+        vip = s.part_v[1], kip = s.part_key[1];
+        ai = s.dvz[Base::row_of(ln)];
       } else {
         // the state boxes (velocity / acceleration limits) are looked at — and the states they bound evaluated — only when no
         // input box and no plane is violated: a third of the instructions of evaluation + scan, spared in most operations
         Base::template states<1>(s, R, ln, N);
         PROF(0)
-        Base::template select<1>(s, c, R, ln, tol, N, vip, ip, &kip);
+        Base::template select<1, false>(s, c, R, ln, tol, N, vip, ip, &kip);
         ip = uni(ip);
         if (ip < 0) {
           Base::template states<2>(s, R, ln, N);
-          Base::template select<2>(s, c, R, ln, tol, N, vip, ip, &kip);
+          Base::template select<2, false>(s, c, R, ln, tol, N, vip, ip, &kip);
           ip = uni(ip);
         }
         if (ip < 0) {
@@ -397,6 +425,10 @@ struct WaveGIB : WaveGI<32, CMAX> {
           break;
         }
         PROF(1)
+        ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
+        OP_PROF(11)
+        OP_PROF(19)
+        OP_PROF(20)
       }
       const bool is_eq = id_kind(ip) == K_E;
       // 1e-20 a^T Z a of the entering row, from the key of its pick (normalised rule: kip = vip / sqrt(a^T Z a)); < 0: not available
@@ -412,7 +444,6 @@ struct WaveGIB : WaveGI<32, CMAX> {
         else printf("  pick kind=%d payload=%d v=%.3e q=%d f=%.6g\n", kd, pl, vip, q, f);
       }
 #endif
-      const double ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
       double lam_p = 0;
       bool stop = false;
       for (;;) {
@@ -480,17 +511,32 @@ struct WaveGIB : WaveGI<32, CMAX> {
         lam_p += t;
         PROF(5)
         if (full) {
-          householder_add(s, R, ip, lam_p, q, lane, dz, zz, dq, ri);
+          if (duo && neq + (is_eq ? 1 : 0) >= 6) {  // the scanner starts on the next pick at the new iterate
+            if (lane == 0) s.cmd = CMD_PICK;
+            __syncthreads();  // go
+            pending = true;
+          }
+          householder_add<true>(s, R, ip, lam_p, q, lane, dz, zz, dq, ri);
           PROF(6)
           ++q;
           if (is_eq) ++neq;
           break;
         }
-        drop(s, R, l, q, lane);
-        PROF(7)
-        --q;
-        Base::states(s, R, lane, N);
-        vip = Base::resid(s, c, ip, N);
+        if (duo) {  // the scanner re-evaluates the entering row at the new iterate while the entry at l leaves
+          if (lane == 0) s.cmd = CMD_RESID, s.part_id[0] = ip;
+          __syncthreads();  // go
+          drop(s, R, l, q, lane);
+          PROF(7)
+          --q;
+          __syncthreads();  // done
+          vip = s.part_v[1];
+        } else {
+          drop(s, R, l, q, lane);
+          PROF(7)
+          --q;
+          Base::states(s, R, lane, N);
+          vip = Base::resid(s, c, ip, N);
+        }
         if (f >= f_cut) {
           rc = GI_CUTOFF;
           if (lane == 0) s.inf_id = ip;  // (gi_run turns a cut on the box bound into a proof of infeasibility: the row on its way in)
@@ -506,11 +552,141 @@ struct WaveGIB : WaveGI<32, CMAX> {
       }
     }
     store_pos(s, R, lane);
+    if (pending) __syncthreads();  // (a scan nobody needs any more: its "done")
     wsync();
     if (lane == 0) s.f = f, s.q = q, s.neq_done = neq, s.cmd = 0;
-    if (blockDim.x > 64) __syncthreads();  // releases the helper waves (they leave on cmd == 0)
+    if (blockDim.x > 64) __syncthreads();  // releases the other waves (they leave on cmd == 0)
     else wsync();
     return rc;
+  }
+
+  // The other waves of the workgroup while wave 0 iterates. Wave 1, the scanner, waits for a command at the workgroup barrier:
+  //   CMD_PICK   trajectory at s.x, then the row that enters next (state boxes only when nothing else is violated, cold rows
+  //              promoted when no hot row is) -> part_id[1] (-1: nothing is violated), part_v[1], part_key[1], and the dense
+  //              normal of the pick, entry `var` in dvz[var] (dvz is otherwise unused by this layout);
+  //   CMD_RESID  trajectory at s.x, then the violation of row part_id[0] -> part_v[1].
+  // Waves 2.. only keep the barrier count. `R` holds this wave's per-lane constants of the scan (init_lane with lane = thread & 63).
+  //
+  // The scanner's answer is on the critical path of every operation (wave 0 waits for it after its Householder update), and what
+  // it costs is LDS round trips in a chain, so everything that does not change during a run is kept in REGISTERS of this wave:
+  // the impulse-response taps of the lane's trajectory point, its input box, and the first RC staged rows of the lane with their
+  // step and pick weight (the staging area only changes between runs, or when this wave itself promotes cold rows). Per pick the
+  // chain is: x (one batch of LDS reads) -> positions -> LDS -> the points of the cached rows (one batch) -> keys -> wave maximum.
+  static constexpr int CMD_PICK = 2, CMD_RESID = 3;
+  static constexpr int RC = 2;  // staged rows per lane held in registers (64 RC rows; longer staging areas: the rest from LDS)
+  static __device__ __forceinline__ void helper_loop(S& s, const Consts& c, Regs& R) {
+    const int w = (int)threadIdx.x >> 6;
+    if (w != 1) {
+      for (;;) {
+        __syncthreads();  // go
+        if (uni(s.cmd) == 0) return;
+        __syncthreads();  // done
+      }
+    }
+    const int N = c.N, n = c.n;
+    const double tol = c.tol;
+    const bool norm = c.pick_rule != 0;
+    int lane = (int)threadIdx.x & 63;
+    keep_in_loop(lane);
+    // this lane's trajectory point: (axis, step m), half h of the taps
+    constexpr int HH = Base::HT / 2;
+    const int row = lane & 31, h = lane >> 5;
+    const bool on = row < 3 * N;
+    const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
+    double gp[HH];
+#pragma unroll
+    for (int k = 0; k < HH; ++k) gp[k] = s.gz[ax][0][MAXH + m - 1 - (h * HH + k)];
+    const double fr0 = h == 0 ? s.fr[ax][m][0] : 0.0;
+    const double* xx = s.x + ax * N + h * HH;
+    const double lbu = s.bnd[R.ax], ubu = s.bnd[3 + R.ax];
+    const int level = uni(s.level);
+    // the lane's staged rows
+    double r0[RC], r1[RC], r2[RC], r3[RC];
+    int rm[RC];
+    float rw[RC];
+    int nc = 0;
+    auto load_rows = [&]() {
+      nc = uni(s.ncand);
+#pragma unroll
+      for (int u = 0; u < RC; ++u) {
+        const int idx = 64 * u + lane;
+        const int ii = idx < nc ? idx : 0;
+        const MW mw = s.cand_mw[ii];
+        const D2 a01 = *reinterpret_cast<const D2*>(&s.cand[ii][0]), a23 = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
+        r0[u] = a01.x, r1[u] = a01.y, r2[u] = a23.x, r3[u] = idx < nc ? a23.y : DINF;  // (a row that is not there is never violated)
+        rm[u] = mw.m, rw[u] = mw.w;
+      }
+    };
+    load_rows();
+    for (;;) {
+      __syncthreads();  // go
+      const int cmd = uni(s.cmd);
+      if (cmd == 0) return;
+      if (cmd == CMD_PICK) {
+        int ip;
+        double vip, kip = 0.0;
+        for (;;) {
+          // positions at s.x
+          double xk[HH];
+#pragma unroll
+          for (int k = 0; k < HH; ++k) xk[k] = xx[k];
+          const double xi = lane < NV ? s.x[lane] : 0.0;
+          double acc = fr0;
+#pragma unroll
+          for (int k = 0; k < HH; ++k) acc += gp[k] * xk[k];
+          acc = half_sum64(acc);
+          if (on && h == 0) s.st[m][ax] = acc;
+          wsync();
+          typename Base::Pick pk{0.0, 0.0, -1};
+          auto offer = [&](double vv, float wgt, int id) {
+            if (vv > tol) {
+              const double key = norm ? (double)((float)vv * wgt) : vv;
+              if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
+            }
+          };
+          // the points of the cached rows: one batch of reads
+          double px[RC], py[RC], pz[RC];
+#pragma unroll
+          for (int u = 0; u < RC; ++u) {
+            const double* pm = s.st[rm[u]];
+            px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
+          }
+          if (lane < n) {  // box of this lane's input
+            const double vu = xi - ubu, vl = lbu - xi;
+            offer(vl > vu ? vl : vu, R.wu, mk_id(K_U, (lane << 1) | (vl > vu ? 1 : 0)));
+          }
+#pragma unroll
+          for (int u = 0; u < RC; ++u) {
+            const double vv = r0[u] * px[u] + r1[u] * py[u] + r2[u] * pz[u] - r3[u];
+            offer(vv, rw[u], mk_kc(64 * u + lane, rm[u]));
+          }
+          if (nc > 64 * RC) Base::scan_rows(s, 64 * RC, nc, lane, tol, norm, pk);
+          if (level > 0) Base::scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
+          const double mk = wave_max64(pk.key);
+          ip = -1, vip = 0.0, kip = mk;
+          if (mk > 0.0) {
+            const int src = __ffsll((long long)__ballot(pk.key == mk && pk.id >= 0)) - 1;
+            ip = __builtin_amdgcn_readlane(pk.id, src);
+            vip = bcast64(pk.v, src);
+          }
+          if (ip < 0) {  // nothing but the state boxes is left: velocities and accelerations too
+            R.xi = xi;
+            Base::template states<2>(s, R, lane, N);
+            Base::template select<2, false>(s, c, R, lane, tol, N, vip, ip, &kip);
+            ip = uni(ip);
+          }
+          if (ip >= 0 || Base::promote_cold(s, lane, tol) <= 0) break;
+          load_rows();
+        }
+        if (ip >= 0 && lane < NV) s.dvz[lane] = Base::normal_entry(s, R, ip, lane, N, n);
+        if (lane == 0) s.part_id[1] = ip, s.part_v[1] = vip, s.part_key[1] = kip;
+      } else {
+        Base::states(s, R, lane, N);
+        const double v = Base::resid(s, c, uni(s.part_id[0]), N);
+        if (lane == 0) s.part_v[1] = v;
+      }
+      __syncthreads();  // done
+    }
   }
 
   // snapshots: J slots from registers (layout [slot][lane]), U rows / multipliers / ids / x from LDS
