@@ -1290,8 +1290,8 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
                                  "sw_load", "sw_body", "sw_tail", "su_stage", "su_grad", "su_fact",
                                  "w_prep", "w_fetch", "w_normal", "w_dir", "w_add", "w_pair", "w_drop", "w_7"};
 #ifdef HDSM_PROF_OP  // record 16..31 = slots 8..23: the inside of a regular operation (OP_PROF in hdsm_wave_gi.h / hdsm_wave_gib.h)
-    static const char* op_nm[16] = {"sel_boxes", "sel_rows", "op10", "normal_entry", "d_reduce", "d_sums", "d_gather_z", "d_urow", "add_scalars", "add_gather",
-                                    "add_update", "probe_a", "probe_cost", "op21", "op22", "op23"};
+    static const char* op_nm[16] = {"sel_boxes", "sel_rows", "w0_wait_done", "normal_entry", "d_reduce", "d_sums", "d_gather_z", "d_urow", "add_scalars", "add_gather",
+                                    "add_update", "sc_states", "sc_rows", "sc_max", "sc_normal", "sc_wait_go"};
     for (int j = 0; j < 16; ++j) nm[16 + j] = op_nm[j];
 #endif
     std::fprintf(stderr, "HDSM_PROFILE worst inst %d:", worst);

@@ -96,7 +96,7 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->box_cut = 1;
   env_int("HDSM_BOX_CUT", 0, 1, &c->box_cut);
   c->scanner = 1;
-  env_int("HDSM_SCANNER", 0, 1, &c->scanner);
+  env_int("HDSM_SCANNER", 0, 2, &c->scanner);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);

@@ -92,6 +92,7 @@ struct Shm {
 #ifdef HDSM_PROFILE
   long long prof_acc[24];  // 0..7 iteration phases, 8..15 sweeps / set-up, 16..23 inside the warm start
   long long prof_last;
+  long long prof_last1;  // ... of the scanner wave (thread 64)
 #endif
   double x[NV], lam[NV], w[NV], grad[NV];
   double inc_x[NV];
@@ -186,14 +187,15 @@ struct Solver {
     return tasc_plane_eval(c, cp, op, out);
   }
 
-  // Gridlock test of the first sweep. The positions of the first `pinned_steps` steps do not depend on the inputs (with jerk
-  // inputs and the Euler model p_1 and p_2 are fixed by the current state), so a neighbour row violated there is violated
-  // by EVERY trajectory: the instance is infeasible whatever the polyhedra, and it is known after one sweep instead of the
-  // dozens of active-set operations the dual method needs to run into the contradiction (two thirds of the infeasible
-  // instances of the bench rounds are of this kind: 114 of 178 in round 170, 222 of 222 in round 175). PINNED_TOL is far
-  // above the feasibility tolerance of the method and far below any real gridlock violation. It generalises the test of
-  // the pinned point p_0 (ftol_fixed); the flag is the same.
-  static constexpr double PINNED_TOL = 1e-7;
+  // Rows on input-independent positions. p_0 is pinned by the current state, and the positions of the first `pinned_steps` steps
+  // do not depend on the inputs either (with jerk inputs and the Euler model p_1 and p_2 are fixed by the current state): a row
+  // there is a CONSTANT. It is judged with the tolerance a solver applies to a row it cannot do anything about (Consts::ftol_fixed =
+  // Gurobi's FeasibilityTol, 1e-6 — in the squeeze the separating planes pass exactly THROUGH the own previous position, slack 0 +-
+  // rounding is the normal case): within it the row holds and is not a constraint, beyond it no trajectory satisfies it — a common
+  // row ends the instance (infeasible whatever the polyhedra: the gridlock test of the first sweep, known after one sweep instead
+  // of the dozens of active-set operations the dual method needs to run into the contradiction; two thirds of the infeasible
+  // instances of the bench rounds are of this kind: 114 of 178 in round 170, 222 of 222 in round 175), a row of a polyhedron makes
+  // that polyhedron inadmissible for the step.
 
   // After a sweep (one thread): the counters were advanced past the capacity by rows that found no slot. No slot is ever
   // written twice (a writer checks the other list's counter AFTER its own atomic increment), so the slots below the clamped
@@ -236,11 +238,10 @@ struct Solver {
         const int m = i + e;
         const double* pm = s.st[m];
         const double v = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-        if (m == 0) {
+        if (m <= c.pinned_steps) {  // a constant row
           if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
           continue;
         }
-        if (check_fixed && m <= c.pinned_steps && v > PINNED_TOL) s.fixed_bad = 1;
         if (v > c.tol) s.nviol = 1;  // benign race: every writer stores the same value
         if (-v < thresh) {
           // violated (or almost) -> hot list, scanned every iteration; merely close -> cold list at the top of
@@ -267,7 +268,7 @@ struct Solver {
   }
 
   // ---- leaf test: which unassigned steps lie in no polyhedron -----------------------------------------------
-  // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if the pinned p_0 is outside.
+  // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if an input-independent end point is outside.
   static HD int leaf_check(S& s, const Consts& c) {
     const int N = c.N, np = s.n_poly;
 #ifdef HDSM_LEAF_MFMA
@@ -304,8 +305,10 @@ struct Solver {
         double vmax = -DINF;
         if (s.assign[i] < 0) {
           const double v0 = s.red_v[j * 16 + i], v1 = s.red_v[j * 16 + i + 1];
-          if (i == 0) vmax = (v0 > c.ftol_fixed) ? DINF : v1;   // rows on the pinned p_0 only gate the choice
-          else vmax = v0 > v1 ? v0 : v1;
+          // rows on input-independent points only gate the choice
+          const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
+          if ((g0 && v0 > c.ftol_fixed) || (g1 && v1 > c.ftol_fixed)) vmax = DINF;
+          else vmax = g1 ? -DINF : (g0 ? v1 : (v0 > v1 ? v0 : v1));
         }
         s.keys[i][j] = vmax;
       }
@@ -336,8 +339,10 @@ struct Solver {
             const double v0 = r0 * ax_ + r1 * ay_ + r2 * az_ - r3, v1 = r0 * bx_ + r1 * by_ + r2 * bz_ - r3;
             v0max = v0 > v0max ? v0 : v0max, v1max = v1 > v1max ? v1 : v1max;
           }
-          if (i == 0) vmax = (v0max > c.ftol_fixed) ? DINF : v1max;  // rows on the pinned p_0 only gate the choice
-          else vmax = v0max > v1max ? v0max : v1max;
+          // rows on input-independent points only gate the choice
+          const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
+          if ((g0 && v0max > c.ftol_fixed) || (g1 && v1max > c.ftol_fixed)) vmax = DINF;
+          else vmax = g1 ? -DINF : (g0 ? v1max : (v0max > v1max ? v0max : v1max));
         }
         if (on) s.keys[i][j] = vmax;
         const unsigned long long inside = __ballot(on && vmax <= c.tol);
@@ -382,8 +387,8 @@ struct Solver {
           for (int r = r0; r < r1; ++r) {
             const double* row = s.sp[j][r];
             const double v = row[0] * px + row[1] * py + row[2] * pz - row[3];
-            if (i + e == 0) {
-              if (v > c.ftol_fixed) vmax = DINF;  // rows on the pinned p_0 only gate the choice
+            if (i + e <= c.pinned_steps) {
+              if (v > c.ftol_fixed) vmax = DINF;  // rows on input-independent points only gate the choice
             } else if (v > vmax) {
               vmax = v;
             }
@@ -561,6 +566,12 @@ struct Solver {
   // in pass 2 of a split launch, the slot of this sub-block; `sub`: the polyhedron this sub-block fixes at the root's
   // branching step (-1: ordinary solve).
   static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub_in) {
+#ifdef HDSM_POISON_LDS
+    // test builds (tests/wave_emu, scripts/gpu_poison.sh): LDS is not cleared between workgroups — whatever is read before it is
+    // written shows up as NaN / garbage here instead of depending on the kernel that ran on the CU before
+    for (int i = (int)threadIdx.x; i < (int)(sizeof(S) / 8); i += (int)blockDim.x) reinterpret_cast<unsigned long long*>(&s)[i] = 0xFFF8DEADBEEF0BADull;
+    SYNC();
+#endif
     if (IS_T0) s.args = a_in;
     SYNC();
     const Args& a = s.args;
@@ -581,7 +592,7 @@ struct Solver {
         s.iters_sh = got;
       }
       SYNC();
-      my_slot = s.iters_sh;
+      my_slot = uni(s.iters_sh);  // (wave-uniform: kept in a scalar register, not in a VGPR across the whole instance)
       no_slot = my_slot < 0;
       snap = a.scratch + (int64_t)(no_slot ? 0 : my_slot) * a.scratch_stride;
       SYNC();
@@ -610,7 +621,7 @@ struct Solver {
     const int nk = 3 * n + 12, nvt = 9 + 6 * N;
     double fw0, fw1;  // weights of the (at most two) tracking residuals this lane of wave 0 squares for the constant term
     double hrow_own;  // Consts::hrow1 of this lane's variable (the box bound of the objective, below)
-    const int np = min_i(a.n_poly[inst], P);
+    const int np = uni(min_i(a.n_poly[inst], P));  // (wave-uniform: a scalar register)
     {
       const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
       constexpr int KH = 3 + 2 * (NV / 3);  // inputs one output of the set-up map depends on (compact form, KTC)
@@ -807,7 +818,7 @@ struct Solver {
     // ---- branch and bound (gi_run and sweep have exactly one call site each: they are inlined)
     int iters = 0, nodes = 1, sweeps = 0;
     // The guess is an infeasibility certificate (see the hand-over below), or the last replan ended on the gridlock test of
-    // its sweep (PINNED_TOL): the neighbourhood was gridlocked. Such an instance sweeps FIRST, at the cold starting point: if
+    // its sweep (a constant row violated): the neighbourhood was gridlocked. Such an instance sweeps FIRST, at the cold starting point: if
     // the gridlock persists the test ends it right there; the certificate's own minimiser is a far-away point, so nothing
     // is pre-staged around it afterwards.
     bool warm_cert = false;
@@ -834,11 +845,13 @@ struct Solver {
     if (sub >= 0) {
       const int step = a.split_info[2 * inst + 1];
       bool admissible = sub < np && step >= 0 && step < N;
-      if (admissible && step == 0)  // rows on the pinned p_0 only gate the choice (leaf_check: keys = DINF)
-        for (int r = 0; r < s.sp_rows[sub]; ++r) {
-          const double* row = s.sp[sub][r];
-          admissible = admissible && !(row[0] * s.st[0][0] + row[1] * s.st[0][1] + row[2] * s.st[0][2] - row[3] > c.ftol_fixed);
-        }
+      for (int e = 0; e < 2; ++e)  // rows on input-independent points only gate the choice (leaf_check: keys = DINF)
+        if (admissible && step + e <= c.pinned_steps)
+          for (int r = 0; r < s.sp_rows[sub]; ++r) {
+            const double* row = s.sp[sub][r];
+            const int m = step + e;  // (such a point is its free response)
+            admissible = admissible && !(row[0] * s.fr[0][m][0] + row[1] * s.fr[1][m][0] + row[2] * s.fr[2][m][0] - row[3] > c.ftol_fixed);
+          }
       run = run && admissible;
       if (run && no_slot) run = false, limit = true, flags |= FLAG_NODE_LIMIT;  // (pool exhausted: reported like a node budget)
       SYNC();

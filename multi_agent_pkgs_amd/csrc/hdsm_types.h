@@ -36,7 +36,8 @@ struct Consts {
   int32_t box_cut;      // 1 (default): a dual objective above the largest objective any point of the input box can have ends an
                         // active-set run as infeasible (HDSM_BOX_CUT); 0: only the formal proof (dependent row, no multiplier to give way)
   int32_t scanner;      // 1 (default): n <= 30, workgroups of two or more wavefronts — wave 1 evaluates the trajectory and picks the next
-                        // row while wave 0 applies the Householder update of the operation before (HDSM_SCANNER; 0: wave 0 does both)
+                        // row while wave 0 applies the Householder update of the operation before (HDSM_SCANNER; 0: wave 0 does both;
+                        // 2, development: as 1 but every pick of the scanner is confirmed by its exact evaluation)
   double tol, ftol_fixed, cand_tau, hot_tau;
   double mip_gap;  // relative gap at which a node is cut off against the incumbent (0 = exact)
   long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)

@@ -136,6 +136,15 @@ __device__ __forceinline__ int tid_here() {
   return t;
 }
 
+// a value the optimiser must treat as used (and redefined) here: keeps its computation above this point
+__device__ __forceinline__ void keep_here(double& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+
 // ... and the same for a pointer
 template <class T>
 __device__ __forceinline__ T* keep_in_loop(T* p) {
@@ -169,6 +178,8 @@ struct alignas(16) D2 {
 #define ST_PROF(k)
 #define WS_PROF(k)
 #define OP_PROF(k) PROF(k)
+#define SC_PROF_DECL if (threadIdx.x == 64) s.prof_last1 = clock64();
+#define SC_PROF(k) if (threadIdx.x == 64) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last1; s.prof_last1 = now_; }
 #elif defined(HDSM_PROFILE) && defined(HDSM_PROF_STAGE)
 #define SW_PROF(k)
 #define ST_PROF(k) PROF(k)
@@ -179,6 +190,14 @@ struct alignas(16) D2 {
 #define ST_PROF(k)
 #define WS_PROF(k) PROF(k)
 #define OP_PROF(k)
+#endif
+#if !defined(SC_PROF) && defined(HDSM_ISA_MARKS)
+#define SC_PROF_DECL
+#define SC_PROF(k) asm volatile("; ISA_MARK SC " #k);
+#endif
+#ifndef SC_PROF
+#define SC_PROF_DECL
+#define SC_PROF(k)
 #endif
 
 template <int NV, int CMAX>
@@ -370,7 +389,7 @@ struct WaveGI {
   // assigned step per trip. The assignment and the row counts are fetched ONCE (lane i holds assign[i], lane j the row count
   // of polyhedron j) and handed round with v_readlane, so a trip is one LDS round trip — row and point together — instead
   // of the three in a chain (assign[i] -> sp_rows[j] -> row) the step-by-step loop paid in every node of a tree.
-  static __device__ __forceinline__ void scan_assigned(const S& s, int lane, int N, double tol, bool norm, Pick& pk) {
+  static __device__ __forceinline__ void scan_assigned(const S& s, int lane, int N, double tol, bool norm, Pick& pk, int pinned) {
     const int aj = lane < N ? s.assign[lane] : -1;
     const int nr = lane < MAXP ? s.sp_rows[lane] : 0;
     unsigned long long am = __ballot(aj >= 0);
@@ -380,7 +399,7 @@ struct WaveGI {
       const int j = __builtin_amdgcn_readlane(aj, i), rows = __builtin_amdgcn_readlane(nr, j);
       for (int t = lane; t < 2 * rows; t += 64) {
         const int e = t >= rows ? 1 : 0, r = t - e * rows;
-        if (i + e == 0) continue;
+        if (i + e <= pinned) continue;  // (rows on input-independent points only gate the choice: leaf_check)
         const double* row = s.sp[j][r];
         const double* pm = s.st[i + e];
         const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
@@ -424,7 +443,7 @@ struct WaveGI {
       }
     }
     OP_PROF(8)
-    if (MODE != 2 && uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
+    if (MODE != 2 && uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk, c.pinned_steps);  // rows of the polyhedra assigned on the current branch
     const int nc = MODE != 2 ? uni(s.ncand) : 0;
     const bool mw = SHARE && blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
@@ -772,11 +791,10 @@ struct WaveGI {
             const int m = i + e;
             const double* pm = s.st[m];
             const double v = fx * pm[0] + fy * pm[1] + fz * pm[2] - rhs;
-            if (m == 0) {
+            if (m <= pinned) {  // a constant row (hdsm_core.h): within ftol_fixed it holds, beyond it nothing can satisfy it
               if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
               continue;
             }
-            if (check_fixed && m <= pinned && v > 1e-7) s.fixed_bad = 1;  // violated on a position no input can move (Solver::PINNED_TOL)
             if (v > tol) s.nviol = 1;
             if (-v < thresh) {
               const bool hot = -v < hot_tau;
@@ -843,7 +861,7 @@ struct WaveGI {
         if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
       } else if (kind == K_C && a.l1_rows == nullptr) {
         const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
-        if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
+        if (i >= 0 && i + e > c.pinned_steps && k != self && k < a.n_rob && a.has_plan[k]) {
           const double* op = a.pos + ((int64_t)k * N + i) * 3;
           if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
         }

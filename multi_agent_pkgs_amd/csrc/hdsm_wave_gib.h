@@ -97,14 +97,35 @@ struct WaveGIB : WaveGI<32, CMAX> {
     return row16_sum64(r0 + r1);
   }
 
+  // ---- hand-over between wave 0 and the scanner (wave 1): workgroup barriers with a command word. (Words in LDS polled by the
+  // other side — no barrier at all — were built and measured: slower, 11.1 against 11.55 M agent-replans/s on the bench line. What
+  // costs is the round trip of the LDS write that carries the message, about 250 cycles either way, and a polling wave adds its
+  // sleep granularity on top.)
+  static constexpr int CMD_PICK = 2, CMD_PREP = 3;
+  // scalars of the Householder reflection that maps d2 onto rho e_q (v = d2 - rho e_q, beta = 2 / v^T v)
+  struct Refl {
+    double rho, inv_rho, beta;
+  };
+  static __device__ __forceinline__ Refl reflection(double zz, double dq) {
+    const double zs = zz > 0 ? zz : 1.0;  // (a dependent row: the scalars are not used)
+    const double inv_rho_abs = rsq_nr(zs);
+    Refl h;
+    h.rho = (dq > 0 ? -1.0 : 1.0) * (zs * inv_rho_abs), h.inv_rho = (dq > 0 ? -1.0 : 1.0) * inv_rho_abs;
+    h.beta = rcp_nr(h.rho * (h.rho - dq));
+    return h;
+  }
+
   // d = J^T(-a) (position layout), ||d||^2, ||d2||^2, d_q, z = J2 d2 (row layout), r = U d1 (position layout), and dz = d with the
   // working-set columns zeroed (position layout: the source of the Householder vector). `ai` = entry row_of(lane) of the normal.
   // WANT_Z = false (warm-start additions: no step is taken): z is not formed (one all-gather and one dot product less).
   // WANT_DD = false: ||d||^2 is not formed (a wave sum less; the regular loop then tests the dependency of the entering row against
   // a^T Z a, which the pick rule hands over with the row — see run()).
+  // prep_msg != 0 (regular loop of a workgroup with a scanner): z goes to LDS (Shm::w) and the scanner is told to prepare the next
+  // pick (CMD_PREP) as soon as z exists — it works while this wave forms r, runs the ratio test and chooses the step.
   template <bool WANT_Z = true, bool WANT_DD = true>
   static __device__ __forceinline__ void direction(S& s, const Regs& R, double ai, int q, int lane, double& dj, double& dz,
-                                                   double& dd, double& zz, double& dq, double& zi, double& ri) {
+                                                   double& dd, double& zz, double& dq, double& zi, double& ri, int prep_msg = 0,
+                                                   Refl* refl = nullptr) {
     double p[NC];
     const double na = -ai;
 #pragma unroll
@@ -118,6 +139,8 @@ struct WaveGIB : WaveGI<32, CMAX> {
     zz = pos_sum(dz * dz, lane);
     dq = (q < NV) ? bcast64(dj, lane_of_pos(q < NV ? q : 0)) : 0.0;
     zi = 0.0;
+    // (two chains of dependent scalar operations: formed here they run in the shadow of the all-gather, not after the step)
+    if (refl != nullptr) *refl = reflection(zz, dq);
     if constexpr (WANT_Z) {
       OP_PROF(13)
       double g[NC];
@@ -127,6 +150,11 @@ struct WaveGIB : WaveGI<32, CMAX> {
       for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
       zi = half_sum64(z0 + z1);
       OP_PROF(14)
+      if (prep_msg != 0) {  // message to the scanner: z is there
+        if (lane < NV) s.w[lane] = zi;
+        if (lane == 0) s.cmd = prep_msg;
+        __syncthreads();  // B1
+      }
     }
     wsync();
     ri = u_row_dot(s, lane);
@@ -137,10 +165,9 @@ struct WaveGIB : WaveGI<32, CMAX> {
   // vector v = d2 - rho e_q: (J2 v) comes from the same gathered v that the rank-1 update multiplies
   template <bool PROBE = false>  // (PROBE: the call of the regular loop, timed by the -DHDSM_PROF_OP build)
   static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane, double dz, double zz,
-                                                         double dq, double ri) {
-    const double inv_rho_abs = rsq_nr(zz);  // (zz > 0: the caller has tested it against ||d||^2)
-    const double rho = (dq > 0 ? -1.0 : 1.0) * (zz * inv_rho_abs), inv_rho = (dq > 0 ? -1.0 : 1.0) * inv_rho_abs;
-    const double beta = rcp_nr(rho * (rho - dq));
+                                                         double dq, double ri, const Refl* refl = nullptr) {
+    const Refl hh = refl != nullptr ? *refl : reflection(zz, dq);  // (zz > 0: the caller has tested it against ||d||^2)
+    const double rho = hh.rho, inv_rho = hh.inv_rho, beta = hh.beta;
     const int pos = pos_of(lane);
     double g[NC];
     if constexpr (PROBE) { OP_PROF(16) }
@@ -251,7 +278,7 @@ struct WaveGIB : WaveGI<32, CMAX> {
         if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
       } else if (kind == K_C && a.l1_rows == nullptr) {
         const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
-        if (i >= 0 && i + e >= 1 && k != self && k < a.n_rob && a.has_plan[k]) {
+        if (i >= 0 && i + e > c.pinned_steps && k != self && k < a.n_rob && a.has_plan[k]) {
           const double* op = a.pos + ((int64_t)k * N + i) * 3;
           if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
         }
@@ -374,12 +401,11 @@ struct WaveGIB : WaveGI<32, CMAX> {
     int rc = GI_OK;
     const int pos = pos_of(lane);
     load_pos(s, R, lane);
-    // Workgroups of more than one wavefront: wave 1 is the SCANNER (scanner_loop below). Evaluating the trajectory at the new
+    // Workgroups of more than one wavefront: wave 1 is the SCANNER (helper_loop below). Evaluating the trajectory at the new
     // iterate and picking the row that enters next reads nothing the Householder update writes, so the scanner does both while
-    // this wave applies the update of the operation before (two workgroup barriers per operation: "go" after the step, "done"
-    // before the next direction); the normal of the picked row comes back through LDS with the pick.
+    // this wave applies the update of the operation before; the normal of the picked row comes back through LDS with the pick.
     const bool duo = blockDim.x > 64 && c.scanner != 0;
-    bool pending = false;  // a scan is under way (posted after the last step): its result is behind the next barrier
+    bool pending = false;  // a pick is under way (requested with the last step): its answer is behind the next barrier
     PROF_DECL
     for (;;) {
       // (the lane masks and addresses of the state evaluation and the scan are formed here, per operation: hoisted out of
@@ -400,9 +426,17 @@ struct WaveGIB : WaveGI<32, CMAX> {
           if (lane == 0) s.cmd = CMD_PICK;
           __syncthreads();  // go
         }
+        OP_PROF(2)          // (what was left of the update: booked with the operation before)
         __syncthreads();    // done
+        OP_PROF(10)         // waiting for the scanner
         pending = false;
         ip = uni(s.part_id[1]);
+        if (ip == -2) {  // nothing is violated at the extrapolated point: the exact evaluation at s.x confirms it (or finds the next row)
+          if (lane == 0) s.cmd = CMD_PICK;
+          __syncthreads();  // go
+          __syncthreads();  // done
+          ip = uni(s.part_id[1]);
+        }
         PROF(1)
         if (ip < 0) break;
         vip = s.part_v[1], kip = s.part_key[1];
@@ -427,8 +461,6 @@ struct WaveGIB : WaveGI<32, CMAX> {
         PROF(1)
         ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
         OP_PROF(11)
-        OP_PROF(19)
-        OP_PROF(20)
       }
       const bool is_eq = id_kind(ip) == K_E;
       // 1e-20 a^T Z a of the entering row, from the key of its pick (normalised rule: kip = vip / sqrt(a^T Z a)); < 0: not available
@@ -464,7 +496,17 @@ struct WaveGIB : WaveGI<32, CMAX> {
         // row arrives with a^T Z a = (vip / kip)^2 at the moment of the pick (dep_thr), and ||d_2||^2 <= a^T Z a <= a^T H^-1 a: the test
         // against a^T Z a differs only where ||d_2||^2 is 1e-20 of either — far below rounding — and spares the wave sum of ||d||^2.
         bool dependent;
-        direction<true, false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri);  // (one call site: the body is inlined)
+        const bool prep = duo && neq >= 6;
+        Refl refl;
+        direction<true, false>(s, R, ai, q, lane, dj, dz, dd, zz, dq, zi, ri, prep ? CMD_PREP : 0, &refl);  // (one call site: the body is inlined)
+        // (after B1 the scanner prepares, then it waits at B2 for the step, or for the word that there is none)
+        auto post_step = [&](double tv) {
+          if (prep) {
+            if (lane == 0) s.part_v[0] = tv;
+            __syncthreads();  // B2
+          }
+        };
+        auto no_step = [&]() { post_step(-1.0); };
         if (dep_thr >= 0.0) {
           dependent = !(zz > dep_thr) || q >= NV;
         } else {
@@ -488,12 +530,14 @@ struct WaveGIB : WaveGI<32, CMAX> {
         if (lane == 0) printf("    step dep=%d t1=%.3e t2=%.3e l=%d zz=%.3e dd=%.3e\n", (int)dependent, t1, dependent ? 0.0 : vip / zz, l, zz, dd);
 #endif
         if (dependent && l < 0) {
+          no_step();
           rc = GI_INFEASIBLE;
           if (lane == 0) s.inf_id = ip;  // the row that cannot be satisfied together with the current working set
           stop = true;
           break;
         }
         if (dependent) {  // dual step only; constraint l leaves
+          no_step();
           if (pos < q) R.lam -= t1 * ri;
           lam_p += t1;
           drop(s, R, l, q, lane);
@@ -505,35 +549,30 @@ struct WaveGIB : WaveGI<32, CMAX> {
         const bool full = is_eq || t2 <= t1;
         const double t = full ? t2 : t1;
         R.xi += t * zi;  // (lanes beyond n carry zeros: z is zero on padded rows)
-        if (lane < n) s.x[lane] = R.xi;
         if (pos < q) R.lam -= t * ri;
         f += t * zz * (0.5 * t + lam_p);
         lam_p += t;
         PROF(5)
         if (full) {
-          if (duo && neq + (is_eq ? 1 : 0) >= 6) {  // the scanner starts on the next pick at the new iterate
-            if (lane == 0) s.cmd = CMD_PICK;
-            __syncthreads();  // go
+          if (prep) {  // the scanner picks the next row at x + t z (it holds x, z and everything it prepared from them)
+            post_step(t);  // (t >= 0)
             pending = true;
           }
-          householder_add<true>(s, R, ip, lam_p, q, lane, dz, zz, dq, ri);
+          if (lane < n) s.x[lane] = R.xi;  // (after B2: the scanner reads the OLD iterate between B1 and B2)
+          householder_add<true>(s, R, ip, lam_p, q, lane, dz, zz, dq, ri, &refl);
           PROF(6)
           ++q;
           if (is_eq) ++neq;
           break;
         }
-        if (duo) {  // the scanner re-evaluates the entering row at the new iterate while the entry at l leaves
-          if (lane == 0) s.cmd = CMD_RESID, s.part_id[0] = ip;
-          __syncthreads();  // go
-          drop(s, R, l, q, lane);
-          PROF(7)
-          --q;
-          __syncthreads();  // done
-          vip = s.part_v[1];
+        no_step();
+        if (lane < n) s.x[lane] = R.xi;
+        drop(s, R, l, q, lane);
+        PROF(7)
+        --q;
+        if (prep) {
+          vip -= t * zz;  // along z the violation of the entering row falls at the rate a^T z = -||d2||^2 (what t2 = vip / zz uses)
         } else {
-          drop(s, R, l, q, lane);
-          PROF(7)
-          --q;
           Base::states(s, R, lane, N);
           vip = Base::resid(s, c, ip, N);
         }
@@ -552,140 +591,185 @@ struct WaveGIB : WaveGI<32, CMAX> {
       }
     }
     store_pos(s, R, lane);
-    if (pending) __syncthreads();  // (a scan nobody needs any more: its "done")
     wsync();
+    if (pending) __syncthreads();  // (a pick nobody needs any more: its "done")
     if (lane == 0) s.f = f, s.q = q, s.neq_done = neq, s.cmd = 0;
     if (blockDim.x > 64) __syncthreads();  // releases the other waves (they leave on cmd == 0)
     else wsync();
     return rc;
   }
 
-  // The other waves of the workgroup while wave 0 iterates. Wave 1, the scanner, waits for a command at the workgroup barrier:
-  //   CMD_PICK   trajectory at s.x, then the row that enters next (state boxes only when nothing else is violated, cold rows
-  //              promoted when no hot row is) -> part_id[1] (-1: nothing is violated), part_v[1], part_key[1], and the dense
-  //              normal of the pick, entry `var` in dvz[var] (dvz is otherwise unused by this layout);
-  //   CMD_RESID  trajectory at s.x, then the violation of row part_id[0] -> part_v[1].
-  // Waves 2.. only keep the barrier count. `R` holds this wave's per-lane constants of the scan (init_lane with lane = thread & 63).
+  // The other waves of the workgroup while wave 0 iterates. Wave 1, the scanner, finds the row that enters next; the other waves
+  // only keep the barrier count. Commands (Shm::cmd at a "go" barrier):
+  //   CMD_PICK   exact: trajectory at s.x, then the pick (state boxes only when nothing else is violated, cold rows promoted when
+  //              no hot row is) -> part_id[1] (-1: nothing is violated), part_v[1], part_key[1], and the dense normal of the pick,
+  //              entry `var` in dvz[var] (dvz is otherwise unused by this layout); one "done" barrier;
+  //   CMD_PREP   (B1) wave 0 has the primal direction z (Shm::w) but not yet the step. Phase 1: trajectory at the OLD iterate and
+  //              its derivative along z, the violation v and its rate dv for the lane's staged rows and its input box — all of it
+  //              while wave 0 forms r = U d and runs the ratio test. Then B2 with the step in part_v[0]:
+  //     t >= 0     a full step t is taken and the row enters. Phase 2: v + t dv for every row -> the pick as above
+  //                (-2 instead of -1: "nothing violated" is only ever believed from the exact evaluation); "done" barrier;
+  //     t = -1     no step / a partial step (wave 0 follows the entering row by itself): nothing more to do.
+  // `R` holds this wave's per-lane constants of the scan (init_lane with lane = thread & 63).
   //
-  // The scanner's answer is on the critical path of every operation (wave 0 waits for it after its Householder update), and what
-  // it costs is LDS round trips in a chain, so everything that does not change during a run is kept in REGISTERS of this wave:
-  // the impulse-response taps of the lane's trajectory point, its input box, and the first RC staged rows of the lane with their
-  // step and pick weight (the staging area only changes between runs, or when this wave itself promotes cold rows). Per pick the
-  // chain is: x (one batch of LDS reads) -> positions -> LDS -> the points of the cached rows (one batch) -> keys -> wave maximum.
-  static constexpr int CMD_PICK = 2, CMD_RESID = 3;
-  static constexpr int RC = 2;  // staged rows per lane held in registers (64 RC rows; longer staging areas: the rest from LDS)
+  // The scanner's answer is on the critical path of every operation (wave 0 needs it after its Householder update), and what it
+  // costs is LDS round trips in a chain. Whatever can be computed before the step length is known is computed then (phase 1 has
+  // the time wave 0 spends on r = U d and the ratio test): after B2 a row costs one multiply-add, and only rows beyond the RC per
+  // lane that phase 1 prepares, or the rows of assigned polyhedra, are evaluated from LDS at the new point.
+  static constexpr int RC = 3;  // staged rows per lane prepared in phase 1 (64 RC rows; longer staging areas: the rest from LDS)
   static __device__ __forceinline__ void helper_loop(S& s, const Consts& c, Regs& R) {
     const int w = (int)threadIdx.x >> 6;
     if (w != 1) {
       for (;;) {
-        __syncthreads();  // go
-        if (uni(s.cmd) == 0) return;
-        __syncthreads();  // done
+        __syncthreads();  // go / B1
+        const int cmd = uni(s.cmd);
+        if (cmd == 0) return;
+        __syncthreads();  // done / B2
+        if (cmd == CMD_PREP && uni(__double2hiint(s.part_v[0])) >= 0) __syncthreads();  // done
       }
     }
     const int N = c.N, n = c.n;
     const double tol = c.tol;
     const bool norm = c.pick_rule != 0;
-    int lane = (int)threadIdx.x & 63;
-    keep_in_loop(lane);
-    // this lane's trajectory point: (axis, step m), half h of the taps
-    constexpr int HH = Base::HT / 2;
-    const int row = lane & 31, h = lane >> 5;
-    const bool on = row < 3 * N;
-    const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
-    double gp[HH];
-#pragma unroll
-    for (int k = 0; k < HH; ++k) gp[k] = s.gz[ax][0][MAXH + m - 1 - (h * HH + k)];
-    const double fr0 = h == 0 ? s.fr[ax][m][0] : 0.0;
-    const double* xx = s.x + ax * N + h * HH;
-    const double lbu = s.bnd[R.ax], ubu = s.bnd[3 + R.ax];
-    const int level = uni(s.level);
-    // the lane's staged rows
-    double r0[RC], r1[RC], r2[RC], r3[RC];
-    int rm[RC];
-    float rw[RC];
-    int nc = 0;
-    auto load_rows = [&]() {
-      nc = uni(s.ncand);
-#pragma unroll
-      for (int u = 0; u < RC; ++u) {
-        const int idx = 64 * u + lane;
-        const int ii = idx < nc ? idx : 0;
-        const MW mw = s.cand_mw[ii];
-        const D2 a01 = *reinterpret_cast<const D2*>(&s.cand[ii][0]), a23 = *reinterpret_cast<const D2*>(&s.cand[ii][2]);
-        r0[u] = a01.x, r1[u] = a01.y, r2[u] = a23.x, r3[u] = idx < nc ? a23.y : DINF;  // (a row that is not there is never violated)
-        rm[u] = mw.m, rw[u] = mw.w;
-      }
-    };
-    load_rows();
+    SC_PROF_DECL
     for (;;) {
-      __syncthreads();  // go
+      __syncthreads();  // go / B1
+      SC_PROF(23)
       const int cmd = uni(s.cmd);
       if (cmd == 0) return;
-      if (cmd == CMD_PICK) {
-        int ip;
-        double vip, kip = 0.0;
-        for (;;) {
-          // positions at s.x
-          double xk[HH];
+      int lane = (int)threadIdx.x & 63;
+      keep_in_loop(lane);
+      // this lane's trajectory point: (axis, step m), half h of the impulse-response taps
+      constexpr int HH = Base::HT / 2;
+      const int row = lane & 31, h = lane >> 5;
+      const bool on = row < 3 * N;
+      const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
+      const double* gp = &s.gz[ax][0][MAXH + m - 1 - h * HH];  // taps gp[-k]
+      const double* xx = s.x + ax * N + h * HH;
+      const double* zx = s.w + ax * N + h * HH;
+      double* dpv = s.red_v;  // derivative of the positions along z: entry 3 m + axis (red_v is free during a run)
+      int ip = -1;
+      double vip = 0.0, kip = 0.0;
+      bool answered = false;
+      if (cmd == CMD_PREP) {
+        // ---- phase 1: everything that needs x and z but not the step
+        const int nc = uni(s.ncand), level = uni(s.level);
+        double xk[HH], zk[HH], gk[HH];
 #pragma unroll
-          for (int k = 0; k < HH; ++k) xk[k] = xx[k];
-          const double xi = lane < NV ? s.x[lane] : 0.0;
-          double acc = fr0;
+        for (int k = 0; k < HH; ++k) xk[k] = xx[k], zk[k] = zx[k], gk[k] = gp[-k];
+        const double xi = lane < NV ? s.x[lane] : 0.0, zl = lane < NV ? s.w[lane] : 0.0;
+        const double lbu = s.bnd[R.ax], ubu = s.bnd[3 + R.ax];
+        int rm[RC];
+        float rw[RC];
+        double r0[RC], r1[RC], r2[RC], r3[RC];
 #pragma unroll
-          for (int k = 0; k < HH; ++k) acc += gp[k] * xk[k];
-          acc = half_sum64(acc);
-          if (on && h == 0) s.st[m][ax] = acc;
-          wsync();
-          typename Base::Pick pk{0.0, 0.0, -1};
-          auto offer = [&](double vv, float wgt, int id) {
-            if (vv > tol) {
-              const double key = norm ? (double)((float)vv * wgt) : vv;
-              if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
-            }
-          };
-          // the points of the cached rows: one batch of reads
-          double px[RC], py[RC], pz[RC];
+        for (int u = 0; u < RC; ++u) {  // the lane's staged rows (a row that is not there is never violated)
+          const int idx = 64 * u + lane;
+          r0[u] = r1[u] = r2[u] = 0.0, r3[u] = DINF, rm[u] = 1, rw[u] = 0.0f;
+          if (idx < nc) {
+            const MW mw = s.cand_mw[idx];
+            const D2 a01 = *reinterpret_cast<const D2*>(&s.cand[idx][0]), a23 = *reinterpret_cast<const D2*>(&s.cand[idx][2]);
+            r0[u] = a01.x, r1[u] = a01.y, r2[u] = a23.x, r3[u] = a23.y;
+            rm[u] = mw.m, rw[u] = mw.w;
+          }
+        }
+        double accx = h == 0 ? s.fr[ax][m][0] : 0.0, accz = 0.0;
+#pragma unroll
+        for (int k = 0; k < HH; ++k) accx += gk[k] * xk[k], accz += gk[k] * zk[k];
+        accx = half_sum64(accx), accz = half_sum64(accz);
+        if (on && h == 0) s.st[m][ax] = accx, dpv[3 * m + ax] = accz;
+        wsync();
+        double v0[RC], dv[RC];
+        {
+          double px[RC], py[RC], pz[RC], qx[RC], qy[RC], qz[RC];
 #pragma unroll
           for (int u = 0; u < RC; ++u) {
             const double* pm = s.st[rm[u]];
-            px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
-          }
-          if (lane < n) {  // box of this lane's input
-            const double vu = xi - ubu, vl = lbu - xi;
-            offer(vl > vu ? vl : vu, R.wu, mk_id(K_U, (lane << 1) | (vl > vu ? 1 : 0)));
+            const double* dm = dpv + 3 * rm[u];
+            px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2], qx[u] = dm[0], qy[u] = dm[1], qz[u] = dm[2];
           }
 #pragma unroll
           for (int u = 0; u < RC; ++u) {
-            const double vv = r0[u] * px[u] + r1[u] * py[u] + r2[u] * pz[u] - r3[u];
-            offer(vv, rw[u], mk_kc(64 * u + lane, rm[u]));
+            v0[u] = r0[u] * px[u] + r1[u] * py[u] + r2[u] * pz[u] - r3[u];
+            dv[u] = r0[u] * qx[u] + r1[u] * qy[u] + r2[u] * qz[u];
           }
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u) keep_here(v0[u]), keep_here(dv[u]);  // (formed BEFORE the barrier, not where they are used)
+        SC_PROF(19)
+        __syncthreads();  // B2
+        SC_PROF(23)
+        // ---- phase 2: the step (one word: t >= 0, or -1 = no step / a partial one that wave 0 follows by itself)
+        const double t_in = s.part_v[0];
+        const int t_hi = uni(__double2hiint(t_in));
+        if (t_hi < 0) continue;
+        const double t = __hiloint2double(t_hi, uni(__double2loint(t_in)));
+        typename Base::Pick pk{0.0, 0.0, -1};
+        auto offer = [&](double vv, float wgt, int id) {
+          if (vv > tol) {
+            const double key = norm ? (double)((float)vv * wgt) : vv;
+            if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id;
+          }
+        };
+        if (lane < n) {  // box of this lane's input
+          const double xn = xi + t * zl;
+          const double vu = xn - ubu, vl = lbu - xn;
+          offer(vl > vu ? vl : vu, R.wu, mk_id(K_U, (lane << 1) | (vl > vu ? 1 : 0)));
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u) offer(v0[u] + t * dv[u], rw[u], mk_kc(64 * u + lane, rm[u]));
+        if (nc > 64 * RC || level > 0) {  // rows that are read from LDS need the new positions there
+          if (on && h == 0) s.st[m][ax] = accx + t * accz;
+          wsync();
           if (nc > 64 * RC) Base::scan_rows(s, 64 * RC, nc, lane, tol, norm, pk);
-          if (level > 0) Base::scan_assigned(s, lane, N, tol, norm, pk);  // rows of the polyhedra assigned on the current branch
-          const double mk = wave_max64(pk.key);
-          ip = -1, vip = 0.0, kip = mk;
-          if (mk > 0.0) {
-            const int src = __ffsll((long long)__ballot(pk.key == mk && pk.id >= 0)) - 1;
-            ip = __builtin_amdgcn_readlane(pk.id, src);
-            vip = bcast64(pk.v, src);
-          }
+          if (level > 0) Base::scan_assigned(s, lane, N, tol, norm, pk, c.pinned_steps);  // rows of the polyhedra assigned on the current branch
+        }
+        SC_PROF(20)
+        const double mk = wave_max64(pk.key);
+        ip = -2, kip = mk;
+        if (mk > 0.0) {
+          const int src = __ffsll((long long)__ballot(pk.key == mk && pk.id >= 0)) - 1;
+          ip = __builtin_amdgcn_readlane(pk.id, src);
+          vip = bcast64(pk.v, src);
+        }
+        SC_PROF(21)
+        if (c.scanner == 2) ip = -2;  // (development switch HDSM_SCANNER=2: every pick through the exact evaluation)
+#ifdef HDSM_CHECK_EXTRAP
+        {  // debugging aid: the same pick from the exact evaluation at the new iterate (wave 0 wrote it right after B2)
+          for (int w8 = 0; w8 < 8; ++w8) __builtin_amdgcn_s_sleep(64);
+          wsync();
+          R.xi = lane < NV ? s.x[lane] : 0.0;
+          int i2;
+          double v2, k2 = 0.0;
+          Base::template states<1>(s, R, lane, N);
+          Base::template select<1, false>(s, c, R, lane, tol, N, v2, i2, &k2);
+          i2 = uni(i2);
+          const int ipx = ip == -2 ? -1 : ip;
+          if (lane == 0 && (i2 != ipx || fabs(v2 - vip) > 1e-9 * (1.0 + fabs(v2))))
+            printf("EXTRAP block %d: extrapolated pick %x v %.12e key %.6e | exact pick %x v %.12e key %.6e | t %.6e nc %d level %d\n", (int)blockIdx.x, ip, vip, kip, i2, v2, k2, t, nc, level);
+        }
+#endif
+        answered = true;
+      }
+      if (!answered) {  // CMD_PICK: the exact evaluation at s.x (first pick of a run; confirmation that nothing is violated)
+        R.xi = lane < NV ? s.x[lane] : 0.0;  // (the box of this lane's input)
+        for (;;) {
+          Base::template states<1>(s, R, lane, N);
+          Base::template select<1, false>(s, c, R, lane, tol, N, vip, ip, &kip);
+          ip = uni(ip);
           if (ip < 0) {  // nothing but the state boxes is left: velocities and accelerations too
-            R.xi = xi;
             Base::template states<2>(s, R, lane, N);
             Base::template select<2, false>(s, c, R, lane, tol, N, vip, ip, &kip);
             ip = uni(ip);
           }
           if (ip >= 0 || Base::promote_cold(s, lane, tol) <= 0) break;
-          load_rows();
         }
-        if (ip >= 0 && lane < NV) s.dvz[lane] = Base::normal_entry(s, R, ip, lane, N, n);
-        if (lane == 0) s.part_id[1] = ip, s.part_v[1] = vip, s.part_key[1] = kip;
-      } else {
-        Base::states(s, R, lane, N);
-        const double v = Base::resid(s, c, uni(s.part_id[0]), N);
-        if (lane == 0) s.part_v[1] = v;
       }
+      if (ip >= 0 && lane < NV) s.dvz[lane] = Base::normal_entry(s, R, ip, lane, N, n);
+      if (lane == 0) s.part_id[1] = ip, s.part_v[1] = vip, s.part_key[1] = kip;
+      SC_PROF(22)
       __syncthreads();  // done
+      SC_PROF(23)
     }
   }
 

@@ -488,6 +488,8 @@ typedef struct {
   con_t* cons;
   int ncons, cap;
   double tol, ftol_fixed;
+  int pinned; /* p_0 .. p_pinned do not depend on the inputs (p_0 always; with jerk inputs and the Euler step also p_1, p_2): a row
+               * there is a constant, judged like a row on p_0 — within feas_tol_fixed it holds, beyond it nothing can satisfy it */
   int have_inc, limit_hit;
   double inc_f, inc_u[ON], second;
   int inc_assign[MAXH], assign[MAXH];
@@ -508,6 +510,19 @@ static void push_con(bnb_t* b, const con_t* c) {
     b->cons = (con_t*)realloc(b->cons, sizeof(con_t) * b->cap);
   }
   b->cons[b->ncons++] = *c;
+}
+
+/* number of leading steps whose POSITION no input reaches (Gam[ax][m][k][0] == 0 for every k < m and every axis) */
+static int pinned_steps(const shared_t* sh) {
+  int pinned = 0;
+  for (int m = 1; m <= sh->N; m++) {
+    int zero = 1;
+    for (int ax = 0; ax < 3; ax++)
+      for (int k = 0; k < m; k++) zero = zero && sh->Gam[ax][m][k][0] == 0.0;
+    if (!zero) break;
+    pinned = m;
+  }
+  return pinned;
 }
 
 /* Constraints that hold whatever the assignment: terminal equalities (AC:2078-2081), input box
@@ -542,9 +557,9 @@ static int build_base(bnb_t* b) {
       const double* row = b->cor->common[i] + 4 * r;
       for (int e = 0; e < 2; e++) {
         int mstep = i + e;
-        if (mstep == 0) { /* pinned point: constant row */
-          double v = row[0] * b->in->fr[0][0][0] + row[1] * b->in->fr[1][0][0] +
-                     row[2] * b->in->fr[2][0][0] - row[3];
+        if (mstep <= b->pinned) { /* pinned point: constant row */
+          double v = row[0] * b->in->fr[0][mstep][0] + row[1] * b->in->fr[1][mstep][0] +
+                     row[2] * b->in->fr[2][mstep][0] - row[3];
           if (v > b->ftol_fixed) return 0;
           continue;
         }
@@ -566,8 +581,8 @@ static int push_poly(bnb_t* b, int i, int j) {
     double rhs = cor->b[i][j][r];
     for (int e = 0; e < 2; e++) {
       int mstep = i + e;
-      if (mstep == 0) {
-        double v = A[0] * b->in->fr[0][0][0] + A[1] * b->in->fr[1][0][0] + A[2] * b->in->fr[2][0][0] - rhs;
+      if (mstep <= b->pinned) {
+        double v = A[0] * b->in->fr[0][mstep][0] + A[1] * b->in->fr[1][mstep][0] + A[2] * b->in->fr[2][mstep][0] - rhs;
         if (v > b->ftol_fixed) return 0;
         continue;
       }
@@ -590,7 +605,7 @@ static double poly_violation(const bnb_t* b, int i, int j, double st[3][MAXH + 1
     for (int e = 0; e < 2; e++) {
       int mstep = i + e;
       double v = A[0] * st[0][mstep][0] + A[1] * st[1][mstep][0] + A[2] * st[2][mstep][0] - rhs;
-      if (mstep == 0) {
+      if (mstep <= b->pinned) {
         if (v > b->ftol_fixed) return INFINITY;
         continue;
       }
@@ -757,6 +772,7 @@ static int miqp_shared(const hdsm_params* prm, const shared_t* sh, const double*
   b->prm = prm, b->in = &in, b->cor = cor;
   b->tol = prm->solver_tol > 0 ? prm->solver_tol : 1e-9;
   b->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
+  b->pinned = pinned_steps(sh);
   b->max_nodes = prm->max_nodes > 0 ? prm->max_nodes : 100000;
   b->iter_budget = prm->max_qp_iters > 0 ? prm->max_qp_iters : 10000000;
   b->inc_f = INFINITY, b->second = INFINITY, b->cut0 = cut0;
@@ -812,6 +828,7 @@ static int qp_fixed_shared(const hdsm_params* prm, const shared_t* sh, const dou
   b->prm = prm, b->in = &in, b->cor = cor;
   b->tol = prm->solver_tol > 0 ? prm->solver_tol : 1e-9;
   b->ftol_fixed = prm->feas_tol_fixed > 0 ? prm->feas_tol_fixed : 1e-6;
+  b->pinned = pinned_steps(sh);
   b->iter_budget = 10000000;
   int ok = build_base(b);
   for (int i = 0; i < N && ok; i++)

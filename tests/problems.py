@@ -154,3 +154,29 @@ def level1_from_snapshot(prm, sn, planes_fn):
                 A[a, i, j, :r] = np.vstack([Aj, rows[:, :3]])
                 b[a, i, j, :r] = np.concatenate([bj, rows[:, 3]])
     return n_poly, n_rows, A, b
+
+
+def constant_row_case(prm, oracle, mstep, delta):
+    """One agent flying along +x in a big box; the polyhedron of step mstep - 1 carries one more row that the input-independent
+    position p_mstep (Euler model, jerk inputs: p_1 and p_2 are fixed by the current state) violates by `delta`."""
+    N, P = prm.n_hor, prm.poly_hor
+    state = np.zeros((1, 9))
+    state[0, :3] = (1.0, 2.0, 1.5)
+    state[0, 3:6] = (2.0, 0.5, 0.0)
+    state[0, 6:9] = (0.3, 0.0, 0.0)
+    ref = ref_from_path(state[0, :3], np.array([1.0, 0.2, 0.0]) / np.hypot(1.0, 0.2), 2.0, prm.dt, N)[None]
+    free = oracle.rollout(prm, state[0], np.zeros((N, 3)))       # p_1, p_2 of ANY trajectory
+    nrm = state[0, 3:6] / np.linalg.norm(state[0, 3:6])
+    Ab, bb = box_rows(np.array([-50.0, -50.0, -50.0]), np.array([50.0, 50.0, 50.0]))
+    r_max = len(bb) + 1
+    n_poly = np.ones((1, N), np.int32)
+    n_rows = np.zeros((1, N, P), np.int32)
+    A, b = np.zeros((1, N, P, r_max, 3)), np.zeros((1, N, P, r_max))
+    for i in range(N):
+        n_rows[0, i, 0] = len(bb)
+        A[0, i, 0, :len(bb)], b[0, i, 0, :len(bb)] = Ab, bb
+    i = mstep - 1
+    A[0, i, 0, len(bb)], b[0, i, 0, len(bb)] = nrm, nrm @ free[mstep, :3] - delta
+    n_rows[0, i, 0] = len(bb) + 1
+    assert nrm @ free[i, :3] < b[0, i, 0, len(bb)] - 1e-3       # the other end point of the segment is well inside
+    return state, ref, n_poly, n_rows, A, b

@@ -69,8 +69,10 @@ def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32, traj
             pts = traj[ids][:, e:N + e, :3]                                                    # p_{i+e}
             viol = np.einsum("minc,mic->min", planes[..., :3], pts) - planes[..., 3]
             lim = np.full((1, N, 1), 1e-7)
-            if e == 0:
-                lim[0, 0, 0] = 1e-6                                                            # rows on the pinned p_0
+            pinned = 0 if prm.rk4 else 2           # p_0 .. p_pinned do not depend on the inputs: rows there are constants judged
+            for i in range(N):                     # with feas_tol_fixed
+                if i + e <= pinned:
+                    lim[0, i, 0] = 1e-6
             assert (viol < lim).all(), (ids[np.argmax(viol.max(axis=(1, 2)))], float(viol.max()))
     # containment in a polyhedron flagged used
     A, b, nr = rec["A"], rec["b"], rec["n_rows"]
@@ -83,7 +85,8 @@ def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32, traj
                 r = int(nr[a, j])
                 v0 = (A[a, j, :r] @ traj[a, i, :3] - b[a, j, :r]).max()
                 v1 = (A[a, j, :r] @ traj[a, i + 1, :3] - b[a, j, :r]).max()
-                if v0 < 1e-6 and v1 < 1e-7:
+                pinned = 0 if prm.rk4 else 2
+                if v0 < (1e-6 if i <= pinned else 1e-7) and v1 < (1e-6 if i + 1 <= pinned else 1e-7):
                     inside = True
                     break
             assert inside, (a, i)

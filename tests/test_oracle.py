@@ -411,3 +411,26 @@ def test_enumerated_miqps_pin_the_combinatorial_part(oracle):
         else:
             n10 += 1
     assert n6 >= 6 and n10 >= 3
+
+
+@pytest.mark.parametrize("mstep", [1, 2])
+def test_rows_on_input_independent_positions_are_judged_with_feas_tol_fixed(oracle, mstep):
+    """Under Euler p_1 and p_2 do not depend on the inputs (jerk inputs reach the position after three steps): a row there is a
+    constant. Within feas_tol_fixed (Gurobi's FeasibilityTol, 1e-6) it holds and changes nothing; beyond it nothing satisfies it."""
+    prm = make_params(n_hor=8, poly_hor=2, max_rows_static=18)
+    base = None
+    for delta, want in ((-1.0, 0), (1e-8, 0), (1e-7, 0), (1e-5, 2)):
+        o = oracle.solve(prm, *problems.constant_row_case(prm, oracle, mstep, delta))
+        assert o["status"][0] == want, (mstep, delta, o["status"])
+        if want == 0:
+            base = o["traj"].copy() if base is None else base
+            assert np.abs(o["traj"] - base).max() < 1e-12
+    # with RK4 every position depends on the inputs: the same row is an ordinary constraint (tolerance solver_tol) that the
+    # solver satisfies by moving p_mstep
+    prm4 = make_params(n_hor=8, poly_hor=2, max_rows_static=18, rk4=True)
+    args = problems.constant_row_case(prm4, oracle, mstep, 1e-5)
+    o = oracle.solve(prm4, *args)
+    assert o["status"][0] == 0
+    A, b = args[4], args[5]
+    r = int(args[3][0, mstep - 1, 0]) - 1
+    assert A[0, mstep - 1, 0, r] @ o["traj"][0, mstep, :3] - b[0, mstep - 1, 0, r] < 1e-8

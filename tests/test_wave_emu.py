@@ -315,3 +315,17 @@ def test_either_branching_rule_reaches_the_same_optimum(wave, oracle, rule, monk
     seen[rule] = nodes
     if len(seen) == 2:
         assert seen["1"] <= seen["0"], seen
+
+
+def test_rows_on_input_independent_positions_are_judged_with_feas_tol_fixed(wave, oracle):
+    """The device source on rows that act on p_1 / p_2 (constants under Euler): feas_tol_fixed decides, as in the oracle."""
+    from multi_agent_pkgs_amd.params import make_params
+    prm = make_params(n_hor=8, poly_hor=2, max_rows_static=18)
+    for mstep in (1, 2):
+        for delta, want in ((1e-8, 0), (1e-7, 0), (1e-5, 2)):
+            args = problems.constant_row_case(prm, oracle, mstep, delta)
+            for threads in (64, 128):
+                e = wave.solve(prm, *args, threads=threads)
+                assert e["status"][0] == want, (mstep, delta, threads, e["status"])
+            if want == 0:
+                compare(e, oracle.solve(prm, *args))

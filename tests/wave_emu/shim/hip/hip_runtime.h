@@ -170,7 +170,10 @@ inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v)
 }
 #define __ATOMIC_RELAXED_SHIM 0
 #define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(ptr, order, scope) (*(ptr))
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_load(ptr, order, scope) (*(volatile decltype(ptr))(ptr))
+#define __hip_atomic_store(ptr, val, order, scope) (*(volatile decltype(ptr))(ptr) = (val))
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 inline unsigned atomicAdd(unsigned* p, unsigned v) {
   const unsigned old = *p;
   *p = old + v;
