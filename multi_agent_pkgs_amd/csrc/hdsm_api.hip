@@ -45,15 +45,21 @@ constexpr int CMAX48 = 1024;  // n <= 48
 // the subtree "polyhedron b % sub_k at the root's branching step" of instance b / sub_k, if pass 1 handed that instance over.
 template <class Sol>
 __device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts& c, const hdsm::Args& a) {
-  int inst, out, sub = -1;  // (ONE call site below: the solver is a single inlined body of ~17 k instructions)
+  int inst, out, sub = -1, self = -1;  // (ONE call site below: the solver is a single inlined body of ~17 k instructions)
   if (a.sub_k > 0) {
     inst = (int)blockIdx.x / a.sub_k, sub = (int)blockIdx.x % a.sub_k, out = (int)blockIdx.x;
     if (a.split_info[2 * inst] == 0) return;  // (uniform: the whole workgroup leaves)
   } else {
-    inst = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, out = inst;
+    if (a.order) {  // (instance, its agent id): one load — the own plan is requested together with the other inputs of the instance
+      const int2 os = reinterpret_cast<const int2*>(a.order)[blockIdx.x];
+      inst = os.x, self = os.y;
+    } else {
+      inst = (int)blockIdx.x;
+    }
+    out = inst;
     if (a.rescue && !(a.st_flags[inst] & hdsm::FLAG_STAGING_OVERFLOW)) return;  // (uniform)
   }
-  Sol::solve_instance(s, c, a, inst, out, sub);
+  Sol::solve_instance(s, c, a, inst, out, sub, self);
 }
 
 template <int NV, int CMAX, int NT>
@@ -81,14 +87,14 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
 //   bounds[n_rob][4]   (only for swarms of at least bounds_min agents) centre of the bounding box of those positions and the
 //                      radius of the sphere around it that holds them (radius -1 = no plan): the sweeps use it to skip
 //                      whole neighbours (hdsm_wave_gi.h, sweep_planes).
-__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order);
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, const int32_t* __restrict__ agent_id, int32_t* __restrict__ order);
 
 __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
                                                       const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
                                                       double* __restrict__ bounds, int n_order, const int32_t* __restrict__ key_prev,
-                                                      int32_t* __restrict__ order) {
+                                                      const int32_t* __restrict__ agent_id, int32_t* __restrict__ order) {
   if (order != nullptr && blockIdx.x == gridDim.x - 1) {  // one extra workgroup: the launch order of the solve that follows
-    launch_order_block(n_order, key_prev, order);
+    launch_order_block(n_order, key_prev, agent_id, order);
     return;
   }
   // 16 lanes per agent (N <= 16 = HDSM_MAX_HOR): lane i copies the position of step i + 1, the box / sphere reductions run
@@ -139,8 +145,9 @@ __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const do
 // dispatched in index order, so workgroup w takes instance order[w], the instances sorted by the key they left in the
 // PREVIOUS launch on this handle (largest first; a counting sort on 256 values): the time the instance took, or the maximum if it
 // found no solution (hdsm_core.h, st_key). The previous replan of the same agent is a good predictor (gridlocked neighbourhoods
-// persist); the answer of an instance does not depend on the order.
-__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order) {
+// persist); the answer of an instance does not depend on the order. An entry is the pair (instance, its agent id): the workgroup
+// then needs no second, dependent load (agent_id[instance]) before it can ask for the agent's own plan.
+__device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, const int32_t* __restrict__ agent_id, int32_t* __restrict__ order) {
   __shared__ int bucket[256];
   const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
   for (int b = tid; b < 256; b += nt) bucket[b] = 0;
@@ -161,11 +168,12 @@ __device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_p
   __syncthreads();
   for (int k = tid; k < n_inst; k += nt) {
     const int it = key_prev[k];
-    order[atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1)] = k;
+    const int slot = atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1);
+    order[2 * slot] = k, order[2 * slot + 1] = agent_id[k];
   }
 }
-__global__ __launch_bounds__(256) void k_launch_order(int n_inst, const int32_t* __restrict__ key_prev, int32_t* __restrict__ order) {
-  launch_order_block(n_inst, key_prev, order);  // level 1 has no pre-pass to ride on
+__global__ __launch_bounds__(256) void k_launch_order(int n_inst, const int32_t* __restrict__ key_prev, const int32_t* __restrict__ agent_id, int32_t* __restrict__ order) {
+  launch_order_block(n_inst, key_prev, agent_id, order);  // level 1 has no pre-pass to ride on
 }
 
 // hdsm_publish_device / hdsm_exchange_device: the has_plan flag travels inside the record (first entry NaN = no plan)
@@ -486,6 +494,7 @@ struct Handle {
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
+  int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
   int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 8 nodes for batches that leave CUs idle, 96 beyond
@@ -508,7 +517,7 @@ struct Handle {
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
   double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
   double* d_rsph = nullptr;   // [n_rob_max][4] their spheres
-  int32_t* d_order = nullptr; // [max_inst] launch order (k_launch_order)
+  int32_t* d_order = nullptr; // [max_inst][2] launch order: (instance, its agent id) per workgroup (k_launch_order)
   int order_min = 0;          // batches of at least this many instances are launched most-expensive-first (0 = never)
   uint8_t* d_zero = nullptr;  // n_rob_max zero bytes (has_plan of level 1)
   hipEvent_t ev_done = nullptr;  // recorded after every launch: orders launches that arrive on different streams
@@ -580,6 +589,33 @@ __global__ __launch_bounds__(NT, 2) void k_replan_tri(const hdsm::Consts* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
   run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+}
+
+// FOUR workgroups of 128 threads per CU: every instance of a 1024-agent round is resident at once (1024 slots), so no instance
+// starts late behind a short one — in the rounds of the bench window whose instances are all of similar length (five of twenty)
+// the three-per-CU launch ended 15-25 us after its slowest instance, set by a late starter. Four instance states fit 160 KB with
+// the small LDS layout (Shm<.., SMALL>: 4 polyhedra of <= 20 rows, 512-neighbour chunks) and a staging area of 256 rows (the
+// bench rounds stage <= 190; an overflow is re-solved by the rescue pass like for the other shared-CU kernels).
+constexpr int CMAX_QUAD = 256;
+template <int NV, int CMAX, int NT>
+__global__ __launch_bounds__(NT, 2) void k_replan_quad(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Sol = hdsm::Solver<NV, CMAX, true>;
+  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+}
+int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
+  using Sol = hdsm::Solver<32, CMAX_QUAD, true>;
+  static_assert(sizeof(typename Sol::S) * 4 <= 160 * 1024, "four instances must fit the LDS of one CU");
+  const size_t shm = sizeof(typename Sol::S);
+  auto kern = k_replan_quad<32, CMAX_QUAD, 128>;
+  static thread_local int attr_dev = -1;
+  if (attr_dev != h->device) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    attr_dev = h->device;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
+  HIP_TRY(hipGetLastError());
+  return HDSM_OK;
 }
 
 // n > 30 (H up to 16): the factor needs more than 256 registers per lane, so a wavefront must have a SIMD to itself — but a
@@ -671,12 +707,12 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
     hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
-                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, ordered ? h->d_order : nullptr);
+                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, a.agent_id, ordered ? h->d_order : nullptr);
     HIP_TRY(hipGetLastError());
     a.pos = h->d_pos;
     a.bounds = pre ? h->d_bounds : nullptr;
   } else if (ordered) {
-    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(256), 0, st, a.n_inst, a.st_key, h->d_order);
+    hipLaunchKernelGGL(k_launch_order, dim3(1), dim3(256), 0, st, a.n_inst, a.st_key, a.agent_id, h->d_order);
     HIP_TRY(hipGetLastError());
   }
   // one workgroup per agent-replan. The active-set iteration runs on wave 0 (factorisation in its registers);
@@ -688,6 +724,8 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     hdsm::Args y = x;
     y.n_inst = x.n_inst;
     small = small || (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min);
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->quad_min > 0 && blocks >= h->quad_min && h->P <= 4 && h->RS <= 20)
+      return launch_quad(h, y, st, blocks);
     if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && blocks >= h->tri_min) return launch_tri(h, y, st, blocks);
     if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo(h, y, st, blocks);
     if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, y, st, blocks) : launch_nv<32, 256>(h, y, st, blocks);
@@ -923,6 +961,8 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_DUO_MIN", 0, INT_MAX, &h->duo_min);  // 0 = never
     h->tri_min = h->duo_min > 0 ? 2 * cus + 1 : 0;     // more instances than the two-per-CU kernel has resident slots
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
+    h->quad_min = h->tri_min > 0 ? 3 * cus + 1 : 0;    // more instances than the three-per-CU kernel has resident slots
+    env_int("HDSM_QUAD_MIN", 0, INT_MAX, &h->quad_min);  // 0 = never
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
     int depth = 3;
@@ -966,7 +1006,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_rpos, (size_t)n_rob_max * (N + 1) * 3));
   ok(dmalloc(&h->d_rsph, (size_t)n_rob_max * 4));
   ok(dmalloc(&h->d_zero, (size_t)n_rob_max));
-  ok(dmalloc(&h->d_order, I));
+  ok(dmalloc(&h->d_order, 2 * I));
   ok(dmalloc(&h->d_traj, I * (N + 1) * 9));
   ok(dmalloc(&h->d_ctrl, I * N * 3));
   ok(dmalloc(&h->d_obj, I));

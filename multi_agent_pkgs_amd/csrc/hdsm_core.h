@@ -74,9 +74,12 @@ HD MW mk_mw(const double (*kap)[4], double nx, double ny, double nz, int m) {
   return MW{m, q > 1e-60 ? (float)(1.0 / sqrt(q)) : 1e30f};
 }
 
-template <int NV, int CMAX>
+// SMALL: the four-workgroups-per-CU shape (40 KB of LDS per instance): capacity for 4 polyhedra of 20 rows (the agile configuration
+// of the reference: poly_hor 4, 18 rows) and 512 neighbours per chunk of a prefiltered sweep instead of the limits of hdsm.h
+template <int NV, int CMAX, bool SMALL = false>
 struct Shm {
   static_assert(CMAX <= 4096, "the slot of a staged row must fit the 12 bits kc_slot() reads");
+  static constexpr int PM = SMALL ? 4 : MAXP, RSM = SMALL ? 20 : MAXRS, LC = SMALL ? 512 : LISTCAP;
   static constexpr int LDT = (NV <= 32) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
   alignas(16) double T[NV > 32 ? NV * LDT : 2];  // NV = 48: transposition buffer for d = J^T a (J rows live in registers)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
@@ -101,8 +104,8 @@ struct Shm {
   double ref[MAXH][6];
   double st[MAXH + 1][9];
   double cprev[MAXH][3];
-  alignas(16) double sp[MAXP][MAXRS][4];  // rows of the instance's polyhedra (A, b): read as two 16-byte halves by scan_assigned
-  double keys[MAXH][MAXP];
+  alignas(16) double sp[PM][RSM][4];  // rows of the instance's polyhedra (A, b): read as two 16-byte halves by scan_assigned
+  double keys[MAXH][PM];
   alignas(16) double cand[CMAX][4];      // staged neighbour rows (n_f, rhs): read as two 16-byte halves by the scans
   double red_v[MAXT];
   double br_f[MAXH];
@@ -110,9 +113,9 @@ struct Shm {
   double f, inc_f, f0;
   MW cand_mw[CMAX];      // step of each staged row + its pick-rule weight (one 8-byte read in the scan)
   int32_t act[NV];
-  int32_t sp_rows[MAXP];
+  int32_t sp_rows[PM];
   int32_t assign[MAXH], contain[MAXH], inc_assign[MAXH];
-  int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][MAXP];
+  int32_t br_step[MAXH], br_pos[MAXH], br_cnt[MAXH], br_order[MAXH][PM];
   int32_t q, neq_done, ncand, n_poly, level, have_inc, fixed_bad, overflow;
   // conflicts learned by the branch and bound: a set of (step, polyhedron) assignments, as a bit mask (bit 4 i + j), that
   // makes the QP infeasible together with the rows common to every node — no node containing it needs to be opened
@@ -124,13 +127,14 @@ struct Shm {
   double inc_shared;   // split launches: best objective found by ANY sub-block of this instance (DINF: none / ordinary launch)
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
+  int32_t warm_head;  // first word of the instance's warm-start record (count | WARM_CERT), fetched by the set-up
   int32_t leaf_pick;  // result of the one-wavefront leaf test
   double* snap;       // this workgroup's snapshot scratch (global memory; kept here, not in a register pair across the active-set run)
   int32_t node_res;   // pass 2 of a split launch: nodes drawn from the instance's pool and not yet opened
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
   int32_t cmd;           // command word for the helper waves (0 = leave, 1 = scan staged rows)
   int32_t nlist;         // sweeps with a.bounds: neighbours of the current chunk that survive the sphere test
-  int32_t list[LISTCAP];
+  int32_t list[LC];
   double sw[5];          // sweep scalars: cull radius, own sphere (centre, radius)
   double sw_ref[MAXH + 1][3];  // positions at the last STAGING sweep and its radius (0 = none): every row not staged then
   double sw_tau;               // had slack >= sw_tau there, so it cannot be violated while |p - sw_ref| |n_f| <= sw_tau
@@ -178,9 +182,9 @@ HD bool tasc_plane_eval(const Consts& c, const double* cp, const double* op, dou
 #include "hdsm_wave_gib.h"
 namespace hdsm {
 
-template <int NV, int CMAX>
+template <int NV, int CMAX, bool SMALL = false>
 struct Solver {
-  using S = Shm<NV, CMAX>;
+  using S = Shm<NV, CMAX, SMALL>;
 
   // ---- neighbour sweep: planes on the fly (AC:1100-1205), stage rows with slack < thresh --------------------
   static HD bool tasc_plane(const Consts& c, const double* cp, const double* op, double* out) {
@@ -214,7 +218,7 @@ struct Solver {
     const int N = c.N;
     const bool explicit_rows = a.l1_rows != nullptr;  // level 1: rows given by the caller
     if (!explicit_rows) {  // device build: one thread per (neighbour, step) pair, sphere prefilter (hdsm_wave_gi.h)
-      WaveGI<NV, CMAX>::sweep_planes(s, c, a, self, thresh, check_fixed, tid_here());
+      WaveGI<NV, CMAX, SMALL>::sweep_planes(s, c, a, self, thresh, check_fixed, tid_here());
       return;
     }
     const int total = explicit_rows ? N * a.l1_rmax : a.n_rob * N;
@@ -439,11 +443,11 @@ struct Solver {
   // n <= 30: rows of J split over two lanes, columns in butterfly order (hdsm_wave_gib.h); larger n: one lane per row
   template <int NV_, class = void>
   struct PickW {
-    using type = WaveGI<NV_, CMAX>;
+    using type = WaveGI<NV_, CMAX, SMALL>;
   };
   template <class V>
   struct PickW<32, V> {
-    using type = WaveGIB<CMAX>;
+    using type = WaveGIB<CMAX, SMALL>;
   };
   using W = typename PickW<NV>::type;
   using GIState = typename W::Regs;
@@ -565,7 +569,8 @@ struct Solver {
   // `inst`: the instance (inputs, warm-start guess); `out`: where its outputs, statistics and scratch live — `inst` itself, or,
   // in pass 2 of a split launch, the slot of this sub-block; `sub`: the polyhedron this sub-block fixes at the root's
   // branching step (-1: ordinary solve).
-  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub_in) {
+  // `self_in`: the agent id of the instance if the caller already has it (launch order pairs), -1 = agent_id[inst]
+  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub_in, int self_in = -1) {
 #ifdef HDSM_POISON_LDS
     // test builds (tests/wave_emu, scripts/gpu_poison.sh): LDS is not cleared between workgroups — whatever is read before it is
     // written shows up as NaN / garbage here instead of depending on the kernel that ran on the CU before
@@ -576,7 +581,7 @@ struct Solver {
     SYNC();
     const Args& a = s.args;
     const int N = c.N, n = c.n, P = c.P, RS = c.RS;
-    const int self = a.agent_id[inst];
+    const int self = self_in >= 0 ? self_in : a.agent_id[inst];
     double* snap = a.scratch + (int64_t)out * a.scratch_stride;
     bool no_slot = false;
     int my_slot = -1;
@@ -618,6 +623,7 @@ struct Solver {
     // the first one is consumed (memory latency is paid once, or twice for the own plan, whose address needs
     // agent_id[inst]); the generic loops of the CPU build above do the same thing one array at a time.
     GIState R;
+    typename W::WarmPre wpre{0, 0, 0, 0.0, 0.0, 0.0};
     const int nk = 3 * n + 12, nvt = 9 + 6 * N;
     double fw0, fw1;  // weights of the (at most two) tracking residuals this lane of wave 0 squares for the constant term
     double hrow_own;  // Consts::hrow1 of this lane's variable (the box bound of the objective, below)
@@ -700,6 +706,11 @@ struct Solver {
         if (vt < 4 * (MAXH + 1)) (&s.kap[0][0])[vt] = r.v_k;
       };
       ST_PROF(8)
+      // the guess of the warm start (wave 0, lane = entry): requested with everything else, not when the warm start begins
+      if (g.warm != nullptr && tid < 64) {
+        const int32_t* wp = g.warm + (int64_t)inst * (MAXNV + 2);
+        wpre.head = wp[0], wpre.code = tid < MAXNV ? wp[1 + tid] : 0;
+      }
       const typename W::LaneReq lane_req = W::init_lane_request(c, tid & 63);  // (every wave: wave 1 scans with its own copy)
       const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
       const double wn0 = c.wn[fk0], wx0 = c.wx[fk0], wn1 = c.wn[fk1], wx1 = c.wx[fk1];
@@ -718,6 +729,9 @@ struct Solver {
       }
       ST_PROF(10)
       commit(tid, r0);
+      // ... and, now that the guess is here, the neighbour positions its plane rows are rebuilt from (the set-up's remaining
+      // steps hide this second round trip)
+      if (g.warm != nullptr && g.l1_rows == nullptr && tid < 64) W::warm_prefetch(g, wpre, tid, self, N);
       ST_PROF(11)
       // (per-lane constants of the iteration: their loads use what they fetch at once, so they come after the staging requests)
       W::init_lane(R, c, tid & 63, lane_req);
@@ -730,6 +744,7 @@ struct Solver {
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
+        s.warm_head = wpre.head;
         s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.inc_shared = DINF, s.node_res = sub_in >= 0 ? a_in.node_cap : 0;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
@@ -822,7 +837,7 @@ struct Solver {
     // the gridlock persists the test ends it right there; the certificate's own minimiser is a far-away point, so nothing
     // is pre-staged around it afterwards.
     bool warm_cert = false;
-    if (a.warm != nullptr && np > 0) warm_cert = (a.warm[(int64_t)inst * (MAXNV + 2)] & WARM_CERT) != 0;
+    if (a.warm != nullptr && np > 0) warm_cert = (s.warm_head & WARM_CERT) != 0;  // (fetched by the set-up; published by its barriers)
 #if defined(HDSM_PROFILE)
     long long t_warm_ = 0;
     int it_warm_ = 0;
@@ -927,7 +942,7 @@ struct Solver {
 #endif
       TL_T0
       if (threadIdx.x < 64) {
-        W::warm_start(s, c, a, R, inst, self, iters);
+        W::warm_start(s, c, a, R, inst, self, iters, wpre);
         if (threadIdx.x == 0) s.iters_sh = iters;
       }
       SYNC();
@@ -1074,6 +1089,9 @@ struct Solver {
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
+#ifdef HDSM_TIMELINE
+    const long long tl_loop_end_ = (long long)wall_clock64();
+#endif
 #ifdef HDSM_PROFILE
     if (IS_T0 && a.prof) {
       long long* pr = a.prof + (int64_t)inst * 32;
@@ -1166,7 +1184,7 @@ struct Solver {
       pr[0] = tl_begin_, pr[1] = (long long)wall_clock64(), pr[2] = (long long)blockIdx.x, pr[3] = (long long)hw | ((long long)(xcc & 15u) << 32), pr[4] = iters;
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
       pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q, pr[14] = s.n_nogood, pr[15] = s.ng_skipped;
-      pr[16] = tl_setup_ - tl_begin_, pr[17] = tl_warm_, pr[18] = tl_warm_it_, pr[19] = tl_sweep_, pr[20] = tl_run_, pr[21] = tl_runs_, pr[22] = tl_leaf_, pr[23] = 0;
+      pr[16] = tl_setup_ - tl_begin_, pr[17] = tl_warm_, pr[18] = tl_warm_it_, pr[19] = tl_sweep_, pr[20] = tl_run_, pr[21] = tl_runs_, pr[22] = tl_leaf_, pr[23] = (long long)wall_clock64() - tl_loop_end_;
     }
 #endif
     if (IS_T0) {

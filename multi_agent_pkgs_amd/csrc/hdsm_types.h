@@ -115,7 +115,8 @@ struct Args {
   // [n_rob][N][3]: positions of steps 1..N of every published plan, packed (24 B per (agent, step) instead of a 72-B
   // stride through the full states); written by the same pre-pass for every launch of level 2
   const double* pos;
-  // launch order: workgroup w solves instance order[w] (most expensive first, judged by the previous launch), or null = w
+  // launch order: workgroup w solves instance order[2 w] (most expensive first, judged by the previous launch) of agent
+  // order[2 w + 1], or null = w
   const int32_t* order;
   int32_t* st_sph;    // sphere records read by the sweeps of this instance
   int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance

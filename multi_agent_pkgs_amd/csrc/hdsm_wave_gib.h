@@ -37,9 +37,9 @@ __device__ __forceinline__ double row16_sum64(double v) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
-template <int CMAX>
-struct WaveGIB : WaveGI<32, CMAX> {
-  using Base = WaveGI<32, CMAX>;
+template <int CMAX, bool SMALL = false>
+struct WaveGIB : WaveGI<32, CMAX, SMALL> {
+  using Base = WaveGI<32, CMAX, SMALL>;
   using S = typename Base::S;
   using Regs = typename Base::Regs;
   static constexpr int NV = 32, NC = 16, LDT = S::LDT;
@@ -257,18 +257,20 @@ struct WaveGIB : WaveGI<32, CMAX> {
 
   // ---- warm start (see hdsm_wave_gi.h): the guess is put into the factorisation without taking steps, then the S-pair in
   // closed form  t = U^T v, lambda = U t, x_W = x0 + J1 t, f_W = f(x0) + |t|^2 / 2
-  static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self, int& iters) {
+  using WarmPre = typename Base::WarmPre;
+  using Base::warm_prefetch;
+  static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self, int& iters,
+                                                    const WarmPre& wpre) {
     const int lane = (int)threadIdx.x;
     const int N = c.N, n = c.n;
-    const int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
-    int nw = uni(wp[0]) & ~WARM_CERT;
+    int nw = uni(wpre.head) & ~WARM_CERT;
     if (nw <= 0) return;
     if (nw > NV) nw = NV;
     PROF_DECL
     int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
     double my_row[4] = {0.0, 0.0, 0.0, 0.0};
     if (lane < nw) {
-      const int code = wp[1 + lane];
+      const int code = wpre.code;
       const int kind = id_kind(code), p = id_payload(code);
       if (kind == K_U) {
         const int var = p >> 1;
@@ -278,8 +280,8 @@ struct WaveGIB : WaveGI<32, CMAX> {
         if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
       } else if (kind == K_C && a.l1_rows == nullptr) {
         const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
-        if (i >= 0 && i + e > c.pinned_steps && k != self && k < a.n_rob && a.has_plan[k]) {
-          const double* op = a.pos + ((int64_t)k * N + i) * 3;
+        if (i >= 0 && i + e > c.pinned_steps && k != self && k < a.n_rob && wpre.has) {
+          const double op[3] = {wpre.ox, wpre.oy, wpre.oz};
           if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
         }
       }

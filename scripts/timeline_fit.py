@@ -40,6 +40,7 @@ if ev[0].shape[1] >= 24:  # phases of an instance (10-ns ticks): set-up, warm st
     B = np.vstack(ev)
     dur = (B[:, 1] - B[:, 0]) * 0.01
     setup, warm, wit, sweep, run, runs, leaf = (B[:, k] * (1.0 if k in (18, 21) else 0.01) for k in (16, 17, 18, 19, 20, 21, 22))
+    tail = B[:, 23] * 0.01  # read-back, outputs, warm-start store (part of "rest")
     reg = B[:, 4] - wit  # regular operations
     has_w, has_r = wit > 0, reg > 0
     slowest = np.array([np.argmax((b[:, 1] - b[:, 0])) + k * b.shape[0] for k, b in enumerate(ev)])
@@ -47,7 +48,7 @@ if ev[0].shape[1] >= 24:  # phases of an instance (10-ns ticks): set-up, warm st
         A = np.vstack([np.ones(len(x)), x]).T
         return [round(float(v), 3) for v in np.linalg.lstsq(A, y, rcond=None)[0]]
     out["phases_us_mean"] = {"setup": setup.mean(), "warm_start": warm.mean(), "sweeps": sweep.mean(), "runs": run.mean(), "leaf": leaf.mean(),
-                             "rest": (dur - setup - warm - sweep - run - leaf).mean(), "total": dur.mean()}
+                             "rest": (dur - setup - warm - sweep - run - leaf).mean(), "tail(in rest)": tail.mean(), "total": dur.mean()}
     out["phases_us_slowest"] = {"setup": setup[slowest].mean(), "warm_start": warm[slowest].mean(), "sweeps": sweep[slowest].mean(), "runs": run[slowest].mean(),
                                 "leaf": leaf[slowest].mean(), "rest": (dur - setup - warm - sweep - run - leaf)[slowest].mean(), "total": dur[slowest].mean(),
                                 "warm_ops": wit[slowest].mean(), "regular_ops": reg[slowest].mean(), "runs_n": runs[slowest].mean()}

@@ -329,3 +329,12 @@ def test_rows_on_input_independent_positions_are_judged_with_feas_tol_fixed(wave
                 assert e["status"][0] == want, (mstep, delta, threads, e["status"])
             if want == 0:
                 compare(e, oracle.solve(prm, *args))
+
+
+def test_small_lds_layout_of_the_four_per_cu_kernel(wave, oracle):
+    """Shm<32, 256, SMALL> (k_replan_quad: 4 polyhedra of <= 20 rows, 512-neighbour chunks, 256 staged rows), two wavefronts."""
+    prm = agile_params(10, max_rows_static=18)
+    for kw in (dict(seed=3, turn=True), dict(seed=8, chamfer=True, narrow=True, turn=True, spacing=1.4)):
+        sn = problems.swarm_snapshot(prm, 12, **kw)
+        args = [sn[k] for k in ARG_KEYS]
+        compare(wave.replan(prm, *args, threads=128, cmax=256), oracle.replan(prm, *args, n_threads=8))

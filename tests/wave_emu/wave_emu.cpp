@@ -92,21 +92,21 @@ const char* last_error() { return g_error; }
 }  // namespace wemu
 
 namespace {
-template <int NV, int CMAX>
+template <int NV, int CMAX, bool SMALL = false>
 struct Job {
-  typename hdsm::Solver<NV, CMAX>::S* s;
+  typename hdsm::Solver<NV, CMAX, SMALL>::S* s;
   const hdsm::Consts* c;
   hdsm::Args a;
   int inst, out, sub;
 };
-template <int NV, int CMAX>
+template <int NV, int CMAX, bool SMALL = false>
 void body(void* p) {
-  auto* j = static_cast<Job<NV, CMAX>*>(p);
-  hdsm::Solver<NV, CMAX>::solve_instance(*j->s, *j->c, j->a, j->inst, j->out, j->sub);
+  auto* j = static_cast<Job<NV, CMAX, SMALL>*>(p);
+  hdsm::Solver<NV, CMAX, SMALL>::solve_instance(*j->s, *j->c, j->a, j->inst, j->out, j->sub);
 }
-template <int NV, int CMAX>
+template <int NV, int CMAX, bool SMALL = false>
 int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
-  using Sol = hdsm::Solver<NV, CMAX>;
+  using Sol = hdsm::Solver<NV, CMAX, SMALL>;
   a.scratch_stride = (int64_t)Sol::SNAP_STRIDE * hdsm::MAXH;
   std::vector<double> scratch((size_t)a.scratch_stride);
   auto shm = std::make_unique<typename Sol::S>();
@@ -126,9 +126,9 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   }
   for (int k = 0; k < a.n_inst; ++k) {
     memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
-    Job<NV, CMAX> job{shm.get(), &c, a, k, k, -1};
+    Job<NV, CMAX, SMALL> job{shm.get(), &c, a, k, k, -1};
     job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds out * stride
-    if (!wemu::run_block(body<NV, CMAX>, &job, k, nthreads)) return -100;
+    if (!wemu::run_block(body<NV, CMAX, SMALL>, &job, k, nthreads)) return -100;
     if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
   }
   if (a.split_budget > 0) {
@@ -151,11 +151,11 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
       const int inst = g / K;
       if (split_info[2 * inst] == 0) continue;
       memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
-      Job<NV, CMAX> job{shm.get(), &c, b, inst, g, g % K};
+      Job<NV, CMAX, SMALL> job{shm.get(), &c, b, inst, g, g % K};
       std::vector<double> sub_scratch;  // (the sub-blocks run one after the other: every one gets a slot of the 4-slot pool)
       sub_scratch.resize((size_t)a.scratch_stride * 4);
       job.a.scratch = sub_scratch.data();
-      if (!wemu::run_block(body<NV, CMAX>, &job, g, nthreads)) return -100;
+      if (!wemu::run_block(body<NV, CMAX, SMALL>, &job, g, nthreads)) return -100;
     }
     for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, c.P, K, a, b, inst, 0, 1);
   }
@@ -168,7 +168,8 @@ extern "C" const char* wave_last_error(void) { return wemu::last_error(); }
 // Level-2 replan through the device source. `warm` = the handle's warm-start store, [(MAXNV + 2) * n_inst] int32, in/out (zeros:
 // cold; pass the same array again to continue like consecutive launches on one handle); null = warm start off.
 // `bounds_min`: swarms of at least this many agents get the sphere prefilter records, as hdsm_api.hip's launch() does.
-// `cmax` in 1..16: a build of the kernel with room for only 16 staged rows (staging-overflow tests); 0 = the product's sizes.
+// `cmax` in 1..16: a build of the kernel with room for only 16 staged rows (staging-overflow tests); 256: the small LDS layout of the
+// four-per-CU kernel; 0 = the product's one-per-CU sizes.
 extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob, const int32_t* agent_id, const double* state_curr,
                            const double* traj_ref, const int32_t* n_poly, const int32_t* n_rows_static, const double* A_static,
                            const double* b_static, const double* plans_all, const uint8_t* has_plan, double* traj_out, double* ctrl_out,
@@ -219,6 +220,8 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
   a.split_budget = split_budget;
   if (cmax > 0 && cmax <= 16)  // tiny staging capacity: exercises the overflow path in tests
     return c->n <= hdsm::SPLIT_N_MAX ? run_all<32, 16>(*c, a, threads) : run_all<48, 16>(*c, a, threads);
+  if (cmax == 256 && c->n <= hdsm::SPLIT_N_MAX && c->P <= 4 && c->RS <= 20)  // the four-workgroups-per-CU shape: small LDS layout, 256 staged rows
+    return run_all<32, 256, true>(*c, a, threads);
   if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
   return run_all<48, 1024>(*c, a, threads);
 }
