@@ -505,6 +505,7 @@ struct Handle {
   hdsm::Args last_args;             // ... and its arguments (the host-buffer path adds the rescue pass at once)
   int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
   int32_t* d_tree_flag = nullptr;
+  int32_t* d_split_steps = nullptr;  // [max_inst][poly_hor + poly_hor^2]: branching steps agreed at the further split levels (Args::split_steps)
   int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
   unsigned long long* d_inc = nullptr;
   int32_t* d_node_pool = nullptr;  // [max_inst] nodes the sub-blocks of an instance may still open (Args::node_pool)
@@ -660,9 +661,16 @@ int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 }
 
 // ---- subtree splitting: set-up of pass 2, merge, lazily allocated state -------------------------------------------------
-__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap, int32_t* node_pool, int nodes_left) {
+__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap, int32_t* node_pool, int nodes_left,
+                                                    const int32_t* split_info, const double* obj, int32_t* split_steps, int split_ss) {
   const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k < n_inst) inc_bits[k] = 0x7ff0000000000000ull, node_pool[k] = nodes_left;  // +inf; the budget pass 1 left
+  if (k < n_inst) {
+    // the incumbent pass 1 left (split_info bit 1; objectives are >= 0: the bit patterns order), else +inf; the pool of the node budget
+    const bool own = (split_info[2 * k] & 2) != 0 && obj[k] >= 0.0;
+    inc_bits[k] = own ? (unsigned long long)__double_as_longlong(obj[k]) : 0x7ff0000000000000ull;
+    node_pool[k] = nodes_left;
+    for (int e = 0; e < split_ss; ++e) split_steps[(size_t)k * split_ss + e] = -1;
+  }
   if (k == 0) sub_slots[0] = 0, sub_slots[1] = cap;
   for (int i = k; i < cap; i += n_inst > 0 ? (int)(gridDim.x * blockDim.x) : 1) sub_slots[2 + i] = 0;
 }
@@ -768,8 +776,10 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     // unused part back to the instance's pool when it finishes; a sub-block that has used its share draws from that pool
     const int total_nodes = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
     const int left_nodes = total_nodes - budget > K ? total_nodes - budget : K;
-    b.node_cap = left_nodes / K;
-    const int nodes_left = left_nodes - b.node_cap * K;  // (the remainder of the division starts in the pool)
+    // (half of what is left goes out as shares, the other half starts in the pool: a sub-block whose subtree outgrows its share
+    // before any sibling has finished finds nodes there instead of ending on a limit the instance has not reached)
+    b.node_cap = left_nodes / (2 * K) > 0 ? left_nodes / (2 * K) : 1;
+    const int nodes_left = left_nodes - b.node_cap * K > 0 ? left_nodes - b.node_cap * K : 0;
     b.node_pool = h->d_node_pool;
     b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
     b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr;
@@ -777,7 +787,9 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     const size_t GI = (size_t)I * K;
     b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
     b.st_flags = reinterpret_cast<uint32_t*>(ss + 6 * GI), b.st_key = ss + 7 * GI;
-    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap, h->d_node_pool, nodes_left);
+    b.split_steps = h->d_split_steps, b.split_ss = h->P + h->P * h->P;
+    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap, h->d_node_pool, nodes_left,
+                       a.split_info, a.obj, h->d_split_steps, b.split_ss);
     HIP_TRY(hipGetLastError());
     // (most of the G blocks leave at once — only the sub-blocks of handed-over instances work — so the kernel shape is chosen for
     // few, long-running workgroups: one per CU with the large staging area, whatever G is)
@@ -846,17 +858,29 @@ hipError_t ensure_sub(Handle* h) {
   auto ok = [&](hipError_t r) {
     if (e == hipSuccess) e = r;
   };
+  ok(dmalloc(&h->d_split_steps, (size_t)h->max_inst * (size_t)(h->P + h->P * h->P)));
   ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_node_pool, (size_t)h->max_inst)), ok(dmalloc(&h->d_sub_slots, 2 + (size_t)h->sub_cap));
   ok(dmalloc(&h->d_sub_stats, 8 * G)), ok(dmalloc(&h->d_sub_warm, (hdsm::MAXNV + 2) * G)), ok(dmalloc(&h->d_sub_status, G));
   ok(dmalloc(&h->d_sub_traj, G * (N + 1) * 9)), ok(dmalloc(&h->d_sub_ctrl, G * N * 3)), ok(dmalloc(&h->d_sub_obj, G)), ok(dmalloc(&h->d_sub_used, G * h->P));
   ok(dmalloc(&h->d_sub_scratch, (size_t)h->sub_cap * (size_t)h->scratch_stride));
   if (e == hipSuccess) e = hipMemset(h->d_split, 0, 2 * (size_t)h->max_inst * sizeof(int32_t));
   h->sub_ready = e == hipSuccess;
+  if (!h->sub_ready) {  // partial failure: give back what was allocated, clear the pending error — the handle goes on without split launches
+    void** sub[] = {(void**)&h->d_split_steps, (void**)&h->d_split, (void**)&h->d_inc, (void**)&h->d_node_pool, (void**)&h->d_sub_slots, (void**)&h->d_sub_stats,
+                    (void**)&h->d_sub_warm, (void**)&h->d_sub_status, (void**)&h->d_sub_traj, (void**)&h->d_sub_ctrl, (void**)&h->d_sub_obj,
+                    (void**)&h->d_sub_used, (void**)&h->d_sub_scratch};
+    for (void** p : sub) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    (void)hipGetLastError();
+    h->split_mode = 0;
+  }
   return e;
 }
 
 void free_all(Handle* h) {
-  void* sub[] = {h->d_split, h->d_inc, h->d_node_pool, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
+  void* sub[] = {h->d_split_steps, h->d_split, h->d_inc, h->d_node_pool, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
                  h->d_sub_used, h->d_sub_scratch};
   for (void* p : sub)
     if (p) (void)hipFree(p);

@@ -530,9 +530,18 @@ struct Solver {
         }
         if (s.args.node_pool != nullptr) {  // pass 2 of a split launch: own share first, then what finished sub-blocks handed back
           SYNC();
-          if (IS_T0 && s.node_res == 0) {
-            const int old = atomicAdd(&s.args.node_pool[inst], -NODE_CHUNK);
-            s.node_res = old >= NODE_CHUNK ? NODE_CHUNK : (old > 0 ? old : 0);
+          if (IS_T0 && s.node_res == 0) {  // (compare-and-swap: the pool never goes negative, nothing handed back later is lost)
+            int cur = __hip_atomic_load(&s.args.node_pool[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), got = 0;
+            while (cur > 0) {
+              const int take = cur < NODE_CHUNK ? cur : NODE_CHUNK;
+              const int old = atomicCAS(&s.args.node_pool[inst], cur, cur - take);
+              if (old == cur) {
+                got = take;
+                break;
+              }
+              cur = old;
+            }
+            s.node_res = got;
           }
           SYNC();
           if (s.node_res == 0) {
@@ -1031,9 +1040,18 @@ struct Solver {
           }
           SYNC();
         } else {  // open a new level on the first step that lies in no polyhedron
-          const int L = s.level;
+          const int L = s.level, bstep_own = bstep;
           snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, true);
           if (IS_T0) {
+            int bstep = bstep_own;
+            if (L >= 1 && L < sub_depth && a.split_steps != nullptr) {
+              // a further split level: the sub-blocks that share this prefix of digits all stand at this node; the first one to
+              // arrive publishes its branching step and everybody branches on THAT (any unassigned step is a valid choice)
+              int pre = sub, dr = sub_rest, off = 0, pw = P;
+              for (int x1 = 1; x1 < L; ++x1) pre = pre * P + dr % P, dr /= P, off += pw, pw *= P;
+              const int old = atomicCAS(&a.split_steps[(int64_t)inst * a.split_ss + off + pre], -1, bstep_own);
+              if (old >= 0 && old < N && s.assign[old] < 0) bstep = old;
+            }
             int cnt = 0;
             for (int j = 0; j < np; ++j)
               if (s.keys[bstep][j] < DINF) s.br_order[L][cnt++] = j;
@@ -1102,13 +1120,11 @@ struct Solver {
 #endif
     // ---- read-back (AC:955-987): controls, literal rollout of the dynamics, literal objective
     // (an instance handed over to pass 2 of a split launch leaves without outputs: the merge kernel writes them)
-    if (handed_over) {
-      SYNC();
-      if (IS_T0) s.have_inc = 0;
-      SYNC();
-      limit = true;
-    }
-    if (IS_T0 && a.split_budget > 0) a.split_info[2 * inst] = handed_over ? 1 : 0, a.split_info[2 * inst + 1] = handed_over ? s.br_step[0] : -1;
+    // (... with one exception: an incumbent pass 1 has already found stays where the outputs go — bit 1 of split_info — so that
+    // pass 2 prunes against it from its first node and the merge can fall back on it)
+    if (handed_over) limit = true;
+    if (IS_T0 && a.split_budget > 0)
+      a.split_info[2 * inst] = handed_over ? (1 | (s.have_inc ? 2 : 0)) : 0, a.split_info[2 * inst + 1] = handed_over ? s.br_step[0] : -1;
     if (IS_T0 && a.tree_flag != nullptr && a.tree_mark > 0 && nodes >= a.tree_mark) *a.tree_flag = 1;  // (split launches: the merge raises it)
     const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
     if (s.have_inc) {
@@ -1149,7 +1165,7 @@ struct Solver {
           if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
       }
     }
-    if (a.warm != nullptr && !handed_over) {  // next replan's guess
+    if (a.warm != nullptr && (!handed_over || s.have_inc)) {  // next replan's guess (handed over: the merge may replace it)
       int32_t* wp = a.warm_out + (int64_t)out * (MAXNV + 2);
       // No solution because the ROOT relaxation is infeasible (the usual case in a gridlocked neighbourhood, and it
       // tends to persist for several rounds): hand over the certificate — the working set at the moment of the proof
@@ -1223,7 +1239,8 @@ HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst,
   if (inst >= a.n_inst || a.split_info[2 * inst] == 0) return;
   int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = 0, sph = 0, pairs = 0;
   unsigned flags = 0;
-  double obj = DINF;
+  const bool own = (a.split_info[2 * inst] & 2) != 0;  // pass 1 left an incumbent in the instance's own outputs
+  double obj = own ? a.obj[inst] : DINF;
   for (int k = 0; k < K; ++k) {
     const int g = inst * K + k;
     const int st = b.status[g];
@@ -1234,13 +1251,13 @@ HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst,
     lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
     if (st != ST_NO_SOLUTION && b.obj[g] < obj) obj = b.obj[g], best = g;
   }
-  const int status = best < 0 ? ST_NO_SOLUTION : (lim ? ST_LIMIT : ST_OPTIMAL);
+  const int status = (best < 0 && !own) ? ST_NO_SOLUTION : (lim ? ST_LIMIT : ST_OPTIMAL);
   if (best >= 0) {
     for (int e = lane; e < (N + 1) * 9; e += lanes) a.traj[(int64_t)inst * (N + 1) * 9 + e] = b.traj[(int64_t)best * (N + 1) * 9 + e];
     for (int e = lane; e < N * 3; e += lanes) a.ctrl[(int64_t)inst * N * 3 + e] = b.ctrl[(int64_t)best * N * 3 + e];
     for (int e = lane; e < P; e += lanes) a.used[(int64_t)inst * P + e] = b.used[(int64_t)best * P + e];
   }
-  if (a.warm != nullptr) {  // next replan's guess: the best sub-block's working set (none: start cold)
+  if (a.warm != nullptr && !(own && best < 0)) {  // next replan's guess: the best sub-block's working set (none: start cold; pass 1's own: in place)
     int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
     const int32_t* src = b.warm_out + (int64_t)(best >= 0 ? best : inst * K) * (MAXNV + 2);
     for (int e = lane; e < MAXNV + 2; e += lanes) wp[e] = best >= 0 ? src[e] : 0;

@@ -133,6 +133,11 @@ struct Args {
   int32_t* node_pool;     // pass 2: [n_inst] nodes handed back by sub-blocks that finished below their share; a sub-block that has used
                           // its share draws from here in chunks — the budget stays the instance's wherever in the tree the work is,
                           // and a tree that overruns it stops all its sub-blocks at about the same time
+  int32_t* split_steps;   // pass 2, further split levels: [n_inst][split_ss] branching step agreed for the node behind every prefix of split
+                          // digits (-1: nobody has reached it): the sub-blocks that share a prefix all solve its node, and the FIRST one to
+                          // get there decides the step for all of them — their own minimisers differ by rounding, and near a tie they would
+                          // otherwise branch on different steps and leave children that nobody searches
+  int32_t split_ss;       // entries per instance in split_steps: poly_hor + poly_hor^2 (levels 1 and 2)
   int32_t* sub_slots;     // pass 2: pool of snapshot-scratch slots: [1] = capacity, [2 + i] = slot i taken (0 / 1)
   int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree reached tree_mark nodes (ordinary launch) or, in a
                           // split launch, by the merge for a handed-over instance with a deep tree (TREE_MARK nodes over all its

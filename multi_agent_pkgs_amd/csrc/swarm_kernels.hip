@@ -446,7 +446,11 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
   // Layout contract of the device loop (hdsm_swarm.h): the plans buffer holds agent a's record at slot a — the all-gather puts
   // rank r's block at r * per, a single rank copies its block to slot 0 — and the solver finds an agent's OWN plan (and skips
   // its own record in the sweeps) by agent id. So the shard must be the block of a rank of the ceil(n_rob / world_size) split.
-  if (d->per > 0 && (d->first % d->per != 0 || (d->n_local < d->per && d->first + d->n_local != d->n_rob) || (world_size == 1 && d->first != 0))) {
+  // (An EMPTY trailing shard — n_rob = 5 on 4 ranks leaves rank 3 with first_id = n_rob and no agent, what swarm.shard_range
+  // produces — is a valid block; its rank comes from the communicator, not from first_id / per.)
+  const bool empty_tail = d->n_local == 0 && d->first == d->n_rob;
+  if (d->per > 0 && !empty_tail &&
+      (d->first % d->per != 0 || (d->n_local < d->per && d->first + d->n_local != d->n_rob) || (world_size == 1 && d->first != 0))) {
     delete d;
     return fail(HDSM_ERR_BAD_ARG, "the shard is not a block of the ceil(n_rob / world_size) split: first_id must be rank * per, a short "
                                   "shard must be the last one (and first_id 0 with world_size 1)");
@@ -521,7 +525,8 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   if (comm) {  // the communicator must be the one this shard was cut for: its rank's block starts at first
     int32_t crank = -1, cworld = -1;
     if (hdsm_comm_info(comm, &crank, &cworld) != HDSM_OK) return fail(HDSM_ERR_COMM, std::string("hdsm_comm_info: ") + hdsm_last_error());
-    if (cworld != d->world || (d->per > 0 && crank != d->first / d->per))
+    const bool empty_tail = d->n_local == 0 && d->first == d->n_rob;  // (any rank behind the last agent)
+    if (cworld != d->world || (d->per > 0 && (empty_tail ? (int64_t)crank * d->per < d->n_rob : crank != d->first / d->per)))
       return fail(HDSM_ERR_BAD_ARG, "communicator rank / size do not match the shard (first_id / per, world_size)");
   }
   HIP_TRY(hipSetDevice(d->device));

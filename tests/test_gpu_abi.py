@@ -332,3 +332,24 @@ def test_staging_overflow_in_a_shared_cu_kernel_is_rescued(hdsm, oracle, monkeyp
         same = (st == 0) & (o["status"] == 0) & (fl & 8 == 0)
         assert np.abs(out["traj"].cpu().numpy() - o["traj"])[same].max() < 1e-6
     assert flagged[0] > 0 and flagged[1] == 0 and (st == o["status"]).all(), flagged
+
+
+def test_device_swarm_accepts_an_empty_trailing_shard(hdsm):
+    """n_rob = 5 on 4 ranks: ceil split 2 + 2 + 1 + 0 — swarm.shard_range gives rank 3 first_id = n_rob and no agent. The device loop
+    must take that shard (it only relays the exchange); a shard that is not a block of the split is still refused."""
+    from multi_agent_pkgs_amd import swarm
+    prm = agile_params(10, max_rows_static=18)
+    cfg = swarm.default_swarm_config()
+    n_rob, world = 5, 4
+    assert [swarm.shard_range(n_rob, r, world) for r in range(world)] == [(0, 2), (2, 2), (4, 1), (5, 0)]
+    for rank in range(world):
+        first, n_local = swarm.shard_range(n_rob, rank, world)
+        loop = swarm.SwarmLoop(prm, cfg, n_rob, rank=rank, world=world, solve=None, allgather=lambda x: x)
+        sol = hdsm.Solver(prm, max(n_local, 1), n_rob)
+        dsw = swarm.DeviceSwarm(loop.shard, sol, world_size=world)
+        assert dsw.per == 2
+        dsw.close()
+    bad = swarm.SwarmShard(prm, cfg, n_rob, 1, np.zeros((2, 3)), np.ones((2, 3)))   # first_id 1 is no multiple of per = 2
+    with pytest.raises(hdsm.HdsmError) as e:
+        swarm.DeviceSwarm(bad, hdsm.Solver(prm, 2, n_rob), world_size=world)
+    assert e.value.code == hdsm.HDSM_ERR_BAD_ARG

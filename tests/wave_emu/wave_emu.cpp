@@ -136,10 +136,15 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
     hdsm::Args b = a;
     sub_status.assign(G, hdsm::ST_NO_SOLUTION), sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
     inc_bits.assign(a.n_inst, 0x7ff0000000000000ull);
+    for (int k = 0; k < a.n_inst; ++k)  // (k_split_init: the incumbent pass 1 left seeds the shared bound)
+      if ((split_info[2 * k] & 2) != 0 && a.obj[k] >= 0.0) memcpy(&inc_bits[k], &a.obj[k], 8);
     const int left_nodes = c.max_nodes - a.split_budget > K ? c.max_nodes - a.split_budget : K;
-    std::vector<int32_t> node_pool((size_t)a.n_inst, left_nodes - (left_nodes / K) * K);
-    b.node_cap = left_nodes / K;
+    b.node_cap = left_nodes / (2 * K) > 0 ? left_nodes / (2 * K) : 1;
+    std::vector<int32_t> node_pool((size_t)a.n_inst, left_nodes - b.node_cap * K > 0 ? left_nodes - b.node_cap * K : 0);
     b.node_pool = node_pool.data();
+    const int ss = c.P + c.P * c.P;
+    std::vector<int32_t> split_steps((size_t)a.n_inst * ss, -1);
+    b.split_steps = split_steps.data(), b.split_ss = ss;
     sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * c.P, 0);
     sub_slots[0] = 0, sub_slots[1] = 4;
     b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = inc_bits.data(), b.sub_slots = sub_slots.data();
