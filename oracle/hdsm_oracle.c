@@ -1254,3 +1254,163 @@ int orc_map_preprocess(const hdsm_map_config* cfg, int32_t n_grids, const int32_
   free(m1), free(m2), free(occ);
   return 0;
 }
+
+/* =====================================================================================================================
+ * Row f2: Agent::GenerateSafeCorridor, agent_class.cpp:1236-1447 — see hdsm_oracle.h. Written from the reference text.
+ * ===================================================================================================================== */
+typedef struct {
+  int rows;
+  const double* A; /* [rows][3] */
+  const double* b;
+  double seed[3];
+} sc_poly;
+
+/* LinearConstraint::inside, polyhedron.h:130-137: d = A pt - b; any d(i) > 0 -> outside */
+static int sc_inside(const sc_poly* p, const double pt[3]) {
+  for (int i = 0; i < p->rows; i++) {
+    double d = (p->A[3 * i] * pt[0] + p->A[3 * i + 1] * pt[1] + p->A[3 * i + 2] * pt[2]) - p->b[i];
+    if (d > 0) return 0;
+  }
+  return 1;
+}
+
+/* VoxelGrid::IsOccupied(Vector3i): GetVoxelInt == ENV_BUILDER_OCC, and GetVoxelInt outside the grid is -1 (voxel_grid.cpp:110-117, 150-155) */
+static int sc_is_occupied(const int8_t* data, const int32_t dim[3], int x, int y, int z) {
+  if (!(x < dim[0] && y < dim[1] && z < dim[2] && x >= 0 && y >= 0 && z >= 0)) return 0;
+  return data[x + y * dim[0] + z * dim[0] * dim[1]] == 100;
+}
+
+int orc_safe_corridor(int32_t poly_hor, int32_t n_it_decomp, int32_t use_cvx_new_cfg, int32_t rows_max, int32_t n_prev,
+                      const int32_t* prev_rows, const double* prev_A, const double* prev_b, const double* prev_seed,
+                      const uint8_t* poly_used, int32_t n_traj, const double* traj_pts, int32_t n_path, const double* path,
+                      const int8_t* grid, const int32_t dim[3], const double origin[3], double voxel_size, orc_decomp_fn decomp,
+                      void* ctx, int32_t* n_out, int32_t* out_rows, double* out_A, double* out_b, double* out_seed) {
+  /* poly_const_vec_new / poly_seeds_new: entries point into prev_* (kept) or out_* (new); written out at the end */
+  sc_poly* fresh = (sc_poly*)calloc((size_t)(n_prev + poly_hor + 1), sizeof(sc_poly));
+  int n_new = 0;
+  sc_poly last;
+  memset(&last, 0, sizeof last);
+
+  /* AC:1253-1267: if the trajectory fits inside the last polyhedron, keep that polyhedron */
+  if (n_prev > 0) {
+    int i = n_prev - 1;
+    last.rows = prev_rows[i], last.A = prev_A + (size_t)i * rows_max * 3, last.b = prev_b + (size_t)i * rows_max;
+    memcpy(last.seed, prev_seed + 3 * i, sizeof last.seed);
+    int used = 1;
+    for (int j = 0; j < n_traj; j++) {
+      if (!sc_inside(&last, traj_pts + 3 * j)) {
+        used = 0;
+        break;
+      }
+    }
+    if (used) fresh[n_new++] = last;
+  }
+  /* AC:1273-1282: else keep the polyhedra that were used in the previous optimisation */
+  if (n_prev > 0 && n_new == 0) {
+    for (int i = 0; i < n_prev; i++) {
+      if (poly_used[i]) {
+        sc_poly p;
+        p.rows = prev_rows[i], p.A = prev_A + (size_t)i * rows_max * 3, p.b = prev_b + (size_t)i * rows_max;
+        memcpy(p.seed, prev_seed + 3 * i, sizeof p.seed);
+        fresh[n_new++] = p;
+      }
+    }
+  }
+
+  /* AC:1292-1296: the voxel grid copy, unknown -> occupied (VoxelGrid::OccupyUnknown, voxel_grid.cpp:234-240) */
+  const size_t nvox = (size_t)dim[0] * dim[1] * dim[2];
+  int8_t* vg = (int8_t*)malloc(nvox);
+  memcpy(vg, grid, nvox);
+  for (size_t i = 0; i < nvox; i++)
+    if (vg[i] == -1) vg[i] = 100;
+  int8_t* grid_data = (int8_t*)malloc(nvox);
+
+  /* storage of the NEW polyhedra (they are referenced by `fresh` while the walk goes on) */
+  double* new_A = (double*)calloc((size_t)(poly_hor + 1) * rows_max * 3, sizeof(double));
+  double* new_b = (double*)calloc((size_t)(poly_hor + 1) * rows_max, sizeof(double));
+  double* rows = (double*)calloc((size_t)rows_max * 4, sizeof(double));
+  int n_made = 0, rc = 0;
+
+  /* AC:1298-1313 */
+  int n_poly = n_new;
+  int path_idx = 1;
+  double curr_pt[3] = {path[0], path[1], path[2]};
+  while (n_poly < poly_hor) {
+    /* AC:1314-1335 */
+    double next_pt[3] = {path[3 * path_idx], path[3 * path_idx + 1], path[3 * path_idx + 2]};
+    double diff[3] = {next_pt[0] - curr_pt[0], next_pt[1] - curr_pt[1], next_pt[2] - curr_pt[2]};
+    double dist_next = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]); /* Eigen norm(): sqrt of the sum in order */
+    double samp_dist = voxel_size / 10;
+    if (dist_next > samp_dist) {
+      /* curr_pt + samp_dist * diff / dist_next: (scalar * vector) / scalar, component-wise */
+      for (int k = 0; k < 3; k++) curr_pt[k] = curr_pt[k] + (samp_dist * diff[k]) / dist_next;
+    } else {
+      for (int k = 0; k < 3; k++) curr_pt[k] = next_pt[k];
+      path_idx = path_idx + 1;
+      if (path_idx == n_path) break; /* we reached the final point */
+    }
+    /* AC:1337-1350: inside at least one polyhedron -> next sample */
+    int inside_at_least_one_poly = 0;
+    for (int i = 0; i < n_new; i++) {
+      if (sc_inside(&fresh[i], curr_pt)) {
+        inside_at_least_one_poly = 1;
+        break;
+      }
+    }
+    if (inside_at_least_one_poly) continue;
+    /* AC:1352-1359: the previous sample is the seed */
+    double seed_pt[3] = {curr_pt[0], curr_pt[1], curr_pt[2]};
+    if (dist_next > 0) {
+      double back = samp_dist < dist_next ? samp_dist : dist_next; /* std::min(samp_dist, dist_next) */
+      for (int k = 0; k < 3; k++) seed_pt[k] = curr_pt[k] - (back * diff[k]) / dist_next;
+    }
+    int32_t seed[3];
+    for (int k = 0; k < 3; k++) seed[k] = (int)((seed_pt[k] - origin[k]) / voxel_size);
+    /* AC:1361-1379: a seed that one of the kept / new polyhedra already has */
+    double seed_world[3];
+    for (int k = 0; k < 3; k++) seed_world[k] = seed[k] * voxel_size + voxel_size / 2 + origin[k];
+    int is_previous_seed = 0;
+    for (int i = 0; i < n_new; i++) {
+      if (seed_world[0] == fresh[i].seed[0] && seed_world[1] == fresh[i].seed[1] && seed_world[2] == fresh[i].seed[2]) {
+        is_previous_seed = 1;
+        break;
+      }
+    }
+    if (is_previous_seed) continue;
+    /* AC:1381-1395: the seed constrained from a direction -> the shape-aware variant */
+    int use_cvx_new = use_cvx_new_cfg;
+    if ((sc_is_occupied(vg, dim, seed[0] - 1, seed[1], seed[2]) && sc_is_occupied(vg, dim, seed[0] + 1, seed[1], seed[2])) ||
+        (sc_is_occupied(vg, dim, seed[0], seed[1] - 1, seed[2]) && sc_is_occupied(vg, dim, seed[0], seed[1] + 1, seed[2])) ||
+        (sc_is_occupied(vg, dim, seed[0], seed[1], seed[2] - 1) && sc_is_occupied(vg, dim, seed[0], seed[1], seed[2] + 1))) {
+      use_cvx_new = 1;
+    }
+    /* AC:1403-1420: the decomposition works on a copy of the grid data */
+    memcpy(grid_data, vg, nvox);
+    int32_t n_rows_new = 0;
+    rc = decomp(ctx, seed, grid_data, dim, n_it_decomp, voxel_size, -(n_poly + 1), origin, use_cvx_new, rows, rows_max, &n_rows_new);
+    if (rc != 0) break;
+    n_poly = n_poly + 1;
+    /* AC:1425-1435: rows (normal, point . normal) -> LinearConstraint3D */
+    double* A = new_A + (size_t)n_made * rows_max * 3;
+    double* bb = new_b + (size_t)n_made * rows_max;
+    for (int i = 0; i < n_rows_new; i++) {
+      A[3 * i] = rows[4 * i], A[3 * i + 1] = rows[4 * i + 1], A[3 * i + 2] = rows[4 * i + 2];
+      bb[i] = rows[4 * i + 3];
+    }
+    sc_poly p;
+    p.rows = n_rows_new, p.A = A, p.b = bb;
+    memcpy(p.seed, seed_world, sizeof p.seed);
+    fresh[n_new++] = p;
+    n_made++;
+  }
+  /* AC:1438-1441: save polyhedra and seeds */
+  *n_out = n_new;
+  for (int i = 0; i < n_new; i++) {
+    out_rows[i] = fresh[i].rows;
+    memcpy(out_A + (size_t)i * rows_max * 3, fresh[i].A, sizeof(double) * 3 * (size_t)fresh[i].rows);
+    memcpy(out_b + (size_t)i * rows_max, fresh[i].b, sizeof(double) * (size_t)fresh[i].rows);
+    memcpy(out_seed + 3 * i, fresh[i].seed, sizeof(double) * 3);
+  }
+  free(fresh), free(vg), free(grid_data), free(new_A), free(new_b), free(rows);
+  return rc;
+}

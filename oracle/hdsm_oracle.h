@@ -105,6 +105,33 @@ int orc_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const doubl
               const double* b, double* traj_out, double* ctrl_out, uint8_t* poly_used, int32_t* status,
               double* obj, int32_t n_threads);
 
+/* ---- row f2: corridor maintenance, Agent::GenerateSafeCorridor (agent_class.cpp:1236-1447) ---------------------------------
+ * A statement-by-statement restatement of the reference method on plain arrays: keep the last polyhedron if the whole previous
+ * plan lies in it (AC:1253-1267, LinearConstraint::inside = "no row with A x - b > 0", decomp_geometry/polyhedron.h:130-137), else
+ * keep the polyhedra the last solve used (AC:1273-1282); walk the path in steps of voxel_size / 10 (AC:1316-1335) until a sample
+ * lies in none of the kept polyhedra (AC:1337-1350); step back one sample, truncate to a voxel (AC:1352-1359), skip it if it is
+ * the seed of a kept polyhedron (AC:1361-1379); a seed pinched between two occupied voxels along an axis takes the shape-aware
+ * decomposition (AC:1385-1395); the new polyhedron's rows are appended (AC:1403-1435). The voxel decomposition itself
+ * (convex_decomp_lib::GetPolyOcta3D / GetPolyOcta3DNew) is NOT restated here: the caller supplies it (`decomp`; the tests hand in
+ * the product's host functions hdsm_poly_octa3d[_new], which are pinned separately against recorded outputs of the reference's
+ * convex_decomp.cpp). Everything else — control flow, arithmetic, evaluation order — follows the reference text, not the product.
+ *
+ *   prev_*      poly_const_vec_ / poly_seeds_ before the call: n_prev polyhedra of prev_rows[i] rows (stride rows_max)
+ *   poly_used   poly_used_idx_[n_prev]
+ *   traj_pts    positions of traj_curr_ (n_traj may be 0: before the first solve the reference's loop body never runs)
+ *   path        path_curr with the current position already pushed in front (AC:1286-1290), n_path >= 2
+ *   grid        the agent's voxel grid [dim[2]][dim[1]][dim[0]] (x fastest), raw: -1 unknown, 0 free, 100 occupied; origin, voxel_size
+ *   decomp      (ctx, seed, grid copy with unknown already occupied — it may mark it, dim, n_it, voxel_size, mark, origin, use_new,
+ *                rows[max_rows][4] = (n, n . p), max_rows, &n_rows) -> 0, or an error code that ends the call (returned)
+ *   out_*       the new poly_const_vec_ / poly_seeds_: n_out polyhedra, same layout as prev_* (capacity poly_hor)                 */
+typedef int (*orc_decomp_fn)(void* ctx, const int32_t seed[3], int8_t* grid, const int32_t dim[3], int32_t n_it, double voxel_size,
+                             int32_t mark, const double origin[3], int32_t use_new, double* rows, int32_t max_rows, int32_t* n_rows);
+int orc_safe_corridor(int32_t poly_hor, int32_t n_it_decomp, int32_t use_cvx_new, int32_t rows_max, int32_t n_prev,
+                      const int32_t* prev_rows, const double* prev_A, const double* prev_b, const double* prev_seed,
+                      const uint8_t* poly_used, int32_t n_traj, const double* traj_pts, int32_t n_path, const double* path,
+                      const int8_t* grid, const int32_t dim[3], const double origin[3], double voxel_size, orc_decomp_fn decomp,
+                      void* ctx, int32_t* n_out, int32_t* out_rows, double* out_A, double* out_b, double* out_seed);
+
 #ifdef __cplusplus
 }
 #endif

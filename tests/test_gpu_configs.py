@@ -406,3 +406,50 @@ def test_device_resident_loop_follows_the_host_mirror(hdsm, scene):
     dev_loop.plans_all, dev_loop.has_plan = plans, has
     out_d, out_h = dev_loop.step(), host.step()
     assert (out_d["status"] == out_h["status"]).all() and np.abs(dev_loop.plans_all - host.plans_all).max() < 1e-6
+
+
+@pytest.mark.parametrize("scene", ["forest", "fwf"])
+def test_device_corridor_kernel_matches_the_reference_restatement(hdsm, oracle, scene):
+    """Row f2 on the device: k_corridor (one wavefront per agent, rows of the kept polyhedra in registers, cooperative voxel
+    decomposition out of LDS) against oracle/hdsm_oracle.c: orc_safe_corridor — GenerateSafeCorridor (agent_class.cpp:1236-1447)
+    restated from the reference text — on every agent of >= 50 rounds of the device-resident loop, in the world of BASELINE
+    cfg 3 (pillar forest around a circle) and of cfg 5 (forest + wall + forest, H = 15): polyhedra, rows and seeds bit for bit."""
+    import corridor_oracle as co
+    from multi_agent_pkgs_amd import swarm
+    from oracle import pyoracle as orc
+    rounds = 52
+    cfg = swarm.default_swarm_config()
+    if scene == "forest":
+        n_rob, N = 64, 10
+        prm = agile_params(N, max_rows_static=18)
+        sol, loop = _device_loop(hdsm, prm, cfg, n_rob)
+        raw, origin = sc.forest_for_circle(n_rob, seed=13)
+    else:
+        n_y, N = 8, 15
+        n_rob = n_y * n_y
+        prm = agile_params(N, max_rows_static=18)
+        starts, goals = sc.lattice_scenario(n_y, n_y)
+        cfg.grid_range[2], cfg.grid_z_min = 12.0, -6.0
+        sol, loop = _device_loop(hdsm, prm, cfg, n_rob, starts=starts, goals=goals)
+        raw, origin = sc.forest_wall_forest(int(np.ceil((10 + 2.01 * n_y) / 30)), int(np.ceil((9 + 2.01 * n_y) / 15)), seed=0)
+    assert loop.set_world(sc.inflate(raw), origin) == 0
+    dsw = swarm.DeviceSwarm(loop.shard, sol)
+    made = carried = 0
+    for r in range(rounds):
+        dsw.download(states=True)
+        pre, prm_s, cfg_s, world, worigin = co.export_agents(loop.shard)
+        dsw.round()
+        dsw.download(states=True)
+        post = co.export_agents(loop.shard)[0]
+        for a in range(n_rob):
+            rc, want = co.oracle_corridor(orc.lib(), prm_s, cfg_s, world, worigin, pre[a])
+            got = co.product_corridor(post[a])
+            if rc != 0 or post[a].corridor_rc != 0:   # (a seed outside the local grid / a polyhedron beyond the row capacity: both stop)
+                assert rc != 0 and post[a].corridor_rc != 0, (r, a, rc, post[a].corridor_rc)
+                continue
+            assert co.same_corridor(got, want), (scene, r, a, [g[0] for g in got], [w[0] for w in want])
+            old = co.product_corridor(pre[a])
+            carried += sum(1 for g in got if any(np.array_equal(g[3], h[3]) for h in old))
+            made += len(got)
+    assert made - carried > n_rob and carried > n_rob   # polyhedra were generated AND carried over
+    dsw.close()

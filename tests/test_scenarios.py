@@ -175,3 +175,36 @@ def test_walk_jump_in_free_space_leaves_the_corridor_unchanged(oracle, monkeypat
         if r:
             new_boxes += int((plain[r]["b"] != plain[r - 1]["b"]).any(axis=(1, 2)).sum())
     assert new_boxes > n          # the corridors really moved on during the flight
+
+
+def test_corridor_maintenance_matches_the_reference_restatement(oracle):
+    """Row f2, the half around the voxel decomposition: GenerateSafeCorridor's keep-last / keep-used / path walk / seed logic
+    (agent_class.cpp:1236-1447). The host mirror's corridor step (csrc/swarm_core.h, the source the device loop runs too) against
+    oracle/hdsm_oracle.c: orc_safe_corridor — written from the reference text — on every agent of every round of a flight through
+    the pillar forest: same polyhedra in the same order, same rows, same seeds, bit for bit."""
+    import corridor_oracle as co
+    from oracle import pyoracle as orc
+    n, rounds = 24, 14
+    prm = agile_params(10, max_rows_static=18)
+    raw, org = sc.forest_for_circle(n, seed=21)
+    occ = sc.inflate(raw)
+
+    def cpu(inp, plans, has):
+        return orc.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=8)
+
+    loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), n, solve=cpu)
+    loop.set_world(occ, org)
+    new_polys = kept = 0
+    for r in range(rounds):
+        pre, prm_s, cfg_s, world, worigin = co.export_agents(loop.shard)
+        loop.shard.prepare_corridor()
+        post = co.export_agents(loop.shard)[0]
+        for a in range(n):
+            rc, want = co.oracle_corridor(orc.lib(), prm_s, cfg_s, world, worigin, pre[a])
+            got = co.product_corridor(post[a])
+            assert rc == 0 and post[a].corridor_rc == 0, (r, a, rc, post[a].corridor_rc)
+            assert co.same_corridor(got, want), (r, a, [g[0] for g in got], [w[0] for w in want])
+            kept += sum(1 for g in got if any(np.array_equal(g[3], h[3]) for h in co.product_corridor(pre[a])))
+            new_polys += len(got)
+        loop.step()
+    assert new_polys - kept > n and kept > n   # polyhedra were generated AND carried over
