@@ -304,12 +304,16 @@ __global__ __launch_bounds__(256) void k_ref_pack(int N, int n_rob, const double
   }
 }
 
-__global__ __launch_bounds__(256) void k_reference(RefArgs a) {
+// NT threads per instance: 256 for small batches (more lanes on the one instance's neighbour scans), 64 — one wavefront, every
+// instance of a 1024-agent round resident at once, the workgroup barriers of the reductions cost nothing — for large ones
+// (46 -> ~20 us per 1024-agent round).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
   __shared__ double own[hdsm::MAXH + 1][3];
   __shared__ double wocc[hdsm::MAXH + 1];
-  __shared__ double red[256];
-  __shared__ double d2w[4][hdsm::MAXH + 1];
-  __shared__ int idx[256];
+  __shared__ double red[NT];
+  __shared__ double d2w[NT / 64][hdsm::MAXH + 1];
+  __shared__ int idx[NT];
   constexpr int PATH_LDS = 64;
   __shared__ double spath[PATH_LDS * 3];
   __shared__ double pts[hdsm::MAXH + 1][3];
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
   const double* pth_g = a.path + (int64_t)inst * a.pmax * 3;
   const bool path_fits = np <= PATH_LDS;
   if (path_fits)
-    for (int e = tid; e < np * 3; e += 256) spath[e] = pth_g[e];
+    for (int e = tid; e < np * 3; e += NT) spath[e] = pth_g[e];
   const double* pth = path_fits ? spath : pth_g;
   if (tid <= N) {
     for (int c = 0; c < 3; ++c) own[tid][c] = own_has ? a.plans[((int64_t)self * (N + 1) + tid) * 9 + c] : 0.0;
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
     const double4 ss = *reinterpret_cast<const double4*>(a.rsph + (int64_t)self * 4);
     double gbest = DBL_MAX;
     int jbest = -1;
-    for (int j = tid; j < a.n_rob; j += 256) {
+    for (int j = tid; j < a.n_rob; j += NT) {
       if (j == self) continue;
       const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
       if (sj.w < 0) continue;  // no plan
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
     red[tid] = gbest;
     idx[tid] = jbest;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
       if (tid < off && idx[tid + off] >= 0 && (idx[tid] < 0 || red[tid + off] < red[tid])) red[tid] = red[tid + off], idx[tid] = idx[tid + off];
       __syncthreads();
     }
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
     double d2min[hdsm::MAXH + 1];
 #pragma unroll
     for (int i = 0; i <= hdsm::MAXH; ++i) d2min[i] = DBL_MAX;
-    for (int j = tid; j < a.n_rob; j += 256) {
+    for (int j = tid; j < a.n_rob; j += NT) {
       if (j == self) continue;
       const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
       if (sj.w < 0) continue;
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
       }
     __syncthreads();
     if (tid <= N) {
-      const double m = fmin(fmin(d2w[0][tid], d2w[1][tid]), fmin(d2w[2][tid], d2w[3][tid]));
+      double m = d2w[0][tid];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w) m = fmin(m, d2w[w][tid]);
       if (m < DBL_MAX) {
         const double d = sqrt(m);
         const double alpha = (1 - wocc[tid] * (1 / exp(a.cfg.sens_dist * d)));
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
       }
     }
   } else if (own_has && np >= 2) {  // (a configuration whose limit is not monotone in the distance: every pair is evaluated)
-    for (int j = tid; j < a.n_rob; j += 256) {
+    for (int j = tid; j < a.n_rob; j += NT) {
       if (j == self || !a.has_plan[j]) continue;
       const double* rec = a.plans + (int64_t)j * (N + 1) * 9;
       for (int i = 0; i <= N; ++i) {
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void k_reference(RefArgs a) {
   }
   red[tid] = pv;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = NT / 2; off > 0; off >>= 1) {
     if (tid < off) red[tid] = fmin(red[tid], red[tid + off]);
     __syncthreads();
   }
@@ -1221,7 +1227,8 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   h->last_stream = st;
   hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16), dim3(256), 0, st, h->N, n_rob, plans_all, has_plan, h->d_rpos, h->d_rsph);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_reference, dim3(n_inst), dim3(256), 0, st, a);
+  if (n_inst >= 256) hipLaunchKernelGGL(k_reference<64>, dim3(n_inst), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_reference<256>, dim3(n_inst), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(h->ev_done, st));
   h->launched = true;

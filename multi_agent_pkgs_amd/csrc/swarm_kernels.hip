@@ -308,7 +308,8 @@ __global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, con
 }
 
 __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* agents, const double* traj, const double* ctrl,
-                                               const uint8_t* used, const int32_t* status, double* plans_local, int32_t* fails) {
+                                               const uint8_t* used, const int32_t* status, double* plans_local, int32_t* fails,
+                                               uint8_t* has_direct) {
   // one wavefront per published record. Lane 0 does the read-back / fallback; the increment check — a walk of ~100 samples per
   // metre of reference — is split by reference segment over the lanes (the samples of a segment do not depend on the others,
   // hdsm_sw::increment_segment_min), the minima meet in a wave reduction; then all lanes write the record.
@@ -378,6 +379,8 @@ __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* ag
   if (!have_s) {  // no plan yet (or padding): the record carries the sentinel instead of a flag (hdsm_exchange_device)
     for (int e = lane; e < rec; e += 64) out[e] = e == 0 ? __longlong_as_double(0x7ff8000000000000LL) : 0.0;
   }
+  // a single rank publishes straight into the plans buffer of the next round (no copy, no flag kernel): the flag too
+  if (has_direct != nullptr && lane == 0) has_direct[k] = have_s ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_flags(int rec, int n, const double* plans, uint8_t* has) {
@@ -554,16 +557,15 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
                             d->d_traj, d->d_ctrl, d->d_used, d->d_status, d->d_obj, st);
     if (rc) return fail(rc, std::string("hdsm_replan_device: ") + hdsm_last_error());
   }
+  // (one rank: the solve of this round is behind us on the stream, so the records go straight into the plans buffer — slot k =
+  // agent k — and the flags with them; several ranks: into the send buffer of the ONE all-gather)
+  const bool direct = d->world == 1;
   hipLaunchKernelGGL(k_commit, dim3((unsigned)(d->per > 0 ? d->per : 1)), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
-                     d->d_local, d->d_fails);
+                     direct ? d->d_plans : d->d_local, d->d_fails, direct ? d->d_has : nullptr);
   HIP_TRY(hipGetLastError());
-  if (d->world > 1) {
+  if (!direct) {
     const int rc = hdsm_exchange_device(comm, d->per, d->d_local, d->d_plans, d->d_has, st);
     if (rc) return fail(rc, std::string("hdsm_exchange_device: ") + hdsm_last_error());
-  } else {
-    HIP_TRY(hipMemcpyAsync(d->d_plans, d->d_local, (size_t)d->per * rec * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_flags, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, rec, G, d->d_plans, d->d_has);
-    HIP_TRY(hipGetLastError());
   }
   ++d->rounds;
   return HDSM_OK;

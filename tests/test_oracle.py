@@ -434,3 +434,22 @@ def test_rows_on_input_independent_positions_are_judged_with_feas_tol_fixed(orac
     A, b = args[4], args[5]
     r = int(args[3][0, mstep - 1, 0]) - 1
     assert A[0, mstep - 1, 0, r] @ o["traj"][0, mstep, :3] - b[0, mstep - 1, 0, r] < 1e-8
+
+
+def test_cpu_port_of_the_product_algorithm_matches_the_oracle(oracle):
+    """oracle/hdsm_cpu_port.c (bench.py's cpu_baseline_warm leg: lazy closed-form planes, sphere prefilter, normalised pick rule, warm
+    start) gives the oracle's answers — cold, and warm-started from its own previous working sets on a second, shifted snapshot."""
+    from oracle import pycpuport as port
+    prm = agile_params(10, max_rows_static=18)
+    keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+    for kw in (dict(seed=3, turn=True), dict(seed=11, spacing=1.3), dict(seed=8, narrow=True, turn=True, spacing=1.5)):
+        sn = problems.swarm_snapshot(prm, 16, **kw)
+        args = [sn[k] for k in keys]
+        o = oracle.replan(prm, *args, n_threads=8)
+        store = port.new_warm_store(16)
+        for rep in range(2):   # second call: warm-started from the sets the first one stored (a wrong guess must not matter either)
+            g = port.replan(prm, *args, warm=store, n_threads=4)
+            assert (g["status"] == o["status"]).all(), (kw, rep, g["status"], o["status"])
+            ok = o["status"] != 2
+            assert np.abs(g["traj"] - o["traj"])[ok].max() < 1e-7 and np.abs(g["obj"] - o["obj"])[ok].max() < 1e-6 * max(1.0, np.abs(o["obj"][ok]).max())
+        assert (store[:, 0] > 0).any()
