@@ -188,6 +188,19 @@ int hdsm_swarm_shutdown(void* swarm, int32_t local_index, const char* dir, int32
 /* Diagnostics: current positions [n_local][3], distance to goal [n_local], failures so far. */
 int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fail);
 
+/* Agent::ComputeYawAngle (AC:1025-1051) for every local agent: the yaw follows the direction from the current position to
+ * reference point `yaw_idx` (projected on the x-y plane) with a P controller, yaw += k_p_yaw * error * dt, error wrapped into
+ * (-pi, pi]; nothing moves while that point is closer than sqrt(0.1) m. Call it where the reference does (AC:177): after the
+ * solve, BEFORE hdsm_swarm_commit advances the state. yaw_out [n_local] = Trajectory.msg:11 of the plans published this round. */
+int hdsm_swarm_yaw(void* swarm, int32_t yaw_idx, double k_p_yaw, double* yaw_out);
+
+/* What the reference's rviz publishers show of local agent `k` (AC:679-857): traj_curr_ positions [n_traj <= N + 1][3],
+ * traj_ref_curr_ positions [n_ref <= N + 1][3], path_curr_ [n_path <= pmax][3], the corridor (poly_const_vec_ rows n . x <= b with
+ * the capacity of hdsm_params: poly_A [poly_hor][max_rows_static][3], poly_b, poly_rows[poly_hor]; poly_seeds_ [poly_hor][3]),
+ * the current position. Any output pointer may be NULL. */
+int hdsm_swarm_view(void* swarm, int32_t k, double* traj_curr, int32_t* n_traj, double* traj_ref, int32_t* n_ref, double* path, int32_t pmax,
+                    int32_t* n_path, int32_t* n_poly, int32_t* poly_rows, double* poly_A, double* poly_b, double* poly_seeds, double pos[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,7 @@ using hdsm_sw::V3;
 struct AgentX {
   void* stats = nullptr;         // hdsm_stats record of this agent (comp_time_*_, state_hist_; f3)
   double sc_ms = 0, ref_ms = 0;  // CPU time of this round's corridor / reference generation
+  double yaw = 0;                // yaw_ (AC:16, 1025-1051)
 };
 
 struct Swarm {
@@ -681,6 +682,67 @@ int hdsm_swarm_state(void* swarm, double* pos, double* dist_goal, int32_t* n_fai
     if (dist_goal) dist_goal[k] = norm(sub(p, ag.goal));
     if (n_fail) n_fail[k] = ag.n_fail;
   }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_yaw(void* swarm, int32_t yaw_idx, double k_p_yaw, double* yaw_out) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || yaw_idx < 0 || yaw_idx > sw->prm.n_hor) return HDSM_ERR_BAD_ARG;
+  const double pi = 3.14159265358979323846;
+  for (int k = 0; k < sw->n_local; ++k) {
+    const AgentS& ag = sw->agents[k];
+    double& yaw = sw->extra[k].yaw;
+    if (ag.n_ref > yaw_idx) {  // AC:1028-1030 (traj_ref_curr_ exists from the first reference on)
+      double v[3] = {ag.traj_ref[yaw_idx][0] - ag.state_curr[0], ag.traj_ref[yaw_idx][1] - ag.state_curr[1], ag.traj_ref[yaw_idx][2] - ag.state_curr[2]};
+      if (v[0] * v[0] + v[1] * v[1] + v[2] * v[2] > 0.1) {  // AC:1033
+        const double yaw_ref = std::atan2(v[1], v[0]);        // AC:1035-1040 (the projection on the x-y plane drops v[2])
+        double error_ang = yaw_ref - yaw;
+        if (error_ang > pi) error_ang = error_ang - 2 * pi;  // AC:1043-1047
+        else if (error_ang < -pi) error_ang = error_ang + 2 * pi;
+        yaw = yaw + k_p_yaw * error_ang * sw->prm.dt;         // AC:1048
+      }
+    }
+    if (yaw_out) yaw_out[k] = yaw;
+  }
+  return HDSM_OK;
+}
+
+int hdsm_swarm_view(void* swarm, int32_t k, double* traj_curr, int32_t* n_traj, double* traj_ref, int32_t* n_ref, double* path, int32_t pmax,
+                    int32_t* n_path, int32_t* n_poly, int32_t* poly_rows, double* poly_A, double* poly_b, double* poly_seeds, double pos[3]) {
+  Swarm* sw = static_cast<Swarm*>(swarm);
+  if (!sw || k < 0 || k >= sw->n_local) return HDSM_ERR_BAD_ARG;
+  const AgentS& ag = sw->agents[k];
+  const int N = sw->prm.n_hor, P = sw->prm.poly_hor, RS = sw->prm.max_rows_static;
+  const int nt = ag.has_traj ? N + 1 : 0, nr = ag.n_ref < N + 1 ? ag.n_ref : N + 1;
+  if (n_traj) *n_traj = nt;
+  if (traj_curr)
+    for (int i = 0; i < nt; ++i)
+      for (int c = 0; c < 3; ++c) traj_curr[3 * i + c] = ag.traj_curr[i][c];
+  if (n_ref) *n_ref = nr;
+  if (traj_ref)
+    for (int i = 0; i < nr; ++i)
+      for (int c = 0; c < 3; ++c) traj_ref[3 * i + c] = ag.traj_ref[i][c];
+  const int np = ag.n_path < pmax ? ag.n_path : pmax;
+  if (n_path) *n_path = np;
+  if (path)
+    for (int i = 0; i < np; ++i)
+      for (int c = 0; c < 3; ++c) path[3 * i + c] = ag.path[i][c];
+  const int npl = ag.n_poly < P ? ag.n_poly : P;
+  if (n_poly) *n_poly = npl;
+  for (int j = 0; j < npl; ++j) {
+    const hdsm_sw::Poly& pl = ag.polys[j];
+    const int rows = pl.rows < RS ? pl.rows : RS;
+    if (poly_rows) poly_rows[j] = rows;
+    for (int r = 0; r < rows; ++r) {
+      if (poly_A)
+        for (int c = 0; c < 3; ++c) poly_A[((size_t)j * RS + r) * 3 + c] = pl.A[r][c];
+      if (poly_b) poly_b[(size_t)j * RS + r] = pl.b[r];
+    }
+    if (poly_seeds)
+      for (int c = 0; c < 3; ++c) poly_seeds[3 * j + c] = pl.seed[c];
+  }
+  if (pos)
+    for (int c = 0; c < 3; ++c) pos[c] = ag.state_curr[c];
   return HDSM_OK;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_creat
            "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new", "hdsm_poly_octa3d_batch",
            "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_poly_octa3d_batch_wave", "hdsm_poly_octa3d_device_wave", "hdsm_corridor_last_error",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
-           "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_swarm_record_solve_ms", "hdsm_swarm_shutdown", "hdsm_swarm_prepare_corridor", "hdsm_swarm_vel_cap",
+           "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_swarm_yaw", "hdsm_swarm_view", "hdsm_swarm_record_solve_ms", "hdsm_swarm_shutdown", "hdsm_swarm_prepare_corridor", "hdsm_swarm_vel_cap",
            "hdsm_dswarm_create", "hdsm_dswarm_upload_plans", "hdsm_dswarm_round", "hdsm_dswarm_download", "hdsm_dswarm_destroy", "hdsm_dswarm_last_error",
            "hdsm_stats_create", "hdsm_stats_destroy", "hdsm_stats_add", "hdsm_stats_add_state", "hdsm_stats_add_latency",
            "hdsm_stats_shutdown", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")

@@ -5,6 +5,7 @@
 #include "../../ros/hdsm_agent_node.cpp"
 #undef main
 #include <cmath>
+#include <map>
 
 int main(int argc, char** argv) {
   const int ticks = argc > 1 ? std::atoi(argv[1]) : 12;
@@ -34,6 +35,12 @@ int main(int argc, char** argv) {
   for (auto& kv : rclcpp::shim::bus().delivered) del += kv.second;
   std::printf("topics %zu published %ld delivered %ld\n", rclcpp::shim::bus().published.size(), pub, del);
   for (int r = 0; r < 2; ++r) std::printf("node %d: remote plans known %d of %d, rounds %d\n", r, nodes[r]->remote_plans_known(), n_rob - per, nodes[r]->rounds());
+  // per topic kind: messages published (8 kinds x 8 agents x rounds, minus the first rounds' missing trajectories)
+  std::map<std::string, long> kinds;
+  for (auto& kv : rclcpp::shim::bus().published) kinds[kv.first.substr(kv.first.rfind('/') + 1)] += kv.second;
+  for (auto& kv : kinds) std::printf("kind %s %ld\n", kv.first.c_str(), kv.second);
+  // agent 0 starts at angle 0 of the circle and flies towards -x: its yaw turns towards pi (ComputeYawAngle)
+  std::printf("yaw agent0 %.6f agent2 %.6f\n", nodes[0]->yaw(0), nodes[0]->yaw(2));
   rclcpp::shutdown();
   return 0;
 }

@@ -283,8 +283,18 @@ def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
     assert r.returncode == 0, r.stdout + r.stderr
     m = re.search(r"topics (\d+) published (\d+) delivered (\d+)", r.stdout)
     topics, pub, dlv = (int(x) for x in m.groups())
-    assert topics == 8 and pub == dlv and pub >= 8 * 14, r.stdout          # one subscriber per topic: the other node
+    kinds = {k: int(v) for k, v in re.findall(r"kind (\w+) (\d+)", r.stdout)}
+    # 8 agents x 8 topics (AC:42-86: traj_full, traj, traj_ref, path, traj_hist, polyhedra, seeds, position); only traj_full has a
+    # subscriber (the other node)
+    assert topics == 64 and set(kinds) == {"traj_full", "traj", "traj_ref", "path", "traj_hist", "polyhedra", "seeds", "position"}, r.stdout
+    assert kinds["traj_full"] == dlv and kinds["traj_full"] >= 8 * 14, r.stdout
+    for k in ("traj_ref", "path", "traj_hist", "polyhedra", "seeds", "position"):
+        assert kinds[k] == 8 * 15, (k, r.stdout)
+    assert kinds["traj"] >= 8 * 14, r.stdout
     assert "node 0: remote plans known 4 of 4, rounds 15" in r.stdout and "node 1: remote plans known 4 of 4, rounds 15" in r.stdout, r.stdout
+    # ComputeYawAngle: agent 0 starts at angle 0 of the ring and flies towards -x (yaw -> +-pi), agent 2 at angle pi/2 towards -y
+    y0, y2 = (float(x) for x in re.search(r"yaw agent0 (\S+) agent2 (\S+)", r.stdout).groups())
+    assert abs(y0) > 1.0 and -2.2 < y2 < -0.5, r.stdout
 
 
 def test_staging_overflow_in_a_shared_cu_kernel_is_rescued(hdsm, oracle, monkeypatch):

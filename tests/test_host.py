@@ -515,3 +515,53 @@ def test_ros_node_type_checks_against_rclcpp_shaped_headers():
         assert r.returncode == 0, r.stdout + r.stderr
     else:
         assert r.returncode == 7 and "hdsm_create" in r.stdout and "no HIP device" in r.stdout, r.stdout + r.stderr
+
+
+def test_yaw_follows_the_reference_with_the_p_controller_of_the_reference():
+    """hdsm_swarm_yaw = Agent::ComputeYawAngle (AC:1025-1051): yaw += k_p * wrap(atan2(dy, dx) - yaw) * dt towards reference point
+    yaw_idx, frozen while that point is within sqrt(0.1) m. Checked against a literal Python rendering over a short flight (the
+    oracle stands in for the device solver), including the wrap across +-pi; hdsm_swarm_view hands back what the rviz publishers show."""
+    import ctypes as C
+    import math
+    from multi_agent_pkgs_amd import swarm
+    from multi_agent_pkgs_amd.params import agile_params
+    from oracle import pyoracle as orc
+    prm = agile_params(10, max_rows_static=18)
+    n = 4
+    starts = np.array([[0.0, 0.0, 1.5], [10.0, 0.0, 1.5], [0.0, 8.0, 1.5], [10.0, 8.0, 1.5]])
+    goals = np.array([[10.0, 0.0, 1.5], [0.0, 0.1, 1.5], [0.0, -8.0, 1.5], [10.0, 8.2, 1.5]])   # +x, -x (wrap), -y, nearly at rest
+
+    def cpu(inp, plans, has):
+        return orc.replan(prm, inp["agent_id"], inp["state"], inp["ref"], inp["n_poly"], inp["n_rows"], inp["A"], inp["b"], plans, has, n_threads=4)
+
+    loop = swarm.SwarmLoop(prm, swarm.default_swarm_config(), n, solve=cpu, starts=starts, goals=goals)
+    L = loop.shard.lib
+    yaw_idx, k_p = 3, 1.0
+    want = np.zeros(n)
+    got = np.zeros(n)
+    N = prm.n_hor
+    for r in range(12):
+        inputs = loop.shard.prepare(loop.plans_all, loop.has_plan)
+        out = cpu(inputs, loop.plans_all, loop.has_plan)
+        # the literal rendering, from what the rviz view shows BEFORE the commit
+        for k in range(n):
+            tr, pos, n_ref = np.zeros((N + 1, 3)), np.zeros(3), C.c_int32()
+            assert L.hdsm_swarm_view(loop.shard.h, k, None, None, tr.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_ref), None, 0, None, None, None,
+                                     None, None, None, pos.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            if n_ref.value > yaw_idx:
+                v = tr[yaw_idx] - pos
+                if v @ v > 0.1:
+                    err = math.atan2(v[1], v[0]) - want[k]
+                    if err > math.pi:
+                        err -= 2 * math.pi
+                    elif err < -math.pi:
+                        err += 2 * math.pi
+                    want[k] = want[k] + k_p * err * prm.dt
+        assert L.hdsm_swarm_yaw(loop.shard.h, yaw_idx, C.c_double(k_p), got.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.array_equal(got, want), (r, got, want)
+        plans_local, has_local = loop.shard.commit(out)
+        loop.plans_all[:], loop.has_plan[:] = plans_local, has_local
+    assert abs(got[0]) < 0.05                             # flying along +x: (almost) no error to correct
+    assert abs(got[1]) > 0.5                              # towards -x: turning (through the wrap branch) towards +-pi
+    assert got[2] < -0.5                                  # towards -y
+    assert abs(got[3]) < 1.6                              # (goal 0.2 m away: the yaw freezes once the reference point is within sqrt(0.1) m)
