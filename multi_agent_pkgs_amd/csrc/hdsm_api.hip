@@ -1331,9 +1331,9 @@ int hdsm_last_stats(void* handle, int32_t n_inst, int32_t* qp_iters, int32_t* no
     for (int k = 0; k < n_inst; ++k) late += pr[(size_t)k * 32] - t0 > 200;  // started more than 2 us after the first
     if (const char* path = std::getenv("HDSM_TIMELINE_DUMP")) {  // raw rows for offline analysis, one block per launch
       if (FILE* f = std::fopen(path, "ab")) {
-        const long long head[2] = {0x54494d454c494e32LL, n_inst};  // ("TIMELIN2": 24 entries per instance)
+        const long long head[2] = {0x54494d454c494e33LL, n_inst};  // ("TIMELIN3": 32 entries per instance)
         std::fwrite(head, sizeof(long long), 2, f);
-        for (int k = 0; k < n_inst; ++k) std::fwrite(&pr[(size_t)k * 32], sizeof(long long), 24, f);
+        for (int k = 0; k < n_inst; ++k) std::fwrite(&pr[(size_t)k * 32], sizeof(long long), 32, f);
         std::fclose(f);
       }
     }

@@ -614,6 +614,9 @@ struct Solver {
     if (IS_T0) s.snap = snap;  // (read back at the few places a snapshot is taken or restored; published by the set-up's barriers)
 
     const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
+#ifdef HDSM_TIMELINE
+    long long tl_su1_ = 0, tl_su2_ = 0, tl_tail1_ = 0, tl_tail2_ = 0;
+#endif
 #ifdef HDSM_PROFILE
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
@@ -666,21 +669,23 @@ struct Solver {
       };
       auto request = [&](int vt) {
         Req r;
-        r.v_in = (vt < nvt) ? (vt < 9 ? g.state[(int64_t)inst * 9 + vt] : g.ref[(int64_t)inst * 6 * N + (vt - 9)]) : 0.0;
+        // (config constants first: their addresses do not need `inst`, whose own load — the launch-order entry — is still in
+        // flight when a workgroup starts; the reads that do need it follow, so nothing that could go out waits behind them)
         r.v_g = (vt < 9 * MAXH) ? (&c.g[0][0][0])[vt] : 0.0;
-        r.sj = (vt < P * RS) ? vt / RS : 0, r.sr = (vt < P * RS) ? vt % RS : 0;
-        const double* Ar = g.A + (((int64_t)inst * P + r.sj) * RS + r.sr) * 3;
-        r.a0 = Ar[0], r.a1 = Ar[1], r.a2 = Ar[2], r.a3 = g.b[((int64_t)inst * P + r.sj) * RS + r.sr];
-        r.nr = g.n_rows[(int64_t)inst * P + (vt < P ? vt : 0)];
         r.fi = (vt < 9 * (N + 1)) ? vt / 9 : 0, r.fcomp = (vt % 9) / 3, r.fax = vt % 3;
         r.p0 = c.phi[r.fax][r.fi][r.fcomp][0], r.p1 = c.phi[r.fax][r.fi][r.fcomp][1], r.p2 = c.phi[r.fax][r.fi][r.fcomp][2];
-        r.q0 = g.state[(int64_t)inst * 9 + r.fax], r.q1 = g.state[(int64_t)inst * 9 + 3 + r.fax],
-        r.q2 = g.state[(int64_t)inst * 9 + 6 + r.fax];
         const int ui = vt / S::LDT, uj = vt % S::LDT;
         r.v_u = (ui < 6 && uj < 6) ? c.Ueq[ui * 6 + uj] : 0.0;
         r.v_b = (vt < 3) ? c.lbu[vt] : (vt < 6) ? c.ubu[vt - 3] : (vt < 15) ? (&c.lbs[0][0])[vt - 6]
                                                                 : (&c.ubs[0][0])[vt < 24 ? vt - 15 : 0];
         r.v_k = (&c.kap[0][0])[vt < 4 * (MAXH + 1) ? vt : 0];
+        r.v_in = (vt < nvt) ? (vt < 9 ? g.state[(int64_t)inst * 9 + vt] : g.ref[(int64_t)inst * 6 * N + (vt - 9)]) : 0.0;
+        r.sj = (vt < P * RS) ? vt / RS : 0, r.sr = (vt < P * RS) ? vt % RS : 0;
+        const double* Ar = g.A + (((int64_t)inst * P + r.sj) * RS + r.sr) * 3;
+        r.a0 = Ar[0], r.a1 = Ar[1], r.a2 = Ar[2], r.a3 = g.b[((int64_t)inst * P + r.sj) * RS + r.sr];
+        r.nr = g.n_rows[(int64_t)inst * P + (vt < P ? vt : 0)];
+        r.q0 = g.state[(int64_t)inst * 9 + r.fax], r.q1 = g.state[(int64_t)inst * 9 + 3 + r.fax],
+        r.q2 = g.state[(int64_t)inst * 9 + 6 + r.fax];
         return r;
       };
       auto commit = [&](int vt, const Req& r) {
@@ -723,6 +728,19 @@ struct Solver {
       const typename W::LaneReq lane_req = W::init_lane_request(c, tid & 63);  // (every wave: wave 1 scans with its own copy)
       const int fi0 = tid / 6 + 1, fk0 = tid % 6, fi1 = (tid + 64) / 6 + 1, fk1 = (tid + 64) % 6;
       const double wn0 = c.wn[fk0], wx0 = c.wx[fk0], wn1 = c.wn[fk1], wx1 = c.wx[fk1];
+      // The arrays that are longer than a workgroup of 128 threads are config constants only (impulse responses: 9 MAXH entries,
+      // the rows of Ueq: 6 LDT): their later items are requested NOW, with everything else, instead of in a second round that
+      // starts when the first one has been written to LDS (a second exposed round trip to global memory per instance).
+      // everything else (the instance's arrays, the short constants) fits one round of 128 threads
+      const int items_inst = max_i(max_i(P * RS, 9 * (N + 1)), max_i(KCOLS + 8, max_i(NV, 4 * (MAXH + 1))));
+      constexpr int KC = ((6 * S::LDT > 9 * MAXH ? 6 * S::LDT : 9 * MAXH) + 63) / 64 - 1;  // enough for a workgroup of one wave
+      double cg_late[KC], cu_late[KC];
+      HDSM_UNROLL
+      for (int u = 0; u < KC; ++u) {
+        const int vt = tid + nt * (u + 1), ui = vt / S::LDT, uj = vt % S::LDT;
+        cg_late[u] = (vt < 9 * MAXH) ? (&c.g[0][0][0])[vt] : 0.0;
+        cu_late[u] = (vt < 6 * S::LDT && ui < 6 && uj < 6) ? c.Ueq[ui * 6 + uj] : 0.0;
+      }
       const Req r0 = request(tid);
 
       ST_PROF(9)
@@ -747,8 +765,19 @@ struct Solver {
       hrow_own = lane_req.hrow;
       fw0 = (tid < 64) ? ((fi0 == N) ? wn0 : wx0) : 0.0;
       fw1 = (tid < 64) ? ((fi1 == N) ? wn1 : wx1) : 0.0;
-      const int items = max_i(max_i(P * RS, 6 * S::LDT), max_i(9 * MAXH, 9 * (N + 1)));
-      for (int vt = tid + nt; vt < items; vt += nt) commit(vt, request(vt));
+      HDSM_UNROLL
+      for (int u = 0; u < KC; ++u) {  // the late items of the constant arrays (requested above)
+        const int vt = tid + nt * (u + 1);
+        if (vt < 9 * MAXH) {
+          (&s.g[0][0][0])[vt] = cg_late[u];
+          const int ax = vt / (3 * MAXH), comp = (vt / MAXH) % 3, lag = vt % MAXH;
+          s.gz[ax][comp][lag] = 0.0;
+          s.gz[ax][comp][MAXH + lag] = (lag < N) ? cg_late[u] : 0.0;
+        }
+        if (vt < 6 * S::LDT) s.U[vt] = cu_late[u];
+      }
+      static_assert(6 * S::LDT <= 64 * (KC + 1) && 9 * MAXH <= 64 * (KC + 1), "the late constant items cover the smallest workgroup");
+      for (int vt = tid + nt; vt < items_inst; vt += nt) commit(vt, request(vt));  // (64-thread workgroups only)
       for (int k = 6 * S::LDT + tid; k < NV * S::LDT; k += nt) s.U[k] = 0.0;
       if (tid == 0) {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
@@ -758,6 +787,9 @@ struct Solver {
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
+#ifdef HDSM_TIMELINE
+      tl_su1_ = (long long)wall_clock64();  // staging done (before the barrier)
+#endif
       SYNC();
       SU_PROF(13)
       // the set-up map: x_eq (minimiser subject to v_N = a_N = 0), x0 (unconstrained minimiser), the gradient at
@@ -790,6 +822,9 @@ struct Solver {
       }
     }
     SU_PROF(14)
+#ifdef HDSM_TIMELINE
+    tl_su2_ = (long long)wall_clock64();  // set-up map applied
+#endif
     SYNC();
     // constant term f0, J(x0) = f0 + grad.x0 / 2 and J(x_eq) = J(x0) + resid.nu / 2
     R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
@@ -1146,6 +1181,9 @@ struct Solver {
         }
       }
       SYNC();
+#ifdef HDSM_TIMELINE
+      tl_tail1_ = (long long)wall_clock64();  // rollout done
+#endif
       PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
       if (threadIdx.x < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
         const int lane = tid_here();
@@ -1165,6 +1203,9 @@ struct Solver {
           if (s.inc_assign[i] >= 0 && s.inc_assign[i] < P) us[s.inc_assign[i]] = 1;
       }
     }
+#ifdef HDSM_TIMELINE
+    tl_tail2_ = (long long)wall_clock64();  // outputs written
+#endif
     if (a.warm != nullptr && (!handed_over || s.have_inc)) {  // next replan's guess (handed over: the merge may replace it)
       int32_t* wp = a.warm_out + (int64_t)out * (MAXNV + 2);
       // No solution because the ROOT relaxation is infeasible (the usual case in a gridlocked neighbourhood, and it
@@ -1201,6 +1242,8 @@ struct Solver {
       pr[5] = nodes, pr[6] = sweeps, pr[7] = s.ncand, pr[8] = (long long)flags, pr[9] = s.ncold, pr[10] = status;
       pr[11] = s.st_pairs, pr[12] = s.st_sph, pr[13] = s.q, pr[14] = s.n_nogood, pr[15] = s.ng_skipped;
       pr[16] = tl_setup_ - tl_begin_, pr[17] = tl_warm_, pr[18] = tl_warm_it_, pr[19] = tl_sweep_, pr[20] = tl_run_, pr[21] = tl_runs_, pr[22] = tl_leaf_, pr[23] = (long long)wall_clock64() - tl_loop_end_;
+      pr[24] = tl_su1_ - tl_begin_, pr[25] = tl_su2_ - tl_su1_, pr[26] = tl_setup_ - tl_su2_;
+      pr[27] = tl_tail1_ ? tl_tail1_ - tl_loop_end_ : 0, pr[28] = tl_tail1_ ? tl_tail2_ - tl_tail1_ : 0, pr[29] = (long long)wall_clock64() - tl_tail2_;
     }
 #endif
     if (IS_T0) {

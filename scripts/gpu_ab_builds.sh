@@ -4,11 +4,11 @@ names=$1; reps=${2:-2}
 cd $GRAFT_REPO_ROOT
 cp multi_agent_pkgs_amd/libhdsm.so /tmp/libhdsm_orig.so
 rec=/tmp/ab_rec_builds.npz
-[ -f $rec ] || timeout 900 python bench.py --no-cpu-baseline --no-event-pass --save-recording $rec > /dev/null 2>&1
+[ -f $rec ] || timeout 900 python bench.py --no-cpu-baseline --no-secondary --no-event-pass --save-recording $rec > /dev/null 2>&1
 for r in $(seq $reps); do
 for n in $names; do
   cp multi_agent_pkgs_amd/libhdsm_$n.so multi_agent_pkgs_amd/libhdsm.so
-  timeout 600 python bench.py --no-cpu-baseline --load-recording $rec 2>&1 | tail -1 > /tmp/ab_line.json
+  timeout 600 python bench.py --no-cpu-baseline --no-secondary --load-recording $rec 2>&1 | tail -1 > /tmp/ab_line.json
   python - "$n" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab_line.json").read())

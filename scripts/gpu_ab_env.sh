@@ -2,9 +2,9 @@
 # per setting.   usage: bash scripts/gpu_ab_env.sh VAR "v1 v2 ..." [bench args]      (development aid; runs on the GPU box)
 var=$1; vals=$2; shift 2
 rec=/tmp/ab_rec_$(echo "$@" | md5sum | cut -c1-10).npz
-[ -f $rec ] || timeout 900 python bench.py --no-cpu-baseline --no-event-pass "$@" --save-recording $rec > /dev/null 2>&1
+[ -f $rec ] || timeout 900 python bench.py --no-cpu-baseline --no-secondary --no-event-pass "$@" --save-recording $rec > /dev/null 2>&1
 for v in $vals; do
-  env $var=$v timeout 600 python bench.py --no-cpu-baseline "$@" --load-recording $rec 2>&1 | tail -1 > /tmp/ab_line.json
+  env $var=$v timeout 600 python bench.py --no-cpu-baseline --no-secondary "$@" --load-recording $rec 2>&1 | tail -1 > /tmp/ab_line.json
   python - "$var" "$v" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/ab_line.json").read())

@@ -20,8 +20,8 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 raw = np.fromfile(path, dtype=np.int64)
 blocks, i = [], 0
 while i < len(raw):
-    assert raw[i] in (0x54494D454C494E45, 0x54494D454C494E32)  # "TIMELINE": 16 entries per instance, "TIMELIN2": 24
-    w = 16 if raw[i] == 0x54494D454C494E45 else 24
+    assert raw[i] in (0x54494D454C494E45, 0x54494D454C494E32, 0x54494D454C494E33)  # "TIMELINE": 16 entries per instance, "TIMELIN2": 24, "TIMELIN3": 32
+    w = {0x54494D454C494E45: 16, 0x54494D454C494E32: 24, 0x54494D454C494E33: 32}[int(raw[i])]
     n = int(raw[i + 1])
     blocks.append(raw[i + 2:i + 2 + n * w].reshape(n, w))  # begin, end (10 ns ticks), block, hw id, iters, nodes, sweeps, staged, flags, cold, status, pairs, spheres, q
     i += 2 + n * w

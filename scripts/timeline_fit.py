@@ -16,8 +16,8 @@ label = sys.argv[3] if len(sys.argv) > 3 else ""
 raw = np.fromfile(path, dtype=np.int64)
 blocks, i = [], 0
 while i < len(raw):
-    assert raw[i] in (0x54494D454C494E45, 0x54494D454C494E32)  # "TIMELINE": 16 entries per instance, "TIMELIN2": 24
-    w = 16 if raw[i] == 0x54494D454C494E45 else 24
+    assert raw[i] in (0x54494D454C494E45, 0x54494D454C494E32, 0x54494D454C494E33)  # "TIMELINE": 16 entries per instance, "TIMELIN2": 24, "TIMELIN3": 32
+    w = {0x54494D454C494E45: 16, 0x54494D454C494E32: 24, 0x54494D454C494E33: 32}[int(raw[i])]
     n = int(raw[i + 1])
     blocks.append(raw[i + 2:i + 2 + n * w].reshape(n, w))
     i += 2 + n * w
@@ -43,7 +43,8 @@ if ev[0].shape[1] >= 24:  # phases of an instance (10-ns ticks): set-up, warm st
     tail = B[:, 23] * 0.01  # read-back, outputs, warm-start store (part of "rest")
     reg = B[:, 4] - wit  # regular operations
     has_w, has_r = wit > 0, reg > 0
-    slowest = np.array([np.argmax((b[:, 1] - b[:, 0])) + k * b.shape[0] for k, b in enumerate(ev)])
+    offs = np.cumsum([0] + [b.shape[0] for b in ev[:-1]])
+    slowest = np.array([np.argmax((b[:, 1] - b[:, 0])) + offs[k] for k, b in enumerate(ev)])
     def fit(x, y):
         A = np.vstack([np.ones(len(x)), x]).T
         return [round(float(v), 3) for v in np.linalg.lstsq(A, y, rcond=None)[0]]
@@ -52,6 +53,10 @@ if ev[0].shape[1] >= 24:  # phases of an instance (10-ns ticks): set-up, warm st
     out["phases_us_slowest"] = {"setup": setup[slowest].mean(), "warm_start": warm[slowest].mean(), "sweeps": sweep[slowest].mean(), "runs": run[slowest].mean(),
                                 "leaf": leaf[slowest].mean(), "rest": (dur - setup - warm - sweep - run - leaf)[slowest].mean(), "total": dur[slowest].mean(),
                                 "warm_ops": wit[slowest].mean(), "regular_ops": reg[slowest].mean(), "runs_n": runs[slowest].mean()}
+    if B.shape[1] >= 32:
+        sub = {"setup_stage": B[:, 24], "setup_map": B[:, 25], "setup_sums": B[:, 26], "tail_rollout": B[:, 27], "tail_outputs": B[:, 28], "tail_store": B[:, 29]}
+        out["setup_and_tail_us_mean"] = {k: float(v.mean() * 0.01) for k, v in sub.items()}
+        out["setup_and_tail_us_slowest"] = {k: float(v[slowest].mean() * 0.01) for k, v in sub.items()}
     out["warm_start_fit_us(const, per_op)"] = fit(wit[has_w], warm[has_w]) if has_w.any() else None
     out["runs_fit_us(const, per_regular_op)"] = fit(reg[has_r], run[has_r]) if has_r.any() else None
     out["run_without_operation_us"] = float(run[~has_r & (runs > 0)].mean()) if (~has_r & (runs > 0)).any() else None
