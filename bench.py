@@ -505,9 +505,14 @@ def main():
                       ["--scenario", "fwf", "--agents", "4096", "--horizon", "15", "--first-round", "8", "--steps", "6", "--warmup", "2"]):
             cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-secondary", "--no-event-pass", "--repeats", "3",
                                                                         "--mip-gap", str(args.mip_gap), "--time-limit-s", str(args.time_limit_s)]
+            # (a profiler attached to this process must see this line's launches only: the children run without its preload)
+            child_env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX"))}
+            pre = [x for x in child_env.pop("LD_PRELOAD", "").split(":") if x and "rocprof" not in x and "roctracer" not in x]
+            if pre:
+                child_env["LD_PRELOAD"] = ":".join(pre)
             try:
                 t1 = time.perf_counter()
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=child_env)
                 z = json.loads(pr.stdout.strip().splitlines()[-1])
                 secondary.append({"workload_key": z["config"]["workload_key"], "workload": z["config"]["workload"], "value": z["value"], "unit": z["unit"],
                                   "ms_per_step": z["ms_per_step"], "ms_per_step_repeats": z["ms_per_step_repeats"],

@@ -570,7 +570,9 @@ int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 
 int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_DUO>;
+#ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
+#endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_duo<32, CMAX_DUO, 256>;
   static thread_local int attr_dev = -1;
@@ -612,7 +614,9 @@ __global__ __launch_bounds__(NT, 2) void k_replan_quad(const hdsm::Consts* __res
 }
 int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_QUAD, true>;
+#ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 4 <= 160 * 1024, "four instances must fit the LDS of one CU");
+#endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_quad<32, CMAX_QUAD, 128>;
   static thread_local int attr_dev = -1;
@@ -638,7 +642,9 @@ __global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __re
 }
 int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<48, CMAX_DUO48>;
+#ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
+#endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_duo48<48, CMAX_DUO48, 128>;
   static thread_local int attr_dev = -1;
@@ -653,7 +659,9 @@ int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 
 int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_TRI>;
+#ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 3 <= 160 * 1024, "three instances must fit the LDS of one CU");
+#endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_tri<32, CMAX_TRI, 128>;
   static thread_local int attr_dev = -1;
