@@ -322,12 +322,34 @@ def main():
     # ---------------------------------------------------------------- third pass: the host-buffer entry point
     # hdsm_replan (host pointers: H2D of the inputs, kernel, D2H of the outputs, synchronous) on the same rounds.
     # Reported next to the line, never as `value`.
-    host_ms = None
+    host_ms = host_pinned_ms = None
     if world == 1 and not args.no_event_pass:
-        t1 = time.perf_counter()
+        from multi_agent_pkgs_amd.lib import host_register, host_unregister
+        keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
+        out_h = dict(traj=np.zeros((n_local, N + 1, 9)), ctrl=np.zeros((n_local, N, 3)), used=np.zeros((n_local, P), dtype=np.uint8),
+                     status=np.zeros(n_local, dtype=np.int32), obj=np.zeros(n_local))
+
+        def host_pass(inputs):
+            t1 = time.perf_counter()
+            for z in inputs:
+                solver.replan(*[z[k] for k in keys], out=out_h, stats=False)
+            return (time.perf_counter() - t1) / len(inputs) * 1e3
+
+        # (a) the caller's arrays are ordinary pageable memory (every copy goes through the driver's staging buffer)
+        host_ms = host_pass([rec[r] for r in range(W, W + K)])
+        # (b) the caller keeps ONE set of arrays, page-locked once with hdsm_host_register, and refills it every round (the
+        # refill — the binding writing its inputs — is outside the clock, like the planner code that produces them)
+        fixed = {k: np.ascontiguousarray(rec[W][k]).copy() for k in keys}
+        for a in list(fixed.values()) + list(out_h.values()):
+            host_register(a)
+        t_pin = 0.0
         for r in range(W, W + K):
-            solve_np(rec[r], rec[r]["plans"], rec[r]["has_plan"])
-        host_ms = (time.perf_counter() - t1) / K * 1e3
+            for k in keys:
+                fixed[k][...] = rec[r][k]
+            t_pin += host_pass([fixed])
+        host_pinned_ms = t_pin / K
+        for a in list(fixed.values()) + list(out_h.values()):
+            host_unregister(a)
 
     # ---------------------------------------------------------------- fourth pass: the device-resident closed loop, LIVE
     # hdsm_dswarm_round continues the flight where the set-up left it (round first_round + steps): corridor, reference,
@@ -606,7 +628,10 @@ def main():
                               "entry_point_ms_mean = the whole hdsm_replan_device call on an idle stream (pre-pass, kernel, launch gaps)",
             "host_buffer_path": None if host_ms is None else {
                 "ms_per_round": host_ms, "agent_replans_per_s": n_rob / (host_ms * 1e-3),
-                "what": "hdsm_replan with host pointers (PCIe-inclusive: H2D inputs, kernel, D2H outputs, sync)"},
+                "ms_per_round_registered_arrays": host_pinned_ms,
+                "what": "hdsm_replan with host pointers (PCIe-inclusive: H2D inputs, kernel, D2H outputs, sync), output arrays allocated once; "
+                        "registered = the caller's arrays page-locked once with hdsm_host_register (DMA without staging, results "
+                        "delivered into them by the device)"},
             "device_resident_loop": dloop,
             "rccl_ranks": comm.world if comm is not None else (1 if world == 1 else None),
             "exchange": ("none (one rank)" if world == 1 else ("RCCL all-gather (hdsm_exchange_device)" if comm is not None

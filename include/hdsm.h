@@ -34,6 +34,7 @@
 #ifndef HDSM_H
 #define HDSM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -174,6 +175,15 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
                        const double* plans_all, const uint8_t* has_plan, double* traj_out,
                        double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj,
                        void* hip_stream);
+
+/* Optional, for the host-pointer entry points: page-locks a LONG-LIVED array of the caller (the binding's input and output
+ * buffers, allocated once and reused every round — the reference's Agent keeps its own members the same way) so that
+ * hdsm_replan / hdsm_solve / hdsm_reference move it by DMA without the driver's staging copy. When ALL FIVE output arrays of an
+ * hdsm_replan call lie in registered memory the results are written straight into them by the device, and only for instances
+ * that have a solution (the "left untouched" rule is kept; no staging download, no host-side copy). Arrays that were never
+ * registered keep working as before. Unregister an array before freeing it. Not needed for device pointers.                 */
+int hdsm_host_register(void* ptr, size_t bytes);
+int hdsm_host_unregister(void* ptr);
 
 /* Level 1 — stand-in for the Gurobi part alone (AC:870-1019): the caller passes the fully formed
  * per-step polyhedra poly_const_final_vec_[N][<=P] (AH:471), i.e. static rows followed by the neighbour

@@ -675,6 +675,60 @@ int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 }
 
 // ---- subtree splitting: set-up of pass 2, merge, lazily allocated state -------------------------------------------------
+// hdsm_replan with page-locked input arrays: ONE kernel reads them from mapped host memory (coalesced reads over PCIe) into the
+// handle's device arrays instead of nine stream-ordered copies, and of the static polyhedra only the rows that exist
+// (n_rows_static of max_rows_static; the rest of the device array is never read by the solver). Blocks 0 .. n_inst - 1 take one
+// instance each, the blocks after them the plans of every agent.
+struct FetchArgs {
+  int32_t n_inst, n_rob, N, P, RS, plan_blocks;
+  const int32_t *agent_id, *n_poly, *n_rows;
+  const double *state, *ref, *A, *b, *plans;
+  const uint8_t* has;
+  int32_t *d_agent, *d_npoly, *d_nrows;
+  double *d_state, *d_ref, *d_A, *d_b, *d_plans;
+  uint8_t* d_has;
+};
+__global__ __launch_bounds__(256) void k_fetch(FetchArgs a) {
+  const int tid = (int)threadIdx.x, blk = (int)blockIdx.x;
+  if (blk >= a.n_inst) {
+    const int64_t total = (int64_t)a.n_rob * (a.N + 1) * 9;
+    for (int64_t e = (int64_t)(blk - a.n_inst) * 256 + tid; e < total; e += (int64_t)a.plan_blocks * 256) a.d_plans[e] = a.plans[e];
+    for (int e = (blk - a.n_inst) * 256 + tid; e < a.n_rob; e += a.plan_blocks * 256) a.d_has[e] = a.has[e];
+    return;
+  }
+  const int k = blk, P = a.P, RS = a.RS;
+  if (tid == 0) a.d_agent[k] = a.agent_id[k];
+  const int np = a.n_poly[k];
+  if (tid == 1) a.d_npoly[k] = np;
+  if (tid < 9) a.d_state[(int64_t)k * 9 + tid] = a.state[(int64_t)k * 9 + tid];
+  for (int e = tid; e < 6 * a.N; e += 256) a.d_ref[(int64_t)k * 6 * a.N + e] = a.ref[(int64_t)k * 6 * a.N + e];
+  if (tid < P) a.d_nrows[(int64_t)k * P + tid] = a.n_rows[(int64_t)k * P + tid];
+  for (int e = tid; e < P * RS * 4; e += 256) {  // entry (polyhedron j, row r, component c): c < 3 -> A, c = 3 -> b
+    const int c = e & 3, jr = e >> 2, j = jr / RS, r = jr % RS;
+    if (j >= np || r >= a.n_rows[(int64_t)k * P + j]) continue;
+    const int64_t row = ((int64_t)k * P + j) * RS + r;
+    if (c < 3) a.d_A[row * 3 + c] = a.A[row * 3 + c];
+    else a.d_b[row] = a.b[row];
+  }
+}
+
+// hdsm_replan with page-locked output arrays (hdsm_host_register): the results go from HBM straight into the caller's arrays —
+// mapped host memory, written over PCIe by the device — and only for instances that HAVE a solution ("outputs are left
+// untouched" otherwise): no staging download, no host-side filter copy. One 64-lane group per instance.
+__global__ __launch_bounds__(256) void k_deliver(int n_inst, int trj, int ctl, int P, const double* __restrict__ traj, const double* __restrict__ ctrl,
+                                                 const double* __restrict__ obj, const int32_t* __restrict__ status, const uint8_t* __restrict__ used,
+                                                 double* o_traj, double* o_ctrl, double* o_obj, int32_t* o_status, uint8_t* o_used) {
+  const int k = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  if (k >= n_inst) return;
+  const int stt = status[k];
+  if (lane == 0) o_status[k] = stt;
+  if (stt == HDSM_NO_SOLUTION) return;
+  for (int e = lane; e < trj; e += 64) o_traj[(int64_t)k * trj + e] = traj[(int64_t)k * trj + e];
+  for (int e = lane; e < ctl; e += 64) o_ctrl[(int64_t)k * ctl + e] = ctrl[(int64_t)k * ctl + e];
+  if (lane < P) o_used[(int64_t)k * P + lane] = used[(int64_t)k * P + lane];
+  if (lane == 0) o_obj[k] = obj[k];
+}
+
 __global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap, int32_t* node_pool, int nodes_left,
                                                     const int32_t* split_info, const double* obj, int32_t* split_steps, int split_ss) {
   const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -925,7 +979,7 @@ int check_common(Handle* h, int n_inst, int n_rob) {
 
 extern "C" {
 
-int32_t hdsm_version(void) { return (1 << 16) | 2; }  // 1.2: + hdsm_poly_octa3d_batch_wave / _device_wave, hdsm_set_kernel_timing / hdsm_last_kernel_ms
+int32_t hdsm_version(void) { return (1 << 16) | 3; }  // 1.2: + hdsm_poly_octa3d_batch_wave / _device_wave, hdsm_set_kernel_timing / hdsm_last_kernel_ms; 1.3: + hdsm_host_register / _unregister
 
 const char* hdsm_last_error(void) { return g_err.c_str(); }
 
@@ -1067,6 +1121,9 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   if (e == hipSuccess) e = hipEventCreate(&h->ev_k1);
   if (e == hipSuccess) e = hipMemset(h->d_stats, 0, 8 * I * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(h->d_zero, 0, (size_t)n_rob_max);
+  // (the fetch kernel of hdsm_replan uploads only the rows of the static polyhedra that exist: the rest stays finite)
+  if (e == hipSuccess) e = hipMemset(h->d_A, 0, I * P * RS * 3 * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->d_b, 0, I * P * RS * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_plans, 0, (size_t)n_rob_max * (N + 1) * 9 * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->d_warm, 0, (hdsm::MAXNV + 2) * I * sizeof(int32_t));
   delete hc;
@@ -1110,6 +1167,38 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
   return launch(h, a, static_cast<hipStream_t>(hip_stream));
 }
 
+// Registered (page-locked, mapped) host memory: its device-side address, or false for ordinary pageable memory.
+static bool mapped_host_pointer(void* p, void** dev) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // (an unknown pointer is an error of the query on some runtimes: it means "pageable")
+    return false;
+  }
+  if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return false;
+  *dev = at.devicePointer;
+  return true;
+}
+
+int hdsm_host_register(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) return set_err(HDSM_ERR_BAD_ARG, "hdsm_host_register: null or empty range");
+  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(HDSM_ERR_DEVICE, std::string("hdsm_host_register: ") + hipGetErrorString(e));
+  }
+  return HDSM_OK;
+}
+
+int hdsm_host_unregister(void* ptr) {
+  if (!ptr) return set_err(HDSM_ERR_BAD_ARG, "hdsm_host_unregister: null pointer");
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(HDSM_ERR_DEVICE, std::string("hdsm_host_unregister: ") + hipGetErrorString(e));
+  }
+  return HDSM_OK;
+}
+
 int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agent_id,
                 const double* state_curr, const double* traj_ref, const int32_t* n_poly,
                 const int32_t* n_rows_static, const double* A_static, const double* b_static,
@@ -1127,15 +1216,36 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   const auto H2D = hipMemcpyHostToDevice;
   const auto D2H = hipMemcpyDeviceToHost;
   if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
-  HIP_TRY(hipMemcpyAsync(h->d_agent, agent_id, I * 4, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_ref, traj_ref, I * N * 6 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_npoly, n_poly, I * 4, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_nrows, n_rows_static, I * P * 4, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_A, A_static, I * P * RS * 3 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_b, b_static, I * P * RS * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, H2D, st));
-  HIP_TRY(hipMemcpyAsync(h->d_has, has_plan, (size_t)n_rob, H2D, st));
+  bool in_mapped = true;
+  {
+    const void* hp[9] = {agent_id, state_curr, traj_ref, n_poly, n_rows_static, A_static, b_static, plans_all, has_plan};
+    void* dp[9];
+    for (int k = 0; k < 9 && in_mapped; ++k) in_mapped = mapped_host_pointer(const_cast<void*>(hp[k]), &dp[k]);
+    if (in_mapped) {  // page-locked arrays of the caller (hdsm_host_register): one fetch kernel
+      FetchArgs f{};
+      f.n_inst = n_inst, f.n_rob = n_rob, f.N = (int)N, f.P = (int)P, f.RS = (int)RS;
+      const int64_t plan_items = (int64_t)n_rob * (int64_t)(N + 1) * 9;
+      f.plan_blocks = (int)((plan_items + 1023) / 1024 < 1 ? 1 : ((plan_items + 1023) / 1024 > 1024 ? 1024 : (plan_items + 1023) / 1024));
+      f.agent_id = static_cast<const int32_t*>(dp[0]), f.state = static_cast<const double*>(dp[1]), f.ref = static_cast<const double*>(dp[2]);
+      f.n_poly = static_cast<const int32_t*>(dp[3]), f.n_rows = static_cast<const int32_t*>(dp[4]), f.A = static_cast<const double*>(dp[5]);
+      f.b = static_cast<const double*>(dp[6]), f.plans = static_cast<const double*>(dp[7]), f.has = static_cast<const uint8_t*>(dp[8]);
+      f.d_agent = h->d_agent, f.d_state = h->d_state, f.d_ref = h->d_ref, f.d_npoly = h->d_npoly, f.d_nrows = h->d_nrows;
+      f.d_A = h->d_A, f.d_b = h->d_b, f.d_plans = h->d_plans, f.d_has = h->d_has;
+      hipLaunchKernelGGL(k_fetch, dim3((unsigned)(n_inst + f.plan_blocks)), dim3(256), 0, st, f);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if (!in_mapped) {
+    HIP_TRY(hipMemcpyAsync(h->d_agent, agent_id, I * 4, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_state, state_curr, I * 9 * 8, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_ref, traj_ref, I * N * 6 * 8, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_npoly, n_poly, I * 4, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_nrows, n_rows_static, I * P * 4, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_A, A_static, I * P * RS * 3 * 8, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_b, b_static, I * P * RS * 8, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_plans, plans_all, (size_t)n_rob * (N + 1) * 9 * 8, H2D, st));
+    HIP_TRY(hipMemcpyAsync(h->d_has, has_plan, (size_t)n_rob, H2D, st));
+  }
   int rc = hdsm_replan_device(handle, n_inst, n_rob, h->d_agent, h->d_state, h->d_ref, h->d_npoly, h->d_nrows,
                               h->d_A, h->d_b, h->d_plans, h->d_has, h->d_traj, h->d_ctrl, h->d_used,
                               h->d_status, h->d_obj, st);
@@ -1152,6 +1262,20 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   // copies (a megabyte each way per 1024 agents): the results come back into a pinned staging block of the handle and only
   // the instances that HAVE a solution are copied into the caller's arrays.
   const size_t trj = (N + 1) * 9, ctl = N * 3;
+  {  // page-locked output arrays (hdsm_host_register): delivered by the device, filtered there
+    void* dp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* hp[5] = {traj_out, ctrl_out, obj, status, poly_used};
+    bool mapped = true;
+    for (int k = 0; k < 5 && mapped; ++k) mapped = mapped_host_pointer(hp[k], &dp[k]);
+    if (mapped) {
+      hipLaunchKernelGGL(k_deliver, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st, n_inst, (int)trj, (int)ctl, (int)P, h->d_traj, h->d_ctrl, h->d_obj,
+                         h->d_status, h->d_used, static_cast<double*>(dp[0]), static_cast<double*>(dp[1]), static_cast<double*>(dp[2]),
+                         static_cast<int32_t*>(dp[3]), static_cast<uint8_t*>(dp[4]));
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(st));
+      return HDSM_OK;
+    }
+  }
   const size_t need = I * (trj * 8 + ctl * 8 + 8 + 4 + P);
   if (need > h->h_out_cap) {
     if (h->h_out) (void)hipHostFree(h->h_out);

@@ -20,7 +20,7 @@ HDSM_COMM_ID_BYTES = 128
 
 EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_create", "hdsm_destroy",
            "hdsm_replan", "hdsm_replan_device", "hdsm_solve", "hdsm_tasc_planes", "hdsm_last_stats",
-           "hdsm_reset_warm_start", "hdsm_last_sweep_stats", "hdsm_set_kernel_timing", "hdsm_last_kernel_ms", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
+           "hdsm_reset_warm_start", "hdsm_host_register", "hdsm_host_unregister", "hdsm_last_sweep_stats", "hdsm_set_kernel_timing", "hdsm_last_kernel_ms", "hdsm_comm_unique_id", "hdsm_comm_create", "hdsm_comm_info",
            "hdsm_comm_destroy", "hdsm_publish_device", "hdsm_exchange_device", "hdsm_reference", "hdsm_reference_device", "hdsm_poly_octa3d", "hdsm_poly_octa3d_new", "hdsm_poly_octa3d_batch",
            "hdsm_poly_octa3d_device", "hdsm_poly_octa3d_scratch_bytes", "hdsm_poly_octa3d_batch_wave", "hdsm_poly_octa3d_device_wave", "hdsm_corridor_last_error",
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
@@ -80,6 +80,22 @@ def _u8(a):
     return np.ascontiguousarray(a, dtype=np.uint8)
 
 
+def host_register(arr):
+    """hdsm_host_register on a C-contiguous numpy array that the caller keeps alive and reuses every round (page-locked,
+    mapped: DMA without staging; output arrays of replan() are then written by the device). Undo with host_unregister()."""
+    assert arr.flags["C_CONTIGUOUS"] and arr.nbytes > 0
+    lib = load()
+    lib.hdsm_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    _check(lib.hdsm_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes))
+    return arr
+
+
+def host_unregister(arr):
+    lib = load()
+    lib.hdsm_host_unregister.argtypes = [C.c_void_p]
+    _check(lib.hdsm_host_unregister(C.c_void_p(arr.ctypes.data)))
+
+
 class Solver:
     """One hdsm handle (= the persistent GRBModel of one planner thread, but batched)."""
 
@@ -103,7 +119,7 @@ class Solver:
             pass
 
     # ---- host-pointer entry point (PCIe inclusive) -------------------------------------------------------
-    def replan(self, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, out=None):
+    def replan(self, agent_id, state, ref, n_poly, n_rows, A, b, plans, has_plan, out=None, stats=True):
         N, P = self.prm.n_hor, self.prm.poly_hor
         agent_id, n_poly, n_rows = _i32(agent_id), _i32(n_poly), _i32(n_rows)
         state, ref, A, b, plans, has_plan = _f64(state), _f64(ref), _f64(A), _f64(b), _f64(plans), _u8(has_plan)
@@ -117,7 +133,8 @@ class Solver:
                                     _p(n_poly, i), _p(n_rows, i), _p(A, d), _p(b, d), _p(plans, d),
                                     _p(has_plan, u), _p(out["traj"], d), _p(out["ctrl"], d),
                                     _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d)))
-        out.update(self.last_stats(n_inst))
+        if stats:
+            out.update(self.last_stats(n_inst))
         return out
 
     # ---- device-pointer entry point: torch tensors (already resident in HBM), async on `stream` ---------

@@ -363,3 +363,34 @@ def test_device_swarm_accepts_an_empty_trailing_shard(hdsm):
     with pytest.raises(hdsm.HdsmError) as e:
         swarm.DeviceSwarm(bad, hdsm.Solver(prm, 2, n_rob), world_size=world)
     assert e.value.code == hdsm.HDSM_ERR_BAD_ARG
+
+
+def test_registered_host_arrays_get_the_same_answers_delivered_by_the_device(hdsm):
+    """hdsm_host_register: with the caller's arrays page-locked, hdsm_replan moves the inputs by DMA and the device writes the
+    results straight into the output arrays — the same numbers as with pageable arrays, and the arrays of instances without a
+    solution are left untouched (include/hdsm.h, HDSM_NO_SOLUTION)."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 96, seed=5, spacing=0.9, turn=True, narrow=True)  # tight: some instances have no solution
+    args = [np.ascontiguousarray(sn[k]).copy() for k in ARG_KEYS]
+    sol = hdsm.Solver(prm, 96, 96)
+    plain = sol.replan(*args)
+    assert (plain["status"] == 2).any() and (plain["status"] == 0).any()
+    sol.reset_warm_start()
+    out = dict(traj=np.full((96, 11, 9), 7.5), ctrl=np.full((96, 10, 3), 7.5), used=np.full((96, prm.poly_hor), 9, dtype=np.uint8),
+               status=np.full(96, -1, dtype=np.int32), obj=np.full(96, 7.5))
+    pinned = [a for a in args if a.nbytes] + list(out.values())
+    for a in pinned:
+        hdsm.host_register(a)
+    try:
+        got = sol.replan(*args, out=out)
+    finally:
+        for a in pinned:
+            hdsm.host_unregister(a)
+    assert (got["status"] == plain["status"]).all()
+    ok = plain["status"] != 2
+    # (two runs of the kernel stage the neighbour rows in a different order: equal to rounding, not bit for bit)
+    assert np.abs(got["traj"][ok] - plain["traj"][ok]).max() < 1e-9 and np.abs(got["ctrl"][ok] - plain["ctrl"][ok]).max() < 1e-8
+    assert np.array_equal(got["used"][ok], plain["used"][ok]) and np.allclose(got["obj"][ok], plain["obj"][ok], rtol=1e-10, atol=0)
+    assert (got["traj"][~ok] == 7.5).all() and (got["ctrl"][~ok] == 7.5).all() and (got["used"][~ok] == 9).all() and (got["obj"][~ok] == 7.5).all()
+    with pytest.raises(hdsm.HdsmError):
+        hdsm.host_unregister(np.zeros(8))  # never registered
