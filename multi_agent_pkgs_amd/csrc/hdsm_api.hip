@@ -243,6 +243,7 @@ struct RefArgs {
   double* path_vel;
   const double* rpos;  // [n_rob][N + 1][3] positions of steps 0..N, packed (k_ref_pack)
   const double* rsph;  // [n_rob][4] enclosing sphere of those positions (radius < 0: no plan)
+  double wocc[hdsm::MAXH + 1];  // GetVelocityLimit's weight of step i (AC:1791-1795, 1805-1817): config only, evaluated by the host's libm
 };
 
 // Positions of steps 0..N of every published plan, packed, and their enclosing sphere: 16 lanes per agent (N + 1 <= 17: lane
@@ -331,9 +332,7 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
   const double* pth = path_fits ? spath : pth_g;
   if (tid <= N) {
     for (int c = 0; c < 3; ++c) own[tid][c] = own_has ? a.plans[((int64_t)self * (N + 1) + tid) * 9 + c] : 0.0;
-    double occ = 100 * pow(a.cfg.sens_other_agents, (double)tid);  // AC:1791-1795
-    occ = occ < 0 ? 0 : (occ > 100 ? 100 : occ);
-    wocc[tid] = pow(occ / 100, a.cfg.sens_pot);  // GetVelocityLimit AC:1805-1817
+    wocc[tid] = a.wocc[tid];
   }
   __syncthreads();
   double pv = a.vel_cap ? a.vel_cap[inst] : a.cfg.path_vel_max;
@@ -348,54 +347,78 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
     const double4 ss = *reinterpret_cast<const double4*>(a.rsph + (int64_t)self * 4);
     double gbest = DBL_MAX;
     int jbest = -1;
-    for (int j = tid; j < a.n_rob; j += NT) {
-      if (j == self) continue;
-      const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
-      if (sj.w < 0) continue;  // no plan
-      const double cx = sj.x - ss.x, cy = sj.y - ss.y, cz = sj.z - ss.z;
-      const double g = sqrt(cx * cx + cy * cy + cz * cz) - sj.w - ss.w;  // every step of j is at least this far (g may be < 0)
-      if (g < gbest || jbest < 0) gbest = g, jbest = j;
+    constexpr int UB = 4;  // sphere records in flight per thread: the scans are chains of L2 round trips otherwise
+    for (int j0 = tid; j0 < a.n_rob; j0 += UB * NT) {
+      double4 sj[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int j = j0 + u * NT;
+        sj[u] = *reinterpret_cast<const double4*>(a.rsph + (int64_t)(j < a.n_rob ? j : self) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int j = j0 + u * NT;
+        if (j >= a.n_rob || j == self || sj[u].w < 0) continue;  // (w < 0: no plan)
+        const double cx = sj[u].x - ss.x, cy = sj[u].y - ss.y, cz = sj[u].z - ss.z;
+        const double g = sqrt(cx * cx + cy * cy + cz * cz) - sj[u].w - ss.w;  // every step of j is at least this far (g may be < 0)
+        if (g < gbest || jbest < 0) gbest = g, jbest = j;
+      }
     }
-    red[tid] = gbest;
-    idx[tid] = jbest;
-    __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) {
-      if (tid < off && idx[tid + off] >= 0 && (idx[tid] < 0 || red[tid + off] < red[tid])) red[tid] = red[tid + off], idx[tid] = idx[tid + off];
+    for (int off = 32; off > 0; off >>= 1) {  // (which of several equally close spheres wins only moves the bound below)
+      const double og = __shfl_xor(gbest, off);
+      const int oj = __shfl_xor(jbest, off);
+      if (oj >= 0 && (jbest < 0 || og < gbest)) gbest = og, jbest = oj;
+    }
+    if constexpr (NT > 64) {
+      if ((tid & 63) == 0) red[tid >> 6] = gbest, idx[tid >> 6] = jbest;
+      __syncthreads();
+      gbest = red[0], jbest = idx[0];
+#pragma unroll
+      for (int w = 1; w < NT / 64; ++w)
+        if (idx[w] >= 0 && (jbest < 0 || red[w] < gbest)) gbest = red[w], jbest = idx[w];
       __syncthreads();
     }
-    const int jstar = idx[0];
-    __syncthreads();
-    if (tid <= N) {
-      double u = 0.0;
-      if (jstar >= 0) {
-        const double* rp = a.rpos + ((int64_t)jstar * (N + 1) + tid) * 3;
-        const double dx = own[tid][0] - rp[0], dy = own[tid][1] - rp[1], dz = own[tid][2] - rp[2];
-        u = dx * dx + dy * dy + dz * dz;
-      }
-      red[tid] = (u == u) ? u : DBL_MAX;  // (a non-finite plan bounds nothing)
-    }
-    __syncthreads();
+    const int jstar = jbest;
     double umax = 0.0;
-    for (int i = 0; i <= N; ++i) umax = fmax(umax, red[i]);
-    __syncthreads();
+    {
+      const int lane = tid & 63;
+      double u = 0.0;
+      if (lane <= N && jstar >= 0) {
+        const double* rp = a.rpos + ((int64_t)jstar * (N + 1) + lane) * 3;
+        const double dx = own[lane][0] - rp[0], dy = own[lane][1] - rp[1], dz = own[lane][2] - rp[2];
+        u = dx * dx + dy * dy + dz * dz;
+        u = (u == u) ? u : DBL_MAX;  // (a non-finite plan bounds nothing)
+      }
+      for (int off = 32; off > 0; off >>= 1) u = fmax(u, __shfl_xor(u, off));
+      umax = u;
+    }
     // (2) minima of the squared distances over the neighbours that can still lower one of them
     double d2min[hdsm::MAXH + 1];
 #pragma unroll
     for (int i = 0; i <= hdsm::MAXH; ++i) d2min[i] = DBL_MAX;
-    for (int j = tid; j < a.n_rob; j += NT) {
-      if (j == self) continue;
-      const double4 sj = *reinterpret_cast<const double4*>(a.rsph + (int64_t)j * 4);
-      if (sj.w < 0) continue;
-      const double cx = sj.x - ss.x, cy = sj.y - ss.y, cz = sj.z - ss.z;
-      const double g = sqrt(cx * cx + cy * cy + cz * cz) - sj.w - ss.w;
-      if (g > 0 && g * g * (1.0 - 1e-9) > umax) continue;  // all its steps are further than the closest neighbour's
-      const double* rp = a.rpos + (int64_t)j * (N + 1) * 3;
+    for (int j0 = tid; j0 < a.n_rob; j0 += UB * NT) {
+      double4 sj[UB];
 #pragma unroll
-      for (int i = 0; i <= hdsm::MAXH; ++i)
-        if (i <= N) {
-          const double dx = own[i][0] - rp[3 * i], dy = own[i][1] - rp[3 * i + 1], dz = own[i][2] - rp[3 * i + 2];
-          d2min[i] = fmin(d2min[i], dx * dx + dy * dy + dz * dz);
-        }
+      for (int u = 0; u < UB; ++u) {
+        const int j = j0 + u * NT;
+        sj[u] = *reinterpret_cast<const double4*>(a.rsph + (int64_t)(j < a.n_rob ? j : self) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int j = j0 + u * NT;
+        if (j >= a.n_rob || j == self || sj[u].w < 0) continue;
+        const double cx = sj[u].x - ss.x, cy = sj[u].y - ss.y, cz = sj[u].z - ss.z;
+        // (squared: all its steps are further than the closest neighbour's when the gap between the spheres is)
+        const double c2 = cx * cx + cy * cy + cz * cz, reach = sj[u].w + ss.w + sqrt(umax) * (1.0 + 1e-9);
+        if (c2 > reach * reach * (1.0 + 1e-9)) continue;
+        const double* rp = a.rpos + (int64_t)j * (N + 1) * 3;
+#pragma unroll
+        for (int i = 0; i <= hdsm::MAXH; ++i)
+          if (i <= N) {
+            const double dx = own[i][0] - rp[3 * i], dy = own[i][1] - rp[3 * i + 1], dz = own[i][2] - rp[3 * i + 2];
+            d2min[i] = fmin(d2min[i], dx * dx + dy * dy + dz * dz);
+          }
+      }
     }
 #pragma unroll
     for (int i = 0; i <= hdsm::MAXH; ++i)
@@ -429,13 +452,14 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
       }
     }
   }
-  red[tid] = pv;
-  __syncthreads();
-  for (int off = NT / 2; off > 0; off >>= 1) {
-    if (tid < off) red[tid] = fmin(red[tid], red[tid + off]);
+  for (int off = 32; off > 0; off >>= 1) pv = fmin(pv, __shfl_xor(pv, off));
+  if constexpr (NT > 64) {
+    if ((tid & 63) == 0) red[tid >> 6] = pv;
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) pv = fmin(pv, red[w]);
   }
-  pv = (np < 2) ? 0.0 : red[0];
+  pv = (np < 2) ? 0.0 : pv;
   if (tid == 0) {  // SamplePath, AC:1591-1663
     int cnt = 0;
     if (np < 2) {
@@ -549,6 +573,7 @@ struct Handle {
   uint8_t *d_has = nullptr, *d_used = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t last_stream = nullptr;
+  bool defer_done = false;  // the device-resident loop records ev_done once per round (hdsm_internal_record_done), not once per call
 };
 
 template <int NV, int NT>
@@ -890,7 +915,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     HIP_TRY(hipEventRecord(h->ev_k1, st));
     h->timed = true;
   }
-  HIP_TRY(hipEventRecord(h->ev_done, st));
+  if (!h->defer_done) HIP_TRY(hipEventRecord(h->ev_done, st));
   h->launched = true;
   return HDSM_OK;
 }
@@ -1353,6 +1378,11 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   a.agent_id = agent_id, a.path = path, a.n_path = n_path, a.vel_cap = vel_cap, a.plans = plans_all;
   a.has_plan = has_plan, a.ref_full = ref_full, a.ref = ref, a.path_vel = path_vel;
   a.rpos = h->d_rpos, a.rsph = h->d_rsph;
+  for (int i = 0; i <= hdsm::MAXH; ++i) {
+    double occ = 100 * std::pow(cfg->sens_other_agents, (double)i);  // AC:1791-1795
+    occ = occ < 0 ? 0 : (occ > 100 ? 100 : occ);
+    a.wocc[i] = std::pow(occ / 100, cfg->sens_pot);  // GetVelocityLimit AC:1805-1817
+  }
   // d_rpos / d_rsph are scratch of the HANDLE: a call that arrives on another stream than the previous launch waits for it
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
@@ -1362,7 +1392,7 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   if (n_inst >= 256) hipLaunchKernelGGL(k_reference<64>, dim3(n_inst), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_reference<256>, dim3(n_inst), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(h->ev_done, st));
+  if (!h->defer_done) HIP_TRY(hipEventRecord(h->ev_done, st));
   h->launched = true;
   return HDSM_OK;
 }
@@ -1418,6 +1448,22 @@ int hdsm_reset_warm_start(void* handle) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->d_warm, 0, (size_t)(hdsm::MAXNV + 2) * h->max_inst * sizeof(int32_t)));
+  return HDSM_OK;
+}
+
+// Internal (csrc/swarm_kernels.hip; not in include/): every device entry point records ev_done so that a later call on ANOTHER
+// stream can wait for the handle's scratch. Each record is a barrier packet — 5-6 us of idle queue in front of the next kernel.
+// The device-resident loop issues its whole round on one stream, so it defers the records and leaves one at the end of the round.
+extern "C" int hdsm_internal_defer_done(void* handle, int on) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return HDSM_ERR_BAD_ARG;
+  h->defer_done = on != 0;
+  return HDSM_OK;
+}
+extern "C" int hdsm_internal_record_done(void* handle, void* hip_stream) {
+  Handle* h = static_cast<Handle*>(handle);
+  if (!h) return HDSM_ERR_BAD_ARG;
+  HIP_TRY(hipEventRecord(h->ev_done, static_cast<hipStream_t>(hip_stream)));
   return HDSM_OK;
 }
 

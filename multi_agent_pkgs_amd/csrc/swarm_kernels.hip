@@ -19,6 +19,10 @@
 #include "../../include/hdsm_swarm.h"
 #include "swarm_core.h"
 
+// (csrc/hdsm_api.hip, internal: see hdsm_dswarm_round)
+extern "C" int hdsm_internal_defer_done(void* handle, int on);
+extern "C" int hdsm_internal_record_done(void* handle, void* hip_stream);
+
 extern "C" int hdsm_swarm_export_state(void* swarm, void* agents_out, int32_t* n_local, int32_t* n_rob, int32_t* first_id,
                                        hdsm_params* prm, hdsm_swarm_config* cfg, const int8_t** world, int32_t wdim[3],
                                        double worigin[3]);
@@ -536,6 +540,17 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const int n = d->n_local, G = d->per * d->world, rec = (d->c.N + 1) * 9;
   const unsigned gb = (unsigned)((n + 63) / 64);
+  // The solver handle's "done" event (what a later call on another stream waits for) is recorded once, when the round has been
+  // issued, instead of after each of its entry points: every record is a barrier packet in front of the next kernel (5-6 us each).
+  struct DoneOnce {
+    void* solver;
+    hipStream_t st;
+    DoneOnce(void* s, hipStream_t q) : solver(s), st(q) { (void)hdsm_internal_defer_done(solver, 1); }
+    ~DoneOnce() {
+      (void)hdsm_internal_defer_done(solver, 0);
+      (void)hdsm_internal_record_done(solver, st);
+    }
+  } done_once(d->solver, st);
   if (n > 0) {
     hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? SLAB : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath);
     HIP_TRY(hipGetLastError());
