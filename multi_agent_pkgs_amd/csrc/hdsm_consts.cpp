@@ -266,7 +266,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
         const bool split = n <= SPLIT_N_MAX;
         if (split && j >= 16) continue;
         // split kernel (hdsm_wave_gib.h): slot j of lane L holds column ((j ^ L) & 15) + 16 (L >> 5) of row L & 31
-        const int row = split ? (lane & 31) : lane, col = split ? ((j ^ lane) & 15) + 16 * (lane >> 5) : j;
+        // NV = 48: one lane per row, slot 16 b + jj holds column 16 b + ((jj ^ L) & 15)
+        const int row = split ? (lane & 31) : lane, col = split ? ((j ^ lane) & 15) + 16 * (lane >> 5) : (j & ~15) + ((j ^ lane) & 15);
         c->JeqP[(size_t)j * 64 + lane] = (row < n && col < n) ? c->Jeq[(size_t)row * n + col] : (row == col ? 1.0 : 0.0);
       }
     {  // pick-rule weights: Z = J2 J2^T (the inverse Hessian on the null space of the terminal equalities), a^T Z a per row family

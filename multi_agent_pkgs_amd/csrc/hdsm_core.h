@@ -440,16 +440,8 @@ struct Solver {
   }
 
   // ---- snapshots of the solver state (global scratch), one per branching depth ----------------------------------
-  // n <= 30: rows of J split over two lanes, columns in butterfly order (hdsm_wave_gib.h); larger n: one lane per row
-  template <int NV_, class = void>
-  struct PickW {
-    using type = WaveGI<NV_, CMAX, SMALL>;
-  };
-  template <class V>
-  struct PickW<32, V> {
-    using type = WaveGIB<CMAX, SMALL>;
-  };
-  using W = typename PickW<NV>::type;
+  // rows of J in registers, columns in butterfly order (hdsm_wave_gib.h): n <= 30 split over two lanes, larger n one lane per row
+  using W = WaveGIB<NV, CMAX, SMALL>;
   using GIState = typename W::Regs;
   static constexpr int SNAP_STRIDE = W::SNAP_DOUBLES + 2;  // doubles per level
   // The factorisation lives in the registers of wave 0; the other waves of the workgroup (they take part in the

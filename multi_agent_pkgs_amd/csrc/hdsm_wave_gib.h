@@ -37,19 +37,55 @@ __device__ __forceinline__ double row16_sum64(double v) {
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
-template <int CMAX, bool SMALL = false>
-struct WaveGIB : WaveGI<32, CMAX, SMALL> {
-  using Base = WaveGI<32, CMAX, SMALL>;
+// v_permlane16_swap / v_permlane32_swap on doubles with two different operands: .v = the new first operand, .s = the new second one.
+//   swap16(a, b): even 16-lane rows get {own a, a of the odd row next to them}, odd rows get {b of the even row, own b}
+//   swap32(a, b): lanes 0..31 get {own a, a of lane + 32}, lanes 32..63 get {b of lane - 32, own b}
+struct Pair64 {
+  double v, s;
+};
+__device__ __forceinline__ Pair64 swap16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return Pair64{__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1])};
+}
+__device__ __forceinline__ Pair64 swap32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return Pair64{__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1])};
+}
+
+// NVT = 32: the layout described above. NVT = 48 (n <= 45, H <= 15; round 4): one lane per row (lanes 0..47; the last DPP row
+// carries zeros), 48 slots = three 16-column blocks, each in butterfly order — slot 16 b + j of lane L holds column
+// 16 b + ((j ^ L) & 15). The reduce-scatter runs per block inside the 16-lane DPP rows and the three DPP rows are then combined so
+// that the total of column k lands in lane k ("position layout" = lane k for position k, one copy): blocks 0 and 1 with ONE
+// v_permlane16_swap of (block 0, block 1) — the even row receives its neighbour's block-0 partial, the odd row its neighbour's
+// block-1 partial — plus a v_permlane32_swap sum; block 2 with the two swap sums. The all-gather is the reverse: three seeds per
+// lane from three swaps, then the butterfly walk per block. No LDS transposition, no select chain on a run-time register index
+// (what the one-lane-per-row code of hdsm_wave_gi.h paid: 48-deep v_cndmask chains, 21 k cycles per operation).
+template <int NVT, int CMAX, bool SMALL = false>
+struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
+  using Base = WaveGI<NVT, CMAX, SMALL>;
   using S = typename Base::S;
   using Regs = typename Base::Regs;
-  static constexpr int NV = 32, NC = 16, LDT = S::LDT;
+  static constexpr bool SPLIT = Base::SPLIT;
+  static constexpr int NV = NVT, NC = Base::NC, NB = NC / 16, LDT = S::LDT;
+  static_assert(NVT == 32 || NVT == 48, "two layouts");
 
-  static __device__ __forceinline__ int pos_of(int lane) { return (lane & 15) + 16 * (lane >> 5); }
-  static __device__ __forceinline__ int lane_of_pos(int k) { return (k & 15) + 32 * (k >> 4); }
-  static __device__ __forceinline__ bool first_copy(int lane) { return (lane & 16) == 0; }
+  static __device__ __forceinline__ int pos_of(int lane) { return SPLIT ? (lane & 15) + 16 * (lane >> 5) : lane; }
+  static __device__ __forceinline__ int lane_of_pos(int k) { return SPLIT ? (k & 15) + 32 * (k >> 4) : k; }
+  static __device__ __forceinline__ bool first_copy(int lane) { return SPLIT ? (lane & 16) == 0 : lane < NV; }
+  // a position that exists, for addresses (NVT = 48: lanes 48..63 hold no position; what they read is never used)
+  static __device__ __forceinline__ int pos_addr(int lane) { return SPLIT ? pos_of(lane) : (lane < NV ? lane : NV - 1); }
+  static __device__ __forceinline__ int row_addr(int lane) { return SPLIT ? (lane & 31) : (lane < NV ? lane : NV - 1); }
+  // first column of this lane's share of a row of U, and the sum over the lanes that share a position
+  static __device__ __forceinline__ int ucol0(int lane) { return SPLIT ? (lane & 16) : 0; }
+  static __device__ __forceinline__ double psum(double v) {
+    if constexpr (SPLIT) return row16_sum64(v);
+    else return v;
+  }
 
-  // sum over the 32 lanes of a half of slot-ordered per-column values: returns, in lane L, the total of column pos_of(L)
-  static __device__ __forceinline__ double reduce_cols(double (&p)[NC]) {
+  // reduce-scatter of one 16-slot block inside the 16-lane DPP row: p[0] = this row's partial of column (L & 15) of the block
+  static __device__ __forceinline__ void reduce_block(double* p) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) p[s] += dpp64<0x140>(p[15 - s]);  // row_mirror: partner L ^ 15
 #pragma unroll
@@ -57,11 +93,8 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
 #pragma unroll
     for (int s = 0; s < 2; ++s) p[s] += dpp64<0x4E>(p[s ^ 2]);    // quad_perm [2,3,0,1]: partner L ^ 2
     p[0] += dpp64<0xB1>(p[1]);                                    // quad_perm [1,0,3,2]: partner L ^ 1
-    return row16_sum64(p[0]);
   }
-  // v = entry pos_of(L) of a column-distributed vector (both DPP rows of a half hold it) -> g[s] = entry col(L, s)
-  static __device__ __forceinline__ void gather_cols(double v, double (&g)[NC]) {
-    g[0] = v;
+  static __device__ __forceinline__ void gather_block(double* g) {  // g[0] = entry (L & 15) of the block -> g[j] = entry (j ^ L) & 15
     g[1] = dpp64<0xB1>(g[0]);
 #pragma unroll
     for (int s = 0; s < 2; ++s) g[s ^ 2] = dpp64<0x4E>(g[s]);
@@ -70,12 +103,40 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
 #pragma unroll
     for (int s = 0; s < 8; ++s) g[15 - s] = dpp64<0x140>(g[s]);
   }
+  // sum over the rows of J of slot-ordered per-column values: returns, in lane L, the total of column pos_of(L)
+  static __device__ __forceinline__ double reduce_cols(double (&p)[NC], int lane = 0) {
+    if constexpr (SPLIT) {
+      reduce_block(p);
+      return row16_sum64(p[0]);
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) reduce_block(p + 16 * b);
+      const Pair64 e = swap16(p[0], p[16]);              // DPP rows 0 / 2: block 0 of rows {0,1} / {2,3}; rows 1 / 3: block 1
+      const double t01 = half_sum64(e.v + e.s);          // rows 0 and 2: all of block 0; rows 1 and 3: all of block 1
+      const double t2 = half_sum64(row16_sum64(p[32]));  // every row: all of block 2
+      return lane < NV ? ((lane & 32) ? t2 : t01) : 0.0;
+    }
+  }
+  // v = entry pos_of(L) of a column-distributed vector -> g[s] = the entry of the column slot s of lane L holds
+  static __device__ __forceinline__ void gather_cols(double v, double (&g)[NC]) {
+    if constexpr (SPLIT) {
+      g[0] = v;
+      gather_block(g);
+    } else {
+      const Pair64 a = swap16(v, v);      // .v: the entry of DPP row 0 (rows 0, 1) / of row 2 (rows 2, 3); .s: of row 1 / of row 3
+      const Pair64 b = swap32(a.v, a.v);  // .v: the entry of row 0 in every row; .s: the entry of row 2 in every row
+      const Pair64 c = swap32(a.s, a.s);  // .v: the entry of row 1 in every row
+      g[0] = b.v, g[16] = c.v, g[32] = b.s;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) gather_block(g + 16 * bb);
+    }
+  }
   // sum over the DISTINCT positions of a position-layout value (every position has two copies)
   static __device__ __forceinline__ double pos_sum(double v, int lane) { return wave_sum64(first_copy(lane) ? v : 0.0); }
 
   // multipliers / ids: LDS (between the phases of an instance, position k at index k) <-> registers (inside a run)
   static __device__ __forceinline__ void load_pos(const S& s, Regs& R, int lane) {
-    R.lam = s.lam[pos_of(lane)], R.act = s.act[pos_of(lane)];
+    R.lam = s.lam[pos_addr(lane)], R.act = first_copy(lane) || SPLIT ? s.act[pos_addr(lane)] : -1;
   }
   static __device__ __forceinline__ void store_pos(S& s, const Regs& R, int lane) {
     if (first_copy(lane)) s.lam[pos_of(lane)] = R.lam, s.act[pos_of(lane)] = R.act;
@@ -85,7 +146,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
   // (Reading only the pairs below q — columns >= q of U are zero — was tried: the data-dependent trip count costs more than the
   // reads it saves, 8.35 -> 7.85 M agent-replans/s on the bench line.)
   static __device__ __forceinline__ double u_row_dot(const S& s, int lane) {
-    const int k = pos_of(lane), c0 = (lane & 16);
+    const int k = pos_addr(lane), c0 = ucol0(lane);
     const D2* urow = reinterpret_cast<const D2*>(&s.U[k * LDT + c0]);
     const D2* dv = reinterpret_cast<const D2*>(&s.dvec[c0]);
     double r0 = 0, r1 = 0;
@@ -94,7 +155,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
       const D2 u = urow[j], d = dv[j];
       r0 += u.x * d.x, r1 += u.y * d.y;
     }
-    return row16_sum64(r0 + r1);
+    return psum(r0 + r1);
   }
 
   // ---- hand-over between wave 0 and the scanner (wave 1): workgroup barriers with a command word. (Words in LDS polled by the
@@ -130,7 +191,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
     const double na = -ai;
 #pragma unroll
     for (int k = 0; k < NC; ++k) p[k] = R.Jr[k] * na;
-    dj = reduce_cols(p);
+    dj = reduce_cols(p, lane);
     if constexpr (WANT_Z) { OP_PROF(12) }
     const int pos = pos_of(lane);
     if (first_copy(lane)) s.dvec[pos] = dj;  // for r = U d (U has zero columns >= q: no mask needed)
@@ -148,7 +209,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
       double z0 = 0, z1 = 0;
 #pragma unroll
       for (int k = 0; k < NC; k += 2) z0 += R.Jr[k] * g[k], z1 += R.Jr[k + 1] * g[k + 1];
-      zi = half_sum64(z0 + z1);
+      zi = Base::hsum(z0 + z1);
       OP_PROF(14)
       if (prep_msg != 0) {  // message to the scanner: z is there
         if (lane < NV) s.w[lane] = zi;
@@ -176,7 +237,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
     double w0 = 0, w1 = 0;
 #pragma unroll
     for (int k = 0; k < NC; k += 2) w0 += R.Jr[k] * g[k], w1 += R.Jr[k + 1] * g[k + 1];
-    const double coef = half_sum64(w0 + w1) * beta;
+    const double coef = Base::hsum(w0 + w1) * beta;
 #pragma unroll
     for (int k = 0; k < NC; ++k) R.Jr[k] -= coef * g[k];
     if constexpr (PROBE) { OP_PROF(18) }
@@ -188,8 +249,8 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
   // working set -= entry at position l: one Householder reflection G with G u_l^T = sigma e_t (u_l = row l of U, t = q - 1).
   // The rows of U (LDS, natural order) are updated by the lane pair of their position; J through the gathered vector.
   static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
-    const int t = q - 1, pos = pos_of(lane), c0 = lane & 16;
-    double uv[NC];  // this lane's 16 columns of row l of U
+    const int t = q - 1, pos = pos_of(lane), pa = pos_addr(lane), c0 = ucol0(lane);
+    double uv[NC];  // this lane's columns of row l of U
     {
       const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT + c0]);
 #pragma unroll
@@ -199,11 +260,11 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
       }
     }
     const double ut = s.U[l * LDT + t];
-    const double ulp = s.U[l * LDT + pos];  // entry pos of u_l: the column-distributed source for J's update
+    const double ulp = s.U[l * LDT + pa];  // entry pos of u_l: the column-distributed source for J's update
     double s0 = 0, s1 = 0;
 #pragma unroll
     for (int j = 0; j < NC; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
-    const double ss = row16_sum64(s0 + s1);  // |u_l|^2 > 0: u_l is a row of the inverse of a regular triangular factor
+    const double ss = psum(s0 + s1);  // |u_l|^2 > 0: u_l is a row of the inverse of a regular triangular factor
     const double sigma = (ut > 0 ? -1.0 : 1.0) * (ss * rsq_nr(ss));
     const double beta = rcp_nr(sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
     // J (registers): x -= (x . v) beta v with the complete v
@@ -213,25 +274,25 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
       double w0 = 0, w1 = 0;
 #pragma unroll
       for (int k = 0; k < NC; k += 2) w0 += R.Jr[k] * g[k], w1 += R.Jr[k + 1] * g[k + 1];
-      const double cj = half_sum64(w0 + w1) * beta;
+      const double cj = Base::hsum(w0 + w1) * beta;
 #pragma unroll
       for (int k = 0; k < NC; ++k) R.Jr[k] -= cj * g[k];
     }
     // own row of U (row pos): x -= (x . v) beta v; column t belongs to the freed direction and is zeroed below
     double ur[NC];
     {
-      const D2* ro = reinterpret_cast<const D2*>(&s.U[pos * LDT + c0]);
+      const D2* ro = reinterpret_cast<const D2*>(&s.U[pa * LDT + c0]);
 #pragma unroll
       for (int j = 0; j < NC; j += 2) {
         const D2 v2 = ro[j / 2];
         ur[j] = v2.x, ur[j + 1] = v2.y;
       }
     }
-    const double urt = s.U[pos * LDT + t];
+    const double urt = s.U[pa * LDT + t];
     double wu0 = 0, wu1 = 0;
 #pragma unroll
     for (int j = 0; j < NC; j += 2) wu0 += ur[j] * uv[j], wu1 += ur[j + 1] * uv[j + 1];
-    const double cu = (row16_sum64(wu0 + wu1) - sigma * urt) * beta;
+    const double cu = (psum(wu0 + wu1) - sigma * urt) * beta;
 #pragma unroll
     for (int j = 0; j < NC; ++j) ur[j] -= cu * uv[j];
     // multipliers / ids of the positions above l move down by one (through LDS: positions cross the DPP rows)
@@ -340,7 +401,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
     store_pos(s, R, lane);  // resid() of K_P rows and the hand-over read act[] from LDS
     wsync();
     Base::states(s, R, lane, N);
-    const int pos = pos_of(lane), c0 = lane & 16;
+    const int pos = pos_of(lane), pa = pos_addr(lane), c0 = ucol0(lane);
     for (;;) {
       const double vk = (pos < q) ? Base::resid(s, c, R.act, N) : 0.0;
       if (first_copy(lane)) s.dvec[pos] = vk;
@@ -351,9 +412,9 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
 #pragma unroll
         for (int k = 0; k < NC; k += 2) {
           const D2 vk2 = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
-          p0 += s.U[(c0 + k) * LDT + pos] * vk2.x, p1 += s.U[(c0 + k + 1) * LDT + pos] * vk2.y;
+          p0 += s.U[(c0 + k) * LDT + pa] * vk2.x, p1 += s.U[(c0 + k + 1) * LDT + pa] * vk2.y;
         }
-        tj = row16_sum64(p0 + p1);
+        tj = psum(p0 + p1);
       }
       wsync();
       if (first_copy(lane)) s.dvec[pos] = tj;
@@ -370,12 +431,12 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
           double x0 = 0, x1 = 0;
 #pragma unroll
           for (int k = 0; k < NC; k += 2) x0 += R.Jr[k] * g[k], x1 += R.Jr[k + 1] * g[k + 1];
-          xw = s.x0[Base::row_of(lane)] + half_sum64(x0 + x1);
+          xw = s.x0[row_addr(lane)] + Base::hsum(x0 + x1);
         }
         const double tt = pos_sum(tj * tj, lane);
         R.lam = (pos < q) ? lk : 0.0;
         if (lane < n) R.xi = xw, s.x[lane] = xw;
-        else if (lane < 64 && Base::row_of(lane) < n) R.xi = xw;
+        else if (lane < 64 && Base::row_ok(lane) && Base::row_of(lane) < n) R.xi = xw;
         if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;
         store_pos(s, R, lane);
         wsync();
@@ -442,7 +503,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
         PROF(1)
         if (ip < 0) break;
         vip = s.part_v[1], kip = s.part_key[1];
-        ai = s.dvz[Base::row_of(ln)];
+        ai = s.dvz[row_addr(ln)];
       } else {
         // the state boxes (velocity / acceleration limits) are looked at — and the states they bound evaluated — only when no
         // input box and no plane is violated: a third of the instructions of evaluation + scan, spared in most operations
@@ -642,8 +703,9 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
       int lane = (int)threadIdx.x & 63;
       keep_in_loop(lane);
       // this lane's trajectory point: (axis, step m), half h of the impulse-response taps
-      constexpr int HH = Base::HT / 2;
-      const int row = lane & 31, h = lane >> 5;
+      // (NVT = 32: the two lanes of a row take half of the taps each; NVT = 48: one lane per point, all taps)
+      constexpr int HH = SPLIT ? Base::HT / 2 : Base::HT;
+      const int row = SPLIT ? (lane & 31) : lane, h = SPLIT ? (lane >> 5) : 0;
       const bool on = row < 3 * N;
       const int ax = on ? R.ax : 0, m = on ? R.kk + 1 : 1;
       const double* gp = &s.gz[ax][0][MAXH + m - 1 - h * HH];  // taps gp[-k]
@@ -678,7 +740,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
         double accx = h == 0 ? s.fr[ax][m][0] : 0.0, accz = 0.0;
 #pragma unroll
         for (int k = 0; k < HH; ++k) accx += gk[k] * xk[k], accz += gk[k] * zk[k];
-        accx = half_sum64(accx), accz = half_sum64(accz);
+        accx = Base::hsum(accx), accz = Base::hsum(accz);
         if (on && h == 0) s.st[m][ax] = accx, dpv[3 * m + ax] = accz;
         wsync();
         double v0[RC], dv[RC];
@@ -779,13 +841,16 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
   static constexpr int SNAP_DOUBLES = Base::SNAP_DOUBLES;
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
     keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
-    const int row = Base::row_of(lane), c0 = Base::col0_of(lane);
-    if (save) {
+    const int row = row_addr(lane), c0 = Base::col0_of(lane);
+    constexpr int JL = SPLIT ? 64 : NV;  // lanes that hold slots of J (NC JL = NV NV doubles)
+    if (Base::row_ok(lane)) {
+      if (save) {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) buf[j * 64 + lane] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
-    } else {
+        for (int j = 0; j < NC; ++j) buf[j * JL + lane] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+      } else {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) R.Jr[j] = buf[j * 64 + lane], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+        for (int j = 0; j < NC; ++j) R.Jr[j] = buf[j * JL + lane], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+      }
     }
     if (lane < NV) {
       if (save) {
@@ -798,7 +863,7 @@ struct WaveGIB : WaveGI<32, CMAX, SMALL> {
         s.x[lane] = buf[2 * NV * NV + lane];
       }
     }
-    if (!save) R.xi = buf[2 * NV * NV + row];  // both copies of a row
+    if (!save && Base::row_ok(lane)) R.xi = buf[2 * NV * NV + row];  // both copies of a row
     if (lane == 0) {
       if (save) {
         buf[(2 * NV + 3) * NV] = s.f;
