@@ -524,6 +524,7 @@ struct Handle {
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
+  int duo48_rows = 736;       // staging rows of the two-per-CU kernel for n > 30 (HDSM_DUO48_ROWS=320: the smaller instantiation)
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
@@ -656,22 +657,25 @@ int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 
 // n > 30 (H up to 16): the factor needs more than 256 registers per lane, so a wavefront must have a SIMD to itself — but a
 // 128-thread workgroup has only two, and TWO such workgroups (four wavefronts, one per SIMD) fit a CU once the staging area is cut
-// to 320 rows (2 x 80.9 KB of LDS). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5: 4096
+// to 736 rows (2 x 80 KB of LDS; 320 rows until the butterfly layout freed the 19 KB transposition buffer of the old code — the
+// 320-row instantiation stays selectable, HDSM_DUO48_ROWS=320: the staging-overflow test needs an area that a dense
+// neighbourhood can fill). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5: 4096
 // instances, 16 per CU one after the other), and every instance is one latency-bound wavefront: the second one doubles the rate.
-constexpr int CMAX_DUO48 = 320;
+constexpr int CMAX_DUO48 = 736, CMAX_DUO48_SMALL = 320;
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
   run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
 }
-int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
-  using Sol = hdsm::Solver<48, CMAX_DUO48>;
+template <int CM>
+int launch_duo48_rows(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
+  using Sol = hdsm::Solver<48, CM>;
 #ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
 #endif
   const size_t shm = sizeof(typename Sol::S);
-  auto kern = k_replan_duo48<48, CMAX_DUO48, 128>;
+  auto kern = k_replan_duo48<48, CM, 128>;
   static thread_local int attr_dev = -1;
   if (attr_dev != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -680,6 +684,10 @@ int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
+}
+
+int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
+  return h->duo48_rows == CMAX_DUO48_SMALL ? launch_duo48_rows<CMAX_DUO48_SMALL>(h, a, st, blocks) : launch_duo48_rows<CMAX_DUO48>(h, a, st, blocks);
 }
 
 int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
@@ -1080,6 +1088,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
     h->quad_min = h->tri_min > 0 ? 3 * cus + 1 : 0;    // more instances than the three-per-CU kernel has resident slots
     env_int("HDSM_QUAD_MIN", 0, INT_MAX, &h->quad_min);  // 0 = never
+    env_int("HDSM_DUO48_ROWS", 320, 736, &h->duo48_rows);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
     int depth = 3;

@@ -81,7 +81,7 @@ struct Shm {
   static_assert(CMAX <= 4096, "the slot of a staged row must fit the 12 bits kc_slot() reads");
   static constexpr int PM = SMALL ? 4 : MAXP, RSM = SMALL ? 20 : MAXRS, LC = SMALL ? 512 : LISTCAP;
   static constexpr int LDT = (NV <= 32) ? 34 : NV + 2;  // even (16-B rows) and conflict-free for b128 row reads
-  alignas(16) double T[NV > 32 ? NV * LDT : 2];  // NV = 48: transposition buffer for d = J^T a (J rows live in registers)
+  alignas(16) double T[2];  // (was the transposition buffer of the one-lane-per-row code for d = J^T a: 19 KB at NV = 48, now staging rows)
   alignas(16) double U[NV * LDT];       // U = R^{-1}, row k = working-set position k (upper triangular, zero-padded)
   alignas(16) double dvec[NV + 2];      // broadcast vector (d, or a row of U)
   alignas(16) double dvz[NV + 2];       // d with the working-set columns (j < q) zeroed
