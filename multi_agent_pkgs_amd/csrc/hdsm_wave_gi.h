@@ -1,24 +1,12 @@
-// hdsm_wave_gi.h — device-only (gfx950): the dual active-set iteration of ONE instance executed by ONE
-// 64-lane wavefront with the factorisation held in REGISTERS.
+// hdsm_wave_gi.h — device-only (gfx950): what the dual active-set iteration of ONE instance needs around its factor algebra, for
+// ONE 64-lane wavefront (plus the scanner wave): lane mapping and per-lane constants, the state evaluation from the impulse
+// responses, the violation scans and the pick rule, normals and residuals of a row, the neighbour sweep, cold rows.
 //
-// Same mathematics as Solver::gi_run in hdsm_core.h (Goldfarb-Idnani, J = L^{-T} Q with J^T N = [R; 0]),
-// different data layout, chosen for CDNA4:
-//   * the rows of J live in statically indexed registers: with n <= 30 (NV = 32) every row is split over TWO lanes
-//     (lane L: columns [16h, 16h+16) of row L & 31, h = L >> 5; partial sums meet through v_permlane32_swap), with
-//     larger n (NV = 48) lane i owns row i; U = R^{-1} is in LDS by rows; the multiplier / id of the working-set
-//     entry at position k live in lane k;
-//   * r = U d1 is a lane-local dot product: no back-substitution chain;
-//   * d = J^T a is a transposition through LDS (T[j][i] = J[i][j] a_i, conflict-free strides), or a single
-//     row broadcast when the incoming row is an input bound (a = +-e_k, the common case in bang-bang plans);
-//   * "add" is ONE Householder reflection of the free columns q..NV-1 of J that maps d2 onto rho e_q: a
-//     rank-1 update J2 -= (J2 v) beta v^T with v = d2 - rho e_q. J2 v = z - rho J[:,q] reuses the primal
-//     direction z that the step needs anyway, so the update costs one FMA per free column, one sqrt and
-//     one division per ITERATION (not per lane) and no coefficient exchange; U gets the column (-r/rho; 1/rho).
-//     R = U^{-1} stays a general invertible matrix (it need not be triangular for the method);
-//   * "drop l": any orthogonal G with G u_l^T = sigma e_{q-1} (u_l = row l of U) gives
-//     U' = (E^T U G^T)[:, :q-1]; G is again one Householder reflection: rank-1 updates of the rows of U (LDS)
-//     and of the columns 0..q-1 of J (registers), then the rows > l of U are written one slot up;
-//   * cross-lane reductions use DPP row rotations + v_readlane, not LDS trees.
+// The algebra itself — J = L^{-T} Q with J^T N = [R; 0] in registers in butterfly order, U = R^{-1} in LDS, Householder add /
+// drop, warm start, the regular loop and the scanner protocol — is hdsm_wave_gib.h (WaveGIB<NV, ...> derives from WaveGI<NV, ...>),
+// for both instantiations: NV = 32 (n <= 30: every row of J split over two lanes) and NV = 48 (one lane per row). Until round 4
+// this file also held the one-lane-per-row algebra of NV = 48 (LDS transposition for d = J^T a, select chains on run-time
+// register indices); it is gone.
 // Dimension handling: the factors are padded to NV (identity beyond n = 3N), so every loop has a
 // compile-time trip count and unrolls; a padded direction never receives a step (d_k = 0 there).
 #pragma once
@@ -288,18 +276,6 @@ struct WaveGI {
     }
   }
 
-  // register array access with a dynamic index (select chain); an index outside [0, NC) reads 0 / writes nothing
-  static __device__ __forceinline__ double reg_get(const double (&a)[NC], int q) {
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) v = (k == q) ? a[k] : v;
-    return v;
-  }
-  static __device__ __forceinline__ void reg_set(double (&a)[NC], int q, double v) {
-#pragma unroll
-    for (int k = 0; k < NC; ++k) a[k] = (k == q) ? v : a[k];
-  }
-
   // trajectory from s.x: lane (ax, m-1) evaluates p, v, a of step m (zero-padded Toeplitz table gz in LDS)
   // PART: 0 = positions, velocities and accelerations; 1 = positions only; 2 = velocities and accelerations only
   template <int PART = 0>
@@ -498,27 +474,6 @@ struct WaveGI {
     if (kbest != nullptr) *kbest = m;  // the winner's key: violation / sqrt(a^T Z a) with the normalised rule
   }
 
-  // The other waves of the workgroup while wave 0 iterates: wait for a command at the workgroup barrier, scan a share of the staged rows.
-  static __device__ __forceinline__ void helper_loop(S& s, const Consts&, Regs&) {
-    const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
-    for (;;) {
-      __syncthreads();
-      if (uni(s.cmd) == 0) return;
-      Pick pk{0.0, 0.0, -1};
-      scan_rows(s, 256 * w, uni(s.ncand), lane, s.part_tol, s.part_norm != 0, pk, 4 * (int)blockDim.x);
-      const double m = wave_max64(pk.key);
-      int best = -1;
-      double mv = 0.0;
-      if (m > 0.0) {
-        const int src = __ffsll((long long)__ballot(pk.key == m && pk.id >= 0)) - 1;
-        best = __builtin_amdgcn_readlane(pk.id, src);
-        mv = bcast64(pk.v, src);
-      }
-      if (lane == 0) s.part_key[w] = m, s.part_v[w] = mv, s.part_id[w] = best;
-      __syncthreads();
-    }
-  }
-
   // No hot row is violated: check the COLD staged rows (kept at the top of the staging area, scanned only
   // here) and promote the violated ones into the hot list. Returns the number promoted.
   static __device__ __forceinline__ int promote_cold(S& s, int lane, double tol) {
@@ -598,118 +553,6 @@ struct WaveGI {
       pm = s.st[kc_m(p)];
     }
     return row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-  }
-
-  // d = J^T (-a) -> s.dvec (all of d) and s.dvz (d with the entries of the working-set columns, j < q, zeroed);
-  // returns d_lane for lane < NV, 0 beyond. `ai` is entry row_of(lane) of the normal.
-  static __device__ __forceinline__ double compute_d(S& s, const Regs& R, int id, double ai, int q, int lane) {
-    const int row = row_of(lane), c0 = col0_of(lane);
-    double dj = 0.0;
-    if (id_kind(id) == K_U) {  // a = sg e_k: d = -sg * (row k of J)
-      const int var = id_payload(id) >> 1;
-      const double msg = (id_payload(id) & 1) ? 1.0 : -1.0;
-      if (row_ok(lane) && row == var) {
-#pragma unroll
-        for (int j = 0; j < NC; j += 2) *reinterpret_cast<D2*>(&s.dvec[c0 + j]) = D2{msg * R.Jr[j], msg * R.Jr[j + 1]};
-      }
-      wsync();
-      if (lane < NV) dj = s.dvec[lane], s.dvz[lane] = (lane >= q) ? dj : 0.0;
-      wsync();
-      return dj;
-    }
-    if (row_ok(lane)) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) s.T[(c0 + j) * LDT + row] = R.Jr[j] * ai;
-    }
-    wsync();
-    {
-      double a0 = 0, a1 = 0;
-      if (row_ok(lane)) {  // entries [c0, c0 + NC) of row `row` of T
-        const D2* tr = reinterpret_cast<const D2*>(&s.T[row * LDT + c0]);
-#pragma unroll
-        for (int i = 0; i < NC / 2; ++i) {
-          const D2 t = tr[i];
-          a0 += t.x;
-          a1 += t.y;
-        }
-      }
-      dj = -hsum(a0 + a1);
-    }
-    if (lane < NV) s.dvec[lane] = dj, s.dvz[lane] = (lane >= q) ? dj : 0.0;
-    else dj = 0.0;
-    wsync();
-    return dj;
-  }
-
-  // d = J^T(-a), ||d||^2, ||d2||^2, d_q, z_i = (J2 d2)_i, r_i = (U d1)_i for the incoming constraint. dv = this lane's
-  // columns of d (split kernel: with the working-set part zeroed — what the Householder update multiplies).
-  static __device__ __forceinline__ void direction(S& s, const Regs& R, int id, double ai, int q, int lane, double (&dv)[NC],
-                                                   double& dd, double& zz, double& dq, double& zi, double& ri) {
-    const double dj = compute_d(s, R, id, ai, q, lane);
-    const double sufj = wave_suffix_sum(dj * dj, lane);  // sum_{k >= lane} d_k^2
-    dd = bcast64(sufj, 0);
-    zz = (q < NV) ? bcast64(sufj, q) : 0.0;
-    dq = (q < NV) ? bcast64(dj, q) : 0.0;
-    const int row = row_of(lane), c0 = col0_of(lane);
-    double r0 = 0, r1 = 0, z0 = 0, z1 = 0;
-    if constexpr (SPLIT) {
-      const D2* urow = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
-#pragma unroll
-      for (int k = 0; k < NC; k += 2) {
-        const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
-        const D2 zk = *reinterpret_cast<const D2*>(&s.dvz[c0 + k]);
-        const D2 uk = urow[k / 2];
-        dv[k] = zk.x, dv[k + 1] = zk.y;
-        r0 += uk.x * dk.x, r1 += uk.y * dk.y;                  // r = U d1: U has zero columns >= q, no mask needed
-        z0 += R.Jr[k] * zk.x, z1 += R.Jr[k + 1] * zk.y;        // z = J2 d2: dvz is zero on the other columns
-      }
-    } else {  // one lane per row: q is wave-uniform against the column index, the free columns are picked by predicate
-#pragma unroll
-      for (int k = 0; k < NC; k += 2) {
-        const D2 dk = *reinterpret_cast<const D2*>(&s.dvec[k]);
-        dv[k] = dk.x, dv[k + 1] = dk.y;
-      }
-      if (lane < NV) {
-        const D2* urow = reinterpret_cast<const D2*>(&s.U[lane * LDT]);
-#pragma unroll
-        for (int k = 0; k < NC; k += 2) {
-          const D2 uk = urow[k / 2];
-          r0 += uk.x * dv[k];
-          r1 += uk.y * dv[k + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-          if (k >= q) {
-            if (k & 1) z1 += R.Jr[k] * dv[k];
-            else z0 += R.Jr[k] * dv[k];
-          }
-        }
-      }
-    }
-    ri = hsum(r0 + r1);
-    zi = hsum(z0 + z1);
-  }
-
-  // working set += id at position q: ONE Householder reflection of the free columns, d2 -> rho e_q
-  static __device__ __forceinline__ void householder_add(S& s, Regs& R, int id, double lam_p, int q, int lane,
-                                                         const double (&dv)[NC], double zz, double dq, double zi, double ri) {
-    const double rho = (dq > 0 ? -1.0 : 1.0) * sqrt(zz);
-    const double beta = 1.0 / (rho * (rho - dq));
-    const int c0 = col0_of(lane);
-    const double jq = hsum(row_ok(lane) ? reg_get(R.Jr, q - c0) : 0.0);  // J[row][q]: held by one of the halves
-    if (row_ok(lane)) {
-      const double coef = (zi - rho * jq) * beta;  // (J2 v) beta, v = d2 - rho e_q
-#pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (SPLIT || k >= q) R.Jr[k] -= coef * dv[k];  // (split kernel: dv is already zero on the working-set columns)
-      reg_set(R.Jr, q - c0, jq - coef * (dq - rho));
-    }
-    if (lane < NV) s.U[lane * LDT + q] = (lane < q) ? -ri / rho : ((lane == q) ? 1.0 / rho : 0.0);
-    if (lane == q) {
-      s.lam[q] = lam_p;
-      s.act[q] = id;
-    }
-    wsync();
   }
 
   // ---- neighbour sweep, device version -----------------------------------------------------------------------
@@ -854,386 +697,15 @@ struct WaveGI {
   }
 
   // ---- warm start ---------------------------------------------------------------------------------------
+  // (implementation: hdsm_wave_gib.h, for both register layouts)
   // The optimal working set of the previous replan of this instance (a.warm, portable ids), moved one step
   // towards the present, seeds the dual method: its rows are put into the factorisation WITHOUT taking steps,
   // the minimiser x_W on them and its multipliers follow in closed form
   //      t = U^T v,   lambda = U t,   x_W = x0 + J1 t,   f_W = f(x0) + |t|^2 / 2        (v = violations at x0)
   // and entries with a negative multiplier are dropped until (x_W, W) is a valid S-pair. The regular loop then
   // continues from there; the result is the same optimum, reached in fewer iterations.
-  static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self,
-                                                    int& iters, const WarmPre& wpre) {
-    const int lane = (int)threadIdx.x;
-    const int N = c.N, n = c.n;
-    int nw = uni(wpre.head) & ~WARM_CERT;
-    if (nw <= 0) return;
-    if (nw > NV) nw = NV;
-    PROF_DECL
-    // Lane g prepares entry g of the guess — translation of the id to this replan's indices and, for a neighbour row,
-    // the global reads and the plane itself — so the sequential loop below only broadcasts (v_readlane) what it needs.
-    int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
-    double my_row[4] = {0.0, 0.0, 0.0, 0.0};
-    if (lane < nw) {
-      const int code = wpre.code;
-      const int kind = id_kind(code), p = id_payload(code);
-      if (kind == K_U) {
-        const int var = p >> 1;
-        if (var % N >= 1) pre = mk_id(K_U, ((var - 1) << 1) | (p & 1));
-      } else if (kind == K_S) {
-        const int i = p >> 5;
-        if (i - 1 >= 1) pre = mk_id(K_S, ((i - 1) << 5) | (p & 31));
-      } else if (kind == K_C && a.l1_rows == nullptr) {
-        const int e = p & 1, i = ((p >> 1) & 31) - 1, k = p >> 6;
-        if (i >= 0 && i + e > c.pinned_steps && k != self && k < a.n_rob && wpre.has) {
-          const double op[3] = {wpre.ox, wpre.oy, wpre.oz};
-          if (tasc_plane_eval(c, s.cprev[i], op, my_row)) pre = -2, my_m = i + e, my_src = (k << 6) | (i << 1) | e;
-        }
-      }
-    }
-    int q = uni(s.q);
-    WS_PROF(16)
-    for (int g = 0; g < nw && q < n; ++g) {
-      int id = __builtin_amdgcn_readlane(pre, g);
-      if (id == -2) {
-        id = -1;
-        const int slot = uni(s.ncand);
-        if (slot < CMAX - uni(s.ncold)) {
-          const double r0 = bcast64(my_row[0], g), r1 = bcast64(my_row[1], g), r2 = bcast64(my_row[2], g),
-                       r3 = bcast64(my_row[3], g);
-          const int m = __builtin_amdgcn_readlane(my_m, g), src = __builtin_amdgcn_readlane(my_src, g);
-          if (lane == 0) {
-            s.cand[slot][0] = r0, s.cand[slot][1] = r1, s.cand[slot][2] = r2, s.cand[slot][3] = r3;
-            s.cand_mw[slot] = mk_mw(s.kap, r0, r1, r2, m);
-            s.cand_src[slot] = src;
-            s.ncand = slot + 1;
-          }
-          wsync();
-          id = mk_kc(slot, m);
-        }
-      }
-      if (id < 0) continue;
-      WS_PROF(17)
-      const double ai = normal_entry(s, R, id, row_of(lane), N, n);
-      WS_PROF(18)
-      double dv[NC], dd, zz, dq, zi, ri;
-      direction(s, R, id, ai, q, lane, dv, dd, zz, dq, zi, ri);
-      WS_PROF(19)
-      ++iters;
-      if (!(zz > 1e-8 * dd)) continue;  // (nearly) dependent on what is already in: leave it out
-      householder_add(s, R, id, 0.0, q, lane, dv, zz, dq, zi, ri);
-      WS_PROF(20)
-      ++q;
-    }
-    if (q == uni(s.q)) return;  // nothing usable
-    // violations of the working-set rows at the unconstrained minimiser x0
-    if (lane < NV) s.x[lane] = s.x0[lane];
-    wsync();
-    states(s, R, lane, N);
-    for (;;) {
-      const double vk = (lane < q) ? resid(s, c, s.act[lane], N) : 0.0;
-      if (lane < NV) s.dvec[lane] = vk;
-      wsync();
-      const int row = row_of(lane), c0 = col0_of(lane);
-      double tj;  // t = U^T v: column `row` of U, this lane's share of the rows (rows >= q of U are zero)
-      {
-        double p0 = 0, p1 = 0;
-        if (row_ok(lane)) {
-#pragma unroll
-          for (int k = 0; k < NC; k += 2) {
-            const D2 vk2 = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
-            p0 += s.U[(c0 + k) * LDT + row] * vk2.x, p1 += s.U[(c0 + k + 1) * LDT + row] * vk2.y;
-          }
-        }
-        tj = hsum(p0 + p1);
-      }
-      wsync();
-      if (lane < NV) s.dvec[lane] = tj;
-      else tj = 0.0;
-      wsync();
-      double lk, xw = 0.0;
-      {
-        double l0 = 0, l1 = 0, x0 = 0, x1 = 0;
-        if (row_ok(lane)) {
-          const D2* urow = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
-#pragma unroll
-          for (int k = 0; k < NC; k += 2) {
-            const D2 tk = *reinterpret_cast<const D2*>(&s.dvec[c0 + k]);
-            const D2 uk = urow[k / 2];
-            l0 += uk.x * tk.x, l1 += uk.y * tk.y;               // lambda = U t
-            x0 += R.Jr[k] * tk.x, x1 += R.Jr[k + 1] * tk.y;     // J1 t  (t is zero beyond q)
-          }
-        }
-        lk = hsum(l0 + l1);
-        const double xs = hsum(x0 + x1);
-        if (lane < NV) xw = s.x0[lane] + xs;
-      }
-      // most negative multiplier among the inequalities
-      const bool ineq = lane < q && id_kind(s.act[lane]) != K_E;
-      const double worst = -wave_max64(ineq ? -lk : -DINF);
-      if (!(worst < -1e-12) || q <= 6) {
-        const double tt = wave_suffix_sum(tj * tj, lane);
-        if (lane < NV) {
-          s.lam[lane] = (lane < q) ? lk : 0.0;
-          if (lane < n) R.xi = xw, s.x[lane] = xw;
-        }
-        if (lane == 0) s.f = s.fx0 + 0.5 * tt, s.q = q;  // (lane 0's suffix sum is the whole sum)
-        wsync();
-        WS_PROF(21)
-#ifdef HDSM_DEBUG
-        states(s, R, lane, N);
-        if (blockIdx.x == 2 && lane < q)
-          printf("WS lane %d q %d nw %d act %x lam %.4e resid@xW %.3e f %.6e fx0 %.6e\n", lane, q, nw, s.act[lane], lk,
-                 resid(s, c, s.act[lane], N), s.f, s.fx0);
-#endif
-        return;
-      }
-      const int l = uni(__ffsll((long long)__ballot(ineq && lk == worst)) - 1);
-      WS_PROF(21)
-      drop(s, R, l, q, lane);
-      WS_PROF(22)
-      --q;
-      ++iters;
-    }
-  }
-
-  // working set -= entry at position l (one Householder reflection, see the header comment)
-  static __device__ __forceinline__ void drop(S& s, Regs& R, int l, int q, int lane) {
-    const int t = q - 1;
-    const int row = row_of(lane), c0 = col0_of(lane);
-    const bool on = row_ok(lane);
-    double uv[NC];  // this lane's columns of row l of U
-    {
-      const D2* rl = reinterpret_cast<const D2*>(&s.U[l * LDT + c0]);
-#pragma unroll
-      for (int j = 0; j < NC; j += 2) {
-        const D2 v2 = rl[j / 2];
-        uv[j] = v2.x, uv[j + 1] = v2.y;
-      }
-    }
-    const double ut = s.U[l * LDT + t];
-    double s0 = 0, s1 = 0;
-#pragma unroll
-    for (int j = 0; j < NC; j += 2) s0 += uv[j] * uv[j], s1 += uv[j + 1] * uv[j + 1];
-    const double sigma = (ut > 0 ? -1.0 : 1.0) * sqrt(hsum(s0 + s1));
-    const double beta = 1.0 / (sigma * (sigma - ut));  // 2 / (v^T v), v = u_l - sigma e_t
-    double lam_next = 0.0;
-    int act_next = -1;
-    if (lane >= l && lane < t) lam_next = s.lam[lane + 1], act_next = s.act[lane + 1];
-    if (on) {  // (always true in the split kernel, so the cross-half sums below are executed by every lane)
-      // own row of U (LDS) and of J (registers): x -= (x . v) beta v
-      double ur[NC];
-      const D2* ro = reinterpret_cast<const D2*>(&s.U[row * LDT + c0]);
-#pragma unroll
-      for (int j = 0; j < NC; j += 2) {
-        const D2 v2 = ro[j / 2];
-        ur[j] = v2.x, ur[j + 1] = v2.y;
-      }
-      const double urt = s.U[row * LDT + t];
-      const double jt = hsum(reg_get(R.Jr, t - c0));
-      double wu0 = 0, wu1 = 0, wj0 = 0, wj1 = 0;
-#pragma unroll
-      for (int j = 0; j < NC; j += 2) {
-        wu0 += ur[j] * uv[j], wu1 += ur[j + 1] * uv[j + 1];
-        wj0 += R.Jr[j] * uv[j], wj1 += R.Jr[j + 1] * uv[j + 1];  // uv is zero beyond column t
-      }
-      const double cu = (hsum(wu0 + wu1) - sigma * urt) * beta, cj = (hsum(wj0 + wj1) - sigma * jt) * beta;
-#pragma unroll
-      for (int j = 0; j < NC; ++j) {
-        ur[j] -= cu * uv[j];
-        R.Jr[j] -= cj * uv[j];
-      }
-      reg_set(R.Jr, t - c0, jt - cj * (ut - sigma));  // the freed direction stays in J as a free column
-      wsync();                                        // every lane has read its row before anybody rewrites a slot
-      // rows above l stay, rows l+1..q-1 move up one slot, row l (the dropped entry) disappears
-      if (row != l && row < q) {
-        D2* dst = reinterpret_cast<D2*>(&s.U[(row > l ? row - 1 : row) * LDT + c0]);
-#pragma unroll
-        for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{ur[j], ur[j + 1]};
-      }
-    } else {
-      wsync();
-    }
-    if (lane >= l && lane < t) s.lam[lane] = lam_next, s.act[lane] = act_next;
-    wsync();
-    // structural zeros: column t of every row belongs to the freed direction, slot t is empty again
-    if (lane < NV) s.U[lane * LDT + t] = 0.0;
-    if (on && row == t) {
-      D2* dst = reinterpret_cast<D2*>(&s.U[row * LDT + c0]);
-#pragma unroll
-      for (int j = 0; j < NC; j += 2) dst[j / 2] = D2{0.0, 0.0};
-    }
-    wsync();
-  }
-
-  // Continues from the current (dual feasible) state until no row of the current node is violated.
-  static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
-    const int lane = (int)threadIdx.x;
-    const int n = c.n, N = c.N, max_iters = c.max_iters;
-    const double tol = c.tol;
-    const long long time_ticks = c.time_ticks;  // 0 = no wall-clock budget (the default)
-    double f = s.f;
-    int q = uni(s.q), neq = uni(s.neq_done);
-    int rc = GI_OK;
-    PROF_DECL
-    for (;;) {
-      int ln = lane;  // (lane masks and addresses of the state evaluation and the scan: formed per operation, see hdsm_wave_gib.h)
-      keep_in_loop(ln);
-      int ip;
-      double vip;
-      if (neq < 6) {
-        states(s, R, ln, N);
-        PROF(0)
-        ip = mk_id(K_E, neq);
-        vip = resid(s, c, ip, N);
-      } else {  // (state boxes last, as in hdsm_wave_gib.h)
-        states<1>(s, R, ln, N);
-        PROF(0)
-        select<1>(s, c, R, ln, tol, N, vip, ip);
-        ip = uni(ip);
-        if (ip < 0) {
-          states<2>(s, R, ln, N);
-          select<2>(s, c, R, ln, tol, N, vip, ip);
-          ip = uni(ip);
-        }
-        if (ip < 0) {
-          if (promote_cold(s, lane, tol) > 0) continue;
-          PROF(1)
-          break;
-        }
-        PROF(1)
-      }
-      const bool is_eq = id_kind(ip) == K_E;
-      const double ai = normal_entry(s, R, ip, row_of(lane), N, n);
-      double lam_p = 0;
-      bool stop = false;
-      for (;;) {
-        if (iters >= max_iters) {
-          rc = GI_ITERLIM;
-          stop = true;
-          break;
-        }
-        if (time_ticks > 0 && (long long)wall_clock64() - s.t_start > time_ticks) {
-          rc = GI_TIMELIM;
-          stop = true;
-          break;
-        }
-        ++iters;
-        PROF(2)
-        double dv[NC], dd, zz, dq, zi, ri;
-        direction(s, R, ip, ai, q, lane, dv, dd, zz, dq, zi, ri);
-        PROF(3)
-        const bool dependent = !(zz > 1e-20 * dd) || q >= NV;
-        double t1 = DINF;
-        int l = -1;
-        if (!is_eq) {  // ratio test over the active inequalities (position k lives in lane k)
-          const bool okk = lane < q && id_kind(s.act[lane]) != K_E && ri > 0;
-          const double ratio = okk ? s.lam[lane] / ri : DINF;
-          const double m = -wave_max64(-ratio);
-          if (m < DINF) {
-            t1 = m;
-            l = uni(__ffsll((long long)__ballot(okk && ratio == m)) - 1);
-          }
-        }
-        PROF(4)
-        if (dependent && l < 0) {
-          rc = GI_INFEASIBLE;
-          if (lane == 0) s.inf_id = ip;  // the row that cannot be satisfied together with the current working set
-          stop = true;
-          break;
-        }
-        if (dependent) {  // dual step only; constraint l leaves
-          if (lane < q) s.lam[lane] -= t1 * ri;
-          lam_p += t1;
-          wsync();
-          drop(s, R, l, q, lane);
-          --q;
-          PROF(7)
-          continue;
-        }
-        const double t2 = vip / zz;
-        const bool full = is_eq || t2 <= t1;
-        const double t = full ? t2 : t1;
-        if (lane < n) {
-          R.xi += t * zi;
-          s.x[lane] = R.xi;
-        }
-        if (lane < q) s.lam[lane] -= t * ri;
-        f += t * zz * (0.5 * t + lam_p);
-        lam_p += t;
-        PROF(5)
-        if (full) {
-          // ---- add at position q: Householder on the free columns, d2 -> rho e_q
-          householder_add(s, R, ip, lam_p, q, lane, dv, zz, dq, zi, ri);
-          PROF(6)
-          ++q;
-          if (is_eq) ++neq;
-          break;
-        }
-        wsync();
-        drop(s, R, l, q, lane);
-        PROF(7)
-        --q;
-        states(s, R, lane, N);
-        vip = resid(s, c, ip, N);
-        if (f >= f_cut) {
-          rc = GI_CUTOFF;
-          if (lane == 0) s.inf_id = ip;  // (gi_run turns a cut on the box bound into a proof of infeasibility: the row on its way in)
-          stop = true;
-          break;
-        }
-      }
-      if (stop) break;
-      if (f >= f_cut) {
-        rc = GI_CUTOFF;
-        if (lane == 0) s.inf_id = ip;
-        break;
-      }
-    }
-    wsync();
-    if (lane == 0) s.f = f, s.q = q, s.neq_done = neq, s.cmd = 0;
-    if (blockDim.x > 64) __syncthreads();  // releases the helper waves (they leave on cmd == 0)
-    else wsync();
-    return rc;
-  }
-
-  // snapshots: J rows from registers, U rows / multipliers / ids / x from LDS; layout [row j][lane]
+  // size of a snapshot of the solver state (hdsm_wave_gib.h writes it: J slots, U rows, multipliers, ids, x, f, q)
   static constexpr int SNAP_DOUBLES = (2 * NV + 3) * NV + 2;
-  static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
-    keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
-    const int row = row_of(lane), c0 = col0_of(lane);
-    if (row_ok(lane)) {
-      if (save) {
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-          buf[(c0 + j) * NV + row] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-          R.Jr[j] = buf[(c0 + j) * NV + row], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
-      }
-    }
-    if (lane < NV) {
-      if (save) {
-        buf[2 * NV * NV + lane] = R.xi;
-        buf[(2 * NV + 1) * NV + lane] = s.lam[lane];
-        buf[(2 * NV + 2) * NV + lane] = (double)s.act[lane];
-      } else {
-        R.xi = buf[2 * NV * NV + lane];
-        s.lam[lane] = buf[(2 * NV + 1) * NV + lane];
-        s.act[lane] = (int)buf[(2 * NV + 2) * NV + lane];
-        s.x[lane] = R.xi;
-      }
-    }
-    if (lane == 0) {
-      if (save) {
-        buf[(2 * NV + 3) * NV] = s.f;
-        buf[(2 * NV + 3) * NV + 1] = (double)s.q;
-      } else {
-        s.f = buf[(2 * NV + 3) * NV];
-        s.q = (int)buf[(2 * NV + 3) * NV + 1];
-      }
-    }
-    wsync();
-  }
 };
 
 }  // namespace hdsm

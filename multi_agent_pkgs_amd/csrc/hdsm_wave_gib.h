@@ -23,7 +23,7 @@
 //     J is ever addressed by a run-time index (the old layout paid a 16-deep select chain per access).
 //
 // Everything that does not touch J's layout (state evaluation, violation scan, helper waves, neighbour sweep, residuals) is
-// inherited from WaveGI<32, CMAX>. NV = 48 (H > 10) keeps the one-lane-per-row code of hdsm_wave_gi.h.
+// inherited from WaveGI<NV, CMAX>. NV = 48 (H > 10): the same source with one lane per row and three blocks of slots (below).
 #pragma once
 #include "hdsm_wave_gi.h"
 
@@ -316,7 +316,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
     wsync();
   }
 
-  // ---- warm start (see hdsm_wave_gi.h): the guess is put into the factorisation without taking steps, then the S-pair in
+  // ---- warm start (described in hdsm_wave_gi.h): the guess is put into the factorisation without taking steps, then the S-pair in
   // closed form  t = U^T v, lambda = U t, x_W = x0 + J1 t, f_W = f(x0) + |t|^2 / 2
   using WarmPre = typename Base::WarmPre;
   using Base::warm_prefetch;
