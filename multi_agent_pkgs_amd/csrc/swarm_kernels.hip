@@ -1,11 +1,12 @@
 // swarm_kernels.hip — the device-resident closed loop: the planner state of a shard of agents (hdsm_sw::AgentS) lives in HBM and
 // one replan round is a chain of launches on ONE stream with no host round trip:
 //   k_corridor   GenerateSafeCorridor (AC:1236-1447; row f2: voxel decomposition on a window of the world grid) + the polyline
-//                of this round's reference (AC:1459-1496)                                        one thread per agent
+//                of this round's reference (AC:1459-1496) + the solver inputs that do not depend on the reference (id, state,
+//                corridor rows in the layouts of hdsm.h)                                          one wavefront per agent
 //   k_reference  GenerateReferenceTrajectory's neighbour speed term + SamplePath (row f1)       hdsm_reference_device
-//   k_inputs     the new reference into the agent state, solver inputs in the layouts of hdsm.h  one thread per agent
 //   k_replan     planes + MIQP (the hot path)                                                   hdsm_replan_device
-//   k_commit     read-back, shift fallback, increment check, state advance, published record    one thread per agent
+//   k_commit     the new reference into the agent state, read-back, shift fallback, increment check, state advance, published
+//                record                                                                          one wavefront per agent
 //   exchange     ONE RCCL all-gather (hdsm_exchange_device), or a local copy on a single rank
 // The per-agent functions are the SAME source as the host mirror (swarm_core.h), which is how the two loops are compared in
 // tests/test_gpu_configs.py. AC = multi_agent_planner/src/agent_class.cpp of the reference.
@@ -234,7 +235,10 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
   if (lane == 0) ag.n_poly = n_poly;
 }
 
-__global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, double* path, int32_t* n_path) {
+// (the solver's inputs that do not depend on the reference — id, state, the corridor just built — leave with this kernel: a kernel
+// of their own cost 5 us per round in the live loop)
+__global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, double* path, int32_t* n_path, int32_t* agent_id,
+                                                 double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A, double* b) {
   __shared__ V3 path_s[hdsm_sw::PATH_PTS + 2];
   __shared__ V3 poly_s[PTS];
   __shared__ int np_s;
@@ -260,6 +264,16 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, d
   const int np = np_s;
   if (lane == 0) n_path[k] = np;
   for (int i = lane; i < PTS * 3; i += 64) path[(size_t)k * PTS * 3 + i] = poly_s[(i / 3) < np ? i / 3 : np - 1][i % 3];
+  const int P = c.P, RS = c.RS, npo = ag.n_poly;
+  if (lane < 9) state_curr[9 * (size_t)k + lane] = ag.state_curr[lane];
+  if (lane == 0) agent_id[k] = ag.id, n_poly[k] = npo;
+  if (lane < P) n_rows[(size_t)k * P + lane] = lane < npo ? ag.polys[lane].rows : 0;
+  for (int t = lane; t < P * RS; t += 64) {
+    const int j = t / RS, r = t % RS;
+    const bool hr = j < npo && r < ag.polys[j].rows;
+    for (int q = 0; q < 3; ++q) A[((size_t)k * P * RS + t) * 3 + q] = hr ? ag.polys[j].A[r][q] : 0.0;
+    b[(size_t)k * P * RS + t] = hr ? ag.polys[j].b[r] : 0.0;
+  }
 }
 
 // the map-dependent half of the reference (row f1 remainder): ComputePathVelocity's voxel term before k_reference ...
@@ -290,30 +304,9 @@ __global__ __launch_bounds__(64) void k_keep_free(Cfg c, int n, const AgentS* ag
     }
 }
 
-__global__ __launch_bounds__(64) void k_inputs(Cfg c, int n, AgentS* agents, const double* ref_full, const double* path_vel,
-                                               int32_t* agent_id, double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A,
-                                               double* b) {
-  // one wavefront per agent: the lanes share the copies (the new reference into the agent state, the solver inputs out)
-  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
-  if (k >= n) return;
-  AgentS& ag = agents[k];
-  const int N = c.N, P = c.P, RS = c.RS;
-  for (int t = lane; t < (N + 1) * 6; t += 64) ag.traj_ref[t / 6][t % 6] = ref_full[(size_t)k * (N + 1) * 6 + t];
-  if (lane < 9) state_curr[9 * (size_t)k + lane] = ag.state_curr[lane];
-  if (lane == 0) ag.n_ref = N + 1, ag.path_vel = path_vel[k], agent_id[k] = ag.id, n_poly[k] = ag.n_poly;
-  const int np = ag.n_poly;
-  if (lane < P) n_rows[(size_t)k * P + lane] = lane < np ? ag.polys[lane].rows : 0;
-  for (int t = lane; t < P * RS; t += 64) {
-    const int j = t / RS, r = t % RS;
-    const bool hr = j < np && r < ag.polys[j].rows;
-    for (int q = 0; q < 3; ++q) A[((size_t)k * P * RS + t) * 3 + q] = hr ? ag.polys[j].A[r][q] : 0.0;
-    b[(size_t)k * P * RS + t] = hr ? ag.polys[j].b[r] : 0.0;
-  }
-}
-
 __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* agents, const double* traj, const double* ctrl,
                                                const uint8_t* used, const int32_t* status, double* plans_local, int32_t* fails,
-                                               uint8_t* has_direct) {
+                                               uint8_t* has_direct, const double* ref_full, const double* path_vel) {
   // one wavefront per published record. Lane 0 does the read-back / fallback; the increment check — a walk of ~100 samples per
   // metre of reference — is split by reference segment over the lanes (the samples of a segment do not depend on the others,
   // hdsm_sw::increment_segment_min), the minima meet in a wave reduction; then all lanes write the record.
@@ -326,6 +319,9 @@ __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* ag
   __syncthreads();
   if (k < n) {
     AgentS& ag = agents[k];
+    // the reference of this round becomes traj_ref_curr_ (the increment check below and the next round's corridor read it)
+    for (int t = lane; t < (N + 1) * 6; t += 64) ag.traj_ref[t / 6][t % 6] = ref_full[(size_t)k * (N + 1) * 6 + t];
+    if (lane == 0) ag.n_ref = N + 1, ag.path_vel = path_vel[k];
     {  // hdsm_sw::commit_copy with the copies spread over the lanes (one lane doing them was a chain of ~130 dependent
        // global accesses, 35 of the kernel's 40 us): flat element e of traj_curr[][9] / ctrl_curr[][3]
       const int st = status[k];
@@ -552,7 +548,8 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
     }
   } done_once(d->solver, st);
   if (n > 0) {
-    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? SLAB : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath);
+    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? SLAB : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath, d->d_id, d->d_state,
+                       d->d_npoly, d->d_nrows, d->d_A, d->d_b);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_vel_cap, dim3(gb), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
@@ -565,9 +562,6 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
       hipLaunchKernelGGL(k_keep_free, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_ref, d->d_pv);
       HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_inputs, dim3((unsigned)n), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_pv, d->d_id, d->d_state, d->d_npoly,
-                       d->d_nrows, d->d_A, d->d_b);
-    HIP_TRY(hipGetLastError());
     rc = hdsm_replan_device(d->solver, n, G, d->d_id, d->d_state, d->d_ref, d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_plans, d->d_has,
                             d->d_traj, d->d_ctrl, d->d_used, d->d_status, d->d_obj, st);
     if (rc) return fail(rc, std::string("hdsm_replan_device: ") + hdsm_last_error());
@@ -576,7 +570,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   // agent k — and the flags with them; several ranks: into the send buffer of the ONE all-gather)
   const bool direct = d->world == 1;
   hipLaunchKernelGGL(k_commit, dim3((unsigned)(d->per > 0 ? d->per : 1)), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
-                     direct ? d->d_plans : d->d_local, d->d_fails, direct ? d->d_has : nullptr);
+                     direct ? d->d_plans : d->d_local, d->d_fails, direct ? d->d_has : nullptr, d->d_ref_full, d->d_pv);
   HIP_TRY(hipGetLastError());
   if (!direct) {
     const int rc = hdsm_exchange_device(comm, d->per, d->d_local, d->d_plans, d->d_has, st);
