@@ -249,9 +249,18 @@ struct RefArgs {
 // Positions of steps 0..N of every published plan, packed, and their enclosing sphere: 16 lanes per agent (N + 1 <= 17: lane
 // 15 also takes step 16). The velocity limit reads 24 B per (neighbour, step) from here instead of a 72-B stride of the
 // records, and skips a neighbour whose sphere is further away than the closest one found.
+// In the device-resident loop (one stream, same plans buffer for the reference and the solve of a round) this kernel also leaves
+// what k_plan_prepass would compute a few microseconds later from the same records — positions of steps 1..N (`pos`), their
+// bounding sphere (`bounds`, may be null), the launch order of the solve (one extra workgroup) — and the solve skips its pre-pass.
 __global__ __launch_bounds__(256) void k_ref_pack(int N, int n_rob, const double* __restrict__ plans,
                                                    const uint8_t* __restrict__ has_plan, double* __restrict__ rpos,
-                                                   double* __restrict__ rsph) {
+                                                   double* __restrict__ rsph, double* __restrict__ pos, double* __restrict__ bounds,
+                                                   int n_order, const int32_t* __restrict__ key_prev, const int32_t* __restrict__ agent_id,
+                                                   int32_t* __restrict__ order) {
+  if (order != nullptr && blockIdx.x == gridDim.x - 1) {
+    launch_order_block(n_order, key_prev, agent_id, order);
+    return;
+  }
   const int tid = (int)threadIdx.x, i = tid & 15;
   const int k = (int)blockIdx.x * 16 + (tid >> 4);
   const bool live = k < n_rob;
@@ -269,6 +278,47 @@ __global__ __launch_bounds__(256) void k_ref_pack(int N, int n_rob, const double
     if (live && st <= N && (u == 0 || i == 0)) {
       double* pk = rpos + ((int64_t)k * (N + 1) + st) * 3;
       pk[0] = p[u][0], pk[1] = p[u][1], pk[2] = p[u][2];
+      if (pos != nullptr && st >= 1) {
+        double* pq = pos + ((int64_t)k * N + st - 1) * 3;
+        pq[0] = p[u][0], pq[1] = p[u][1], pq[2] = p[u][2];
+      }
+    }
+  }
+  if (bounds != nullptr) {  // the sphere of steps 1..N, exactly as k_plan_prepass forms it
+    const bool in0 = on[0] && i >= 1;
+    double lo[3], hi[3];
+    for (int ax = 0; ax < 3; ++ax) {
+      lo[ax] = in0 ? p[0][ax] : 1e300, hi[ax] = in0 ? p[0][ax] : -1e300;
+      if (on[1]) lo[ax] = fmin(lo[ax], p[1][ax]), hi[ax] = fmax(hi[ax], p[1][ax]);
+    }
+    for (int off = 8; off > 0; off >>= 1)
+      for (int ax = 0; ax < 3; ++ax) {
+        lo[ax] = fmin(lo[ax], __shfl_xor(lo[ax], off, 16));
+        hi[ax] = fmax(hi[ax], __shfl_xor(hi[ax], off, 16));
+      }
+    const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]), cz = 0.5 * (lo[2] + hi[2]);
+    double r2 = 0.0;
+    if (in0) {
+      const double ux = p[0][0] - cx, uy = p[0][1] - cy, uz = p[0][2] - cz;
+      r2 = ux * ux + uy * uy + uz * uz;
+    }
+    if (on[1]) {
+      const double ux = p[1][0] - cx, uy = p[1][1] - cy, uz = p[1][2] - cz;
+      r2 = fmax(r2, ux * ux + uy * uy + uz * uz);
+    }
+    bool finite = r2 == r2;
+    for (int off = 8; off > 0; off >>= 1) {
+      r2 = fmax(r2, __shfl_xor(r2, off, 16));
+      finite = finite && __shfl_xor((int)finite, off, 16);
+    }
+    if (live && i == 0) {
+      double4 out = {0.0, 0.0, 0.0, -1.0};
+      if (has) {
+        out.x = cx, out.y = cy, out.z = cz;
+        out.w = sqrt(r2) * (1.0 + 1e-9);
+        if (!finite || !(out.w >= 0.0) || !(out.w < 1e299)) out.w = 1e300;
+      }
+      *reinterpret_cast<double4*>(bounds + 4 * (int64_t)k) = out;
     }
   }
   double lo[3], hi[3];
@@ -574,6 +624,9 @@ struct Handle {
   uint8_t *d_has = nullptr, *d_used = nullptr;
   hipStream_t stream = nullptr;
   hipStream_t last_stream = nullptr;
+  const double* prepass_for = nullptr;  // device loop: the plans buffer k_ref_pack has just packed for the solve as well (launch() skips its pre-pass once)
+  int prepass_n_rob = 0, prepass_n_inst = 0;
+  bool prepass_ordered = false;
   bool defer_done = false;  // the device-resident loop records ev_done once per round (hdsm_internal_record_done), not once per call
 };
 
@@ -813,7 +866,13 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.bounds = nullptr, a.pos = nullptr, a.order = nullptr;
   const bool ordered = a.warm != nullptr && h->order_min > 0 && a.n_inst >= h->order_min;
   if (ordered) a.order = h->d_order;
-  if (a.l1_rows == nullptr) {
+  const bool packed = h->defer_done && a.l1_rows == nullptr && h->prepass_for == a.plans && h->prepass_n_rob == a.n_rob &&
+                      h->prepass_n_inst == a.n_inst && h->prepass_ordered == ordered;
+  h->prepass_for = nullptr;  // (good for one solve: the plans change with the commit that follows it)
+  if (packed) {
+    a.pos = h->d_pos;
+    a.bounds = a.n_rob >= h->bounds_min ? h->d_bounds : nullptr;
+  } else if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
     hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
                        h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, a.agent_id, ordered ? h->d_order : nullptr);
@@ -1396,7 +1455,16 @@ int hdsm_reference_device(void* handle, const hdsm_ref_config* cfg, int32_t n_in
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   if (h->launched && st != h->last_stream) HIP_TRY(hipStreamWaitEvent(st, h->ev_done, 0));
   h->last_stream = st;
-  hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16), dim3(256), 0, st, h->N, n_rob, plans_all, has_plan, h->d_rpos, h->d_rsph);
+  {
+    // device-resident loop (defer_done: one stream, the solve of this round follows on the same plans): the pre-pass rides along
+    const bool with_pre = h->defer_done;
+    const bool ordered = with_pre && h->prm.warm_start && h->order_min > 0 && n_inst >= h->order_min;
+    const bool pre = n_rob >= h->bounds_min;
+    hipLaunchKernelGGL(k_ref_pack, dim3((n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, n_rob, plans_all, has_plan, h->d_rpos, h->d_rsph,
+                       with_pre ? h->d_pos : nullptr, with_pre && pre ? h->d_bounds : nullptr, n_inst, h->d_stats + 7 * h->max_inst, agent_id,
+                       ordered ? h->d_order : nullptr);
+    h->prepass_for = with_pre ? plans_all : nullptr, h->prepass_n_rob = n_rob, h->prepass_n_inst = n_inst, h->prepass_ordered = ordered;
+  }
   HIP_TRY(hipGetLastError());
   if (n_inst >= 256) hipLaunchKernelGGL(k_reference<64>, dim3(n_inst), dim3(64), 0, st, a);
   else hipLaunchKernelGGL(k_reference<256>, dim3(n_inst), dim3(256), 0, st, a);
