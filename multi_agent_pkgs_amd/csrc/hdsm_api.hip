@@ -783,15 +783,20 @@ __global__ __launch_bounds__(256) void k_fetch(FetchArgs a) {
     return;
   }
   const int k = blk, P = a.P, RS = a.RS;
+  __shared__ int32_t rows_s[HDSM_MAX_POLY];  // (read once over PCIe, not once per entry)
   if (tid == 0) a.d_agent[k] = a.agent_id[k];
   const int np = a.n_poly[k];
   if (tid == 1) a.d_npoly[k] = np;
   if (tid < 9) a.d_state[(int64_t)k * 9 + tid] = a.state[(int64_t)k * 9 + tid];
+  if (tid < P) {
+    const int32_t nr = a.n_rows[(int64_t)k * P + tid];
+    rows_s[tid] = nr, a.d_nrows[(int64_t)k * P + tid] = nr;
+  }
   for (int e = tid; e < 6 * a.N; e += 256) a.d_ref[(int64_t)k * 6 * a.N + e] = a.ref[(int64_t)k * 6 * a.N + e];
-  if (tid < P) a.d_nrows[(int64_t)k * P + tid] = a.n_rows[(int64_t)k * P + tid];
+  __syncthreads();
   for (int e = tid; e < P * RS * 4; e += 256) {  // entry (polyhedron j, row r, component c): c < 3 -> A, c = 3 -> b
     const int c = e & 3, jr = e >> 2, j = jr / RS, r = jr % RS;
-    if (j >= np || r >= a.n_rows[(int64_t)k * P + j]) continue;
+    if (j >= np || r >= rows_s[j]) continue;
     const int64_t row = ((int64_t)k * P + j) * RS + r;
     if (c < 3) a.d_A[row * 3 + c] = a.A[row * 3 + c];
     else a.d_b[row] = a.b[row];
