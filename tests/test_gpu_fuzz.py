@@ -7,6 +7,8 @@ second order directly (the enumeration in step order needs minutes per instance 
 LIMIT is never accepted as a verdict. Every case also goes through the OTHER launch forms the handle would pick for large
 batches or deep trees — the kernels that share a CU (reduced staging area, with the rescue pass for instances that overflow
 it) and the three-kernel subtree split with a two-node budget — forced here by the HDSM_* environment knobs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 K = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")
 THREADS = 64
-N_CASES = 100
+N_CASES = int(os.environ.get("HDSM_FUZZ_CASES", "100"))  # (the round's evidence run uses 500: profiles/r04_fuzz.txt)
 
 
 def _case(rng, case):
