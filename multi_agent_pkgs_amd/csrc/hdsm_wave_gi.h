@@ -392,19 +392,37 @@ struct WaveGI {
     const int aj = lane < N ? s.assign[lane] : -1;
     const int nr = lane < S::PM ? s.sp_rows[lane] : 0;
     unsigned long long am = __ballot(aj >= 0);
+    // One assigned step = at most 2 x 32 rows (both end points of the segment): one item per lane. Deep in a tree a dozen steps are
+    // assigned and their rows were a chain of as many LDS round trips per pick; four steps go through a trip now, loads first.
+    constexpr int UA = 4;
     while (am != 0ull) {
-      const int i = __ffsll((long long)am) - 1;
-      am &= am - 1ull;
-      const int j = __builtin_amdgcn_readlane(aj, i), rows = __builtin_amdgcn_readlane(nr, j);
-      for (int t = lane; t < 2 * rows; t += 64) {
-        const int e = t >= rows ? 1 : 0, r = t - e * rows;
-        if (i + e <= pinned) continue;  // (rows on input-independent points only gate the choice: leaf_check)
-        const double* row = s.sp[j][r];
-        const double* pm = s.st[i + e];
-        const double vv = row[0] * pm[0] + row[1] * pm[1] + row[2] * pm[2] - row[3];
-        if (vv > tol) {
-          const double key = norm ? (double)((float)vv * plane_weight(s, row[0], row[1], row[2], i + e)) : vv;
-          if (key > pk.key) pk.key = key, pk.v = vv, pk.id = mk_id(K_P, (i << 7) | (e << 6) | r);
+      int st[UA], id0[UA];
+      bool on[UA];
+      D2 a01[UA], a23[UA];
+      double px[UA], py[UA], pz[UA];
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        on[u] = false, st[u] = 1, id0[u] = 0;
+        const double* row = s.sp[0][0];
+        if (am != 0ull) {
+          const int i = __ffsll((long long)am) - 1;
+          am &= am - 1ull;
+          const int j = __builtin_amdgcn_readlane(aj, i), rows = __builtin_amdgcn_readlane(nr, j);
+          const int e = lane >= rows ? 1 : 0, r = lane - e * rows;
+          on[u] = lane < 2 * rows && i + e > pinned;  // (rows on input-independent points only gate the choice: leaf_check)
+          st[u] = on[u] ? i + e : 1, id0[u] = mk_id(K_P, (i << 7) | (e << 6) | r);
+          row = s.sp[j][on[u] ? r : 0];
+        }
+        a01[u] = *reinterpret_cast<const D2*>(row), a23[u] = *reinterpret_cast<const D2*>(row + 2);
+        const double* pm = s.st[st[u]];
+        px[u] = pm[0], py[u] = pm[1], pz[u] = pm[2];
+      }
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        const double vv = a01[u].x * px[u] + a01[u].y * py[u] + a23[u].x * pz[u] - a23[u].y;
+        if (on[u] && vv > tol) {
+          const double key = norm ? (double)((float)vv * plane_weight(s, a01[u].x, a01[u].y, a23[u].x, st[u])) : vv;
+          if (key > pk.key) pk.key = key, pk.v = vv, pk.id = id0[u];
         }
       }
     }
