@@ -4,6 +4,9 @@
 // There is no CPU path in this library: without a HIP device hdsm_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <functional>
+
 #include <cfloat>
 #include <rccl/rccl.h>
 
@@ -967,6 +970,35 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, h->P, K, a, b);
     HIP_TRY(hipGetLastError());
+#ifdef HDSM_SPLIT_TRACE  // development aid (scripts/gpu_split_trace.sh): how the nodes of the handed-over instances spread over their sub-blocks
+    {
+      HIP_TRY(hipStreamSynchronize(st));
+      std::vector<int32_t> info(2 * (size_t)a.n_inst), nd(GI), it(GI);
+      HIP_TRY(hipMemcpy(info.data(), a.split_info, info.size() * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(it.data(), ss, GI * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(nd.data(), ss + GI, GI * 4, hipMemcpyDeviceToHost));
+      int handed = 0, working = 0, deep_max = 0;
+      long long nodes_total = 0, iters_total = 0;
+      std::vector<int> tops;
+      for (int k = 0; k < a.n_inst; ++k) {
+        if (!(info[2 * (size_t)k] & 1)) continue;
+        ++handed;
+        int best = 0;
+        for (int j = 0; j < K; ++j) {
+          const int v = nd[(size_t)k * K + j];
+          working += v > 0, nodes_total += v, iters_total += it[(size_t)k * K + j];
+          best = v > best ? v : best;
+        }
+        tops.push_back(best);
+        deep_max = best > deep_max ? best : deep_max;
+      }
+      std::sort(tops.begin(), tops.end(), std::greater<int>());
+      std::fprintf(stderr, "HDSM_SPLIT_TRACE handed over %d of %d instances, %d sub-blocks of %d worked, nodes %lld iters %lld, largest sub-block %d nodes; top instances' largest sub-block:",
+                   handed, a.n_inst, working, handed * K, nodes_total, iters_total, deep_max);
+      for (size_t q = 0; q < tops.size() && q < 12; ++q) std::fprintf(stderr, " %d", tops[q]);
+      std::fprintf(stderr, "\n");
+    }
+#endif
   }
   if (rc) return rc;
   // Staging overflow. The kernels that share a CU have a fraction of the staging rows of the one-per-CU kernel (384 / 768 / 320
