@@ -117,6 +117,11 @@ typedef struct hdsm_params {
    * set next is the most violated one in the metric of the problem (violation / sqrt(a' Z a)) / the most violated one.
    * HDSM_BOX_CUT 1 (default) / 0: a dual objective above the largest objective any point of the input box can have ends an
    * active-set run as infeasible / only the formal proof does.
+   * HDSM_QUAD_MIN: batches of at least this many instances with n_hor <= 10 run FOUR 128-thread workgroups per CU (small
+   * LDS layout; default 3 x compute units + 1, 0 = never). HDSM_SCANNER 1 (default) / 0: in workgroups of more than one
+   * wavefront the second one evaluates the trajectory and picks the row that enters next while the first applies the update
+   * of the operation before / the iterating wavefront does both. HDSM_DUO48_ROWS 736 (default) / 320: staging rows of the
+   * two-per-CU kernel for n_hor > 10 (the smaller instantiation exists for the staging-overflow test).
    * None of these changes an answer that is HDSM_OPTIMAL.)                                                       */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and
