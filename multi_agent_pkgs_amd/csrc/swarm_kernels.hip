@@ -82,38 +82,42 @@ __device__ void build_occ2(const Cfg& c, const V3& origin, const int seed[3], ui
 __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, uint32_t* occ2, V3* path, int lane) {
   using namespace hdsm_sw;
   const int P = c.P, N = c.N, RS = c.RS;
-  __shared__ int sh_npoly, sh_npath;
-  if (lane == 0) {  // keep-last / keep-used (AC:1253-1282) and the path ahead (AC:1286-1290): a handful of operations
-    ag.corridor_rc = 0;
-    Poly* fresh = ag.polys;
-    int n_poly = 0;
+  __shared__ int sh_npath;
+  // keep-last / keep-used (AC:1253-1282), by the whole wavefront: lane j tests point j of the current plan against the last
+  // polyhedron (the verdict is a ballot — the serial loop's early exit does not change it) and a polyhedron that moves to another
+  // slot is copied by all lanes (1 KB: one lane copying it was a chain of a hundred global accesses per round)
+  static_assert(sizeof(Poly) % 8 == 0, "copied as 8-byte words");
+  auto copy_poly = [&](Poly* dst, const Poly* src) {
+    const unsigned long long* sw = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* dw = reinterpret_cast<unsigned long long*>(dst);
+    for (int e = lane; e < (int)(sizeof(Poly) / 8); e += 64) dw[e] = sw[e];
+  };
+  int n_poly = 0;
+  {
+    const int np0 = ag.n_poly;
     bool kept_last = false;
-    if (ag.n_poly > 0) {
-      bool all_in = true;
-      if (ag.has_traj)
-        for (int j = 0; j <= N; ++j)
-          if (!inside(ag.polys[ag.n_poly - 1], V3{{ag.traj_curr[j][0], ag.traj_curr[j][1], ag.traj_curr[j][2]}})) {
-            all_in = false;
-            break;
-          }
-      if (all_in) {
-        if (ag.n_poly - 1 != 0) fresh[0] = ag.polys[ag.n_poly - 1];
+    if (np0 > 0) {
+      bool ok = true;
+      if (ag.has_traj && lane <= N) ok = inside(ag.polys[np0 - 1], V3{{ag.traj_curr[lane][0], ag.traj_curr[lane][1], ag.traj_curr[lane][2]}});
+      if (__ballot(!ok) == 0ull) {
+        if (np0 - 1 != 0) copy_poly(&ag.polys[0], &ag.polys[np0 - 1]);
         n_poly = 1, kept_last = true;
       }
     }
-    if (ag.n_poly > 0 && !kept_last)
-      for (int i = 0; i < P && i < ag.n_poly; ++i)
+    if (np0 > 0 && !kept_last)
+      for (int i = 0; i < P && i < np0; ++i)
         if (ag.poly_used[i]) {
-          if (n_poly != i) fresh[n_poly] = ag.polys[i];
+          if (n_poly != i) copy_poly(&ag.polys[n_poly], &ag.polys[i]);
           ++n_poly;
         }
+  }
+  if (lane == 0) {  // the path ahead (AC:1286-1290): a handful of operations
+    ag.corridor_rc = 0;
     const V3 path_head = ag.n_ref == 0 ? ag.path[0] : V3{{ag.traj_ref[0][0], ag.traj_ref[0][1], ag.traj_ref[0][2]}};
     path[0] = {{ag.state_curr[0], ag.state_curr[1], ag.state_curr[2]}};
     sh_npath = 1 + path_ahead(ag, path_head, path + 1);
-    sh_npoly = n_poly;
   }
   __syncthreads();
-  int n_poly = sh_npoly;
   const int n_path = sh_npath;
   const double vs = c.voxel_size;
   V3 origin;
