@@ -572,6 +572,35 @@ CD_HD double increment_segment_min(const AgentS& ag, int seg, const V3& pt) {
   }
   return best;
 }
+// The same minimum in closed form, to about 1e-11 m: the samples of a segment lie on the straight line from ref[seg] to
+// ref[seg + 1] at multiples of 0.01 m (the literal walk accumulates a rounding of a few ulp of the position per step — with
+// ~100 steps per segment and positions of hundreds of metres that is ~1e-11 m), then the end point; the distance to `pt` along
+// a line is convex, so the closest sample is one of the two next to the foot of the perpendicular, or the end point. Whether the
+// count of full steps is m or m + 1 when |segment| / 0.01 is within rounding of an integer does not matter: the extra sample
+// then coincides with the end point to the same accuracy. The caller uses this value only when the decision of
+// increment_from_minima does not depend on 1e-9 m, and walks the segment literally otherwise (k_commit).
+CD_HD double increment_segment_min_closed_form(const AgentS& ag, int seg, const V3& pt) {
+  const V3 s0 = {{ag.traj_ref[seg][0], ag.traj_ref[seg][1], ag.traj_ref[seg][2]}};
+  const V3 target = {{ag.traj_ref[seg + 1][0], ag.traj_ref[seg + 1][1], ag.traj_ref[seg + 1][2]}};
+  const double samp = 0.01;
+  const V3 diff = sub(target, s0);
+  const double len = norm(diff);
+  double best = norm(sub(pt, target));
+  if (!(len > samp)) return best;  // (a single sample: the end point)
+  const V3 dir = {{diff[0] / len, diff[1] / len, diff[2] / len}};
+  const double foot = dot(sub(pt, s0), dir) / samp;
+  const double m = ceil(len / samp) - 1.0;  // full steps before the end point (>= 1 here)
+  double k0 = floor(foot);
+  k0 = k0 < 1.0 ? 1.0 : (k0 > m ? m : k0);
+  const double k1 = k0 + 1.0 > m ? m : k0 + 1.0;
+  for (int u = 0; u < 2; ++u) {
+    const double t = (u == 0 ? k0 : k1) * samp;
+    const V3 q = {{s0[0] + t * dir[0], s0[1] + t * dir[1], s0[2] + t * dir[2]}};
+    const double d = norm(sub(pt, q));
+    if (d < best) best = d;
+  }
+  return best;
+}
 // check_increment from the per-segment minima: the reference advances iff some sample after the starting point is STRICTLY
 // closer to p_1 than the starting point (then progress_final > 0) and the closest sample is within thresh_dist.
 CD_HD int increment_from_minima(const Cfg& c, double d_start, double d_min_rest) {

@@ -707,6 +707,22 @@ int hdsm_swarm_yaw(void* swarm, int32_t yaw_idx, double k_p_yaw, double* yaw_out
   return HDSM_OK;
 }
 
+// Test hook (tests/test_host.py; not in include/): the minimum distance of the samples of the increment check (AC:569-585) to `pt`,
+// per segment, from the literal 1-cm walk and from the closed form the device's k_commit tries first. ref [n_ref][3].
+extern "C" int hdsm_internal_increment_minima(const double* ref, int32_t n_ref, const double* pt, double* literal, double* closed_form) {
+  if (!ref || !pt || n_ref < 2 || n_ref > hdsm::MAXH + 1) return HDSM_ERR_BAD_ARG;
+  static thread_local AgentS ag;
+  ag.n_ref = n_ref;
+  for (int i = 0; i < n_ref; ++i)
+    for (int k = 0; k < 3; ++k) ag.traj_ref[i][k] = ref[3 * i + k];
+  const hdsm_sw::V3 p = {{pt[0], pt[1], pt[2]}};
+  for (int seg = 0; seg + 1 < n_ref; ++seg) {
+    if (literal) literal[seg] = hdsm_sw::increment_segment_min(ag, seg, p);
+    if (closed_form) closed_form[seg] = hdsm_sw::increment_segment_min_closed_form(ag, seg, p);
+  }
+  return HDSM_OK;
+}
+
 int hdsm_swarm_view(void* swarm, int32_t k, double* traj_curr, int32_t* n_traj, double* traj_ref, int32_t* n_ref, double* path, int32_t pmax,
                     int32_t* n_path, int32_t* n_poly, int32_t* poly_rows, double* poly_A, double* poly_b, double* poly_seeds, double pos[3]) {
   Swarm* sw = static_cast<Swarm*>(swarm);

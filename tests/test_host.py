@@ -565,3 +565,28 @@ def test_yaw_follows_the_reference_with_the_p_controller_of_the_reference():
     assert abs(got[1]) > 0.5                              # towards -x: turning (through the wrap branch) towards +-pi
     assert got[2] < -0.5                                  # towards -y
     assert abs(got[3]) < 1.6                              # (goal 0.2 m away: the yaw freezes once the reference point is within sqrt(0.1) m)
+
+
+def test_closed_form_of_the_increment_check_stays_within_1e_10_of_the_literal_walk():
+    """k_commit (device loop) first takes the minimum distance of the increment check's samples (AC:569-585: a walk in 1-cm steps
+    along the reference) in closed form and walks literally only when the decision hangs on less than 1e-9 m. The closed form
+    must then be within that margin of the literal walk: random references at swarm-scale coordinates, points near and far,
+    segments shorter than a step, segments whose length is a multiple of the step."""
+    import ctypes as C
+    from multi_agent_pkgs_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(3)
+    d = C.POINTER(C.c_double)
+    worst = 0.0
+    for case in range(400):
+        n_ref = int(rng.integers(2, 12))
+        base = rng.uniform(-300, 300, 3)
+        steps = rng.uniform(-1.0, 1.0, (n_ref - 1, 3)) * rng.choice([0.002, 0.3, 0.9, 1.5])
+        if case % 7 == 0:
+            steps = np.tile(np.array([[0.05, 0.0, 0.0]]), (n_ref - 1, 1))       # |segment| / 0.01 an integer
+        ref = np.ascontiguousarray(np.vstack([base, base + np.cumsum(steps, 0)]))
+        pt = np.ascontiguousarray(ref[rng.integers(0, n_ref)] + rng.normal(0, rng.choice([1e-3, 0.05, 2.0]), 3))
+        lit, cf = np.zeros(n_ref - 1), np.zeros(n_ref - 1)
+        assert L.hdsm_internal_increment_minima(ref.ctypes.data_as(d), n_ref, pt.ctypes.data_as(d), lit.ctypes.data_as(d), cf.ctypes.data_as(d)) == 0
+        worst = max(worst, float(np.abs(lit - cf).max()))
+    assert worst < 1e-10, worst
