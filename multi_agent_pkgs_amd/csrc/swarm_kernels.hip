@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "../../include/hdsm.h"
 #include "../../include/hdsm_swarm.h"
@@ -77,6 +78,24 @@ __device__ void build_occ2(const Cfg& c, const V3& origin, const int seed[3], ui
     }
     occ2[w] = word;
   }
+}
+
+// min over the 64 lanes of a double, in every lane: four DPP row rotations + four v_readlane (six __shfl_xor stages are twelve
+// ds_bpermute round trips)
+__device__ __forceinline__ double wave_min_f64(double v) {
+  auto rot = [](double x, auto ctrl) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  };
+  v = fmin(v, rot(v, std::integral_constant<int, 0x121>{}));  // row_ror:1
+  v = fmin(v, rot(v, std::integral_constant<int, 0x122>{}));  // row_ror:2
+  v = fmin(v, rot(v, std::integral_constant<int, 0x124>{}));  // row_ror:4
+  v = fmin(v, rot(v, std::integral_constant<int, 0x128>{}));  // row_ror:8
+  auto lane_of = [](double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+  };
+  return fmin(fmin(lane_of(v, 0), lane_of(v, 16)), fmin(lane_of(v, 32), lane_of(v, 48)));
 }
 
 __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, uint32_t* occ2, V3* path, int lane) {
@@ -144,6 +163,10 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
   V3 curr = path[0];
   V3 next = path[1];
   const double samp = vs / 10;  // AC:1316
+  // (the shortcut below is pure bookkeeping — it never changes a sample — so it is not tried again where it has just found nothing
+  // to skip: same polyhedron, same path segment, closer to the exit than its margin. Computing the exit distance for each of the
+  // last samples before an exit was most of this kernel's time in free space.)
+  int hold_j = -1, hold_seg = -1;
   while (n_poly < P) {
     const V3 diff = sub(next, curr);
     const double dist_next = norm(diff);
@@ -171,7 +194,7 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       // ray from that polyhedron is inside it too and the reference loop would just `continue`: those samples are generated
       // (same statements, same rounding) without being tested. The exit distance is a min over the rows held by the lanes; three
       // samples of margin cover the rounding of the accumulated positions.
-      if (c.fast_walk && dist_next > samp) {
+      if (c.fast_walk && dist_next > samp && !(j_in == hold_j && path_idx == hold_seg)) {
         double t_exit = DBL_MAX;
         for (int h = 0; h < 2; ++h)
           if (rv[h] && ((pm[h][j_in] >> lane) & 1ull)) {
@@ -183,9 +206,10 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
             if (!(slack > kWalkTol)) t_exit = 0;
             else if (rate > 0) t_exit = fmin(t_exit, (slack - kWalkTol) / rate);
           }
-        for (int off = 32; off > 0; off >>= 1) t_exit = fmin(t_exit, __shfl_xor(t_exit, off));
+        t_exit = wave_min_f64(t_exit);
         const double cap = t_exit / samp - 3.0;
         int n_safe = cap > 1e6 ? 1000000 : (cap > 0 ? (int)cap : 0);
+        hold_j = n_safe == 0 ? j_in : -1, hold_seg = path_idx;
         if (!c.has_world) {
           // free space: the skipped samples are not even generated one by one (walk_jump). Only where the polyhedra are the
           // large boxes of an empty grid: next to obstacles a routed path slides along faces, the outcome of the first
@@ -235,6 +259,7 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
     if (rc != HDSM_OK) break;
     ++n_poly;
     load_rows();
+    hold_j = -1;
   }
   if (lane == 0) ag.n_poly = n_poly;
 }
