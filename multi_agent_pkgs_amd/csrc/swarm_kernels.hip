@@ -144,18 +144,14 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
   // rows lane and lane + 64 of the flattened [P][RS] table
   double ra[2][4];
   bool rv[2];
-  unsigned long long pm[2][hdsm::MAXP];  // which ballot bits belong to polyhedron j
+  int pj[2];  // the polyhedron the row belongs to (-1: no row)
   auto load_rows = [&]() {
     for (int h = 0; h < 2; ++h) {
       const int lin = lane + 64 * h, j = lin / RS, r = lin % RS;
       rv[h] = j < n_poly && r < ag.polys[j].rows;
+      pj[h] = rv[h] ? j : -1;
       for (int q = 0; q < 3; ++q) ra[h][q] = rv[h] ? ag.polys[j].A[r][q] : 0.0;
       ra[h][3] = rv[h] ? ag.polys[j].b[r] : 0.0;
-      for (int jj = 0; jj < hdsm::MAXP; ++jj) {  // bits of the rows [jj RS, (jj + 1) RS) that fall into this half's 64 rows
-        const int lo = jj * RS - 64 * h, hi = lo + RS;
-        const int a0 = lo < 0 ? 0 : lo, a1 = hi > 64 ? 64 : hi;
-        pm[h][jj] = a1 > a0 ? ((a1 - a0 == 64 ? ~0ull : ((1ull << (a1 - a0)) - 1ull)) << a0) : 0ull;
-      }
     }
   };
   load_rows();
@@ -178,14 +174,11 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       next = path[path_idx];
     }
     // inside at least one kept polyhedron? (LinearConstraint::inside: no row with A x - b > 0)
-    unsigned long long viol[2];
-    for (int h = 0; h < 2; ++h) {
-      const bool bad = rv[h] && (((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]) - ra[h][3] > 0);
-      viol[h] = __ballot(bad);
-    }
+    bool bad[2];
+    for (int h = 0; h < 2; ++h) bad[h] = rv[h] && (((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]) - ra[h][3] > 0);
     int j_in = -1;
-    for (int j = 0; j < n_poly; ++j)
-      if (((viol[0] & pm[0][j]) | (viol[1] & pm[1][j])) == 0) {
+    for (int j = 0; j < n_poly; ++j)  // (one ballot per kept polyhedron: the first one without a violated row)
+      if (__ballot((bad[0] && pj[0] == j) || (bad[1] && pj[1] == j)) == 0ull) {
         j_in = j;
         break;
       }
@@ -197,7 +190,7 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
       if (c.fast_walk && dist_next > samp && !(j_in == hold_j && path_idx == hold_seg)) {
         double t_exit = DBL_MAX;
         for (int h = 0; h < 2; ++h)
-          if (rv[h] && ((pm[h][j_in] >> lane) & 1ull)) {
+          if (pj[h] == j_in) {
             const double rate = ((ra[h][0] * diff[0] + ra[h][1] * diff[1]) + ra[h][2] * diff[2]) / dist_next;
             const double slack = ra[h][3] - ((ra[h][0] * curr[0] + ra[h][1] * curr[1]) + ra[h][2] * curr[2]);
             // every skipped sample keeps a slack >= kWalkTol in every row, far above the rounding of A x - b: a path
