@@ -358,6 +358,10 @@ __global__ __launch_bounds__(256) void k_ref_pack(int N, int n_rob, const double
   }
 }
 
+// wave reductions of k_reference: DPP row rotations + v_readlane (hdsm_wave_gi.h) — a __shfl_xor stage on a double is two
+// ds_bpermute round trips, and the kernel reduces 14 values per instance
+__device__ __forceinline__ double ref_wave_min(double v) { return -hdsm::wave_max64(-v); }
+
 // NT threads per instance: 256 for small batches (more lanes on the one instance's neighbour scans), 64 — one wavefront, every
 // instance of a 1024-agent round resident at once, the workgroup barriers of the reductions cost nothing — for large ones
 // (46 -> ~20 us per 1024-agent round).
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
     const double4 ss = *reinterpret_cast<const double4*>(a.rsph + (int64_t)self * 4);
     double gbest = DBL_MAX;
     int jbest = -1;
-    constexpr int UB = 4;  // sphere records in flight per thread: the scans are chains of L2 round trips otherwise
+    constexpr int UB = 8;  // sphere records in flight per thread: the scans are chains of L2 round trips otherwise
     for (int j0 = tid; j0 < a.n_rob; j0 += UB * NT) {
       double4 sj[UB];
 #pragma unroll
@@ -417,10 +421,13 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
         if (g < gbest || jbest < 0) gbest = g, jbest = j;
       }
     }
-    for (int off = 32; off > 0; off >>= 1) {  // (which of several equally close spheres wins only moves the bound below)
-      const double og = __shfl_xor(gbest, off);
-      const int oj = __shfl_xor(jbest, off);
-      if (oj >= 0 && (jbest < 0 || og < gbest)) gbest = og, jbest = oj;
+    {  // (which of several equally close spheres wins only moves the bound below)
+      const double key = jbest >= 0 ? gbest : DBL_MAX;
+      const double m = ref_wave_min(key);
+      const unsigned long long who = __ballot(jbest >= 0 && key == m);
+      const int src = who != 0ull ? __ffsll((long long)who) - 1 : 0;
+      jbest = who != 0ull ? __builtin_amdgcn_readlane(jbest, src) : -1;
+      gbest = m;
     }
     if constexpr (NT > 64) {
       if ((tid & 63) == 0) red[tid >> 6] = gbest, idx[tid >> 6] = jbest;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
         u = dx * dx + dy * dy + dz * dz;
         u = (u == u) ? u : DBL_MAX;  // (a non-finite plan bounds nothing)
       }
-      for (int off = 32; off > 0; off >>= 1) u = fmax(u, __shfl_xor(u, off));
+      u = hdsm::wave_max64(u);
       umax = u;
     }
     // (2) minima of the squared distances over the neighbours that can still lower one of them
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
     for (int i = 0; i <= hdsm::MAXH; ++i)
       if (i <= N) {
         double m = d2min[i];
-        for (int off = 32; off > 0; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+        m = ref_wave_min(m);
         if ((tid & 63) == 0) d2w[tid >> 6][i] = m;
       }
     __syncthreads();
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
       }
     }
   }
-  for (int off = 32; off > 0; off >>= 1) pv = fmin(pv, __shfl_xor(pv, off));
+  pv = ref_wave_min(pv);
   if constexpr (NT > 64) {
     if ((tid & 63) == 0) red[tid >> 6] = pv;
     __syncthreads();
