@@ -376,6 +376,9 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
   __shared__ double spath[PATH_LDS * 3];
   __shared__ double pts[hdsm::MAXH + 1][3];
   __shared__ int cnt_s;
+  constexpr int SURV_CAP = 2048;
+  __shared__ int surv[SURV_CAP];
+  __shared__ int surv_n;
   const int inst = blockIdx.x, tid = threadIdx.x, N = a.N;
   const int self = a.agent_id[inst];
   const int np = min(max(a.n_path[inst], 1), a.pmax);  // the host wrapper rejects counts outside [1, pmax]; device callers are clamped
@@ -456,7 +459,30 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
     double d2min[hdsm::MAXH + 1];
 #pragma unroll
     for (int i = 0; i <= hdsm::MAXH; ++i) d2min[i] = DBL_MAX;
-    for (int j0 = tid; j0 < a.n_rob; j0 += UB * NT) {
+    // The neighbours that pass the sphere test are first LISTED (LDS) and then shared out evenly, one per thread and trip: taken
+    // where they are found, a trip of the scan cost a full round trip to memory for the whole wavefront whenever ANY lane had a
+    // survivor in it — 16 round trips per instance in a dense ring, half of this kernel's time.
+    auto drain = [&]() {
+      __syncthreads();
+      const int cnt = surv_n < SURV_CAP ? surv_n : SURV_CAP;
+      for (int k = tid; k < cnt; k += NT) {
+        const double* rp = a.rpos + (int64_t)surv[k] * (N + 1) * 3;
+#pragma unroll
+        for (int i = 0; i <= hdsm::MAXH; ++i)
+          if (i <= N) {
+            const double dx = own[i][0] - rp[3 * i], dy = own[i][1] - rp[3 * i + 1], dz = own[i][2] - rp[3 * i + 2];
+            d2min[i] = fmin(d2min[i], dx * dx + dy * dy + dz * dz);
+          }
+      }
+      __syncthreads();
+      if (tid == 0) surv_n = 0;
+      __syncthreads();
+    };
+    if (tid == 0) surv_n = 0;
+    __syncthreads();
+    int listed = 0;  // (an upper bound of surv_n, the same in every thread)
+    for (int j0 = tid; j0 - tid < a.n_rob; j0 += UB * NT) {
+      if (listed + UB * NT > SURV_CAP) drain(), listed = 0;
       double4 sj[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -471,15 +497,11 @@ __global__ __launch_bounds__(NT) void k_reference(RefArgs a) {
         // (squared: all its steps are further than the closest neighbour's when the gap between the spheres is)
         const double c2 = cx * cx + cy * cy + cz * cz, reach = sj[u].w + ss.w + sqrt(umax) * (1.0 + 1e-9);
         if (c2 > reach * reach * (1.0 + 1e-9)) continue;
-        const double* rp = a.rpos + (int64_t)j * (N + 1) * 3;
-#pragma unroll
-        for (int i = 0; i <= hdsm::MAXH; ++i)
-          if (i <= N) {
-            const double dx = own[i][0] - rp[3 * i], dy = own[i][1] - rp[3 * i + 1], dz = own[i][2] - rp[3 * i + 2];
-            d2min[i] = fmin(d2min[i], dx * dx + dy * dy + dz * dz);
-          }
+        surv[atomicAdd(&surv_n, 1)] = j;
       }
+      listed += UB * NT;
     }
+    drain();
 #pragma unroll
     for (int i = 0; i <= hdsm::MAXH; ++i)
       if (i <= N) {
