@@ -437,11 +437,11 @@ CD_HD bool raycast(const RawWindow& g, const V3& start, const V3& end, double ma
 // pts[0] = the sampling start): the minimum of GetVelocityLimit over the voxels the path crosses inside the agent's local grid.
 // Quirks kept: the distance of a visited voxel is measured between path_start in WORLD metres and the visited point in LOCAL
 // voxel units, times the voxel size (AC:1739); after a collision the distance is in voxel units (AC:1755) and the walk stops.
-CD_HD double voxel_velocity_cap(const Cfg& c, const hdsm_ref_config& rc, const V3& grid_origin, const V3* pts, int n) {
+// One segment of that walk: the smallest limit it contributes (path_vel_max if none) and whether it ended in a collision (the
+// reference stops at the first segment that does). The segments do not depend on each other: the device gives one to each lane.
+CD_HD double voxel_velocity_cap_segment(const Cfg& c, const hdsm_ref_config& rc, const RawWindow& g, const V3& grid_origin, const V3& path_start,
+                                        const V3& a, const V3& b, bool* collided_out) {
   double path_vel = rc.path_vel_max;
-  if (!c.has_world || n < 1) return path_vel;
-  const RawWindow g = raw_window(c, grid_origin);
-  const V3 path_start = pts[0];
   const double vs = c.voxel_size;
   auto local = [&](const V3& p) { return V3{{(p[0] - grid_origin[0]) / vs, (p[1] - grid_origin[1]) / vs, (p[2] - grid_origin[2]) / vs}}; };
   auto consider = [&](const V3& pt) {
@@ -450,20 +450,30 @@ CD_HD double voxel_velocity_cap(const Cfg& c, const hdsm_ref_config& rc, const V
     const double v = velocity_limit(rc, val, norm(sub(path_start, pt)) * vs);
     if (v < path_vel) path_vel = v;
   };
+  const V3 start = local(a), end = local(b);
+  V3 hit = {{-1, -1, -1}};
+  // a segment is scanned twice in the reference too: IsLineClear decides, then the visited points are weighed
+  const bool collided = raycast(g, start, end, norm(sub(start, end)), &hit, [](const V3&) {});
+  if (!collided) {
+    raycast(g, start, end, norm(sub(start, end)), &hit, consider);
+    consider(start);
+  } else {
+    const double val = (double)(int8_t)g.value((int)hit[0], (int)hit[1], (int)hit[2]);
+    const double v = velocity_limit(rc, val, norm(sub(start, hit)));
+    if (v < path_vel) path_vel = v;
+  }
+  *collided_out = collided;
+  return path_vel;
+}
+CD_HD double voxel_velocity_cap(const Cfg& c, const hdsm_ref_config& rc, const V3& grid_origin, const V3* pts, int n) {
+  double path_vel = rc.path_vel_max;
+  if (!c.has_world || n < 1) return path_vel;
+  const RawWindow g = raw_window(c, grid_origin);
   for (int i = 0; i + 1 < n; ++i) {
-    const V3 start = local(pts[i]), end = local(pts[i + 1]);
-    V3 hit = {{-1, -1, -1}};
-    // a segment is scanned twice in the reference too: IsLineClear decides, then the visited points are weighed
-    const bool collided = raycast(g, start, end, norm(sub(start, end)), &hit, [](const V3&) {});
-    if (!collided) {
-      raycast(g, start, end, norm(sub(start, end)), &hit, consider);
-      consider(start);
-    } else {
-      const double val = (double)(int8_t)g.value((int)hit[0], (int)hit[1], (int)hit[2]);
-      const double v = velocity_limit(rc, val, norm(sub(start, hit)));
-      if (v < path_vel) path_vel = v;
-      break;
-    }
+    bool collided = false;
+    const double v = voxel_velocity_cap_segment(c, rc, g, grid_origin, pts[0], pts[i], pts[i + 1], &collided);
+    if (v < path_vel) path_vel = v;
+    if (collided) break;
   }
   return path_vel;
 }

@@ -301,13 +301,31 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, d
 // the map-dependent half of the reference (row f1 remainder): ComputePathVelocity's voxel term before k_reference ...
 __global__ __launch_bounds__(64) void k_vel_cap(Cfg c, hdsm_ref_config rc, int n, const AgentS* agents, const double* path, const int32_t* n_path,
                                                 double* vel_cap) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  // one wavefront per agent, one path segment per lane (two ray casts each): the reference stops at the first segment that collides,
+  // i.e. the cap is the minimum over the segments up to and including that one
+  const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (k >= n) return;
-  V3 pl[PTS];
   const int np = n_path[k];
-  for (int i = 0; i < np; ++i)
-    for (int a = 0; a < 3; ++a) pl[i][a] = path[((size_t)k * PTS + i) * 3 + a];
-  vel_cap[k] = hdsm_sw::voxel_velocity_cap(c, rc, hdsm_sw::local_grid_origin(c, agents[k]), pl, np);
+  double cap = rc.path_vel_max;
+  if (c.has_world && np >= 1) {
+    const V3 origin = hdsm_sw::local_grid_origin(c, agents[k]);
+    const hdsm_sw::RawWindow g = hdsm_sw::raw_window(c, origin);
+    auto pt = [&](int i) { return V3{{path[((size_t)k * PTS + i) * 3], path[((size_t)k * PTS + i) * 3 + 1], path[((size_t)k * PTS + i) * 3 + 2]}}; };
+    const V3 p0 = pt(0);
+    for (int base = 0; base + 1 < np; base += 64) {  // (PTS <= 64 segments in practice: one trip)
+      const int i = base + lane;
+      bool collided = false;
+      double v = rc.path_vel_max;
+      if (i + 1 < np) v = hdsm_sw::voxel_velocity_cap_segment(c, rc, g, origin, p0, pt(i), pt(i + 1), &collided);
+      const unsigned long long hit = __ballot(collided);
+      const int first = hit != 0ull ? __ffsll((long long)hit) - 1 : 64;
+      if (lane > first) v = rc.path_vel_max;
+      for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+      cap = fmin(cap, v);
+      if (hit != 0ull) break;
+    }
+  }
+  if (lane == 0) vel_cap[k] = cap;
 }
 
 // ... and KeepOnlyFreeReference (AC:1665-1693) after it, on the rows k_reference wrote
@@ -583,7 +601,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
                        d->d_npoly, d->d_nrows, d->d_A, d->d_b);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {
-      hipLaunchKernelGGL(k_vel_cap, dim3(gb), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
+      hipLaunchKernelGGL(k_vel_cap, dim3((unsigned)n), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
       HIP_TRY(hipGetLastError());
     }
     int rc = hdsm_reference_device(d->solver, &d->rcfg, n, G, d->d_id, d->d_path, d->d_npath, PTS, d->c.has_world ? d->d_cap : nullptr,
