@@ -321,7 +321,8 @@ const char* hdsm_last_error(void);
 
 /* Library/ABI version: (major << 16) | minor. 1.1: hdsm_params grew the execution knobs and time_limit_s;
  * 1.2: + hdsm_poly_octa3d_batch_wave / hdsm_poly_octa3d_device_wave (hdsm_swarm.h), hdsm_set_kernel_timing /
- * hdsm_last_kernel_ms; nothing removed or changed.                                                          */
+ * hdsm_last_kernel_ms; 1.3: + hdsm_host_register / hdsm_host_unregister, hdsm_swarm_yaw / hdsm_swarm_view
+ * (hdsm_swarm.h); nothing removed or changed.                                                                */
 int32_t hdsm_version(void);
 
 #ifdef __cplusplus
