@@ -257,7 +257,7 @@ def test_bench_self_launches_two_ranks_and_reports_rccl_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--agents", "128",
-                        "--first-round", "20", "--repeats", "1", "--device-loop-multi", "--no-cpu-baseline"],
+                        "--first-round", "20", "--repeats", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -266,7 +266,12 @@ def test_bench_self_launches_two_ranks_and_reports_rccl_ranks():
     assert z["n_gpus"] == 2 and z["rccl_ranks"] == 2 and z["scaling"] == "strong" and z["value"] > 0
     w = z["weak_scaling_record"]
     assert w["scaling"] == "weak" and w["agents_per_gpu"] == 1024 and w["agents"] == 2048 and w["value"] > 0
-    assert z["device_resident_loop"]["ms_per_round"] > 0
+    # the device-resident loop over the two-rank communicator runs by default (last, under a watchdog that cannot cost the line)
+    assert z["device_resident_loop"]["ms_per_round"] > 0 and z["device_resident_loop"]["ranks"] == 2
+    # the exchange alone (events around hdsm_exchange_device) and every rank's own time for the timed steps
+    assert z["exchange_ms_p50"] > 0 and z["exchange_ms"]["samples"] >= 5 and z["exchange_ms"]["bytes_per_rank"] == 64 * 11 * 9 * 8
+    assert len(z["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in z["ms_per_step_per_rank"])
+    assert max(z["ms_per_step_per_rank"]) <= z["ms_per_step"] * 1.5
 
 
 def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
