@@ -120,7 +120,7 @@ typedef struct hdsm_params {
    * HDSM_QUAD_MIN: batches of at least this many instances with n_hor <= 10 run FOUR 128-thread workgroups per CU (small
    * LDS layout; default 3 x compute units + 1, 0 = never). HDSM_SCANNER 1 (default) / 0: in workgroups of more than one
    * wavefront the second one evaluates the trajectory and picks the row that enters next while the first applies the update
-   * of the operation before / the iterating wavefront does both. HDSM_DUO48_ROWS 736 (default) / 320: staging rows of the
+   * of the operation before / the iterating wavefront does both. HDSM_DUO48_ROWS 720 (default) / 320: staging rows of the
    * two-per-CU kernel for n_hor > 10 (the smaller instantiation exists for the staging-overflow test).
    * None of these changes an answer that is HDSM_OPTIMAL.)                                                       */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's

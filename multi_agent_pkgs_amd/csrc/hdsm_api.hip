@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
+#include <mutex>
 
 #include <cfloat>
 #include <rccl/rccl.h>
@@ -606,7 +608,7 @@ struct Handle {
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
-  int duo48_rows = 736;       // staging rows of the two-per-CU kernel for n > 30 (HDSM_DUO48_ROWS=320: the smaller instantiation)
+  int duo48_rows = 720;       // staging rows of the two-per-CU kernel for n > 30 (HDSM_DUO48_ROWS=320: the smaller instantiation)
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
@@ -742,11 +744,11 @@ int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 
 // n > 30 (H up to 16): the factor needs more than 256 registers per lane, so a wavefront must have a SIMD to itself — but a
 // 128-thread workgroup has only two, and TWO such workgroups (four wavefronts, one per SIMD) fit a CU once the staging area is cut
-// to 736 rows (2 x 80 KB of LDS; 320 rows until the butterfly layout freed the 19 KB transposition buffer of the old code — the
+// to 720 rows (2 x 80 KB of LDS; 736 until round 5 added the per-level child bounds; 320 rows until the butterfly layout freed the 19 KB transposition buffer of the old code — the
 // 320-row instantiation stays selectable, HDSM_DUO48_ROWS=320: the staging-overflow test needs an area that a dense
 // neighbourhood can fill). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5: 4096
 // instances, 16 per CU one after the other), and every instance is one latency-bound wavefront: the second one doubles the rate.
-constexpr int CMAX_DUO48 = 736, CMAX_DUO48_SMALL = 320;
+constexpr int CMAX_DUO48 = 720, CMAX_DUO48_SMALL = 320;
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -928,13 +930,25 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   auto solve = [&](const hdsm::Args& x, int blocks) -> int {  // the kernel shape that suits `blocks` workgroups
     hdsm::Args y = x;
     y.n_inst = x.n_inst;
-    small = small || (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min);
-    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->quad_min > 0 && blocks >= h->quad_min && h->P <= 4 && h->RS <= 20)
+    // (`small` follows the shape that is actually launched — every shared-CU kernel has a reduced staging area — not the
+    // thresholds: with HDSM_DUO_MIN=0 and HDSM_QUAD_MIN / HDSM_TRI_MIN set by hand the two can disagree)
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->quad_min > 0 && blocks >= h->quad_min && h->P <= 4 && h->RS <= 20) {
+      small = true;
       return launch_quad(h, y, st, blocks);
-    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && blocks >= h->tri_min) return launch_tri(h, y, st, blocks);
-    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo(h, y, st, blocks);
+    }
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->tri_min > 0 && blocks >= h->tri_min) {
+      small = true;
+      return launch_tri(h, y, st, blocks);
+    }
+    if (h->n <= hdsm::SPLIT_N_MAX && h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) {
+      small = true;
+      return launch_duo(h, y, st, blocks);
+    }
     if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, y, st, blocks) : launch_nv<32, 256>(h, y, st, blocks);
-    if (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) return launch_duo48(h, y, st, blocks);
+    if (h->threads == 256 && h->duo_min > 0 && blocks >= h->duo_min) {
+      small = true;
+      return launch_duo48(h, y, st, blocks);
+    }
     return h->threads == 64 ? launch_nv<48, 64>(h, y, st, blocks) : launch_nv<48, 256>(h, y, st, blocks);
   };
   a.warm_out = a.warm;
@@ -1213,7 +1227,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
     h->quad_min = h->tri_min > 0 ? 3 * cus + 1 : 0;    // more instances than the three-per-CU kernel has resident slots
     env_int("HDSM_QUAD_MIN", 0, INT_MAX, &h->quad_min);  // 0 = never
-    env_int("HDSM_DUO48_ROWS", 320, 736, &h->duo48_rows);
+    env_int("HDSM_DUO48_ROWS", 320, 720, &h->duo48_rows);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
     int depth = 3;
@@ -1326,30 +1340,64 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
   return launch(h, a, static_cast<hipStream_t>(hip_stream));
 }
 
-// Registered (page-locked, mapped) host memory: its device-side address, or false for ordinary pageable memory.
-static bool mapped_host_pointer(void* p, void** dev) {
-  hipPointerAttribute_t at{};
-  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-    (void)hipGetLastError();  // (an unknown pointer is an error of the query on some runtimes: it means "pageable")
-    return false;
-  }
-  if (at.type != hipMemoryTypeHost || at.devicePointer == nullptr) return false;
-  *dev = at.devicePointer;
-  return true;
+// Registered (page-locked, mapped) host memory. hdsm_host_register records every range it maps — base, length, device-side
+// address — and hdsm_replan takes the kernel paths (k_fetch / k_deliver) only for arrays that lie INSIDE a recorded range with all
+// the bytes the call will touch (an array that merely starts in one, or memory page-locked by somebody else, goes through the copy
+// path like pageable memory). While nothing is registered the look-up is one load: no runtime query per array and call.
+namespace {
+struct HostRange {
+  char* base;
+  size_t bytes;
+  char* dev;
+};
+std::mutex g_reg_mutex;
+std::vector<HostRange> g_reg;
+std::atomic<int> g_reg_count{0};
+
+bool mapped_host_range(const void* p, size_t bytes, void** dev) {
+  if (g_reg_count.load(std::memory_order_acquire) == 0) return false;
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  const char* c = static_cast<const char*>(p);
+  for (const HostRange& r : g_reg)
+    if (c >= r.base && bytes <= r.bytes && (size_t)(c - r.base) <= r.bytes - bytes) {
+      *dev = r.dev + (c - r.base);
+      return true;
+    }
+  return false;
 }
+}  // namespace
 
 int hdsm_host_register(void* ptr, size_t bytes) {
   if (!ptr || bytes == 0) return set_err(HDSM_ERR_BAD_ARG, "hdsm_host_register: null or empty range");
-  const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return set_err(HDSM_ERR_DEVICE, std::string("hdsm_host_register: ") + hipGetErrorString(e));
   }
+  void* dev = nullptr;
+  e = hipHostGetDevicePointer(&dev, ptr, 0);
+  if (e != hipSuccess || dev == nullptr) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(ptr);
+    return set_err(HDSM_ERR_DEVICE, std::string("hdsm_host_register: no device address for the range: ") + hipGetErrorString(e));
+  }
+  std::lock_guard<std::mutex> lock(g_reg_mutex);
+  g_reg.push_back(HostRange{static_cast<char*>(ptr), bytes, static_cast<char*>(dev)});
+  g_reg_count.store((int)g_reg.size(), std::memory_order_release);
   return HDSM_OK;
 }
 
 int hdsm_host_unregister(void* ptr) {
   if (!ptr) return set_err(HDSM_ERR_BAD_ARG, "hdsm_host_unregister: null pointer");
+  {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
+    for (size_t k = 0; k < g_reg.size(); ++k)
+      if (g_reg[k].base == static_cast<char*>(ptr)) {
+        g_reg.erase(g_reg.begin() + (long)k);
+        break;
+      }
+    g_reg_count.store((int)g_reg.size(), std::memory_order_release);
+  }
   const hipError_t e = hipHostUnregister(ptr);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -1378,8 +1426,9 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   bool in_mapped = true;
   {
     const void* hp[9] = {agent_id, state_curr, traj_ref, n_poly, n_rows_static, A_static, b_static, plans_all, has_plan};
+    const size_t hb[9] = {I * 4, I * 9 * 8, I * N * 6 * 8, I * 4, I * P * 4, I * P * RS * 3 * 8, I * P * RS * 8, (size_t)n_rob * (N + 1) * 9 * 8, (size_t)n_rob};
     void* dp[9];
-    for (int k = 0; k < 9 && in_mapped; ++k) in_mapped = mapped_host_pointer(const_cast<void*>(hp[k]), &dp[k]);
+    for (int k = 0; k < 9 && in_mapped; ++k) in_mapped = mapped_host_range(hp[k], hb[k], &dp[k]);
     if (in_mapped) {  // page-locked arrays of the caller (hdsm_host_register): one fetch kernel
       FetchArgs f{};
       f.n_inst = n_inst, f.n_rob = n_rob, f.N = (int)N, f.P = (int)P, f.RS = (int)RS;
@@ -1421,46 +1470,49 @@ int hdsm_replan(void* handle, int32_t n_inst, int32_t n_rob, const int32_t* agen
   // copies (a megabyte each way per 1024 agents): the results come back into a pinned staging block of the handle and only
   // the instances that HAVE a solution are copied into the caller's arrays.
   const size_t trj = (N + 1) * 9, ctl = N * 3;
-  {  // page-locked output arrays (hdsm_host_register): delivered by the device, filtered there
-    void* dp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  void* dp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  {  // page-locked output arrays (hdsm_host_register, every array inside a registered range): delivered by the device, filtered there
     void* hp[5] = {traj_out, ctrl_out, obj, status, poly_used};
+    const size_t hb[5] = {I * trj * 8, I * ctl * 8, I * 8, I * 4, I * P};
     bool mapped = true;
-    for (int k = 0; k < 5 && mapped; ++k) mapped = mapped_host_pointer(hp[k], &dp[k]);
-    if (mapped) {
-      hipLaunchKernelGGL(k_deliver, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st, n_inst, (int)trj, (int)ctl, (int)P, h->d_traj, h->d_ctrl, h->d_obj,
-                         h->d_status, h->d_used, static_cast<double*>(dp[0]), static_cast<double*>(dp[1]), static_cast<double*>(dp[2]),
-                         static_cast<int32_t*>(dp[3]), static_cast<uint8_t*>(dp[4]));
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipStreamSynchronize(st));
-      return HDSM_OK;
+    for (int k = 0; k < 5 && mapped; ++k) mapped = mapped_host_range(hp[k], hb[k], &dp[k]);
+    if (!mapped) dp[0] = nullptr;
+  }
+  if (dp[0] != nullptr) {
+    hipLaunchKernelGGL(k_deliver, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, st, n_inst, (int)trj, (int)ctl, (int)P, h->d_traj, h->d_ctrl, h->d_obj,
+                       h->d_status, h->d_used, static_cast<double*>(dp[0]), static_cast<double*>(dp[1]), static_cast<double*>(dp[2]),
+                       static_cast<int32_t*>(dp[3]), static_cast<uint8_t*>(dp[4]));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    const size_t need = I * (trj * 8 + ctl * 8 + 8 + 4 + P);
+    if (need > h->h_out_cap) {
+      if (h->h_out) (void)hipHostFree(h->h_out);
+      h->h_out = nullptr, h->h_out_cap = 0;
+      HIP_TRY(hipHostMalloc(&h->h_out, need, hipHostMallocDefault));
+      h->h_out_cap = need;
+    }
+    double* o_traj = static_cast<double*>(h->h_out);
+    double* o_ctrl = o_traj + I * trj;
+    double* o_obj = o_ctrl + I * ctl;
+    int32_t* o_status = reinterpret_cast<int32_t*>(o_obj + I);
+    uint8_t* o_used = reinterpret_cast<uint8_t*>(o_status + I);
+    HIP_TRY(hipMemcpyAsync(o_traj, h->d_traj, I * trj * 8, D2H, st));
+    HIP_TRY(hipMemcpyAsync(o_ctrl, h->d_ctrl, I * ctl * 8, D2H, st));
+    HIP_TRY(hipMemcpyAsync(o_obj, h->d_obj, I * 8, D2H, st));
+    HIP_TRY(hipMemcpyAsync(o_status, h->d_status, I * 4, D2H, st));
+    HIP_TRY(hipMemcpyAsync(o_used, h->d_used, I * P, D2H, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t k = 0; k < I; ++k) {
+      status[k] = o_status[k];
+      if (o_status[k] == HDSM_NO_SOLUTION) continue;
+      std::memcpy(traj_out + k * trj, o_traj + k * trj, trj * 8);
+      std::memcpy(ctrl_out + k * ctl, o_ctrl + k * ctl, ctl * 8);
+      std::memcpy(poly_used + k * P, o_used + k * P, P);
+      obj[k] = o_obj[k];
     }
   }
-  const size_t need = I * (trj * 8 + ctl * 8 + 8 + 4 + P);
-  if (need > h->h_out_cap) {
-    if (h->h_out) (void)hipHostFree(h->h_out);
-    h->h_out = nullptr, h->h_out_cap = 0;
-    HIP_TRY(hipHostMalloc(&h->h_out, need, hipHostMallocDefault));
-    h->h_out_cap = need;
-  }
-  double* o_traj = static_cast<double*>(h->h_out);
-  double* o_ctrl = o_traj + I * trj;
-  double* o_obj = o_ctrl + I * ctl;
-  int32_t* o_status = reinterpret_cast<int32_t*>(o_obj + I);
-  uint8_t* o_used = reinterpret_cast<uint8_t*>(o_status + I);
-  HIP_TRY(hipMemcpyAsync(o_traj, h->d_traj, I * trj * 8, D2H, st));
-  HIP_TRY(hipMemcpyAsync(o_ctrl, h->d_ctrl, I * ctl * 8, D2H, st));
-  HIP_TRY(hipMemcpyAsync(o_obj, h->d_obj, I * 8, D2H, st));
-  HIP_TRY(hipMemcpyAsync(o_status, h->d_status, I * 4, D2H, st));
-  HIP_TRY(hipMemcpyAsync(o_used, h->d_used, I * P, D2H, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  for (size_t k = 0; k < I; ++k) {
-    status[k] = o_status[k];
-    if (o_status[k] == HDSM_NO_SOLUTION) continue;
-    std::memcpy(traj_out + k * trj, o_traj + k * trj, trj * 8);
-    std::memcpy(ctrl_out + k * ctl, o_ctrl + k * ctl, ctl * 8);
-    std::memcpy(poly_used + k * P, o_used + k * P, P);
-    obj[k] = o_obj[k];
-  }
+  // (one exit for both delivery paths: anything added after the download applies to registered callers too)
   return HDSM_OK;
 }
 

@@ -59,7 +59,7 @@ HD int mk_kc(int slot, int m) { return mk_id(K_C, (m << 12) | slot); }
 HD int kc_slot(int payload) { return payload & 0xfff; }
 HD int kc_m(int payload) { return payload >> 12; }
 
-constexpr int LISTCAP = 1024;  // neighbours per chunk of a sphere-prefiltered sweep
+constexpr int LISTCAP = 768;   // neighbours per chunk of a sphere-prefiltered sweep
 
 // ---------------------------------------------------------------------------------------------------------
 // All solver state of one instance. NV = capacity for n = 3N; CMAX = staged neighbour rows.
@@ -106,6 +106,27 @@ struct Shm {
   double cprev[MAXH][3];
   alignas(16) double sp[PM][RSM][4];  // rows of the instance's polyhedra (A, b): read as two 16-byte halves by scan_assigned
   double keys[MAXH][PM];
+  // child bound (leaf_check -> select_child): klb[i][j] = a lower bound of what assigning polyhedron j to step i adds to the
+  // node's objective; br_lb[L][pos] = the resulting lower bound of the child at position pos of level L
+  static constexpr int HTS = NV / 3;  // steps of this instantiation (10 for NV = 32, 16 for NV = 48)
+  // Per open level of the branch and bound, per child position (leaf_check -> level open -> select_child):
+  //   br_lb  lower bound of the child's objective: a child whose bound reaches the incumbent is never opened;
+  //   br_pk / br_pv  the child's FIRST entering row — the row of its polyhedron with the largest v^2 / (a^T Z a) at the node's minimiser,
+  //          code = (end point << 6) | row, -1: none — and its violation v. The child starts at that minimiser (a snapshot restores it
+  //          exactly), where every row of the node holds: what enters first is known without evaluating anything.
+  // (the leaf test leaves its per-(step, polyhedron) values in red_v, which nothing else uses between two runs: lb_at / pv_at / pk_at)
+  double br_lb[HTS][PM], br_pv[HTS][PM];
+  int32_t br_pk[HTS][PM];
+  // (item = step * n_poly + polyhedron < 64: the one-wavefront leaf test; the other forms of the test leave leaf_lb = 0 and no values)
+  HD double& lb_at(int item) { return red_v[item]; }  // what assigning the polyhedron to the step adds at least
+  HD double& pv_at(int item) { return red_v[64 + item]; }
+  HD int32_t& pk_at(int item) { return reinterpret_cast<int32_t*>(&red_v[128])[item]; }
+  static_assert(128 + 32 <= MAXT, "the leaf test's per-(step, polyhedron) values fit the reduction scratch");
+  int32_t leaf_lb;  // the last leaf test left child bounds and first picks (1) or not (0)
+  int32_t first_id;  // the run that is about to start enters this row first (ids as in act[]; -1: pick as usual)
+  double first_v;
+  double lb_top1, lb_top2;  // largest / second largest over the uncontained steps of min_j klb[i][j] (the node bound), and the step
+  int32_t lb_step;          // of the largest (-1: none)
   alignas(16) double cand[CMAX][4];      // staged neighbour rows (n_f, rhs): read as two 16-byte halves by the scans
   double red_v[MAXT];
   double br_f[MAXH];
@@ -122,6 +143,7 @@ struct Shm {
   int32_t inf_id;  // row whose addition proved the last node infeasible (ids as in act[])
   unsigned long long nogood[NOGOODS];
   int32_t n_nogood, ng_skipped, ng_global;  // ng_global: a node proved the instance infeasible whatever the assignment
+  int32_t lb_skipped;                       // children never opened because their lower bound reached the incumbent
   int32_t ncold;  // rows staged but not scanned every iteration (top of cand[])
   double f_box;        // upper bound of the objective over the input box (DINF: no box / Consts::box_cut off)
   double inc_shared;   // split launches: best objective found by ANY sub-block of this instance (DINF: none / ordinary launch)
@@ -337,16 +359,31 @@ struct Solver {
           const double* p1 = s.st[i + 1];
           const double ax_ = p0[0], ay_ = p0[1], az_ = p0[2], bx_ = p1[0], by_ = p1[1], bz_ = p1[2];
           double v0max = -DINF, v1max = -DINF;
+          // rows on input-independent points only gate the choice
+          const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
+          // Child bound. The node's minimiser x_p is optimal for the rows of the node; a child must also satisfy row r of the
+          // polyhedron it assigns, violated by v at x_p: every point that does is at least v / sqrt(a^T Z a) away from x_p in the
+          // metric of the problem, so the child's optimum is >= f + v^2 / (2 a^T Z a) (Z: inverse Hessian on the null space of
+          // the terminal equalities; a^T Z a = sum_ax n_ax^2 kap[m][ax] for a row on point m — the quantity behind the pick rule).
+          // The best such ratio over the rows and both end points is kept by cross-multiplication: one division per lane.
+          double bv2 = 0.0, bq = 1.0, bv = 0.0;
+          int bcode = -1;
+          const double k00 = s.kap[i][0], k01 = s.kap[i][1], k02 = s.kap[i][2];
+          const double k10 = s.kap[i + 1][0], k11 = s.kap[i + 1][1], k12 = s.kap[i + 1][2];
           for (int r = 0; r < rows; ++r) {
             const double* row = s.sp[j][r];
             const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
             const double v0 = r0 * ax_ + r1 * ay_ + r2 * az_ - r3, v1 = r0 * bx_ + r1 * by_ + r2 * bz_ - r3;
             v0max = v0 > v0max ? v0 : v0max, v1max = v1 > v1max ? v1 : v1max;
+            const double s0 = r0 * r0, s1 = r1 * r1, s2 = r2 * r2;
+            const double q0 = s0 * k00 + s1 * k01 + s2 * k02, q1 = s0 * k10 + s1 * k11 + s2 * k12;
+            if (!g0 && v0 > c.tol && q0 > 1e-60 && v0 * v0 * bq > bv2 * q0) bv2 = v0 * v0, bq = q0, bv = v0, bcode = r;
+            if (!g1 && v1 > c.tol && q1 > 1e-60 && v1 * v1 * bq > bv2 * q1) bv2 = v1 * v1, bq = q1, bv = v1, bcode = 64 | r;
           }
-          // rows on input-independent points only gate the choice
-          const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
+          if (on) s.pk_at(lane) = c.child_bound != 0 ? bcode : -1, s.pv_at(lane) = bv;
           if ((g0 && v0max > c.ftol_fixed) || (g1 && v1max > c.ftol_fixed)) vmax = DINF;
           else vmax = g1 ? -DINF : (g0 ? v1max : (v0max > v1max ? v0max : v1max));
+          if (on) s.lb_at(lane) = c.child_bound != 0 ? 0.5 * (bv2 / bq) * (1.0 - 1e-9) : 0.0;  // (rounded towards "no bound")
         }
         if (on) s.keys[i][j] = vmax;
         const unsigned long long inside = __ballot(on && vmax <= c.tol);
@@ -371,7 +408,20 @@ struct Solver {
             pick = __ffsll((long long)__ballot(lane < N && cont < 0 && best == worst)) - 1;
           }
         }
-        if (lane == 0) s.leaf_pick = pick;
+        // Node bound: EVERY uncontained step must still take a polyhedron, so the cheapest admissible choice of any one of them
+        // bounds the whole subtree: f + max_i min_j klb[i][j]. Kept as the largest and the second largest of those minima (and
+        // whose step the largest is), so that a child of step i gets max(its own klb, the best of the OTHER steps).
+        double mine = 0.0;
+        if (lane < N && cont < 0) {
+          mine = DINF;
+          for (int jj = 0; jj < np; ++jj)
+            if (s.keys[lane][jj] < DINF) mine = s.lb_at(lane * np + jj) < mine ? s.lb_at(lane * np + jj) : mine;
+          if (!(mine < DINF)) mine = 0.0;  // (no admissible polyhedron: the branching finds no child anyway)
+        }
+        const double top1 = wave_max64(mine);
+        const int l1 = top1 > 0.0 ? __ffsll((long long)__ballot(mine == top1)) - 1 : -1;
+        const double top2 = wave_max64(lane == l1 ? 0.0 : mine);
+        if (lane == 0) s.leaf_pick = pick, s.lb_top1 = top1, s.lb_top2 = top2, s.lb_step = l1, s.leaf_lb = 1;
       }
       SYNC();
       return s.leaf_pick;
@@ -422,6 +472,7 @@ struct Solver {
       s.contain[i] = cont;
     }
     SYNC();
+    if (IS_T0) s.lb_top1 = 0.0, s.lb_top2 = 0.0, s.lb_step = -1, s.leaf_lb = 0;  // (no node / child bound on this path: more than 64 (step, polyhedron) pairs)
     // the step to branch on among those whose segment lies in no polyhedron: the first in time (rule 0), or the MOST
     // infeasible one — largest violation of its best polyhedron (rule 1). Any choice is exact; it only shapes the tree.
     int pick = -1;
@@ -503,6 +554,12 @@ struct Solver {
       const int L = level - 1;
       const int pos = s.br_pos[L];
       if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s, c))) {
+        if (s.br_lb[L][pos] >= cutoff(s, c)) {  // the child's lower bound (leaf_check) reaches the incumbent: neither opened nor counted
+          SYNC();
+          if (IS_T0) s.br_pos[L] = pos + 1, ++s.lb_skipped;
+          SYNC();
+          continue;
+        }
         if (s.n_nogood > 0) {  // a child whose assignments contain a learned conflict is infeasible: not opened, not counted
           unsigned long long cur = 1ull << (4 * s.br_step[L] + s.br_order[L][pos]);
           for (int i = 0; i < c.N; ++i)
@@ -553,6 +610,8 @@ struct Solver {
         if (IS_T0) {
           s.br_pos[L] = pos + 1;
           s.assign[s.br_step[L]] = j;
+          const int code = s.br_pk[L][pos];
+          s.first_id = code >= 0 ? mk_id(K_P, (s.br_step[L] << 7) | code) : -1, s.first_v = s.br_pv[L][pos];
         }
         SYNC();
         return true;
@@ -775,7 +834,7 @@ struct Solver {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
         s.warm_head = wpre.head;
-        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.inc_shared = DINF, s.node_res = sub_in >= 0 ? a_in.node_cap : 0;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = sub_in >= 0 ? a_in.node_cap : 0;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -906,7 +965,7 @@ struct Solver {
       run = run && admissible;
       if (run && no_slot) run = false, limit = true, flags |= FLAG_NODE_LIMIT;  // (pool exhausted: reported like a node budget)
       SYNC();
-      if (IS_T0 && run) s.assign[step] = sub, s.level = 1, s.br_step[0] = step, s.br_cnt[0] = 0, s.br_pos[0] = 0, s.br_f[0] = 0.0;
+      if (IS_T0 && run) s.assign[step] = sub, s.level = 1, s.br_step[0] = step, s.br_cnt[0] = 0, s.br_pos[0] = 0, s.br_f[0] = 0.0, s.br_lb[0][0] = 0.0, s.br_pk[0][0] = -1;
     }
     SYNC();
     // all neighbour rows near (first call) or violated at (later calls) the current point -> staging area; a staging
@@ -1066,6 +1125,8 @@ struct Solver {
             if (a.inc_bits != nullptr && s.f >= 0.0) atomicMin(&a.inc_bits[inst], (unsigned long long)__double_as_longlong(s.f));
           }
           SYNC();
+        } else if (s.f + s.lb_top1 >= cutoff(s, c)) {
+          // the node bound reaches the incumbent: no leaf below this node can beat it — closed without a snapshot, without a level
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level, bstep_own = bstep;
           snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, true);
@@ -1095,6 +1156,13 @@ struct Solver {
               bool mine = false;
               for (int x1 = 0; x1 < cnt; ++x1) mine = mine || s.br_order[L][x1] == digit;
               s.br_order[L][0] = digit, cnt = mine ? 1 : 0;
+            }
+            const double others = bstep == s.lb_step ? s.lb_top2 : s.lb_top1;  // the node bound of the steps that stay uncontained
+            for (int x1 = 0; x1 < cnt; ++x1) {
+              const int item = bstep * np + s.br_order[L][x1];
+              const double own = s.leaf_lb ? s.lb_at(item) : 0.0;
+              s.br_lb[L][x1] = s.f + (own > others ? own : others);
+              s.br_pk[L][x1] = s.leaf_lb ? s.pk_at(item) : -1, s.br_pv[L][x1] = s.leaf_lb ? s.pv_at(item) : 0.0;
             }
             s.br_cnt[L] = cnt, s.br_pos[L] = 0, s.br_step[L] = bstep, s.br_f[L] = s.f;
             s.level = L + 1;

@@ -38,6 +38,9 @@ struct Consts {
   int32_t scanner;      // 1 (default): n <= 30, workgroups of two or more wavefronts — wave 1 evaluates the trajectory and picks the next
                         // row while wave 0 applies the Householder update of the operation before (HDSM_SCANNER; 0: wave 0 does both;
                         // 2, development: as 1 but every pick of the scanner is confirmed by its exact evaluation)
+  int32_t child_bound;  // 1 (default): a child of a branch-and-bound node whose lower bound f + v^2 / (2 a^T Z a) — v the violation of a row
+                        // of its polyhedron at the node's minimiser — reaches the incumbent is not opened (HDSM_CHILD_BOUND=0: off). Exact.
+  int32_t pad_child_bound;
   double tol, ftol_fixed, cand_tau, hot_tau;
   double mip_gap;  // relative gap at which a node is cut off against the incumbent (0 = exact)
   long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)

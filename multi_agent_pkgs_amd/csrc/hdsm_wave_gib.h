@@ -469,6 +469,10 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
     // this wave applies the update of the operation before; the normal of the picked row comes back through LDS with the pick.
     const bool duo = blockDim.x > 64 && c.scanner != 0;
     bool pending = false;  // a pick is under way (requested with the last step): its answer is behind the next barrier
+    // a child of a branch-and-bound node starts at the node's minimiser, where only rows of its new polyhedron are violated: the
+    // leaf test of the node has already found the one to enter first (hdsm_core.h, select_child) — no evaluation, no scan
+    int first_id = uni(s.first_id);
+    if (lane == 0) s.first_id = -1;
     PROF_DECL
     for (;;) {
       // (the lane masks and addresses of the state evaluation and the scan are formed here, per operation: hoisted out of
@@ -483,6 +487,10 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
         PROF(0)
         ip = mk_id(K_E, neq);
         vip = Base::resid(s, c, ip, N);
+        ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
+      } else if (first_id >= 0) {
+        ip = first_id, vip = s.first_v, kip = 0.0;  // (no key: the dependency test of this operation forms ||d||^2 itself)
+        first_id = -1;
         ai = Base::normal_entry(s, R, ip, Base::row_of(lane), N, n);
       } else if (duo) {
         if (!pending) {

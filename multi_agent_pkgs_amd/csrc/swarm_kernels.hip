@@ -413,7 +413,11 @@ __global__ __launch_bounds__(64) void k_commit(Cfg c, int n, int per, AgentS* ag
         double best = DBL_MAX;
         if (lane < ag.n_ref - 1) best = hdsm_sw::increment_segment_min_closed_form(ag, lane, pt);
         for (int off = 32; off > 0; off >>= 1) best = fmin(best, __shfl_xor(best, off));
-        if (!(fabs(best - d0) > 1e-9 && fabs(best - c.thresh_dist) > 1e-9)) {
+        // (the literal walk's accumulated rounding is ~100 steps x ulp(position): the guard grows with the magnitude of the
+        // coordinates, 1e-9 m up to a few hundred metres, so that worlds of 1e5 m keep the same safety factor)
+        const double mag = fmax(fmax(fabs(pt.v[0]), fabs(pt.v[1])), fabs(pt.v[2]));
+        const double guard = 1e-9 * fmax(1.0, mag * 0.01);
+        if (!(fabs(best - d0) > guard && fabs(best - c.thresh_dist) > guard)) {
           best = DBL_MAX;
           if (lane < ag.n_ref - 1) best = hdsm_sw::increment_segment_min(ag, lane, pt);
           for (int off = 32; off > 0; off >>= 1) best = fmin(best, __shfl_xor(best, off));

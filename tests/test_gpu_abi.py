@@ -305,7 +305,7 @@ def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
 def test_staging_overflow_in_a_shared_cu_kernel_is_rescued(hdsm, oracle, monkeypatch):
     """The kernels that share a CU have a fraction of the staging rows of the one-per-CU kernel. A dense H = 15 neighbourhood
     (36 agents 1.3 m apart, all within reach over the horizon) fills the 320 rows of the two-per-CU kernel's smaller instantiation
-    (HDSM_DUO48_ROWS=320; the default has 736 rows since the butterfly layout freed LDS) with violated rows alone. Host buffers (hdsm_replan): the instances that overflowed are solved again at once with the large staging area —
+    (HDSM_DUO48_ROWS=320; the default has 720 rows since the butterfly layout freed LDS) with violated rows alone. Host buffers (hdsm_replan): the instances that overflowed are solved again at once with the large staging area —
     the oracle's answers come back. Device pointers (hdsm_replan_device, nothing to wait for): the first launch reports
     them honestly (HDSM_FLAG_STAGING_OVERFLOW, never a wrong optimum); once the handle has seen the flag the following
     launches carry the rescue pass."""
