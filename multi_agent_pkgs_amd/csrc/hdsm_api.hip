@@ -46,14 +46,62 @@ int set_err(int code, const std::string& msg) {
 constexpr int CMAX30 = 1536;  // n <= 30
 constexpr int CMAX48 = 1024;  // n <= 48
 
-// What a workgroup works on. Ordinary launch: block b -> instance order[b] (or b). Pass 2 of a split launch (a.sub_k > 0): block b ->
-// the subtree "polyhedron b % sub_k at the root's branching step" of instance b / sub_k, if pass 1 handed that instance over.
+// What a workgroup works on. Ordinary launch: block b -> instance order[b] (or b). Pass 2 of a split launch (a.item_mode): the
+// workgroups are PERSISTENT — each draws items from the queue pass 1 filled (Args::items: one open child of an open level of a
+// handed-over instance) until the queue is empty; blockIdx only names the workgroup's snapshot scratch.
 template <class Sol>
-__device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts& c, const hdsm::Args& a) {
-  int inst, out, sub = -1, self = -1;  // (ONE call site below: the solver is a single inlined body of ~17 k instructions)
-  if (a.sub_k > 0) {
-    inst = (int)blockIdx.x / a.sub_k, sub = (int)blockIdx.x % a.sub_k, out = (int)blockIdx.x;
-    if (a.split_info[2 * inst] == 0) return;  // (uniform: the whole workgroup leaves)
+__device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Consts* cp, const hdsm::Args& a) {
+  typename Sol::S& s = *sp;
+  int inst, out, item = -1, self = -1, slot = 0;  // (ONE call site of the solver per kernel: it is a single inlined body of ~17 k instructions)
+  if (a.item_mode) {
+    // Pass 2 of a split launch: this workgroup takes ONE item from the queue (Args::items: an open child of an open level of a
+    // handed-over instance) and a snapshot-scratch slot, and leaves. The queue can still GROW while items are running (an item
+    // whose subtree turns out large hands over again), so a workgroup that finds it empty waits — on a CU that would be idle
+    // anyway — until an item appears or no workgroup holds one any more (rec_count[4]). The grid is an upper bound of the items
+    // of the launch (hdsm_api.hip, launch()); the workgroups beyond them find the queue empty and nothing running, and leave.
+    // (the few launch arguments the loops below need, as plain values: `a` itself referenced inside a loop is kept as a private copy
+    // of the whole struct — 256 bytes of scratch per lane in every kernel that shares this function)
+    int32_t* const rcnt = a.rec_count;
+    int32_t* const busy = a.slot_busy;
+    const int icap = a.items_cap, pcap = a.pool_cap;
+    if (threadIdx.x == 0) {
+      int got = -1;
+      for (int spins = 0; spins < (1 << 21); ++spins) {  // (seconds: whatever holds the last items up, this workgroup is not needed for them)
+        atomicAdd(&rcnt[4], 1);
+        for (;;) {
+          const int d = __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q = q < icap ? q : icap;
+          if (d >= q) break;
+          if (atomicCAS(&rcnt[2], d, d + 1) == d) {
+            got = d;
+            break;
+          }
+        }
+        if (got >= 0) break;
+        const int active = atomicSub(&rcnt[4], 1) - 1;
+        int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = q < icap ? q : icap;
+        if (active <= 0 && __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q) break;
+        __builtin_amdgcn_s_sleep(127);
+      }
+      int sl = -1;
+      if (got >= 0) {  // a scratch slot: at most gridDim-resident + records slots are ever busy (a slot left to a record stays busy)
+        for (int probe = 0; probe < pcap && sl < 0; ++probe) {
+          const int i = (int)(((unsigned)blockIdx.x * 7u + (unsigned)probe) % (unsigned)pcap);
+          if (atomicCAS(&busy[i], 0, 1) == 0) sl = i;
+        }
+        if (sl < 0) atomicSub(&rcnt[4], 1), got = -2;  // (cannot happen by the count above; the item stays pending: the merge reports a limit)
+      }
+      s.iters_sh = got, s.rc = sl;
+    }
+    __syncthreads();
+    const int k = hdsm::uni(s.iters_sh);
+    slot = hdsm::uni(s.rc);
+    __syncthreads();
+    if (k < 0) return;  // (uniform: the whole workgroup leaves)
+    __threadfence();    // (the item, its record and the snapshots it names were written by another workgroup)
+    item = __hip_atomic_load(&a.items[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), out = k, inst = a.recs[item >> 8].inst;
   } else {
     if (a.order) {  // (instance, its agent id): one load — the own plan is requested together with the other inputs of the instance
       const int2 os = reinterpret_cast<const int2*>(a.order)[blockIdx.x];
@@ -64,14 +112,25 @@ __device__ __forceinline__ void run_block(typename Sol::S& s, const hdsm::Consts
     out = inst;
     if (a.rescue && !(a.st_flags[inst] & hdsm::FLAG_STAGING_OVERFLOW)) return;  // (uniform)
   }
-  Sol::solve_instance(s, c, a, inst, out, sub, self);
+  // (every solver kernel has the signature (const Consts*, Args): the arguments start at byte 8 of the kernel-argument segment)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const HDSM_KERNARG_WORD* words = (const HDSM_KERNARG_WORD*)__builtin_amdgcn_kernarg_segment_ptr() + 1;
+#else
+  const HDSM_KERNARG_WORD* words = nullptr;
+#endif
+  Sol::solve_instance(s, *cp, a, inst, out, item, self, slot, words);
+  if (item >= 0 && threadIdx.x == 0) {  // (the launch arguments from the copy in LDS: the kernel's own are dead after the solver's prologue)
+    if (slot >= 0) atomicExch(&s.args.slot_busy[slot], 0);  // (slot < 0: the item handed over again and its scratch stays with its record)
+    __threadfence();
+    atomicSub(&s.args.rec_count[4], 1);                     // this item is done; what it queued is in the queue already
+  }
 }
 
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT) void k_replan(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+  run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
 
 // The same solver budgeted for TWO workgroups per CU (registers: 2 waves per SIMD; LDS: a staging area of CMAX_DUO
@@ -83,7 +142,7 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+  run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
 
 // Pre-pass of every level-2 launch, one thread per agent of the swarm:
@@ -611,8 +670,8 @@ struct Handle {
   int duo48_rows = 720;       // staging rows of the two-per-CU kernel for n > 30 (HDSM_DUO48_ROWS=320: the smaller instantiation)
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
-  int sub_k = 0;              // sub-blocks per handed-over instance: poly_hor^D, D = 1 .. 3 split levels (HDSM_SPLIT_DEPTH, default 3)
-  int split_mode = 2, split_budget = 0, sub_cap = 0, split_ttl = 0;  // split_budget 0: 8 nodes for batches that leave CUs idle, 96 beyond
+  int split_mode = 2, split_budget = 0, split_ttl = 0;  // split_budget 0: by batch size, see launch()
+  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
   int32_t* h_ovf_flag = nullptr;    // pinned host word: an instance ended on a staging overflow (Args::ovf_flag), and its device alias
   int32_t* d_ovf_flag = nullptr;
   int rescue_ttl = 0;               // launches left that carry the rescue pass
@@ -620,8 +679,13 @@ struct Handle {
   hdsm::Args last_args;             // ... and its arguments (the host-buffer path adds the rescue pass at once)
   int32_t* h_tree_flag = nullptr;   // pinned host word the kernels raise (Args::tree_flag), and its device alias
   int32_t* d_tree_flag = nullptr;
-  int32_t* d_split_steps = nullptr;  // [max_inst][poly_hor + poly_hor^2]: branching steps agreed at the further split levels (Args::split_steps)
-  int32_t *d_split = nullptr, *d_sub_slots = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
+  hdsm::SplitRec* d_recs = nullptr;  // hand-over records of pass 1 and their staged rows (Args::recs, rec_cand, rec_mw, rec_src)
+  double* d_rec_cand = nullptr;
+  long long* d_rec_mw = nullptr;
+  int32_t *d_rec_src = nullptr, *d_rec_count = nullptr, *d_items = nullptr;
+  int32_t* d_slot_busy = nullptr;    // [pool_cap] snapshot-scratch slots of pass 2 taken (Args::slot_busy)
+  int32_t *h_item_total = nullptr, *d_item_total = nullptr;  // pinned host word: items queued by the last split launch (the merge writes it)
+  int32_t *d_split = nullptr, *d_sub_stats = nullptr, *d_sub_warm = nullptr, *d_sub_status = nullptr;
   unsigned long long* d_inc = nullptr;
   int32_t* d_node_pool = nullptr;  // [max_inst] nodes the sub-blocks of an instance may still open (Args::node_pool)
   double *d_sub_traj = nullptr, *d_sub_ctrl = nullptr, *d_sub_obj = nullptr, *d_sub_scratch = nullptr;
@@ -670,11 +734,11 @@ int launch_nv(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<NV, CM>;
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan<NV, CM, NT>;
-  static thread_local int attr_dev = -1;
-  if (attr_dev != h->device) {
+  static thread_local int attr_dev[2] = {-1, -1};
+  if (attr_dev[a.item_mode ? 1 : 0] != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    attr_dev = h->device;
+    attr_dev[a.item_mode ? 1 : 0] = h->device;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
@@ -688,11 +752,11 @@ int launch_duo(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 #endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_duo<32, CMAX_DUO, 256>;
-  static thread_local int attr_dev = -1;
-  if (attr_dev != h->device) {
+  static thread_local int attr_dev[2] = {-1, -1};
+  if (attr_dev[a.item_mode ? 1 : 0] != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    attr_dev = h->device;
+    attr_dev[a.item_mode ? 1 : 0] = h->device;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
@@ -710,7 +774,7 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 2) void k_replan_tri(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+  run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
 
 // FOUR workgroups of 128 threads per CU: every instance of a 1024-agent round is resident at once (1024 slots), so no instance
@@ -723,7 +787,7 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 2) void k_replan_quad(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX, true>;
-  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+  run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
 int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
   using Sol = hdsm::Solver<32, CMAX_QUAD, true>;
@@ -753,7 +817,7 @@ template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
-  run_block<Sol>(*reinterpret_cast<typename Sol::S*>(smem), *cp, a);
+  run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
 template <int CM>
 int launch_duo48_rows(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
@@ -763,10 +827,10 @@ int launch_duo48_rows(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks
 #endif
   const size_t shm = sizeof(typename Sol::S);
   auto kern = k_replan_duo48<48, CM, 128>;
-  static thread_local int attr_dev = -1;
-  if (attr_dev != h->device) {
+  static thread_local int attr_dev[2] = {-1, -1};
+  if (attr_dev[a.item_mode ? 1 : 0] != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    attr_dev = h->device;
+    attr_dev[a.item_mode ? 1 : 0] = h->device;
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
@@ -854,24 +918,11 @@ __global__ __launch_bounds__(256) void k_deliver(int n_inst, int trj, int ctl, i
   if (lane == 0) o_obj[k] = obj[k];
 }
 
-__global__ __launch_bounds__(256) void k_split_init(int n_inst, unsigned long long* inc_bits, int32_t* sub_slots, int cap, int32_t* node_pool, int nodes_left,
-                                                    const int32_t* split_info, const double* obj, int32_t* split_steps, int split_ss) {
-  const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (k < n_inst) {
-    // the incumbent pass 1 left (split_info bit 1; objectives are >= 0: the bit patterns order), else +inf; the pool of the node budget
-    const bool own = (split_info[2 * k] & 2) != 0 && obj[k] >= 0.0;
-    inc_bits[k] = own ? (unsigned long long)__double_as_longlong(obj[k]) : 0x7ff0000000000000ull;
-    node_pool[k] = nodes_left;
-    for (int e = 0; e < split_ss; ++e) split_steps[(size_t)k * split_ss + e] = -1;
-  }
-  if (k == 0) sub_slots[0] = 0, sub_slots[1] = cap;
-  for (int i = k; i < cap; i += n_inst > 0 ? (int)(gridDim.x * blockDim.x) : 1) sub_slots[2 + i] = 0;
-}
-
-// One wavefront per instance that pass 1 handed over: the best answer of its sub-blocks becomes the instance's answer. `a` holds
-// the instance-indexed arrays of the launch, `b` the arrays of pass 2 (index instance * K + subtree).
-__global__ __launch_bounds__(64) void k_split_merge(int N, int P, int K, hdsm::Args a, hdsm::Args b) {
-  hdsm::split_merge(N, P, K, a, b, (int)blockIdx.x, (int)threadIdx.x, 64);
+// One wavefront per instance that pass 1 handed over: the best answer of its items becomes the instance's answer. `a` holds
+// the instance-indexed arrays of the launch, `b` the arrays of pass 2 (indexed by the item's place in the queue).
+__global__ __launch_bounds__(64) void k_split_merge(int N, int P, hdsm::Args a, hdsm::Args b) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && b.item_total != nullptr) *b.item_total = a.rec_count[1];  // (sizes the grid of the next split launch)
+  hdsm::split_merge(N, P, a, b, (int)blockIdx.x, (int)threadIdx.x, 64);
 }
 
 hipError_t ensure_sub(Handle* h);
@@ -879,8 +930,8 @@ hipError_t ensure_sub(Handle* h);
 // the one-per-CU kernel (largest staging area) over the batch of `a`; only instances flagged HDSM_FLAG_STAGING_OVERFLOW work
 int launch_rescue(Handle* h, const hdsm::Args& a, hipStream_t st) {
   hdsm::Args r = a;
-  r.rescue = 1, r.order = nullptr, r.split_budget = 0, r.sub_k = 0, r.split_info = nullptr, r.inc_bits = nullptr, r.node_pool = nullptr;
-  r.sub_slots = nullptr, r.tree_flag = nullptr, r.tree_mark = 0, r.warm_out = r.warm, r.ovf_flag = nullptr;
+  r.rescue = 1, r.order = nullptr, r.split_budget = 0, r.item_mode = 0, r.split_info = nullptr, r.inc_bits = nullptr, r.node_pool = nullptr;
+  r.tree_flag = nullptr, r.tree_mark = 0, r.warm_out = r.warm, r.ovf_flag = nullptr;
   if (h->n <= hdsm::SPLIT_N_MAX) return h->threads == 64 ? launch_nv<32, 64>(h, r, st, r.n_inst) : launch_nv<32, 256>(h, r, st, r.n_inst);
   return h->threads == 64 ? launch_nv<48, 64>(h, r, st, r.n_inst) : launch_nv<48, 256>(h, r, st, r.n_inst);
 }
@@ -977,68 +1028,63 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   if (!split) {
     rc = solve(a, a.n_inst);
   } else {
-    const int K = h->sub_k, G = a.n_inst * K, I = h->max_inst;
     a.split_budget = budget, a.split_info = h->d_split, a.tree_mark = 0;  // (a.tree_flag stays: k_split_merge raises it for trees that are still deep)
-    rc = solve(a, a.n_inst);
+    a.recs = h->d_recs, a.rec_cand = h->d_rec_cand, a.rec_mw = h->d_rec_mw, a.rec_src = h->d_rec_src, a.rec_count = h->d_rec_count, a.items = h->d_items;
+    a.rec_cap = h->rec_cap, a.rows_cap = h->rows_cap, a.items_cap = h->items_cap, a.inc_bits = nullptr, a.node_pool = nullptr, a.item_status = h->d_sub_status;
+    // the node budget is the INSTANCE's: every item starts with a small share of what pass 1 left of it and hands the unused part
+    // back to the instance's pool when it finishes; an item that has used its share draws from that pool (NODE_CHUNK at a time)
+    const int total_nodes = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
+    const int left_nodes = total_nodes - budget > 64 ? total_nodes - budget : 64;
+    const int node_cap = left_nodes / 128 > 0 ? left_nodes / 128 : 1;
+    a.nodes_pool0 = left_nodes, a.node_cap = node_cap;
+    HIP_TRY(hipMemsetAsync(h->d_rec_count, 0, 8 * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(h->d_slot_busy, 0, (size_t)h->pool_cap * sizeof(int32_t), st));
+    hdsm::Args a1 = a;
+    a1.inc_bits = h->d_inc, a1.node_pool = h->d_node_pool;  // (pass 1 only WRITES them, at a hand-over: its own search runs on Consts::max_nodes)
+    rc = solve(a1, a.n_inst);
     if (rc) return rc;
     hdsm::Args b = a;
-    b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = h->d_inc, b.sub_slots = h->d_sub_slots, b.tree_flag = nullptr;
-    // the node budget is the INSTANCE's: every sub-block starts with an equal share of what pass 1 left of it and hands the
-    // unused part back to the instance's pool when it finishes; a sub-block that has used its share draws from that pool
-    const int total_nodes = h->prm.max_nodes > 0 ? h->prm.max_nodes : 2000;
-    const int left_nodes = total_nodes - budget > K ? total_nodes - budget : K;
-    // (half of what is left goes out as shares, the other half starts in the pool: a sub-block whose subtree outgrows its share
-    // before any sibling has finished finds nodes there instead of ending on a limit the instance has not reached)
-    b.node_cap = left_nodes / (2 * K) > 0 ? left_nodes / (2 * K) : 1;
-    const int nodes_left = left_nodes - b.node_cap * K > 0 ? left_nodes - b.node_cap * K : 0;
-    b.node_pool = h->d_node_pool;
+    b.item_mode = 1, b.order = nullptr, b.inc_bits = h->d_inc, b.node_pool = h->d_node_pool, b.tree_flag = nullptr;
     b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
-    b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr;
+    b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr, b.pool_cap = h->pool_cap, b.slot_busy = h->d_slot_busy, b.item_total = h->d_item_total;
+    b.split_budget = h->item_budget;  // an item whose subtree outgrows this many nodes hands over again (0: never)
     int32_t* ss = h->d_sub_stats;
-    const size_t GI = (size_t)I * K;
+    const size_t GI = (size_t)h->items_cap;
     b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
     b.st_flags = reinterpret_cast<uint32_t*>(ss + 6 * GI), b.st_key = ss + 7 * GI;
-    b.split_steps = h->d_split_steps, b.split_ss = h->P + h->P * h->P;
-    hipLaunchKernelGGL(k_split_init, dim3((a.n_inst + 255) / 256), dim3(256), 0, st, a.n_inst, h->d_inc, h->d_sub_slots, h->sub_cap, h->d_node_pool, nodes_left,
-                       a.split_info, a.obj, h->d_split_steps, b.split_ss);
-    HIP_TRY(hipGetLastError());
-    // (most of the G blocks leave at once — only the sub-blocks of handed-over instances work — so the kernel shape is chosen for
-    // few, long-running workgroups: one per CU with the large staging area, whatever G is)
-    // (two split levels: up to poly_hor^2 workgroups per handed-over instance — two per CU, as for a large batch)
-    const bool many = h->threads == 256 && h->duo_min > 0 && (a.n_inst >= h->duo_min || K > h->P);
-    small = small || many;
-    if (h->n <= hdsm::SPLIT_N_MAX) rc = many ? launch_duo(h, b, st, G) : (h->threads == 64 ? launch_nv<32, 64>(h, b, st, G) : launch_nv<32, 256>(h, b, st, G));
-    else if (many) rc = launch_duo48(h, b, st, G);  // (large batches hand over hundreds of instances)
-    else rc = h->threads == 64 ? launch_nv<48, 64>(h, b, st, G) : launch_nv<48, 256>(h, b, st, G);
+    // pass 2: persistent workgroups, as many as fit the GPU at once (two per CU where the shape allows it)
+    const bool two = h->threads == 256 && h->duo_min > 0;
+    small = small || two;
+    // the grid: an upper bound of the items of this launch — four times what the last split launch queued (the merge leaves the
+    // count in pinned host memory), at least 4096; a launch that outgrows it leaves items pending and their instances end as LIMIT
+    int grid = 4096;
+    if (h->h_item_total != nullptr && 4 * *h->h_item_total > grid) grid = 4 * *h->h_item_total;
+    if (grid > h->items_cap) grid = h->items_cap;
+    if (h->n <= hdsm::SPLIT_N_MAX) rc = two ? launch_duo(h, b, st, grid) : (h->threads == 64 ? launch_nv<32, 64>(h, b, st, grid) : launch_nv<32, 256>(h, b, st, grid));
+    else if (two) rc = launch_duo48(h, b, st, grid);
+    else rc = h->threads == 64 ? launch_nv<48, 64>(h, b, st, grid) : launch_nv<48, 256>(h, b, st, grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, h->P, K, a, b);
+    hipLaunchKernelGGL(k_split_merge, dim3(a.n_inst), dim3(64), 0, st, h->N, h->P, a, b);
     HIP_TRY(hipGetLastError());
-#ifdef HDSM_SPLIT_TRACE  // development aid (scripts/gpu_split_trace.sh): how the nodes of the handed-over instances spread over their sub-blocks
+#ifdef HDSM_SPLIT_TRACE  // development aid (scripts/gpu_split_trace.sh): how the nodes of the handed-over instances spread over their items
     {
       HIP_TRY(hipStreamSynchronize(st));
-      std::vector<int32_t> info(2 * (size_t)a.n_inst), nd(GI), it(GI);
-      HIP_TRY(hipMemcpy(info.data(), a.split_info, info.size() * 4, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(it.data(), ss, GI * 4, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(nd.data(), ss + GI, GI * 4, hipMemcpyDeviceToHost));
-      int handed = 0, working = 0, deep_max = 0;
-      long long nodes_total = 0, iters_total = 0;
-      std::vector<int> tops;
-      for (int k = 0; k < a.n_inst; ++k) {
-        if (!(info[2 * (size_t)k] & 1)) continue;
-        ++handed;
-        int best = 0;
-        for (int j = 0; j < K; ++j) {
-          const int v = nd[(size_t)k * K + j];
-          working += v > 0, nodes_total += v, iters_total += it[(size_t)k * K + j];
-          best = v > best ? v : best;
-        }
-        tops.push_back(best);
-        deep_max = best > deep_max ? best : deep_max;
+      int32_t cnt[4];
+      HIP_TRY(hipMemcpy(cnt, h->d_rec_count, sizeof cnt, hipMemcpyDeviceToHost));
+      const size_t q = (size_t)(cnt[1] < h->items_cap ? cnt[1] : h->items_cap);
+      std::vector<int32_t> nd(q), it(q);
+      if (q) {
+        HIP_TRY(hipMemcpy(it.data(), ss, q * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nd.data(), ss + GI, q * 4, hipMemcpyDeviceToHost));
       }
+      long long nodes_total = 0, iters_total = 0;
+      int working = 0;
+      std::vector<int> tops(nd.begin(), nd.end());
+      for (size_t k = 0; k < q; ++k) working += nd[k] > 0, nodes_total += nd[k], iters_total += it[k];
       std::sort(tops.begin(), tops.end(), std::greater<int>());
-      std::fprintf(stderr, "HDSM_SPLIT_TRACE handed over %d of %d instances, %d sub-blocks of %d worked, nodes %lld iters %lld, largest sub-block %d nodes; top instances' largest sub-block:",
-                   handed, a.n_inst, working, handed * K, nodes_total, iters_total, deep_max);
-      for (size_t q = 0; q < tops.size() && q < 12; ++q) std::fprintf(stderr, " %d", tops[q]);
+      std::fprintf(stderr, "HDSM_SPLIT_TRACE handed over %d of %d instances (records cap %d), %d items queued, %d worked, nodes %lld iters %lld; largest items:",
+                   cnt[0], a.n_inst, h->rec_cap, cnt[1], working, nodes_total, iters_total);
+      for (size_t k = 0; k < tops.size() && k < 12; ++k) std::fprintf(stderr, " %d", tops[k]);
       std::fprintf(stderr, "\n");
     }
 #endif
@@ -1089,24 +1135,43 @@ int64_t scratch_stride_for(int n) {
                  : (int64_t)hdsm::Solver<48, CMAX48>::SNAP_STRIDE * hdsm::MAXH;
 }
 
-// state of the split launches, allocated on the first one: outputs / statistics / guesses per sub-block (max_inst x poly_hor), a
-// pool of snapshot scratch for the sub-blocks that really work (at most 2048 at a time)
+// state of the split launches, allocated on the first one: the hand-over records of pass 1 with their staged rows, the item queue,
+// outputs / statistics / guesses per item, snapshot scratch for the persistent workgroups of pass 2
 hipError_t ensure_sub(Handle* h) {
-  const size_t G = (size_t)h->max_inst * h->sub_k, N = (size_t)h->N;
-  h->sub_cap = (int)(G < 2048 ? G : 2048);
+  const size_t N = (size_t)h->N;
+  const bool two = h->threads == 256 && h->duo_min > 0;
+  h->sub_slots_n = (two ? 2 : 1) * h->cus;
+  h->rows_cap = h->n <= hdsm::SPLIT_N_MAX ? (two ? CMAX_DUO : CMAX30) : (two ? h->duo48_rows : CMAX48);
+  h->rec_cap = 2048;  // (records: one per instance that hands its search over + one per item that hands over again)
+  if (const char* ev = std::getenv("HDSM_SPLIT_RECORDS")) {
+    const long v = std::strtol(ev, nullptr, 10);
+    if (v >= 1 && v <= (1 << 20)) h->rec_cap = (int)v;
+  }
+  h->items_cap = h->rec_cap * 16 < 4096 ? 4096 : h->rec_cap * 16;
+  // snapshot scratch of pass 2: one slot per workgroup that can be resident + one per record (an item that hands over again leaves
+  // its slot to its record for the rest of the launch)
+  h->pool_cap = h->sub_slots_n + h->rec_cap;
+  if (const char* ev = std::getenv("HDSM_ITEM_BUDGET")) {
+    const long v = std::strtol(ev, nullptr, 10);
+    if (v >= 0 && v <= 100000) h->item_budget = (int)v;
+  }
+  const size_t G = (size_t)h->items_cap, R = (size_t)h->rec_cap;
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) {
     if (e == hipSuccess) e = r;
   };
-  ok(dmalloc(&h->d_split_steps, (size_t)h->max_inst * (size_t)(h->P + h->P * h->P)));
-  ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_node_pool, (size_t)h->max_inst)), ok(dmalloc(&h->d_sub_slots, 2 + (size_t)h->sub_cap));
+  ok(dmalloc(&h->d_recs, R)), ok(dmalloc(&h->d_rec_cand, R * h->rows_cap * 4)), ok(dmalloc(&h->d_rec_mw, R * h->rows_cap)), ok(dmalloc(&h->d_rec_src, R * h->rows_cap));
+  ok(dmalloc(&h->d_rec_count, 8)), ok(dmalloc(&h->d_items, G)), ok(dmalloc(&h->d_slot_busy, (size_t)h->pool_cap));
+  ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_node_pool, (size_t)h->max_inst));
   ok(dmalloc(&h->d_sub_stats, 8 * G)), ok(dmalloc(&h->d_sub_warm, (hdsm::MAXNV + 2) * G)), ok(dmalloc(&h->d_sub_status, G));
   ok(dmalloc(&h->d_sub_traj, G * (N + 1) * 9)), ok(dmalloc(&h->d_sub_ctrl, G * N * 3)), ok(dmalloc(&h->d_sub_obj, G)), ok(dmalloc(&h->d_sub_used, G * h->P));
-  ok(dmalloc(&h->d_sub_scratch, (size_t)h->sub_cap * (size_t)h->scratch_stride));
+  ok(dmalloc(&h->d_sub_scratch, (size_t)h->pool_cap * (size_t)h->scratch_stride));
   if (e == hipSuccess) e = hipMemset(h->d_split, 0, 2 * (size_t)h->max_inst * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(h->d_rec_count, 0, 8 * sizeof(int32_t));
   h->sub_ready = e == hipSuccess;
   if (!h->sub_ready) {  // partial failure: give back what was allocated, clear the pending error — the handle goes on without split launches
-    void** sub[] = {(void**)&h->d_split_steps, (void**)&h->d_split, (void**)&h->d_inc, (void**)&h->d_node_pool, (void**)&h->d_sub_slots, (void**)&h->d_sub_stats,
+    void** sub[] = {(void**)&h->d_recs, (void**)&h->d_rec_cand, (void**)&h->d_rec_mw, (void**)&h->d_rec_src, (void**)&h->d_rec_count, (void**)&h->d_items, (void**)&h->d_slot_busy,
+                    (void**)&h->d_split, (void**)&h->d_inc, (void**)&h->d_node_pool, (void**)&h->d_sub_stats,
                     (void**)&h->d_sub_warm, (void**)&h->d_sub_status, (void**)&h->d_sub_traj, (void**)&h->d_sub_ctrl, (void**)&h->d_sub_obj,
                     (void**)&h->d_sub_used, (void**)&h->d_sub_scratch};
     for (void** p : sub) {
@@ -1120,11 +1185,12 @@ hipError_t ensure_sub(Handle* h) {
 }
 
 void free_all(Handle* h) {
-  void* sub[] = {h->d_split_steps, h->d_split, h->d_inc, h->d_node_pool, h->d_sub_slots, h->d_sub_stats, h->d_sub_warm, h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj,
-                 h->d_sub_used, h->d_sub_scratch};
+  void* sub[] = {h->d_recs, h->d_rec_cand, h->d_rec_mw, h->d_rec_src, h->d_rec_count, h->d_items, h->d_slot_busy, h->d_split, h->d_inc, h->d_node_pool, h->d_sub_stats, h->d_sub_warm,
+                 h->d_sub_status, h->d_sub_traj, h->d_sub_ctrl, h->d_sub_obj, h->d_sub_used, h->d_sub_scratch};
   for (void* p : sub)
     if (p) (void)hipFree(p);
   if (h->h_tree_flag) (void)hipHostFree(h->h_tree_flag);
+  if (h->h_item_total) (void)hipHostFree(h->h_item_total);
   if (h->h_ovf_flag) (void)hipHostFree(h->h_ovf_flag);
   if (h->h_out) (void)hipHostFree(h->h_out);
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
@@ -1230,10 +1296,6 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_DUO48_ROWS", 320, 720, &h->duo48_rows);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
-    int depth = 3;
-    env_int("HDSM_SPLIT_DEPTH", 1, 3, &depth);
-    h->sub_k = h->P;
-    for (int l = 1; l < depth; ++l) h->sub_k *= h->P;
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
     h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
     env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never
@@ -1286,6 +1348,11 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   if (e == hipSuccess) {
     *h->h_tree_flag = 0;
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_tree_flag), h->h_tree_flag, 0);
+  }
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&h->h_item_total), sizeof(int32_t), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *h->h_item_total = 0;
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_item_total), h->h_item_total, 0);
   }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMemcpy(h->d_consts, hc, sizeof *hc, hipMemcpyHostToDevice);

@@ -31,22 +31,38 @@
 #define PAR_FOR(i, cnt) for (int i = tid_here(); i < (cnt); i += (int)blockDim.x)  // (tid_here: hdsm_wave_gi.h)
 #define HDSM_UNROLL _Pragma("unroll")
 #define SYNC() __syncthreads()
-#define IS_T0 (threadIdx.x == 0)
+#define IS_T0 (HDSM_TX == 0)
 namespace hdsm {
 __device__ __forceinline__ int atomic_inc_i32(int* p) { return atomicAdd(p, 1); }
+// The thread index as a value formed WHERE IT IS READ (HDSM_TX replaces threadIdx.x in the solver): whatever depends on it is then
+// computed below that point. The persistent workgroups of pass 2 (hdsm_api.hip, run_items) run the solver inside a loop over items; with
+// the plain built-in the optimiser computed every lane mask and lane address once, before the loop, and kept them alive — spilled,
+// 700 bytes per lane — across all items and their active-set runs.
+__device__ __forceinline__ unsigned tx() {
+  unsigned t = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
 }  // namespace hdsm
+#define HDSM_TX (hdsm::tx())
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HDSM_KERNARG_WORD __attribute__((address_space(4))) long long
+#else
+#define HDSM_KERNARG_WORD long long
+#endif
 
 #include "hdsm_types.h"
 
 namespace hdsm {
 
 enum { GI_OK = 0, GI_INFEASIBLE = 1, GI_CUTOFF = 2, GI_ITERLIM = 3, GI_DONE = 4, GI_TIMELIM = 5 };
-constexpr int NOGOODS = 48;      // conflicts kept per instance (branch and bound)
 constexpr int NODE_CHUNK = 4;       // nodes a sub-block of a split launch takes from its instance's pool at a time
 constexpr int TREE_MARK = 32;       // nodes from which a tree counts as deep (the split form of a launch pays from about there)
 constexpr int WARM_CERT = 1 << 30;  // bit of the stored working-set size: the set is an infeasibility certificate
 enum { FLAG_NODE_LIMIT = 1, FLAG_ITER_LIMIT = 2, FLAG_TIME_LIMIT = 4, FLAG_STAGING_OVERFLOW = 8 };  // HDSM_FLAG_* of hdsm.h
-enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2 };
+enum { ST_OPTIMAL = 0, ST_LIMIT = 1, ST_NO_SOLUTION = 2, ST_PENDING = 3 };  // (ST_PENDING: internal, a queued item of a split launch)
 
 // constraint ids: kind in bits 28..30
 enum { K_U = 0, K_S = 1, K_P = 2, K_C = 3, K_E = 4 };
@@ -68,6 +84,7 @@ struct alignas(8) MW {
   int32_t m;
   float w;
 };
+static_assert(sizeof(MW) == 8, "hand-over records copy MW as one 8-byte word");
 HD MW mk_mw(const double (*kap)[4], double nx, double ny, double nz, int m) {
   const double q = nx * nx * kap[m][0] + ny * ny * kap[m][1] + nz * nz * kap[m][2];
   // (a row on a pinned position cannot be moved at all: if it is violated it goes first and ends the instance)
@@ -308,7 +325,7 @@ struct Solver {
       // D: col = lane & 15, row = (lane >> 4) + 4 reg). Wave w takes polyhedra w and w + 4; the row maxima per point are
       // reduced in the lane (4 registers x 2 tiles) and across the four 16-lane groups, and land in red_v[j * 16 + m].
       using v4d = double __attribute__((ext_vector_type(4)));
-      const int lane = (int)threadIdx.x & 63, w = (int)threadIdx.x >> 6;
+      const int lane = (int)HDSM_TX & 63, w = (int)HDSM_TX >> 6;
       const int col = lane & 15, kk = lane >> 4;
       const double bop = (kk < 3) ? ((col <= N) ? s.st[col][kk] : 0.0) : 1.0;
       for (int j = w; j < np; j += 4) {
@@ -346,7 +363,7 @@ struct Solver {
       // row of j, then the containing polyhedron per step from a ballot and the step to branch on from one wave reduction — no
       // workgroup barrier inside (the version below spends four, and two runtime divisions per item: 2.7 us per leaf test on
       // the bench rounds against 0.4 us for this one). The other wavefronts wait at the barrier that publishes the result.
-      if (threadIdx.x < 64) {
+      if (HDSM_TX < 64) {
         const int lane = tid_here();
         const bool on = lane < N * np;
         // (N np <= 64: the quotient by a small runtime np is exact in single precision)
@@ -501,7 +518,7 @@ struct Solver {
     // (the per-lane addresses of a snapshot are formed here, when one is taken: hoisted out of the branch-and-bound loop they
     // were kept alive across the whole active-set run — 37 dwords per lane spilled to scratch by EVERY instance, tree or not)
     buf = keep_in_loop(buf);
-    if (threadIdx.x < 64) W::snapshot(s, R, buf, save, tid_here());
+    if (HDSM_TX < 64) W::snapshot(s, R, buf, save, tid_here());
     SYNC();
   }
   // No point of the input box has an objective above f_box (set-up), and the dual method's f only grows: once it passes f_box the
@@ -517,9 +534,9 @@ struct Solver {
       SYNC();
       return rc0;
     }
-    if (threadIdx.x < 64) {
+    if (HDSM_TX < 64) {
       const int rc = W::run(s, c, R, f_eff, iters);
-      if (threadIdx.x == 0) s.rc = (rc == GI_CUTOFF && !(s.f >= f_cut)) ? GI_INFEASIBLE : rc, s.iters_sh = iters;
+      if (HDSM_TX == 0) s.rc = (rc == GI_CUTOFF && !(s.f >= f_cut)) ? GI_INFEASIBLE : rc, s.iters_sh = iters;
     } else {
       W::helper_loop(s, c, R);  // n <= 30: wave 1 evaluates and picks while wave 0 updates; larger n: waves 1..3 share long scans
     }
@@ -539,8 +556,8 @@ struct Solver {
 
   // Moves to the next unexplored child of the deepest open level: restores the parent's solver state and
   // assigns the child's polyhedron. Returns false when the tree is exhausted (or the node budget is).
-  static HD bool select_child(S& s, const Consts& c, GIState& R, int& nodes, bool& limit, int inst, bool& handed_over) {
-    if (s.args.inc_bits != nullptr) {  // pass 2 of a split launch: what the other sub-blocks of this instance have found
+  static HD bool select_child(S& s, const Consts& c, GIState& R, int& nodes, bool& limit, int inst, bool& handed_over, int& rec_slot) {
+    if (s.args.item_mode) {  // pass 2 of a split launch: what the other items of this instance have found
       SYNC();
       if (IS_T0) {
         const unsigned long long bits = __hip_atomic_load(&s.args.inc_bits[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -573,11 +590,28 @@ struct Solver {
             continue;
           }
         }
-        if (s.args.split_budget > 0 && nodes >= s.args.split_budget) {  // pass 1 of a split launch: hand the tree over
-          handed_over = true;
-          return false;
+        if (s.args.split_budget > 0 && nodes >= s.args.split_budget) {  // pass 1 of a split launch: hand the search over
+          // (if there is a record slot left and the staged rows fit the staging area of pass 2 — otherwise the search goes on here)
+          SYNC();
+          if (IS_T0) {
+            int slot = -1;
+            if (s.ncand + s.ncold <= s.args.rows_cap) {
+              slot = atomicAdd(&s.args.rec_count[0], 1);
+              if (slot >= s.args.rec_cap) slot = -1;
+            }
+            s.iters_sh = slot;
+            if (slot < 0) s.args.split_budget = 0;
+          }
+          SYNC();
+          const int slot = uni(s.iters_sh);
+          SYNC();
+          if (slot >= 0) {
+            rec_slot = slot;
+            handed_over = true;
+            return false;
+          }
         }
-        if (s.args.node_pool != nullptr) {  // pass 2 of a split launch: own share first, then what finished sub-blocks handed back
+        if (s.args.item_mode) {  // pass 2 of a split launch: own share first, then what finished items handed back
           SYNC();
           if (IS_T0 && s.node_res == 0) {  // (compare-and-swap: the pool never goes negative, nothing handed back later is lost)
             int cur = __hip_atomic_load(&s.args.node_pool[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), got = 0;
@@ -626,42 +660,35 @@ struct Solver {
   }
 
   // ---- one instance, start to finish ------------------------------------------------------------------------
-  // `inst`: the instance (inputs, warm-start guess); `out`: where its outputs, statistics and scratch live — `inst` itself, or,
-  // in pass 2 of a split launch, the slot of this sub-block; `sub`: the polyhedron this sub-block fixes at the root's
-  // branching step (-1: ordinary solve).
+  // `inst`: the instance (inputs, warm-start guess); `out`: where its outputs and statistics live — `inst` itself, or, in pass 2 of a
+  // split launch, the item's index in the queue; `item`: -1 = an ordinary solve, else (record << 8) | (level << 3) | child position:
+  // continue the handed-over search of the record's instance inside the subtree of that child (Args, SplitRec).
   // `self_in`: the agent id of the instance if the caller already has it (launch order pairs), -1 = agent_id[inst]
-  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int sub_in, int self_in = -1) {
+  // `args_words`: the launch arguments once more, as the 8-byte words of the kernel-argument segment (device kernels; null: copy `a_in`).
+  // The copy of the arguments in LDS is made from THEM, one word per thread: as a struct assignment from the by-value kernel parameter
+  // it went through a private copy of the whole struct (256 bytes of scratch per lane) as soon as the kernel did anything with
+  // ordering semantics — the atomics of the item queue — before it.
+  static HD void solve_instance(S& s, const Consts& c, const Args& a_in, int inst, int out, int item, int self_in, int& wg_slot,
+                                const HDSM_KERNARG_WORD* args_words = nullptr) {
 #ifdef HDSM_POISON_LDS
     // test builds (tests/wave_emu, scripts/gpu_poison.sh): LDS is not cleared between workgroups — whatever is read before it is
     // written shows up as NaN / garbage here instead of depending on the kernel that ran on the CU before
-    for (int i = (int)threadIdx.x; i < (int)(sizeof(S) / 8); i += (int)blockDim.x) reinterpret_cast<unsigned long long*>(&s)[i] = 0xFFF8DEADBEEF0BADull;
+    for (int i = (int)HDSM_TX; i < (int)(sizeof(S) / 8); i += (int)blockDim.x) reinterpret_cast<unsigned long long*>(&s)[i] = 0xFFF8DEADBEEF0BADull;
     SYNC();
 #endif
-    if (IS_T0) s.args = a_in;
+    if (args_words != nullptr) {
+      static_assert(sizeof(Args) % 8 == 0 && sizeof(Args) / 8 <= 64, "one word of the launch arguments per thread of the smallest workgroup");
+      const int t = (int)HDSM_TX;
+      if (t < (int)(sizeof(Args) / 8)) reinterpret_cast<long long*>(&s.args)[t] = args_words[t];
+    } else if (IS_T0) {
+      s.args = a_in;
+    }
     SYNC();
     const Args& a = s.args;
     const int N = c.N, n = c.n, P = c.P, RS = c.RS;
     const int self = self_in >= 0 ? self_in : a.agent_id[inst];
-    double* snap = a.scratch + (int64_t)out * a.scratch_stride;
-    bool no_slot = false;
-    int my_slot = -1;
-    if (sub_in >= 0) {  // pass 2: snapshot scratch comes from a pool of slots, taken for the lifetime of the workgroup (the pool is
-      SYNC();        // larger than the number of workgroups that can be resident at once, so a free slot always exists)
-      if (IS_T0) {
-        const int cap = a.sub_slots[1];
-        int got = -1;
-        for (int probe = 0; probe < cap && got < 0; ++probe) {
-          const int i = (int)(((unsigned)blockIdx.x * 7u + (unsigned)probe) % (unsigned)cap);
-          if (atomicCAS(&a.sub_slots[2 + i], 0, 1) == 0) got = i;
-        }
-        s.iters_sh = got;
-      }
-      SYNC();
-      my_slot = uni(s.iters_sh);  // (wave-uniform: kept in a scalar register, not in a VGPR across the whole instance)
-      no_slot = my_slot < 0;
-      snap = a.scratch + (int64_t)(no_slot ? 0 : my_slot) * a.scratch_stride;
-      SYNC();
-    }
+    // snapshot scratch: the instance's own, or — pass 2, persistent workgroups — the slot this workgroup holds at the moment (`wg_slot`)
+    double* snap = a.scratch + (int64_t)(item >= 0 ? wg_slot : out) * a.scratch_stride;
     if (IS_T0) s.snap = snap;  // (read back at the few places a snapshot is taken or restored; published by the set-up's barriers)
 
     const long long tl_begin_ = (long long)wall_clock64();  // constant-rate clock (100 MHz), common to all CUs
@@ -671,7 +698,7 @@ struct Solver {
 #ifdef HDSM_PROFILE
     const long long t_begin_ = clock64();
     long long t_sweep_ = 0, t_leaf_ = 0;
-    if (threadIdx.x < 24) s.prof_acc[threadIdx.x] = 0;
+    if (HDSM_TX < 24) s.prof_acc[HDSM_TX] = 0;
     SYNC();
     PROF_DECL
 #ifdef HDSM_PROF_OP
@@ -692,7 +719,7 @@ struct Solver {
     double hrow_own;  // Consts::hrow1 of this lane's variable (the box bound of the objective, below)
     const int np = uni(min_i(a.n_poly[inst], P));  // (wave-uniform: a scalar register)
     {
-      const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+      const int tid = (int)HDSM_TX, nt = (int)blockDim.x;
       constexpr int KH = 3 + 2 * (NV / 3);  // inputs one output of the set-up map depends on (compact form, KTC)
       // one output of the set-up map per thread: its coefficients
       double kv[KH];
@@ -834,7 +861,7 @@ struct Solver {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
         s.warm_head = wpre.head;
-        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = sub_in >= 0 ? a_in.node_cap : 0;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = item >= 0 ? a_in.node_cap : 0;
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)
@@ -878,10 +905,10 @@ struct Solver {
 #endif
     SYNC();
     // constant term f0, J(x0) = f0 + grad.x0 / 2 and J(x_eq) = J(x0) + resid.nu / 2
-    R.xi = ((int)threadIdx.x < NV) ? s.x[threadIdx.x] : 0.0;
+    R.xi = ((int)HDSM_TX < NV) ? s.x[HDSM_TX] : 0.0;
     PAR_FOR(k, NV) s.x0[k] = (k < n) ? s.w[k] : 0.0;
-    if (threadIdx.x < 64) {
-      const int lane = (int)threadIdx.x;
+    if (HDSM_TX < 64) {
+      const int lane = (int)HDSM_TX;
       double t0 = 0.0;
       if (lane < 6 * N) {
         const int i = lane / 6 + 1, k = lane % 6;
@@ -938,34 +965,49 @@ struct Solver {
     int it_warm_ = 0;
 #endif
     bool limit = false, handed_over = false;
+    int rec_slot = -1;  // pass 1 of a split launch: the record this instance writes when it hands its search over
     unsigned flags = 0;
     bool run = np > 0;
     if (IS_T0) s.sw_tau = 0.0;
-    // pass 2 of a split launch: this workgroup owns the subtree "polyhedron `sub` at the root's branching step" — or, with D
-    // split levels (sub_k = poly_hor^D), the part of it that the further digits of its index select: digit l = the polyhedron
-    // at the step the node of depth l branches on (the workgroups that share a prefix all solve the nodes of that prefix: a
-    // few nodes of redundant work buy a partition poly_hor times finer per level)
-    int sub = sub_in, sub_depth = sub_in >= 0 ? 1 : 0, sub_rest = 0;  // sub_rest: digits 1 .. D-1, the first one lowest
-    if (sub_in >= 0)
-      for (int k = a.sub_k; k > P; k /= P) {
-        sub_rest = sub_rest * P + sub % P;
-        sub /= P;
-        ++sub_depth;
-      }
-    if (sub >= 0) {
-      const int step = a.split_info[2 * inst + 1];
-      bool admissible = sub < np && step >= 0 && step < N;
-      for (int e = 0; e < 2; ++e)  // rows on input-independent points only gate the choice (leaf_check: keys = DINF)
-        if (admissible && step + e <= c.pinned_steps)
-          for (int r = 0; r < s.sp_rows[sub]; ++r) {
-            const double* row = s.sp[sub][r];
-            const int m = step + e;  // (such a point is its free response)
-            admissible = admissible && !(row[0] * s.fr[0][m][0] + row[1] * s.fr[1][m][0] + row[2] * s.fr[2][m][0] - row[3] > c.ftol_fixed);
-          }
-      run = run && admissible;
-      if (run && no_slot) run = false, limit = true, flags |= FLAG_NODE_LIMIT;  // (pool exhausted: reported like a node budget)
+    // pass 2 of a split launch: this workgroup continues the search of a handed-over instance inside ONE open child of one of its
+    // open levels. The set-up above has rebuilt what depends on the instance's inputs only; the record brings back what the
+    // search had accumulated: staged rows in their slots (the working set of the snapshot names them), conflicts, the displacement
+    // reference of the sweeps, the assignments of the path down to the item's level; the snapshot of that level is the solver state.
+    bool item_run = false;
+    int sweeps0 = 0;
+    if (item >= 0) {
+      const SplitRec& rc = a.recs[item >> 8];
+      const int L = (item >> 3) & 15, pos = item & 7;
+      const int nh = rc.ncand, ncl = rc.ncold;
+      const int64_t rbase = (int64_t)(item >> 8) * a.rows_cap;
       SYNC();
-      if (IS_T0 && run) s.assign[step] = sub, s.level = 1, s.br_step[0] = step, s.br_cnt[0] = 0, s.br_pos[0] = 0, s.br_f[0] = 0.0, s.br_lb[0][0] = 0.0, s.br_pk[0][0] = -1;
+      PAR_FOR(k, nh + ncl) {  // hot rows keep their slots; the cold ones go back to the top of the staging area
+        const int slot = k < nh ? k : CMAX - ncl + (k - nh);
+        const double* src = a.rec_cand + (rbase + k) * 4;
+        s.cand[slot][0] = src[0], s.cand[slot][1] = src[1], s.cand[slot][2] = src[2], s.cand[slot][3] = src[3];
+        *reinterpret_cast<long long*>(&s.cand_mw[slot]) = a.rec_mw[rbase + k];  // (MW: 8 bytes, copied as they are)
+        s.cand_src[slot] = a.rec_src[rbase + k];
+      }
+      PAR_FOR(k, 3 * (N + 1)) s.sw_ref[k / 3][k % 3] = rc.sw_ref[k / 3][k % 3];
+      PAR_FOR(k, rc.n_nogood) s.nogood[k] = rc.nogood[k];
+      PAR_FOR(l, L + 1) {
+        s.br_step[l] = rc.br_step[l], s.br_cnt[l] = 0, s.br_pos[l] = 0, s.br_f[l] = rc.br_f[l];
+        s.assign[rc.br_step[l]] = l < L ? rc.assign[rc.br_step[l]] : rc.br_order[L][pos];  // (rc.assign: the path at the hand-over)
+      }
+      if (IS_T0) {
+        s.ncand = nh, s.ncold = ncl, s.n_nogood = rc.n_nogood, s.sw_tau = rc.sw_tau, s.level = L + 1;
+        const int code = rc.br_pk[L][pos];
+        s.first_id = code >= 0 ? mk_id(K_P, (rc.br_step[L] << 7) | code) : -1, s.first_v = rc.br_pv[L][pos];
+        const unsigned long long bits = __hip_atomic_load(&a.inc_bits[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.inc_shared = __longlong_as_double((long long)bits);
+      }
+      SYNC();
+      item_run = run && nh + ncl <= CMAX && !(rc.br_lb[L][pos] >= cutoff(s, c));  // (the bound may have been reached since the hand-over)
+      if (item_run) snapshot_io(s, c, R, const_cast<double*>(rc.snap) + (int64_t)L * SNAP_STRIDE, false);
+      if (IS_T0) s.neq_done = 6;
+      run = item_run;
+      sweeps = sweeps0 = rc.sweeps_done;  // (a staging sweep that pass 1 has made is not made again: the rows are here)
+      nodes = item_run ? 1 : 0;
     }
     SYNC();
     // all neighbour rows near (first call) or violated at (later calls) the current point -> staging area; a staging
@@ -977,7 +1019,7 @@ struct Solver {
         // Verification: rows left unstaged by the staging sweep had slack >= sw_tau at sw_ref; a row's slack moves by
         // at most |n_f| |dp| with |n_f| <= sqrt(1 + (3 pert)^2) (the planes themselves are fixed during an instance).
         // If no trajectory point has moved further than that allows, nothing unstaged can be violated: no sweep.
-        if (threadIdx.x < 64) {
+        if (HDSM_TX < 64) {
           const int m = tid_here();
           double d2 = 0;
           if (m <= N) {
@@ -1025,20 +1067,20 @@ struct Solver {
         SYNC();
       }
     };
-    if (run && warm_cert && c.presweep != 0 && a.l1_rows == nullptr) {
-      if (threadIdx.x < 64) W::states(s, R, tid_here(), N);
+    if (run && item < 0 && warm_cert && c.presweep != 0 && a.l1_rows == nullptr) {
+      if (HDSM_TX < 64) W::states(s, R, tid_here(), N);
       SYNC();
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // still gridlocked: infeasible whatever the choice
     }
-    if (run && a.warm != nullptr) {
+    if (run && item < 0 && a.warm != nullptr) {
 #ifdef HDSM_PROFILE
       const long long tw_ = clock64();
 #endif
       TL_T0
-      if (threadIdx.x < 64) {
+      if (HDSM_TX < 64) {
         W::warm_start(s, c, a, R, inst, self, iters, wpre);
-        if (threadIdx.x == 0) s.iters_sh = iters;
+        if (HDSM_TX == 0) s.iters_sh = iters;
       }
       SYNC();
       iters = s.iters_sh;
@@ -1051,11 +1093,11 @@ struct Solver {
       it_warm_ = iters;
 #endif
     }
-    if (run && sweeps == 0 && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
+    if (run && item < 0 && sweeps == 0 && (c.presweep == 1 || (c.presweep == 2 && (a.bounds == nullptr || s.ncand > 0)))) {
       // stage around the starting point (x_eq, or the warm-start point) before iterating. Automatic mode: always for
       // small swarms; for large (prefiltered) ones only when the warm start already holds neighbour rows, i.e. in a
       // dense neighbourhood (early in a flight the one sweep after the run is cheaper)
-      if (threadIdx.x < 64) W::states(s, R, tid_here(), N);
+      if (HDSM_TX < 64) W::states(s, R, tid_here(), N);
       SYNC();
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // a common row is violated at the pinned point: infeasible whatever the choice
@@ -1122,7 +1164,7 @@ struct Solver {
           if (IS_T0) {
             s.inc_f = s.f, s.have_inc = 1;
             // split launches: the other sub-blocks of this instance prune against it (objectives are >= 0: the bit patterns order)
-            if (a.inc_bits != nullptr && s.f >= 0.0) atomicMin(&a.inc_bits[inst], (unsigned long long)__double_as_longlong(s.f));
+            if (a.item_mode && s.f >= 0.0) atomicMin(&a.inc_bits[inst], (unsigned long long)__double_as_longlong(s.f));
           }
           SYNC();
         } else if (s.f + s.lb_top1 >= cutoff(s, c)) {
@@ -1131,15 +1173,7 @@ struct Solver {
           const int L = s.level, bstep_own = bstep;
           snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, true);
           if (IS_T0) {
-            int bstep = bstep_own;
-            if (L >= 1 && L < sub_depth && a.split_steps != nullptr) {
-              // a further split level: the sub-blocks that share this prefix of digits all stand at this node; the first one to
-              // arrive publishes its branching step and everybody branches on THAT (any unassigned step is a valid choice)
-              int pre = sub, dr = sub_rest, off = 0, pw = P;
-              for (int x1 = 1; x1 < L; ++x1) pre = pre * P + dr % P, dr /= P, off += pw, pw *= P;
-              const int old = atomicCAS(&a.split_steps[(int64_t)inst * a.split_ss + off + pre], -1, bstep_own);
-              if (old >= 0 && old < N && s.assign[old] < 0) bstep = old;
-            }
+            const int bstep = bstep_own;
             int cnt = 0;
             for (int j = 0; j < np; ++j)
               if (s.keys[bstep][j] < DINF) s.br_order[L][cnt++] = j;
@@ -1149,14 +1183,6 @@ struct Solver {
                 s.br_order[L][y] = s.br_order[L][y - 1];
                 s.br_order[L][y - 1] = t;
               }
-            if (L >= 1 && L < sub_depth) {  // a further split level: of the children of this node the workgroup owns one
-              int digit = sub_rest;
-              for (int x1 = 1; x1 < L; ++x1) digit /= P;
-              digit %= P;
-              bool mine = false;
-              for (int x1 = 0; x1 < cnt; ++x1) mine = mine || s.br_order[L][x1] == digit;
-              s.br_order[L][0] = digit, cnt = mine ? 1 : 0;
-            }
             const double others = bstep == s.lb_step ? s.lb_top2 : s.lb_top1;  // the node bound of the steps that stay uncontained
             for (int x1 = 0; x1 < cnt; ++x1) {
               const int item = bstep * np + s.br_order[L][x1];
@@ -1198,7 +1224,7 @@ struct Solver {
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
       const bool lim_before = limit;
-      run = select_child(s, c, R, nodes, limit, inst, handed_over);
+      run = select_child(s, c, R, nodes, limit, inst, handed_over, rec_slot);
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
@@ -1217,9 +1243,80 @@ struct Solver {
     // (an instance handed over to pass 2 of a split launch leaves without outputs: the merge kernel writes them)
     // (... with one exception: an incumbent pass 1 has already found stays where the outputs go — bit 1 of split_info — so that
     // pass 2 prunes against it from its first node and the merge can fall back on it)
-    if (handed_over) limit = true;
-    if (IS_T0 && a.split_budget > 0)
-      a.split_info[2 * inst] = handed_over ? (1 | (s.have_inc ? 2 : 0)) : 0, a.split_info[2 * inst + 1] = handed_over ? s.br_step[0] : -1;
+    if (handed_over) {
+      // The record of the hand-over (Args, SplitRec): the open levels with their orders, bounds and first picks, the path's
+      // assignments, the staged rows (hot ones first, then the cold ones), conflicts, the sweeps' displacement reference — and one
+      // ITEM per child of an open level that is still to be explored and whose bound does not reach the incumbent (shallow levels,
+      // the large subtrees, first). The snapshots of the open levels are in this instance's scratch already.
+      SplitRec& rc = a.recs[rec_slot];
+      const int lev = s.level, nh = s.ncand, ncl = s.ncold;
+      const int64_t rbase = (int64_t)rec_slot * a.rows_cap;
+      SYNC();
+      PAR_FOR(k, nh + ncl) {
+        const int slot = k < nh ? k : CMAX - ncl + (k - nh);
+        double* dst = a.rec_cand + (rbase + k) * 4;
+        dst[0] = s.cand[slot][0], dst[1] = s.cand[slot][1], dst[2] = s.cand[slot][2], dst[3] = s.cand[slot][3];
+        a.rec_mw[rbase + k] = *reinterpret_cast<const long long*>(&s.cand_mw[slot]);
+        a.rec_src[rbase + k] = s.cand_src[slot];
+      }
+      PAR_FOR(k, 3 * (N + 1)) rc.sw_ref[k / 3][k % 3] = s.sw_ref[k / 3][k % 3];
+      PAR_FOR(k, s.n_nogood) rc.nogood[k] = s.nogood[k];
+      PAR_FOR(k, MAXH) rc.assign[k] = s.assign[k];
+      PAR_FOR(k, lev * S::PM) {
+        const int l = k / S::PM, x1 = k % S::PM;
+        if (x1 < MAXP) rc.br_order[l][x1] = s.br_order[l][x1], rc.br_pk[l][x1] = s.br_pk[l][x1], rc.br_lb[l][x1] = s.br_lb[l][x1], rc.br_pv[l][x1] = s.br_pv[l][x1];
+      }
+      PAR_FOR(l, lev) rc.br_step[l] = s.br_step[l], rc.br_cnt[l] = s.br_cnt[l], rc.br_pos[l] = s.br_pos[l], rc.br_f[l] = s.br_f[l];
+      __threadfence();  // (pass 2 draws items while it runs: the record must be visible before its items are)
+      SYNC();
+      if (IS_T0) {
+        rc.inst = inst, rc.level = lev, rc.ncand = nh, rc.ncold = ncl, rc.n_nogood = s.n_nogood, rc.sw_tau = s.sw_tau;
+        rc.nodes_done = nodes, rc.sweeps_done = sweeps, rc.snap = s.snap;
+        // (an item that hands over again: its record goes in front of the instance's chain, and the workgroup moves to a fresh scratch slot)
+        rc.next = item >= 0 ? atomicExch(&a.split_info[2 * inst + 1], rec_slot) : -1;
+        const double cut = cutoff(s, c);
+        auto open_child = [&](int l, int x1, unsigned long long path) {  // still to be explored: bound below the incumbent, no learnt conflict
+          if (s.br_lb[l][x1] >= cut) return false;
+          const unsigned long long cur = path | (1ull << (4 * s.br_step[l] + s.br_order[l][x1]));
+          bool blocked = false;
+          if (c.P <= 4 && N <= 16)
+            for (int k = 0; k < s.n_nogood; ++k) blocked = blocked || (s.nogood[k] & ~cur) == 0ull;
+          return !blocked;
+        };
+        int cnt = 0;
+        unsigned long long path = 0ull;
+        for (int l = 0; l < lev; ++l) {
+          for (int x1 = s.br_pos[l]; x1 < s.br_cnt[l]; ++x1) cnt += open_child(l, x1, path) ? 1 : 0;
+          if (l + 1 < lev) path |= 1ull << (4 * s.br_step[l] + s.assign[s.br_step[l]]);
+        }
+        // the items' places in the queue are RESERVED first ([5]: the reserved end), written, and then PUBLISHED in order ([1]: the
+        // end of what the workgroups of pass 2 may draw) — an item is never drawn before it is there
+        const int first = atomicAdd(&a.rec_count[5], cnt);
+        const int room = a.items_cap - first < 0 ? 0 : a.items_cap - first;
+        rc.first_item = first, rc.n_items = cnt < room ? cnt : room, rc.truncated = cnt > room ? 1 : 0;  // (a queue that is full: the merge reports a limit)
+        int w = 0;
+        path = 0ull;
+        for (int l = 0; l < lev; ++l) {
+          for (int x1 = s.br_pos[l]; x1 < s.br_cnt[l]; ++x1)
+            if (open_child(l, x1, path) && w < rc.n_items) {
+              a.item_status[first + w] = ST_PENDING;  // (an item no workgroup gets to — a grid or a queue too short — is reported as a limit)
+              a.items[first + w++] = (rec_slot << 8) | (l << 3) | x1;
+            }
+          if (l + 1 < lev) path |= 1ull << (4 * s.br_step[l] + s.assign[s.br_step[l]]);
+        }
+        // what pass 2 starts from: the incumbent found so far (objectives are >= 0: the bit patterns order) and the rest of the node budget
+        if (item < 0) {
+          a.inc_bits[inst] = s.have_inc && s.inc_f >= 0.0 ? (unsigned long long)__double_as_longlong(s.inc_f) : 0x7ff0000000000000ull;
+          a.node_pool[inst] = a.nodes_pool0;
+        }
+        __threadfence();
+        while (__hip_atomic_load(&a.rec_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != first) __builtin_amdgcn_s_sleep(1);  // (those before: a few stores away)
+        __hip_atomic_store(&a.rec_count[1], first + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (item >= 0) wg_slot = -1;  // (pass 2: this workgroup's scratch, with the snapshots of the open levels, stays with the record)
+    }
+    if (IS_T0 && a_in.split_budget > 0 && item < 0)  // (an item of pass 2 that hands over again only chains its record in, above)
+      a.split_info[2 * inst] = handed_over ? (1 | (s.have_inc ? 2 : 0)) : 0, a.split_info[2 * inst + 1] = handed_over ? rec_slot : -1;
     if (IS_T0 && a.tree_flag != nullptr && a.tree_mark > 0 && nodes >= a.tree_mark) *a.tree_flag = 1;  // (split launches: the merge raises it)
     const int status = s.have_inc ? (limit ? ST_LIMIT : ST_OPTIMAL) : ST_NO_SOLUTION;
     if (s.have_inc) {
@@ -1245,7 +1342,7 @@ struct Solver {
       tl_tail1_ = (long long)wall_clock64();  // rollout done
 #endif
       PAR_FOR(k, 9 * (N + 1)) tr[k] = s.st[k / 9][k % 9];
-      if (threadIdx.x < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
+      if (HDSM_TX < 64) {  // literal objective (AC:870-883, AC:2098), one term per lane, summed across the wave
         const int lane = tid_here();
         double part = (lane < n) ? c.r_u * s.inc_x[lane] * s.inc_x[lane] : 0.0;
         for (int idx = lane; idx < 6 * N; idx += 64) {
@@ -1272,7 +1369,7 @@ struct Solver {
       // tends to persist for several rounds): hand over the certificate — the working set at the moment of the proof
       // and the row that could not join it. Seeded with it, the next replan finds the contradiction (or its absence)
       // after a few operations instead of rebuilding it from the unconstrained optimum.
-      const bool certificate = !s.have_inc && !limit && (sub < 0 ? (nodes == 1 || s.ng_global) : s.ng_global != 0) && last_rc == GI_INFEASIBLE && s.q < NV;
+      const bool certificate = !s.have_inc && !limit && (item < 0 ? (nodes == 1 || s.ng_global) : s.ng_global != 0) && last_rc == GI_INFEASIBLE && s.q < NV;
       if (certificate) {
         SYNC();
         PAR_FOR(k, NV) {
@@ -1310,7 +1407,7 @@ struct Solver {
       a.status[out] = status;
       if (a.st_iters) a.st_iters[out] = iters;
       if (a.st_nodes) a.st_nodes[out] = nodes;
-      if (a.st_sweeps) a.st_sweeps[out] = sweeps;
+      if (a.st_sweeps) a.st_sweeps[out] = sweeps - sweeps0;
       if (a.st_cand) a.st_cand[out] = s.ncand + s.ncold;
       if (a.st_sph) a.st_sph[out] = s.st_sph;
       if (a.st_pairs) a.st_pairs[out] = s.st_pairs;
@@ -1325,8 +1422,7 @@ struct Solver {
         a.st_key[out] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
       if (a.ovf_flag != nullptr && (flags & FLAG_STAGING_OVERFLOW)) *a.ovf_flag = 1;
-      if (my_slot >= 0) atomicExch(&a.sub_slots[2 + my_slot], 0);  // (all snapshot traffic of this workgroup is behind it)
-      if (a.node_pool != nullptr && s.node_res > 0) atomicAdd(&a.node_pool[inst], s.node_res);  // the unused part of the share: to the instance's pool
+      if (a.item_mode && s.node_res > 0) atomicAdd(&a.node_pool[inst], s.node_res);  // the unused part of the share: to the instance's pool
     }
     SYNC();
   }
@@ -1335,24 +1431,32 @@ struct Solver {
   static HD int max_i(int x, int y) { return x > y ? x : y; }
 };
 
-// Split launches, last step (k_split_merge: one wavefront per instance; `lane` of `lanes`): the best answer of the sub-blocks of an
+// Split launches, last step (k_split_merge: one wavefront per instance; `lane` of `lanes`): the best answer of the items of an
 // instance that pass 1 handed over becomes the instance's answer. `a` holds the instance-indexed arrays of the launch, `b` the
-// arrays of pass 2 (index instance * K + subtree, K = P or P^2 sub-blocks per instance).
-HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst, int lane, int lanes) {
+// arrays of pass 2 (indexed by the item's place in the queue; the record of the instance names its range).
+HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int lane, int lanes) {
   if (inst >= a.n_inst || a.split_info[2 * inst] == 0) return;
-  int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = 0, sph = 0, pairs = 0;
+  int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = a.st_cand[inst], sph = 0, pairs = 0;
   unsigned flags = 0;
   const bool own = (a.split_info[2 * inst] & 2) != 0;  // pass 1 left an incumbent in the instance's own outputs
   double obj = own ? a.obj[inst] : DINF;
-  for (int k = 0; k < K; ++k) {
-    const int g = inst * K + k;
-    const int st = b.status[g];
-    iters += b.st_iters[g], nodes += b.st_nodes[g], sweeps += b.st_sweeps[g];
-    if (b.st_sph) sph += b.st_sph[g], pairs += b.st_pairs[g];
-    cand = b.st_cand[g] > cand ? b.st_cand[g] : cand;
-    flags |= b.st_flags[g];
-    lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
-    if (st != ST_NO_SOLUTION && b.obj[g] < obj) obj = b.obj[g], best = g;
+  if (a.st_sph) sph = a.st_sph[inst], pairs = a.st_pairs[inst];
+  for (int r = a.split_info[2 * inst + 1]; r >= 0; r = a.recs[r].next) {  // the record of pass 1 and those of the items that handed over again
+    const SplitRec& rc = a.recs[r];
+    if (rc.truncated) lim = 1, flags |= (unsigned)FLAG_NODE_LIMIT;
+    for (int g = rc.first_item; g < rc.first_item + rc.n_items; ++g) {
+      const int st = b.status[g];
+      if (st == ST_PENDING) {  // never started
+        lim = 1, flags |= (unsigned)FLAG_NODE_LIMIT;
+        continue;
+      }
+      iters += b.st_iters[g], nodes += b.st_nodes[g], sweeps += b.st_sweeps[g];
+      if (b.st_sph) sph += b.st_sph[g], pairs += b.st_pairs[g];
+      cand = b.st_cand[g] > cand ? b.st_cand[g] : cand;
+      flags |= b.st_flags[g];
+      lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
+      if (st != ST_NO_SOLUTION && b.obj[g] < obj) obj = b.obj[g], best = g;
+    }
   }
   const int status = (best < 0 && !own) ? ST_NO_SOLUTION : (lim ? ST_LIMIT : ST_OPTIMAL);
   if (best >= 0) {
@@ -1360,9 +1464,9 @@ HD void split_merge(int N, int P, int K, const Args& a, const Args& b, int inst,
     for (int e = lane; e < N * 3; e += lanes) a.ctrl[(int64_t)inst * N * 3 + e] = b.ctrl[(int64_t)best * N * 3 + e];
     for (int e = lane; e < P; e += lanes) a.used[(int64_t)inst * P + e] = b.used[(int64_t)best * P + e];
   }
-  if (a.warm != nullptr && !(own && best < 0)) {  // next replan's guess: the best sub-block's working set (none: start cold; pass 1's own: in place)
+  if (a.warm != nullptr && !(own && best < 0)) {  // next replan's guess: the best item's working set (none: start cold; pass 1's own: in place)
     int32_t* wp = a.warm + (int64_t)inst * (MAXNV + 2);
-    const int32_t* src = b.warm_out + (int64_t)(best >= 0 ? best : inst * K) * (MAXNV + 2);
+    const int32_t* src = b.warm_out + (int64_t)(best >= 0 ? best : 0) * (MAXNV + 2);
     for (int e = lane; e < MAXNV + 2; e += lanes) wp[e] = best >= 0 ? src[e] : 0;
   }
   if (lane == 0) {

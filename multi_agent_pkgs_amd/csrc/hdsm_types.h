@@ -83,6 +83,22 @@ struct Consts {
   double kap[MAXH + 1][4];        // a row n . p_m <= b has a^T Z a = sum_ax n_ax^2 kap[m][ax]
 };
 
+constexpr int NOGOODS = 48;        // conflicts kept per instance (branch and bound)
+constexpr int ITEMS_PER_REC = 64;   // items an instance can queue when it hands its search over (open children of <= MAXH levels)
+
+// What an instance writes when it hands its search over to pass 2 of a split launch (Args::recs; see Args).
+struct SplitRec {
+  int32_t inst, level, ncand, ncold, n_nogood, first_item, n_items, nodes_done, sweeps_done, truncated;
+  int32_t next, pad_next;  // the next record of the same instance (-1: none): an item of pass 2 that hands over again chains its record in
+  const double* snap;      // snapshots of the open levels (level l at snap + l * SNAP_STRIDE): the scratch the search was using
+  double sw_tau;
+  int32_t br_step[MAXH], br_cnt[MAXH], br_pos[MAXH], assign[MAXH];
+  int32_t br_order[MAXH][MAXP], br_pk[MAXH][MAXP];
+  double br_f[MAXH], br_lb[MAXH][MAXP], br_pv[MAXH][MAXP];
+  double sw_ref[MAXH + 1][3];
+  unsigned long long nogood[NOGOODS];
+};
+
 // Per-launch arguments (device pointers), layouts of include/hdsm.h.
 struct Args {
   int32_t n_inst, n_rob;
@@ -124,24 +140,35 @@ struct Args {
   int32_t* st_sph;    // sphere records read by the sweeps of this instance
   int32_t* st_pairs;  // (neighbour, step) positions loaded by the sweeps of this instance
   uint32_t* st_flags; // HDSM_FLAG_* bits
-  // ---- subtree splitting (hdsm_api.hip, launch_split): a launch in three kernels for batches with deep branch-and-bound trees
-  int32_t split_budget;   // pass 1: an instance whose tree is not finished after this many nodes stops WITHOUT outputs and
-                          // records the step its root branched on in split_info (0 = ordinary launch)
-  int32_t sub_k;          // pass 2: block b continues instance b / sub_k inside the subtree "root step = polyhedron b % sub_k";
-                          // instances that were not handed over leave at once (0 = ordinary launch)
-  int32_t* split_info;    // [n_inst][2]: handed over (0 / 1), root branching step
-  unsigned long long* inc_bits;  // [n_inst]: best objective any sub-block has found so far (bits of a non-negative double,
-                                 // +inf at the start): the sub-blocks of an instance prune against each other's incumbents
-  int32_t node_cap;       // pass 2: share of the instance's node budget (what pass 1 left of Consts::max_nodes) every sub-block starts with
-  int32_t* node_pool;     // pass 2: [n_inst] nodes handed back by sub-blocks that finished below their share; a sub-block that has used
+  // ---- subtree splitting (hdsm_api.hip, launch()): a launch in three kernels for batches with deep branch-and-bound trees.
+  // Pass 1 = the ordinary solve with a node budget: an instance whose tree is not finished by then stops and HANDS ITS SEARCH OVER — a
+  // record of its open levels (branching steps, child orders, bounds, first picks), its staged neighbour rows and the assignments of
+  // its current path goes to global memory (SplitRec + row arrays; the snapshots of the open levels are in its scratch already), and
+  // every child of an open level that has not been explored yet becomes an ITEM of pass 2. Pass 2 = persistent workgroups that draw
+  // items from one queue: set-up of the instance, the record, the snapshot of the item's level, and the search continues inside the
+  // item's subtree exactly where pass 1 would have continued it — no warm start, no sweep, no node solved twice. Pass 3 = the merge.
+  int32_t split_budget;   // pass 1: nodes after which an instance hands its search over (0 = ordinary launch)
+  int32_t item_mode;      // pass 2: 1 = the workgroups draw items (instances come from the records; blockIdx is only a slot number)
+  int32_t* split_info;    // [n_inst][2]: bit 0 handed over, bit 1 pass 1 left an incumbent in the instance's outputs; the record's slot
+  unsigned long long* inc_bits;  // [n_inst]: best objective any item has found so far (bits of a non-negative double,
+                                 // +inf at the start): the items of an instance prune against each other's incumbents
+  int32_t node_cap;       // share of the instance's node budget (what pass 1 left of Consts::max_nodes) every item starts with
+  int32_t nodes_pool0;    // ... and what pass 1 puts into the instance's pool when it hands over
+  int32_t* node_pool;     // [n_inst] nodes handed back by items that finished below their share; an item that has used
                           // its share draws from here in chunks — the budget stays the instance's wherever in the tree the work is,
-                          // and a tree that overruns it stops all its sub-blocks at about the same time
-  int32_t* split_steps;   // pass 2, further split levels: [n_inst][split_ss] branching step agreed for the node behind every prefix of split
-                          // digits (-1: nobody has reached it): the sub-blocks that share a prefix all solve its node, and the FIRST one to
-                          // get there decides the step for all of them — their own minimisers differ by rounding, and near a tie they would
-                          // otherwise branch on different steps and leave children that nobody searches
-  int32_t split_ss;       // entries per instance in split_steps: poly_hor + poly_hor^2 (levels 1 and 2)
-  int32_t* sub_slots;     // pass 2: pool of snapshot-scratch slots: [1] = capacity, [2 + i] = slot i taken (0 / 1)
+                          // and a tree that overruns it stops all its items at about the same time
+  SplitRec* recs;         // [rec_cap] hand-over records
+  double* rec_cand;       // [rec_cap][rows_cap][4] staged rows of a record: hot rows first, then the cold ones
+  long long* rec_mw;      // [rec_cap][rows_cap] their (step, pick weight) pairs (MW of hdsm_core.h, 8 bytes)
+  int32_t* rec_src;       // [rec_cap][rows_cap] their origins (Shm::cand_src)
+  int32_t* rec_count;     // [0] records taken, [1] items queued (published), [2] items drawn, [4] workgroups of pass 2 that hold an item or
+                          // are drawing one, [5] places of the queue reserved (zeroed before pass 1)
+  int32_t pool_cap;       // pass 2: snapshot-scratch slots (Args::scratch), taken by the workgroup of an item for its lifetime
+  int32_t* slot_busy;     // [pool_cap] 0 / 1; an item that hands over again leaves its slot (busy) to its record
+  int32_t* item_total;    // host-visible word: the merge leaves the number of items this launch queued
+  int32_t* items;         // [items_cap]: (record << 8) | (level << 3) | child position
+  int32_t* item_status;   // [items_cap] the status array of pass 2 (a queued item starts as pending)
+  int32_t rec_cap, rows_cap, items_cap;
   int32_t* tree_flag;     // host-visible word: set to 1 by an instance whose tree reached tree_mark nodes (ordinary launch) or, in a
                           // split launch, by the merge for a handed-over instance with a deep tree (TREE_MARK nodes over all its
                           // sub-blocks) — the handle keeps the NEXT launches in the split form while it sees it

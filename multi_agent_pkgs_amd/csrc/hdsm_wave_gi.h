@@ -116,10 +116,10 @@ __device__ __forceinline__ void keep_in_loop(int& v) {
 #endif
 }
 
-// threadIdx.x as a value formed HERE: the thread-indexed LDS addresses of the all-thread loops (PAR_FOR) are then computed where
+// the thread index as a value formed HERE: the thread-indexed LDS addresses of the all-thread loops (PAR_FOR) are then computed where
 // they are used; hoisted out of the branch-and-bound loop they stayed alive across the active-set run and were spilled
 __device__ __forceinline__ int tid_here() {
-  int t = (int)threadIdx.x;
+  int t = (int)HDSM_TX;
   keep_in_loop(t);
   return t;
 }
@@ -148,8 +148,8 @@ struct alignas(16) D2 {
 
 #ifdef HDSM_PROFILE
 // cycle counters accumulated in LDS by lane 0 (keeps them out of the SGPR file)
-#define PROF_DECL if (threadIdx.x == 0) s.prof_last = clock64();
-#define PROF(k) if (threadIdx.x == 0) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last; s.prof_last = now_; }
+#define PROF_DECL if (HDSM_TX == 0) s.prof_last = clock64();
+#define PROF(k) if (HDSM_TX == 0) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last; s.prof_last = now_; }
 #elif defined(HDSM_ISA_MARKS)
 // ISA study build (hipcc -S -DHDSM_ISA_MARKS): the phase boundaries show up as comments in the listing
 #define PROF_DECL
@@ -166,8 +166,8 @@ struct alignas(16) D2 {
 #define ST_PROF(k)
 #define WS_PROF(k)
 #define OP_PROF(k) PROF(k)
-#define SC_PROF_DECL if (threadIdx.x == 64) s.prof_last1 = clock64();
-#define SC_PROF(k) if (threadIdx.x == 64) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last1; s.prof_last1 = now_; }
+#define SC_PROF_DECL if (HDSM_TX == 64) s.prof_last1 = clock64();
+#define SC_PROF(k) if (HDSM_TX == 64) { const long long now_ = clock64(); s.prof_acc[k] += now_ - s.prof_last1; s.prof_last1 = now_; }
 #elif defined(HDSM_PROFILE) && defined(HDSM_PROF_STAGE)
 #define SW_PROF(k)
 #define ST_PROF(k) PROF(k)

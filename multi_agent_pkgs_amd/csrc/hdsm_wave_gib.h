@@ -322,7 +322,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
   using Base::warm_prefetch;
   static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self, int& iters,
                                                     const WarmPre& wpre) {
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)HDSM_TX;
     const int N = c.N, n = c.n;
     int nw = uni(wpre.head) & ~WARM_CERT;
     if (nw <= 0) return;
@@ -454,7 +454,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
 
   // Continues from the current (dual feasible) state until no row of the current node is violated.
   static __device__ __forceinline__ int run(S& s, const Consts& c, Regs& R, double f_cut, int& iters) {
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)HDSM_TX;
     const int n = c.n, N = c.N, max_iters = c.max_iters;
     const double tol = c.tol;
     const long long time_ticks = c.time_ticks;  // 0 = no wall-clock budget (the default)
@@ -689,7 +689,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
   // lane that phase 1 prepares, or the rows of assigned polyhedra, are evaluated from LDS at the new point.
   static constexpr int RC = 3;  // staged rows per lane prepared in phase 1 (64 RC rows; longer staging areas: the rest from LDS)
   static __device__ __forceinline__ void helper_loop(S& s, const Consts& c, Regs& R) {
-    const int w = (int)threadIdx.x >> 6;
+    const int w = (int)HDSM_TX >> 6;
     if (w != 1) {
       for (;;) {
         __syncthreads();  // go / B1
@@ -708,7 +708,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
       SC_PROF(23)
       const int cmd = uni(s.cmd);
       if (cmd == 0) return;
-      int lane = (int)threadIdx.x & 63;
+      int lane = (int)HDSM_TX & 63;
       keep_in_loop(lane);
       // this lane's trajectory point: (axis, step m), half h of the impulse-response taps
       // (NVT = 32: the two lanes of a row take half of the taps each; NVT = 48: one lane per point, all taps)

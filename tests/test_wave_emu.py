@@ -128,22 +128,23 @@ def test_branch_and_bound_with_conflict_learning(wave, oracle):
     assert nodes > 3 * 10
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3])
-def test_subtree_splitting_gives_the_unsplit_answer(wave, oracle, depth, monkeypatch):
-    """The split launch of hdsm_api.hip (pass 1 with a node budget, poly_hor^depth sub-blocks per handed-over instance that
-    prune against a shared incumbent, merge), run here one workgroup after the other on the device source: with a budget
-    of two nodes every instance that branches at all is handed over, and the answer is the oracle's whatever the depth."""
-    monkeypatch.setenv("WEMU_SPLIT_DEPTH", str(depth))
+@pytest.mark.parametrize("budget", [1, 2, 5])
+def test_subtree_splitting_gives_the_unsplit_answer(wave, oracle, budget):
+    """The split launch of hdsm_api.hip, run here one workgroup after the other on the device source: pass 1 with a node budget —
+    an instance that exceeds it writes a hand-over record (open levels, staged rows, conflicts) and queues one item per open child —
+    then every item (set-up, record, snapshot of its level, the search continues inside the child's subtree, pruning against the
+    instance's shared incumbent), then the merge. With budgets of one, two and five nodes the hand-over happens at different depths
+    of the dive (items on one level, on several levels, with and without an incumbent); the answer is the oracle's every time."""
     prm = agile_params(10, max_rows_static=18)
     handed = 0
     for seed in (3, 5):
         sn = problems.swarm_snapshot(prm, 10, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
         args = [sn[k] for k in ARG_KEYS]
         plain = wave.replan(prm, *args)
-        e = wave.replan(prm, *args, split_budget=2)
+        e = wave.replan(prm, *args, split_budget=budget)
         compare(e, oracle.replan(prm, *args, n_threads=8))
         assert np.array_equal(e["status"], plain["status"]) and np.abs(e["traj"] - plain["traj"]).max() < 1e-9
-        handed += int((plain["nodes"] > 2).sum())
+        handed += int((plain["nodes"] > budget).sum())
     assert handed >= 3
 
 

@@ -98,11 +98,13 @@ struct Job {
   const hdsm::Consts* c;
   hdsm::Args a;
   int inst, out, sub;
+  int* wg_slot = nullptr;  // pass 2: the scratch slot the (one) emulated workgroup holds, kept across items
 };
 template <int NV, int CMAX, bool SMALL = false>
 void body(void* p) {
   auto* j = static_cast<Job<NV, CMAX, SMALL>*>(p);
-  hdsm::Solver<NV, CMAX, SMALL>::solve_instance(*j->s, *j->c, j->a, j->inst, j->out, j->sub);
+  int own_slot = 0;
+  hdsm::Solver<NV, CMAX, SMALL>::solve_instance(*j->s, *j->c, j->a, j->inst, j->out, j->sub, -1, j->wg_slot ? *j->wg_slot : own_slot);
 }
 template <int NV, int CMAX, bool SMALL = false>
 int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
@@ -112,57 +114,65 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   auto shm = std::make_unique<typename Sol::S>();
   if (a.warm_out == nullptr) a.warm_out = a.warm;
   // split_budget > 0: the three steps of hdsm_api.hip's split launch, one workgroup after the other — pass 1 with the node
-  // budget, then for every instance it handed over one sub-block per polyhedron (own outputs, shared incumbent word), then
-  // the merge (hdsm::split_merge, the body of k_split_merge)
-  int K = c.P;  // sub-blocks per instance: poly_hor^D (hdsm_api.hip: HDSM_SPLIT_DEPTH, default 3)
-  for (int l = 1, d = getenv("WEMU_SPLIT_DEPTH") ? atoi(getenv("WEMU_SPLIT_DEPTH")) : 3; l < d && l < 3; ++l) K *= c.P;
-  std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, sub_slots(2 + 4, 0);
+  // budget (an instance that exceeds it writes a hand-over record and queues one item per open child of its open levels), then
+  // every queued item (own outputs, the instance's shared incumbent word and node pool, the snapshots of pass 1 read from its
+  // scratch), then the merge (hdsm::split_merge, the body of k_split_merge)
+  const int rec_cap = a.n_inst * 64 < 256 ? 256 : a.n_inst * 64, rows_cap = CMAX, items_cap = rec_cap * 8;
+  std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, rec_count(8, 0), items, rec_src, node_pool;
   std::vector<unsigned long long> inc_bits;
-  std::vector<double> sub_traj, sub_ctrl, sub_obj;
+  std::vector<double> sub_traj, sub_ctrl, sub_obj, rec_cand, all_scratch;
+  std::vector<long long> rec_mw;
+  std::vector<hdsm::SplitRec> recs;
   std::vector<uint8_t> sub_used;
+  double* pass1_scratch = scratch.data();
   if (a.split_budget > 0) {
     split_info.assign((size_t)2 * a.n_inst, 0);
     a.split_info = split_info.data();
+    recs.resize(rec_cap), rec_cand.assign((size_t)rec_cap * rows_cap * 4, 0.0), rec_mw.assign((size_t)rec_cap * rows_cap, 0), rec_src.assign((size_t)rec_cap * rows_cap, 0);
+    items.assign(items_cap, 0), inc_bits.assign(a.n_inst, 0x7ff0000000000000ull), node_pool.assign(a.n_inst, 0);
+    a.recs = recs.data(), a.rec_cand = rec_cand.data(), a.rec_mw = rec_mw.data(), a.rec_src = rec_src.data(), a.rec_count = rec_count.data(), a.items = items.data();
+    a.rec_cap = rec_cap, a.rows_cap = rows_cap, a.items_cap = items_cap, a.inc_bits = inc_bits.data(), a.node_pool = node_pool.data();
+    sub_status.assign((size_t)items_cap, hdsm::ST_NO_SOLUTION), a.item_status = sub_status.data();
+    const int left_nodes = c.max_nodes - a.split_budget > 64 ? c.max_nodes - a.split_budget : 64;
+    a.nodes_pool0 = left_nodes, a.node_cap = left_nodes / 128 > 0 ? left_nodes / 128 : 1;
+    all_scratch.assign((size_t)a.scratch_stride * a.n_inst, 0.0);  // (pass 2 reads the snapshots of pass 1: every instance keeps its own)
+    pass1_scratch = all_scratch.data();
   }
   for (int k = 0; k < a.n_inst; ++k) {
     memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
     Job<NV, CMAX, SMALL> job{shm.get(), &c, a, k, k, -1};
-    job.a.scratch = scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds out * stride
+    job.a.scratch = a.split_budget > 0 ? pass1_scratch : scratch.data() - (int64_t)k * a.scratch_stride;  // solve_instance adds out * stride
     if (!wemu::run_block(body<NV, CMAX, SMALL>, &job, k, nthreads)) return -100;
     if (getenv("WEMU_OPS")) fprintf(stderr, "instance %d: %ld lockstep points (barrier %ld, readlane %ld, ballot %ld, dpp %ld, permlane %ld, wsync %ld), %d active-set operations\n", k, wemu::rt().ops, wemu::rt().by_kind[1], wemu::rt().by_kind[2], wemu::rt().by_kind[3], wemu::rt().by_kind[6], wemu::rt().by_kind[7] + wemu::rt().by_kind[8], wemu::rt().by_kind[9], a.st_iters ? a.st_iters[k] : -1);
   }
   if (a.split_budget > 0) {
-    const size_t G = (size_t)a.n_inst * K, N = (size_t)c.N;
+    const size_t G = (size_t)items_cap, N = (size_t)c.N;
     hdsm::Args b = a;
-    sub_status.assign(G, hdsm::ST_NO_SOLUTION), sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
-    inc_bits.assign(a.n_inst, 0x7ff0000000000000ull);
-    for (int k = 0; k < a.n_inst; ++k)  // (k_split_init: the incumbent pass 1 left seeds the shared bound)
-      if ((split_info[2 * k] & 2) != 0 && a.obj[k] >= 0.0) memcpy(&inc_bits[k], &a.obj[k], 8);
-    const int left_nodes = c.max_nodes - a.split_budget > K ? c.max_nodes - a.split_budget : K;
-    b.node_cap = left_nodes / (2 * K) > 0 ? left_nodes / (2 * K) : 1;
-    std::vector<int32_t> node_pool((size_t)a.n_inst, left_nodes - b.node_cap * K > 0 ? left_nodes - b.node_cap * K : 0);
-    b.node_pool = node_pool.data();
-    const int ss = c.P + c.P * c.P;
-    std::vector<int32_t> split_steps((size_t)a.n_inst * ss, -1);
-    b.split_steps = split_steps.data(), b.split_ss = ss;
+    sub_stats.assign(8 * G, 0), sub_warm.assign((hdsm::MAXNV + 2) * G, 0);
     sub_traj.assign(G * (N + 1) * 9, 0.0), sub_ctrl.assign(G * N * 3, 0.0), sub_obj.assign(G, 0.0), sub_used.assign(G * c.P, 0);
-    sub_slots[0] = 0, sub_slots[1] = 4;
-    b.split_budget = 0, b.sub_k = K, b.order = nullptr, b.inc_bits = inc_bits.data(), b.sub_slots = sub_slots.data();
+    b.item_mode = 1, b.order = nullptr;
+    // an item whose subtree outgrows the budget hands over again (hdsm_api.hip: HDSM_ITEM_BUDGET, default 32; here the budget of pass 1,
+    // so that the tests reach it): its scratch stays with its record, the emulated workgroup moves to a fresh slot of the pool
+    b.split_budget = getenv("WEMU_ITEM_BUDGET") ? atoi(getenv("WEMU_ITEM_BUDGET")) : a.split_budget;
+    const int pool_cap = 1 + rec_cap;
+    std::vector<double> pool((size_t)a.scratch_stride * pool_cap, 0.0);
+    b.scratch = pool.data(), b.pool_cap = pool_cap;
     b.traj = sub_traj.data(), b.ctrl = sub_ctrl.data(), b.used = sub_used.data(), b.status = sub_status.data(), b.obj = sub_obj.data();
     b.warm_out = sub_warm.data();
     b.st_iters = sub_stats.data(), b.st_nodes = sub_stats.data() + G, b.st_sweeps = sub_stats.data() + 2 * G, b.st_cand = sub_stats.data() + 3 * G;
     b.st_sph = nullptr, b.st_pairs = nullptr, b.st_flags = reinterpret_cast<uint32_t*>(sub_stats.data() + 6 * G), b.st_key = nullptr;
-    for (int g = 0; g < (int)G; ++g) {
-      const int inst = g / K;
-      if (split_info[2 * inst] == 0) continue;
+    if (getenv("WEMU_SPLIT_TRACE")) fprintf(stderr, "split: %d records, %d items queued by pass 1\n", rec_count[0], rec_count[1]);
+    int next_free = 0;
+    for (int g = 0; g < (rec_count[1] < items_cap ? rec_count[1] : items_cap); ++g) {  // (the queue grows while items hand over again)
+      const int item = items[g], inst = recs[item >> 8].inst;
       memset(static_cast<void*>(shm.get()), 0, sizeof(typename Sol::S));
-      Job<NV, CMAX, SMALL> job{shm.get(), &c, b, inst, g, g % K};
-      std::vector<double> sub_scratch;  // (the sub-blocks run one after the other: every one gets a slot of the 4-slot pool)
-      sub_scratch.resize((size_t)a.scratch_stride * 4);
-      job.a.scratch = sub_scratch.data();
-      if (!wemu::run_block(body<NV, CMAX, SMALL>, &job, g, nthreads)) return -100;
+      int wg_slot = next_free;  // (run_block's slot table: a slot left to a record stays busy)
+      Job<NV, CMAX, SMALL> job{shm.get(), &c, b, inst, g, item, &wg_slot};
+      if (!wemu::run_block(body<NV, CMAX, SMALL>, &job, 0, nthreads)) return -100;
+      if (wg_slot < 0) ++next_free;
     }
-    for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, c.P, K, a, b, inst, 0, 1);
+    if (getenv("WEMU_SPLIT_TRACE")) fprintf(stderr, "split: %d records, %d items in the end\n", rec_count[0], rec_count[1]);
+    for (int inst = 0; inst < a.n_inst; ++inst) hdsm::split_merge(c.N, c.P, a, b, inst, 0, 1);
   }
   return 0;
 }
