@@ -186,7 +186,10 @@ int hdsm_replan_device(void* handle, int32_t n_inst, int32_t n_rob, const int32_
  * hdsm_replan / hdsm_solve / hdsm_reference move it by DMA without the driver's staging copy. When ALL FIVE output arrays of an
  * hdsm_replan call lie in registered memory the results are written straight into them by the device, and only for instances
  * that have a solution (the "left untouched" rule is kept; no staging download, no host-side copy). Arrays that were never
- * registered keep working as before. Unregister an array before freeing it. Not needed for device pointers.                 */
+ * registered keep working as before. Unregister an array before freeing it. Not needed for device pointers.
+ * The library records every range registered HERE and takes the direct paths only for arrays that lie inside one of them with all
+ * the bytes the call touches (n_inst / n_rob items): an array that runs past its registered range, or memory page-locked by other
+ * means, goes through the copy path like pageable memory — never a device fault.                                             */
 int hdsm_host_register(void* ptr, size_t bytes);
 int hdsm_host_unregister(void* ptr);
 

@@ -65,25 +65,31 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
     int32_t* const busy = a.slot_busy;
     const int icap = a.items_cap, pcap = a.pool_cap;
     if (threadIdx.x == 0) {
+      // rcnt[4] counts the workgroups that HOLD an item (or are in the act of taking one: raised before the compare-and-swap that
+      // draws, so that "queue empty and nobody holds an item" cannot be seen while somebody is between the two). A workgroup that
+      // waits only READS the three counters: hundreds of waiting workgroups must not keep each other's view of rcnt[4] above zero.
       int got = -1;
       for (int spins = 0; spins < (1 << 21); ++spins) {  // (seconds: whatever holds the last items up, this workgroup is not needed for them)
-        atomicAdd(&rcnt[4], 1);
-        for (;;) {
-          const int d = __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q = q < icap ? q : icap;
-          if (d >= q) break;
+        const int d = __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = q < icap ? q : icap;
+        if (d < q) {
+          atomicAdd(&rcnt[4], 1);
           if (atomicCAS(&rcnt[2], d, d + 1) == d) {
             got = d;
             break;
           }
+          atomicSub(&rcnt[4], 1);
+          continue;  // (somebody else took that one: look again at once)
         }
-        if (got >= 0) break;
-        const int active = atomicSub(&rcnt[4], 1) - 1;
-        int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q = q < icap ? q : icap;
-        if (active <= 0 && __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q) break;
-        __builtin_amdgcn_s_sleep(127);
+        if (__hip_atomic_load(&rcnt[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
+          // nobody holds an item: nothing can be queued any more — unless it was queued between the two reads above
+          int q2 = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q2 = q2 < icap ? q2 : icap;
+          if (__hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q2) break;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(64);
       }
       int sl = -1;
       if (got >= 0) {  // a scratch slot: at most gridDim-resident + records slots are ever busy (a slot left to a record stays busy)

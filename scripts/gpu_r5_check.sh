@@ -4,9 +4,9 @@ var=${1:-HDSM_CHILD_BOUND}; vals=${2:-"0 1"}; tests=${3:-1}; bench=${4:-1}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5
 if [ "$tests" = "1" ]; then
-  python -m pytest tests -m gpu -x -q > gpurun_out/r5/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/r5/gpu_tests.log
+  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r5/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/r5/gpu_tests.log
 fi
-run() { python bench.py --no-cpu-baseline --no-secondary --no-event-pass --repeats 2 "${@:3}" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], '%.4f ms' % d['ms_per_step'], 'limit', d['limit_instances_timed_rounds'], 'failed', d['failed_instances_timed_rounds'], 'nodes_max', d['solver_stats_timed_rounds']['nodes_max'])" "$1" "$2"; }
+run() { timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-event-pass --repeats 2 "${@:3}" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], sys.argv[2], '%.4f ms' % d['ms_per_step'], 'limit', d['limit_instances_timed_rounds'], 'failed', d['failed_instances_timed_rounds'], 'nodes_max', d['solver_stats_timed_rounds']['nodes_max'])" "$1" "$2"; }
 for rep in 1 2; do
 for v in $vals; do
   export $var=$v
@@ -17,7 +17,7 @@ for v in $vals; do
 done
 done
 if [ "$bench" = "1" ]; then
-  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5/bench.json 2> gpurun_out/r5/bench.err; echo "bench rc=$?"
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5/bench.json 2> gpurun_out/r5/bench.err; echo "bench rc=$?"
   python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r5/bench.json').read().strip().splitlines()[-1])

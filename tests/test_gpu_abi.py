@@ -401,3 +401,34 @@ def test_registered_host_arrays_get_the_same_answers_delivered_by_the_device(hds
     assert (got["traj"][~ok] == 7.5).all() and (got["ctrl"][~ok] == 7.5).all() and (got["used"][~ok] == 9).all() and (got["obj"][~ok] == 7.5).all()
     with pytest.raises(hdsm.HdsmError):
         hdsm.host_unregister(np.zeros(8))  # never registered
+
+
+def test_an_array_that_runs_past_its_registered_range_goes_through_the_copy_path(hdsm):
+    """hdsm_replan decided "registered" from the base pointer alone. The library now records the ranges registered
+    through hdsm_host_register and takes the kernel paths (fetch from / delivery into mapped host memory) only for arrays that lie inside
+    one with every byte the call touches. Here only the FIRST HALF of each array is registered: the call must neither fault nor read
+    short — it falls back to the staged copies and returns the same numbers as with pageable arrays."""
+    prm = agile_params(10, max_rows_static=18)
+    sn = problems.swarm_snapshot(prm, 64, seed=9, spacing=1.1, turn=True)
+    args = [np.ascontiguousarray(sn[k]).copy() for k in ARG_KEYS]
+    sol = hdsm.Solver(prm, 64, 64)
+    plain = sol.replan(*args)
+    sol.reset_warm_start()
+    out = dict(traj=np.zeros((64, 11, 9)), ctrl=np.zeros((64, 10, 3)), used=np.zeros((64, prm.poly_hor), dtype=np.uint8),
+               status=np.full(64, -1, dtype=np.int32), obj=np.zeros(64))
+    import ctypes as C
+    lib = hdsm.load()
+    lib.hdsm_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.hdsm_host_unregister.argtypes = [C.c_void_p]
+    halves = [a for a in args + list(out.values()) if a.nbytes >= 8192]   # (whole pages: half of the array is at least a page)
+    assert len(halves) >= 4
+    for a in halves:
+        assert lib.hdsm_host_register(C.c_void_p(a.ctypes.data), a.nbytes // 2) == 0
+    try:
+        got = sol.replan(*args, out=out)
+    finally:
+        for a in halves:
+            assert lib.hdsm_host_unregister(C.c_void_p(a.ctypes.data)) == 0
+    assert (got["status"] == plain["status"]).all()
+    ok = plain["status"] != 2
+    assert np.abs(got["traj"][ok] - plain["traj"][ok]).max() < 1e-9

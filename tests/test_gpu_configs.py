@@ -104,12 +104,14 @@ def _check_round(sol, oracle, prm, rec, out, n_parity, rng, plane_chunk=32, traj
     return len(ok), int((status == 2).sum())
 
 
-def _oracle_proved(oracle, prm, rec, sub, hint=None, threads=8, nodes=200000, iters=30000000):
+def _oracle_proved(oracle, prm, rec, sub, hint=None, threads=0, nodes=200000, iters=30000000):
     """The oracle on instances `sub` of a recorded round, with a PROOF wherever the budgets allow one. H <= 10: the step-ordered
     search first (bounded), then — where that ran into its budget — the oracle's other search order (most infeasible step
     first), which finishes the trees the enumeration in step order cannot; H > 10: the second order directly. An oracle
     answer with status LIMIT (budget exhausted in both orders) is returned as such: the callers never compare against it."""
     keys = ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")
+    import os
+    threads = threads or min(64, os.cpu_count() or 8)
     if prm.n_hor <= 10:
         bounded = prm.copy()
         bounded.max_nodes, bounded.max_qp_iters = 100000, 1000000
@@ -216,7 +218,7 @@ def test_config_3_256_agents_through_a_forest(hdsm, oracle):
         pos, dist, _ = loop.shard.state()
         hits += _pillar_hits(pos, raw, origin)
         if r in (5, 40, 80, 110, 125):
-            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 16, rng)
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 64, rng)   # 64 of 256 instances per checked round against the oracle
             checked += n_ok
             assert n_ok > n_rob // 2
     assert rows_max > 6 and rows_max <= 18 and chamfered > 100    # the forest really shapes the corridors
@@ -275,11 +277,11 @@ def test_config_5_4096_agents_forest_wall_forest(hdsm, oracle):
         assert loop.shard.corridor_errors()[0] == 0
         rows_max = max(rows_max, int(rec[0]["n_rows"].max()))
         if r in (3, 15):
-            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 6, rng, plane_chunk=8)
+            n_ok, n_bad = _check_round(sol, oracle, prm, rec[0], out, 64, rng, plane_chunk=8)   # 64 random instances per checked round against the oracle
             assert n_ok > 0.9 * n_rob
         # instances that ended on the node budget: incumbent vs the proven optimum (a few per flight: the proofs are expensive)
-        if (out["status"] == 1).any() and len(limited) < 1:
-            limited += _check_limit_instances(sol, oracle, prm, rec[0], out, max_check=1)
+        if (out["status"] == 1).any() and len(limited) < 8:
+            limited += _check_limit_instances(sol, oracle, prm, rec[0], out, max_check=8 - len(limited))
     pos, _, _ = loop.shard.state()
     assert _pillar_hits(pos, raw, origin) == 0
     assert pos[:, 0].mean() > 3.0 and rows_max > 6                 # moving into the first forest on shaped corridors
