@@ -677,7 +677,7 @@ struct Handle {
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int split_mode = 2, split_budget = 0, split_ttl = 0;  // split_budget 0: by batch size, see launch()
-  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
+  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32, item_min = 2;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
   int32_t* h_ovf_flag = nullptr;    // pinned host word: an instance ended on a staging overflow (Args::ovf_flag), and its device alias
   int32_t* d_ovf_flag = nullptr;
   int rescue_ttl = 0;               // launches left that carry the rescue pass
@@ -1054,6 +1054,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
     b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr, b.pool_cap = h->pool_cap, b.slot_busy = h->d_slot_busy, b.item_total = h->d_item_total;
     b.split_budget = h->item_budget;  // an item whose subtree outgrows this many nodes hands over again (0: never)
+    b.split_min = h->item_min;        // ... or this many, while workgroups are waiting for items
     int32_t* ss = h->d_sub_stats;
     const size_t GI = (size_t)h->items_cap;
     b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
@@ -1160,6 +1161,10 @@ hipError_t ensure_sub(Handle* h) {
   if (const char* ev = std::getenv("HDSM_ITEM_BUDGET")) {
     const long v = std::strtol(ev, nullptr, 10);
     if (v >= 0 && v <= 100000) h->item_budget = (int)v;
+  }
+  if (const char* ev = std::getenv("HDSM_ITEM_MIN")) {
+    const long v = std::strtol(ev, nullptr, 10);
+    if (v >= 1 && v <= 100000) h->item_min = (int)v;
   }
   const size_t G = (size_t)h->items_cap, R = (size_t)h->rec_cap;
   hipError_t e = hipSuccess;

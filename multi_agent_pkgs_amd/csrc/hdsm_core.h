@@ -590,17 +590,27 @@ struct Solver {
             continue;
           }
         }
-        if (s.args.split_budget > 0 && nodes >= s.args.split_budget) {  // pass 1 of a split launch: hand the search over
+        if (s.args.split_budget > 0 && (nodes >= s.args.split_budget || (s.args.item_mode && nodes >= s.args.split_min && (nodes & 1) == 0))) {
+          // a split launch: hand the search over — pass 1 after its node budget; an item of pass 2 after its own, or, from
+          // split_min nodes on, as soon as the queue is empty (workgroups are waiting for items: looked at every other node)
           // (if there is a record slot left and the staged rows fit the staging area of pass 2 — otherwise the search goes on here)
           SYNC();
           if (IS_T0) {
             int slot = -1;
-            if (s.ncand + s.ncold <= s.args.rows_cap) {
-              slot = atomicAdd(&s.args.rec_count[0], 1);
-              if (slot >= s.args.rec_cap) slot = -1;
+            bool want = nodes >= s.args.split_budget;
+            if (!want) {
+              int q = __hip_atomic_load(&s.args.rec_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              q = q < s.args.items_cap ? q : s.args.items_cap;
+              want = __hip_atomic_load(&s.args.rec_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q;
+            }
+            if (want) {
+              if (s.ncand + s.ncold <= s.args.rows_cap) {
+                slot = atomicAdd(&s.args.rec_count[0], 1);
+                if (slot >= s.args.rec_cap) slot = -1;
+              }
+              if (slot < 0) s.args.split_budget = 0;  // (no record left, or rows that do not fit: this search stays here to its end)
             }
             s.iters_sh = slot;
-            if (slot < 0) s.args.split_budget = 0;
           }
           SYNC();
           const int slot = uni(s.iters_sh);
@@ -861,7 +871,7 @@ struct Solver {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
         s.warm_head = wpre.head;
-        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = item >= 0 ? a_in.node_cap : 0;
+        s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = 0;  // (pass 2: every node after the item's own is drawn from the instance's pool)
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
       ST_PROF(12)

@@ -147,7 +147,10 @@ struct Args {
   // every child of an open level that has not been explored yet becomes an ITEM of pass 2. Pass 2 = persistent workgroups that draw
   // items from one queue: set-up of the instance, the record, the snapshot of the item's level, and the search continues inside the
   // item's subtree exactly where pass 1 would have continued it — no warm start, no sweep, no node solved twice. Pass 3 = the merge.
-  int32_t split_budget;   // pass 1: nodes after which an instance hands its search over (0 = ordinary launch)
+  int32_t split_budget;   // pass 1: nodes after which an instance hands its search over (0 = ordinary launch); pass 2: ... an item hands over again
+  int32_t split_min;      // pass 2: an item that has opened at least this many nodes hands over again as soon as the queue is EMPTY
+                          // (workgroups are waiting for items): large subtrees are cut up while there is nobody to search them
+  int32_t pad_split;
   int32_t item_mode;      // pass 2: 1 = the workgroups draw items (instances come from the records; blockIdx is only a slot number)
   int32_t* split_info;    // [n_inst][2]: bit 0 handed over, bit 1 pass 1 left an incumbent in the instance's outputs; the record's slot
   unsigned long long* inc_bits;  // [n_inst]: best objective any item has found so far (bits of a non-negative double,

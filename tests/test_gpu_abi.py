@@ -403,11 +403,13 @@ def test_registered_host_arrays_get_the_same_answers_delivered_by_the_device(hds
         hdsm.host_unregister(np.zeros(8))  # never registered
 
 
-def test_an_array_that_runs_past_its_registered_range_goes_through_the_copy_path(hdsm):
-    """hdsm_replan decided "registered" from the base pointer alone. The library now records the ranges registered
-    through hdsm_host_register and takes the kernel paths (fetch from / delivery into mapped host memory) only for arrays that lie inside
-    one with every byte the call touches. Here only the FIRST HALF of each array is registered: the call must neither fault nor read
-    short — it falls back to the staged copies and returns the same numbers as with pageable arrays."""
+def test_an_array_that_runs_past_its_registered_range_never_reaches_the_fetch_kernel(hdsm):
+    """hdsm_replan decided "registered" from the base pointer alone, so an array that ran past its registered range was
+    handed to k_fetch / k_deliver, which read or wrote beyond the mapping: a GPU memory fault and a dead process. The library now records
+    the ranges registered through hdsm_host_register and takes the kernel paths only for arrays that lie INSIDE one with every byte the
+    call touches. Here only the first half of each large array is registered: the call takes the copy path, where the HIP runtime itself
+    refuses a copy that straddles a registration (a clean HDSM_ERR_DEVICE, no fault) or performs it; afterwards the process and the
+    handle are alive and a call with properly registered arrays uses the direct paths again."""
     prm = agile_params(10, max_rows_static=18)
     sn = problems.swarm_snapshot(prm, 64, seed=9, spacing=1.1, turn=True)
     args = [np.ascontiguousarray(sn[k]).copy() for k in ARG_KEYS]
@@ -424,11 +426,24 @@ def test_an_array_that_runs_past_its_registered_range_goes_through_the_copy_path
     assert len(halves) >= 4
     for a in halves:
         assert lib.hdsm_host_register(C.c_void_p(a.ctypes.data), a.nbytes // 2) == 0
+    ok = plain["status"] != 2
     try:
-        got = sol.replan(*args, out=out)
+        try:
+            got = sol.replan(*args, out=out)
+            assert (got["status"] == plain["status"]).all() and np.abs(got["traj"][ok] - plain["traj"][ok]).max() < 1e-9
+        except hdsm.HdsmError as e:
+            assert e.code == hdsm.HDSM_ERR_DEVICE      # refused by the runtime's copy, reported — not a fault
     finally:
         for a in halves:
             assert lib.hdsm_host_unregister(C.c_void_p(a.ctypes.data)) == 0
-    assert (got["status"] == plain["status"]).all()
-    ok = plain["status"] != 2
-    assert np.abs(got["traj"][ok] - plain["traj"][ok]).max() < 1e-9
+    # the handle is alive: whole arrays registered -> the direct paths, same numbers
+    sol.reset_warm_start()
+    pinned = [a for a in args if a.nbytes] + list(out.values())
+    for a in pinned:
+        hdsm.host_register(a)
+    try:
+        got = sol.replan(*args, out=out)
+    finally:
+        for a in pinned:
+            hdsm.host_unregister(a)
+    assert (got["status"] == plain["status"]).all() and np.abs(got["traj"][ok] - plain["traj"][ok]).max() < 1e-9

@@ -154,6 +154,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
     // an item whose subtree outgrows the budget hands over again (hdsm_api.hip: HDSM_ITEM_BUDGET, default 32; here the budget of pass 1,
     // so that the tests reach it): its scratch stays with its record, the emulated workgroup moves to a fresh slot of the pool
     b.split_budget = getenv("WEMU_ITEM_BUDGET") ? atoi(getenv("WEMU_ITEM_BUDGET")) : a.split_budget;
+    b.split_min = getenv("WEMU_ITEM_MIN") ? atoi(getenv("WEMU_ITEM_MIN")) : 2;  // (one workgroup after the other: the queue is empty whenever the last queued item runs)
     const int pool_cap = 1 + rec_cap;
     std::vector<double> pool((size_t)a.scratch_stride * pool_cap, 0.0);
     b.scratch = pool.data(), b.pool_cap = pool_cap;
