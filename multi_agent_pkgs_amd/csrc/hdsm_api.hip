@@ -37,8 +37,10 @@ int set_err(int code, const std::string& msg) {
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess)                                                                               \
+    if (e_ != hipSuccess) {                                                                             \
+      (void)hipGetLastError(); /* reported here: the next call must not trip over it again */            \
       return set_err(HDSM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    }                                                                                                   \
   } while (0)
 
 // staged neighbour rows (LDS). One workgroup per CU is resident anyway (the iteration wave needs > 256 registers,
@@ -63,33 +65,26 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
     // of the whole struct — 256 bytes of scratch per lane in every kernel that shares this function)
     int32_t* const rcnt = a.rec_count;
     int32_t* const busy = a.slot_busy;
-    const int icap = a.items_cap, pcap = a.pool_cap;
+    const int icap = a.items_cap, pcap = a.pool_cap, psleep = a.poll_sleep;
     if (threadIdx.x == 0) {
-      // rcnt[4] counts the workgroups that HOLD an item (or are in the act of taking one: raised before the compare-and-swap that
-      // draws, so that "queue empty and nobody holds an item" cannot be seen while somebody is between the two). A workgroup that
-      // waits only READS the three counters: hundreds of waiting workgroups must not keep each other's view of rcnt[4] above zero.
+      // ONE atomic per workgroup: a ticket (rcnt[2]). Ticket k is item k of the queue — when it has been published (rcnt[1] > k)
+      // the workgroup takes it; until then it waits, READING only. It leaves without an item when every published item has been
+      // completed (rcnt[4], raised by a workgroup after its item — and after whatever that item queued was published) and the
+      // queue still ends at or before its ticket: nothing is running, so nothing can be queued any more. (Drawing with a
+      // compare-and-swap on a shared counter was measured first: 512 workgroups retrying against each other cost a millisecond.)
+      const int ticket = atomicAdd(&rcnt[2], 1);
       int got = -1;
-      for (int spins = 0; spins < (1 << 21); ++spins) {  // (seconds: whatever holds the last items up, this workgroup is not needed for them)
-        const int d = __hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; spins < (1 << 19) && ticket < icap; ++spins) {  // (seconds: whatever holds the last items up)
+        const int done = __hip_atomic_load(&rcnt[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q = q < icap ? q : icap;
-        if (d < q) {
-          atomicAdd(&rcnt[4], 1);
-          if (atomicCAS(&rcnt[2], d, d + 1) == d) {
-            got = d;
-            break;
-          }
-          atomicSub(&rcnt[4], 1);
-          continue;  // (somebody else took that one: look again at once)
+        if (ticket < q) {
+          got = ticket;
+          break;
         }
-        if (__hip_atomic_load(&rcnt[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) {
-          // nobody holds an item: nothing can be queued any more — unless it was queued between the two reads above
-          int q2 = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          q2 = q2 < icap ? q2 : icap;
-          if (__hip_atomic_load(&rcnt[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q2) break;
-          continue;
-        }
-        __builtin_amdgcn_s_sleep(64);
+        if (done >= q) break;  // (read BEFORE the queue's end: all of it was completed, and only a running item can extend it)
+        // (hundreds of workgroups may be waiting, and every look is a device-scope read that no L2 can serve)
+        for (int w = 0; w < psleep; ++w) __builtin_amdgcn_s_sleep(127);
       }
       int sl = -1;
       if (got >= 0) {  // a scratch slot: at most gridDim-resident + records slots are ever busy (a slot left to a record stays busy)
@@ -97,7 +92,7 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
           const int i = (int)(((unsigned)blockIdx.x * 7u + (unsigned)probe) % (unsigned)pcap);
           if (atomicCAS(&busy[i], 0, 1) == 0) sl = i;
         }
-        if (sl < 0) atomicSub(&rcnt[4], 1), got = -2;  // (cannot happen by the count above; the item stays pending: the merge reports a limit)
+        if (sl < 0) atomicAdd(&rcnt[4], 1), got = -2;  // (cannot happen by the count above; the item stays pending: the merge reports a limit)
       }
       s.iters_sh = got, s.rc = sl;
     }
@@ -128,7 +123,7 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
   if (item >= 0 && threadIdx.x == 0) {  // (the launch arguments from the copy in LDS: the kernel's own are dead after the solver's prologue)
     if (slot >= 0) atomicExch(&s.args.slot_busy[slot], 0);  // (slot < 0: the item handed over again and its scratch stays with its record)
     __threadfence();
-    atomicSub(&s.args.rec_count[4], 1);                     // this item is done; what it queued is in the queue already
+    atomicAdd(&s.args.rec_count[4], 1);                     // this item is completed; what it queued has been published
   }
 }
 
@@ -677,7 +672,7 @@ struct Handle {
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int split_mode = 2, split_budget = 0, split_ttl = 0;  // split_budget 0: by batch size, see launch()
-  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32, item_min = 2;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
+  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32, item_min = 0, poll_sleep = 2;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
   int32_t* h_ovf_flag = nullptr;    // pinned host word: an instance ended on a staging overflow (Args::ovf_flag), and its device alias
   int32_t* d_ovf_flag = nullptr;
   int rescue_ttl = 0;               // launches left that carry the rescue pass
@@ -1013,7 +1008,11 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   a.ovf_flag = h->d_ovf_flag, a.rescue = 0;
   // nodes after which an instance is handed over: small batches leave most CUs idle, so sub-blocks are free; in a batch that
   // fills the GPU every handed-over instance costs poly_hor set-ups and sweeps on busy CUs, so only the deep trees go
-  const int budget = h->split_budget > 0 ? h->split_budget : (a.n_inst <= 2 * h->cus ? 8 : 96);
+  // (measured on MI355X with the hand-over records of round 5 — a hand-over costs about one node, no search is repeated: cfg 3, 256
+  // instances, 2 / 4 / 8 / 16 nodes -> 0.65 / 0.70 / 0.84 / 0.93 ms per round; cfg 5, 4096 instances, 16 / 24 / 32 / 48 / 96 nodes ->
+  // 8.1 / 8.4 / 8.9 / 9.4 / 11.3 ms)
+  const bool roomy = a.n_inst <= 2 * h->cus;
+  const int budget = h->split_budget > 0 ? h->split_budget : (roomy ? 2 : 16);
   a.tree_mark = budget > hdsm::TREE_MARK ? budget : hdsm::TREE_MARK;
   // Subtree splitting. A launch lasts as long as its slowest instance, and in obstacle worlds that is one agent between pillars
   // whose branch and bound needs hundreds of nodes while the other workgroups have been idle for milliseconds. When the last
@@ -1054,7 +1053,10 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     b.traj = h->d_sub_traj, b.ctrl = h->d_sub_ctrl, b.used = h->d_sub_used, b.status = h->d_sub_status, b.obj = h->d_sub_obj;
     b.scratch = h->d_sub_scratch, b.warm_out = h->d_sub_warm, b.prof = nullptr, b.pool_cap = h->pool_cap, b.slot_busy = h->d_slot_busy, b.item_total = h->d_item_total;
     b.split_budget = h->item_budget;  // an item whose subtree outgrows this many nodes hands over again (0: never)
-    b.split_min = h->item_min;        // ... or this many, while workgroups are waiting for items
+    // ... or, while workgroups are waiting for items, this many: 2 in a batch that leaves CUs idle (cfg 3: 0.84 ms against 1.14 without),
+    // 16 in one that fills the GPU (every look at the queue is two device-scope reads per node: cfg 5 8.15 ms with 2 - 4, 7.5 with >= 8)
+    b.split_min = h->item_min > 0 ? h->item_min : (roomy ? 2 : 16);
+    b.poll_sleep = h->poll_sleep;
     int32_t* ss = h->d_sub_stats;
     const size_t GI = (size_t)h->items_cap;
     b.st_iters = ss, b.st_nodes = ss + GI, b.st_sweeps = ss + 2 * GI, b.st_cand = ss + 3 * GI, b.st_sph = ss + 4 * GI, b.st_pairs = ss + 5 * GI;
@@ -1161,6 +1163,10 @@ hipError_t ensure_sub(Handle* h) {
   if (const char* ev = std::getenv("HDSM_ITEM_BUDGET")) {
     const long v = std::strtol(ev, nullptr, 10);
     if (v >= 0 && v <= 100000) h->item_budget = (int)v;
+  }
+  if (const char* ev = std::getenv("HDSM_POLL_SLEEP")) {
+    const long v = std::strtol(ev, nullptr, 10);
+    if (v >= 1 && v <= 1000) h->poll_sleep = (int)v;
   }
   if (const char* ev = std::getenv("HDSM_ITEM_MIN")) {
     const long v = std::strtol(ev, nullptr, 10);

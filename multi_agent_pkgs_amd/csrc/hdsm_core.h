@@ -601,7 +601,7 @@ struct Solver {
             if (!want) {
               int q = __hip_atomic_load(&s.args.rec_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               q = q < s.args.items_cap ? q : s.args.items_cap;
-              want = __hip_atomic_load(&s.args.rec_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q;
+              want = __hip_atomic_load(&s.args.rec_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q;  // (tickets beyond the queue: workgroups wait)
             }
             if (want) {
               if (s.ncand + s.ncold <= s.args.rows_cap) {
@@ -1446,15 +1446,16 @@ struct Solver {
 // arrays of pass 2 (indexed by the item's place in the queue; the record of the instance names its range).
 HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int lane, int lanes) {
   if (inst >= a.n_inst || a.split_info[2 * inst] == 0) return;
-  int best = -1, lim = 0, iters = a.st_iters[inst], nodes = a.st_nodes[inst], sweeps = a.st_sweeps[inst], cand = a.st_cand[inst], sph = 0, pairs = 0;
+  // every lane takes the items lane, lane + lanes, ... of each record (the reads are dependent global round trips: one lane walking
+  // all of them took 30 - 200 us per launch); the lanes' partial results meet through shuffles (device) — one lane: nothing to meet
+  int best = -1, lim = 0, iters = 0, nodes = 0, sweeps = 0, cand = 0, sph = 0, pairs = 0;
   unsigned flags = 0;
   const bool own = (a.split_info[2 * inst] & 2) != 0;  // pass 1 left an incumbent in the instance's own outputs
-  double obj = own ? a.obj[inst] : DINF;
-  if (a.st_sph) sph = a.st_sph[inst], pairs = a.st_pairs[inst];
+  double obj = DINF;
   for (int r = a.split_info[2 * inst + 1]; r >= 0; r = a.recs[r].next) {  // the record of pass 1 and those of the items that handed over again
     const SplitRec& rc = a.recs[r];
     if (rc.truncated) lim = 1, flags |= (unsigned)FLAG_NODE_LIMIT;
-    for (int g = rc.first_item; g < rc.first_item + rc.n_items; ++g) {
+    for (int g = rc.first_item + lane; g < rc.first_item + rc.n_items; g += lanes) {
       const int st = b.status[g];
       if (st == ST_PENDING) {  // never started
         lim = 1, flags |= (unsigned)FLAG_NODE_LIMIT;
@@ -1465,9 +1466,27 @@ HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int la
       cand = b.st_cand[g] > cand ? b.st_cand[g] : cand;
       flags |= b.st_flags[g];
       lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
-      if (st != ST_NO_SOLUTION && b.obj[g] < obj) obj = b.obj[g], best = g;
+      if (st != ST_NO_SOLUTION && (b.obj[g] < obj || (b.obj[g] == obj && best >= 0 && g < best))) obj = b.obj[g], best = g;
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (lanes > 1) {
+    for (int off = 32; off > 0; off >>= 1) {
+      iters += __shfl_xor(iters, off), nodes += __shfl_xor(nodes, off), sweeps += __shfl_xor(sweeps, off), sph += __shfl_xor(sph, off), pairs += __shfl_xor(pairs, off);
+      const int c2 = __shfl_xor(cand, off);
+      cand = c2 > cand ? c2 : cand;
+      flags |= (unsigned)__shfl_xor((int)flags, off), lim |= __shfl_xor(lim, off);
+      const double o2 = __shfl_xor(obj, off);
+      const int b2 = __shfl_xor(best, off);
+      if (b2 >= 0 && (o2 < obj || (o2 == obj && (best < 0 || b2 < best)))) obj = o2, best = b2;  // (ties: the first item of the queue, in every lane)
+    }
+  }
+#endif
+  iters += a.st_iters[inst], nodes += a.st_nodes[inst], sweeps += a.st_sweeps[inst];
+  cand = a.st_cand[inst] > cand ? a.st_cand[inst] : cand;
+  if (a.st_sph) sph += a.st_sph[inst], pairs += a.st_pairs[inst];
+  if (own && !(obj < a.obj[inst])) obj = a.obj[inst], best = -1;  // (pass 1's own incumbent is at least as good)
+  if (!own && best < 0) obj = DINF;
   const int status = (best < 0 && !own) ? ST_NO_SOLUTION : (lim ? ST_LIMIT : ST_OPTIMAL);
   if (best >= 0) {
     for (int e = lane; e < (N + 1) * 9; e += lanes) a.traj[(int64_t)inst * (N + 1) * 9 + e] = b.traj[(int64_t)best * (N + 1) * 9 + e];

@@ -150,7 +150,7 @@ struct Args {
   int32_t split_budget;   // pass 1: nodes after which an instance hands its search over (0 = ordinary launch); pass 2: ... an item hands over again
   int32_t split_min;      // pass 2: an item that has opened at least this many nodes hands over again as soon as the queue is EMPTY
                           // (workgroups are waiting for items): large subtrees are cut up while there is nobody to search them
-  int32_t pad_split;
+  int32_t poll_sleep;     // pass 2: a workgroup that waits for items looks at the queue every poll_sleep x ~3.4 us (s_sleep 127)
   int32_t item_mode;      // pass 2: 1 = the workgroups draw items (instances come from the records; blockIdx is only a slot number)
   int32_t* split_info;    // [n_inst][2]: bit 0 handed over, bit 1 pass 1 left an incumbent in the instance's outputs; the record's slot
   unsigned long long* inc_bits;  // [n_inst]: best objective any item has found so far (bits of a non-negative double,
@@ -164,8 +164,8 @@ struct Args {
   double* rec_cand;       // [rec_cap][rows_cap][4] staged rows of a record: hot rows first, then the cold ones
   long long* rec_mw;      // [rec_cap][rows_cap] their (step, pick weight) pairs (MW of hdsm_core.h, 8 bytes)
   int32_t* rec_src;       // [rec_cap][rows_cap] their origins (Shm::cand_src)
-  int32_t* rec_count;     // [0] records taken, [1] items queued (published), [2] items drawn, [4] workgroups of pass 2 that hold an item or
-                          // are drawing one, [5] places of the queue reserved (zeroed before pass 1)
+  int32_t* rec_count;     // [0] records taken, [1] items queued (published), [2] tickets taken by the workgroups of pass 2 (ticket k = item k),
+                          // [4] items completed, [5] places of the queue reserved (zeroed before pass 1)
   int32_t pool_cap;       // pass 2: snapshot-scratch slots (Args::scratch), taken by the workgroup of an item for its lifetime
   int32_t* slot_busy;     // [pool_cap] 0 / 1; an item that hands over again leaves its slot (busy) to its record
   int32_t* item_total;    // host-visible word: the merge leaves the number of items this launch queued

@@ -10,9 +10,9 @@ run() { timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-event-
 for rep in 1 2; do
 for v in $vals; do
   export $var=$v
-  run $var=$v cfg5 --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2
-  run $var=$v cfg3 --scenario forest --agents 256 --first-round 60 --steps 8 --warmup 2
-  run $var=$v c4096h15 --agents 4096 --horizon 15 --first-round 20 --steps 8 --warmup 2
+  case "${WL:-cfg5 cfg3 c4096h15}" in *cfg5*) run $var=$v cfg5 --scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2;; esac
+  case "${WL:-cfg5 cfg3 c4096h15}" in *cfg3*) run $var=$v cfg3 --scenario forest --agents 256 --first-round 60 --steps 8 --warmup 2;; esac
+  case "${WL:-cfg5 cfg3 c4096h15}" in *c4096h15*) run $var=$v c4096h15 --agents 4096 --horizon 15 --first-round 20 --steps 8 --warmup 2;; esac
   unset $var
 done
 done
