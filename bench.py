@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--mip-gap", type=float, default=0.0, help="hdsm_params.mip_gap (0 = exact, the default; the reference runs "
                     "Gurobi at its default MIPGap 1e-4)")
     ap.add_argument("--time-limit-s", type=float, default=0.0, help="hdsm_params.time_limit_s (0 = none; AC:952 sets 0.08)")
+    ap.add_argument("--max-nodes", type=int, default=0, help="development: hdsm_params.max_nodes (0 = the default, 2000 branch-and-bound nodes per instance)")
     ap.add_argument("--device-loop-multi", action="store_true", help="(kept for old command lines: the device-resident-loop pass now runs "
                     "with --gpus > 1 by default, last and under a watchdog)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,6 +144,8 @@ def main():
 
     N = args.horizon
     prm = agile_params(N, max_rows_static=18, mip_gap=args.mip_gap, time_limit_s=args.time_limit_s, warm_start=not args.cold_start)
+    if args.max_nodes > 0:
+        prm.max_nodes = args.max_nodes
     P, RS = prm.poly_hor, prm.max_rows_static
     n_rob = args.agents
     radius = args.radius if args.radius > 0 else max(22.0, n_rob / (2 * np.pi))
