@@ -154,14 +154,59 @@ __global__ __launch_bounds__(NT, 2) void k_replan_duo(const hdsm::Consts* __rest
 //                      whole neighbours (hdsm_wave_gi.h, sweep_planes).
 __device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_prev, const int32_t* __restrict__ agent_id, int32_t* __restrict__ order);
 
+// The set-up map of ALL instances of a launch as ONE dense product on the matrix cores. Everything an instance needs before its first
+// iteration — x_eq, x0, the gradient at u = 0, the residual of the terminal equalities and their multipliers — is linear in
+// v = (state_curr, traj_ref) (Consts::KT, built once by hdsm_create from the Hessian factor): OUT[row][inst] = sum_j KT[j][row] v[inst][j],
+// (3n + 12) x (9 + 6N) times (9 + 6N) x n_inst — the one contraction of the path with matrix-matrix shape and more than a handful of
+// columns. One wavefront = one 16 x 16 tile of OUT through v_mfma_f64_16x16x4_f64 (A[i = lane & 15][k = lane >> 4] = KT[4 k0 + k][row0 + i],
+// B[k = lane >> 4][j = lane & 15] = v[inst0 + j][4 k0 + k], D[row = (lane >> 4) + 4 r][col = lane & 15] in register r). The solver's
+// set-up then reads one number per thread instead of 23 coefficients and a 23-term dot product (hdsm_core.h, Args::setup).
+struct SetupMapArgs {
+  const hdsm::Consts* c;
+  const double* state;  // [n_inst][9]
+  const double* ref;    // [n_inst][N][6]
+  double* out;          // [n_inst][KROWS]
+  int32_t n_inst, N, nk, row_tiles, first_block;  // first_block: the workgroup of the pre-pass kernel at which the tiles begin
+};
+__device__ void setup_map_tile(const SetupMapArgs& m, int tile) {
+  using v4d = double __attribute__((ext_vector_type(4)));
+  const int lane = (int)threadIdx.x & 63;
+  const int rt = tile % m.row_tiles, it = tile / m.row_tiles;
+  if (it * 16 >= m.n_inst) return;
+  const int i = lane & 15, kk = lane >> 4;
+  const int row = rt * 16 + i, inst = it * 16 + i, nvt = 9 + 6 * m.N;
+  const bool row_on = row < m.nk, inst_on = inst < m.n_inst;
+  const double* st = m.state + (int64_t)(inst_on ? inst : 0) * 9;
+  const double* rf = m.ref + (int64_t)(inst_on ? inst : 0) * 6 * m.N;
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < nvt; k0 += 4) {
+    const int j = k0 + kk;
+    const double aop = (row_on && j < nvt) ? m.c->KT[(int64_t)j * hdsm::KROWS + row] : 0.0;
+    const double bop = (inst_on && j < nvt) ? (j < 9 ? st[j] : rf[j - 9]) : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+  }
+  const int col = lane & 15, oi = it * 16 + col;
+  if (oi < m.n_inst) {
+    for (int r = 0; r < 4; ++r) {
+      const int orow = rt * 16 + (lane >> 4) + 4 * r;
+      if (orow < m.nk) m.out[(int64_t)oi * hdsm::KROWS + orow] = acc[r];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_plan_prepass(int N, int n_rob, const double* __restrict__ plans,
                                                       const uint8_t* __restrict__ has_plan, double* __restrict__ pos,
                                                       double* __restrict__ bounds, int n_order, const int32_t* __restrict__ key_prev,
-                                                      const int32_t* __restrict__ agent_id, int32_t* __restrict__ order) {
-  if (order != nullptr && blockIdx.x == gridDim.x - 1) {  // one extra workgroup: the launch order of the solve that follows
+                                                      const int32_t* __restrict__ agent_id, int32_t* __restrict__ order, SetupMapArgs sm) {
+  if (sm.out != nullptr && (int)blockIdx.x >= sm.first_block) {  // the workgroups behind the pre-pass proper: four tiles of the set-up map each
+    setup_map_tile(sm, ((int)blockIdx.x - sm.first_block) * 4 + ((int)threadIdx.x >> 6));
+    return;
+  }
+  if (order != nullptr && (int)blockIdx.x == (n_rob + 15) / 16) {  // one extra workgroup: the launch order of the solve that follows
     launch_order_block(n_order, key_prev, agent_id, order);
     return;
   }
+  if ((int)blockIdx.x >= (n_rob + 15) / 16) return;
   // 16 lanes per agent (N <= 16 = HDSM_MAX_HOR): lane i copies the position of step i + 1, the box / sphere reductions run
   // over the 16-lane group with DPP-able shuffles — every load of a plan is issued at once instead of N dependent ones
   const int tid = (int)threadIdx.x, i = tid & 15;
@@ -695,6 +740,8 @@ struct Handle {
   void* h_out = nullptr;      // pinned staging of hdsm_replan's outputs (grow-only)
   size_t h_out_cap = 0;
   double* d_bounds = nullptr; // [n_rob_max][4]
+  double* d_setup = nullptr;  // [max_inst][KROWS] the set-up map of every instance of a launch (Args::setup)
+  int setup_mfma = 1;         // 0 (HDSM_SETUP_MFMA=0): every instance applies the map itself (the form of rounds 1-4)
   double* d_pos = nullptr;    // [n_rob_max][N][3] packed positions (pre-pass)
   double* d_rpos = nullptr;   // [n_rob_max][N + 1][3] packed positions of steps 0..N (k_ref_pack)
   double* d_rsph = nullptr;   // [n_rob_max][4] their spheres
@@ -960,13 +1007,28 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   const bool packed = h->defer_done && a.l1_rows == nullptr && h->prepass_for == a.plans && h->prepass_n_rob == a.n_rob &&
                       h->prepass_n_inst == a.n_inst && h->prepass_ordered == ordered;
   h->prepass_for = nullptr;  // (good for one solve: the plans change with the commit that follows it)
+  // the set-up map of every instance as one product on the matrix cores (k_plan_prepass, setup_map_tile): rides on the pre-pass launch
+  SetupMapArgs sm{};
+  a.setup = nullptr;
+  if (a.l1_rows == nullptr && h->setup_mfma && h->d_setup != nullptr) {
+    sm.c = h->d_consts, sm.state = a.state, sm.ref = a.ref, sm.out = h->d_setup, sm.n_inst = a.n_inst, sm.N = h->N, sm.nk = 3 * h->n + 12;
+    sm.row_tiles = (sm.nk + 15) / 16;
+    a.setup = h->d_setup;
+  }
+  const int sm_blocks = sm.out != nullptr ? (sm.row_tiles * ((a.n_inst + 15) / 16) + 3) / 4 : 0;
   if (packed) {
     a.pos = h->d_pos;
     a.bounds = a.n_rob >= h->bounds_min ? h->d_bounds : nullptr;
+    if (sm_blocks > 0) {  // (the device-resident loop packs the plans elsewhere: the tiles alone)
+      sm.first_block = 0;
+      hipLaunchKernelGGL(k_plan_prepass, dim3(sm_blocks), dim3(256), 0, st, h->N, 0, a.plans, a.has_plan, h->d_pos, nullptr, 0, a.st_key, a.agent_id, nullptr, sm);
+      HIP_TRY(hipGetLastError());
+    }
   } else if (a.l1_rows == nullptr) {
     const bool pre = a.n_rob >= h->bounds_min;
-    hipLaunchKernelGGL(k_plan_prepass, dim3((a.n_rob + 15) / 16 + (ordered ? 1 : 0)), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
-                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, a.agent_id, ordered ? h->d_order : nullptr);
+    sm.first_block = (a.n_rob + 15) / 16 + (ordered ? 1 : 0);
+    hipLaunchKernelGGL(k_plan_prepass, dim3(sm.first_block + sm_blocks), dim3(256), 0, st, h->N, a.n_rob, a.plans, a.has_plan,
+                       h->d_pos, pre ? h->d_bounds : nullptr, a.n_inst, a.st_key, a.agent_id, ordered ? h->d_order : nullptr, sm);
     HIP_TRY(hipGetLastError());
     a.pos = h->d_pos;
     a.bounds = pre ? h->d_bounds : nullptr;
@@ -1211,7 +1273,7 @@ void free_all(Handle* h) {
   if (h->h_ovf_flag) (void)hipHostFree(h->h_ovf_flag);
   if (h->h_out) (void)hipHostFree(h->h_out);
   void* ptrs[] = {h->d_warm, h->d_prof, h->d_consts, h->d_scratch, h->d_stats, h->d_agent, h->d_npoly, h->d_nrows, h->d_status,
-                  h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_traj,  h->d_ctrl,
+                  h->d_state,  h->d_ref,     h->d_A,     h->d_b,     h->d_plans, h->d_bounds, h->d_setup, h->d_traj,  h->d_ctrl,
                   h->d_obj,    h->d_has,     h->d_used,  h->d_pos,   h->d_rpos,  h->d_rsph,  h->d_zero,  h->d_order, h->b_planes.p, h->b_common.p,
                   h->b_ncommon.p, h->b_path.p, h->b_cap.p, h->b_full.p, h->b_pv.p, h->b_np.p};
   for (void* p : ptrs)
@@ -1311,6 +1373,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     h->quad_min = h->tri_min > 0 ? 3 * cus + 1 : 0;    // more instances than the three-per-CU kernel has resident slots
     env_int("HDSM_QUAD_MIN", 0, INT_MAX, &h->quad_min);  // 0 = never
     env_int("HDSM_DUO48_ROWS", 320, 720, &h->duo48_rows);
+    env_int("HDSM_SETUP_MFMA", 0, 1, &h->setup_mfma);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
@@ -1346,6 +1409,7 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
   ok(dmalloc(&h->d_b, I * P * RS));
   ok(dmalloc(&h->d_plans, (size_t)n_rob_max * (N + 1) * 9));
   ok(dmalloc(&h->d_bounds, (size_t)n_rob_max * 4));
+  ok(dmalloc(&h->d_setup, I * hdsm::KROWS));
   ok(dmalloc(&h->d_pos, (size_t)n_rob_max * N * 3));
   ok(dmalloc(&h->d_rpos, (size_t)n_rob_max * (N + 1) * 3));
   ok(dmalloc(&h->d_rsph, (size_t)n_rob_max * 4));

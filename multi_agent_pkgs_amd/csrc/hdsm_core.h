@@ -735,7 +735,13 @@ struct Solver {
       double kv[KH];
       const bool k_on = tid < nk;
       const int krow = k_on ? tid : 0, kbase = c.kax[krow];
-      if (tid < ((nk + 63) & ~63)) {  // whole wavefronts only
+      // (Args::setup: the outputs of the map for every instance of the launch, formed by the pre-pass kernel as one dense product on
+      // the matrix cores — then a thread asks for ONE number here instead of its 23 coefficients)
+      const bool pre_map = a_in.setup != nullptr;
+      double pre_v = 0.0;
+      if (pre_map) {
+        if (k_on) pre_v = a_in.setup[(int64_t)inst * KROWS + krow];
+      } else if (tid < ((nk + 63) & ~63)) {  // whole wavefronts only
         HDSM_UNROLL
         for (int u = 0; u < KH; ++u) kv[u] = c.KTC[u * KROWS + krow];
       }
@@ -890,17 +896,22 @@ struct Solver {
         else if (row < 3 * n + 6) s.red_v[row - 3 * n] = acc;
         else s.lam[row - 3 * n - 6] = acc;
       };
-      if (tid < ((nk + 63) & ~63)) {
-        double acc = 0;
-        HDSM_UNROLL
-        for (int u = 0; u < KH; ++u) acc += kv[u] * vin[kbase + 3 * u];
-        if (k_on) store(tid, acc);
-      }
-      for (int row = tid + nt; row < nk; row += nt) {  // 64-thread launches
-        const int base = c.kax[row];
-        double acc = 0;
-        for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * vin[base + 3 * u];
-        store(row, acc);
+      if (pre_map) {
+        if (k_on) store(tid, pre_v);
+        for (int row = tid + nt; row < nk; row += nt) store(row, a_in.setup[(int64_t)inst * KROWS + row]);
+      } else {
+        if (tid < ((nk + 63) & ~63)) {
+          double acc = 0;
+          HDSM_UNROLL
+          for (int u = 0; u < KH; ++u) acc += kv[u] * vin[kbase + 3 * u];
+          if (k_on) store(tid, acc);
+        }
+        for (int row = tid + nt; row < nk; row += nt) {  // workgroups with fewer threads than outputs
+          const int base = c.kax[row];
+          double acc = 0;
+          for (int u = 0; u < 3 + 2 * N; ++u) acc += c.KTC[u * KROWS + row] * vin[base + 3 * u];
+          store(row, acc);
+        }
       }
       if constexpr (NV > 32) {
         if (tid < 64) {

@@ -134,6 +134,9 @@ struct Args {
   // [n_rob][N][3]: positions of steps 1..N of every published plan, packed (24 B per (agent, step) instead of a 72-B
   // stride through the full states); written by the same pre-pass for every launch of level 2
   const double* pos;
+  // [n_inst][KROWS] the set-up map applied to every instance of the launch (rows [0, 3n + 12): x_eq, x0, gradient, residuals and
+  // multipliers of the terminal equalities), written by the pre-pass kernel; null: every instance applies Consts::KTC itself
+  const double* setup;
   // launch order: workgroup w solves instance order[2 w] (most expensive first, judged by the previous launch) of agent
   // order[2 w + 1], or null = w
   const int32_t* order;

@@ -63,6 +63,28 @@ for f in glob.glob(os.path.join(out_dir, "pmc_*", "*counter_collection.csv")):
         if vals:
             counters[name] = {"mean_per_timed_launch": sum(vals) / len(vals), "launches": len(vals), "dispatches_in_process": len(v)}
 summ["pmc"] = counters
+# the pre-pass kernel of the same launches: since round 5 it also applies the set-up map of all instances as one dense product on the
+# matrix cores (hdsm_api.hip, setup_map_tile) — the MFMA instructions of the path are HERE, not in k_replan
+pre_counters = {}
+for f in glob.glob(os.path.join(out_dir, "pmc_*", "*counter_collection.csv")):
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_plan_prepass" not in r["Kernel_Name"]:
+            continue
+        per.setdefault(r["Counter_Name"], []).append((int(r["Start_Timestamp"]), float(r["Counter_Value"])))
+    for name, v in per.items():
+        v.sort()
+        vals = [x[1] for x in v[lo:hi]]
+        if vals:
+            pre_counters[name] = {"mean_per_timed_launch": sum(vals) / len(vals), "launches": len(vals)}
+summ["pmc_prepass_kernel"] = pre_counters
+if "SQ_INSTS_VALU_MFMA_F64" in pre_counters or "SQ_INSTS_MFMA" in pre_counters:
+    pc = {k: v["mean_per_timed_launch"] for k, v in pre_counters.items()}
+    summ["mfma"] = {"kernel": "k_plan_prepass (set-up map of all instances: (3n + 12) x (9 + 6N) times (9 + 6N) x n_inst, v_mfma_f64_16x16x4_f64)",
+                    "SQ_INSTS_VALU_MFMA_F64_per_launch": pc.get("SQ_INSTS_VALU_MFMA_F64"), "SQ_INSTS_MFMA_per_launch": pc.get("SQ_INSTS_MFMA"),
+                    "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": pc.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                    "mfma_busy_over_sq_busy_in_that_kernel": (pc["SQ_VALU_MFMA_BUSY_CYCLES"] / pc["SQ_BUSY_CYCLES"]) if pc.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and pc.get("SQ_BUSY_CYCLES") else None,
+                    "k_replan_SQ_INSTS_VALU_MFMA_F64_per_launch": counters.get("SQ_INSTS_VALU_MFMA_F64", {}).get("mean_per_timed_launch")}
 pm = {k: v["mean_per_timed_launch"] for k, v in counters.items()}
 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # rocprofv3 reports KiB. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts the 128-B requests of wide coalesced

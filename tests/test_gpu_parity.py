@@ -596,3 +596,27 @@ def test_pick_rule_changes_the_path_not_the_answer(hdsm, oracle, monkeypatch):
             ops[k] += int(g["qp_iters"].sum())
     print("operations, raw rule vs normalised rule:", ops)
     assert ops[1] <= ops[0]
+
+
+def test_the_set_up_map_on_the_matrix_cores_gives_the_answers_of_the_per_instance_form(hdsm, oracle, monkeypatch):
+    """Round 5: everything an instance needs before its first iteration is linear in (state_curr, traj_ref); the pre-pass kernel now
+    applies that map to ALL instances of a launch as one dense product through v_mfma_f64_16x16x4_f64 (hdsm_api.hip, setup_map_tile)
+    and the solver reads one number per thread. HDSM_SETUP_MFMA=0 keeps the per-instance form of rounds 1-4 (a 23-term dot product per
+    thread): same statuses, trajectories equal to rounding, both equal to the oracle — at H = 10 and at H = 15 (147 outputs per
+    instance: more than a 128-thread workgroup has threads), with a batch that is not a multiple of the 16-instance tile."""
+    for N, n_inst, seed in ((10, 37, 3), (15, 21, 4)):
+        prm = agile_params(N, max_rows_static=18)
+        sn = problems.swarm_snapshot(prm, n_inst, seed=seed, spacing=1.2, turn=True, narrow=True)
+        args = [sn[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b", "plans", "has_plan")]
+        monkeypatch.setenv("HDSM_SETUP_MFMA", "0")
+        plain = hdsm.Solver(prm, n_inst, n_inst).replan(*args)
+        monkeypatch.setenv("HDSM_SETUP_MFMA", "1")
+        mfma = hdsm.Solver(prm, n_inst, n_inst).replan(*args)
+        monkeypatch.delenv("HDSM_SETUP_MFMA")
+        o = oracle.replan(prm, *args, n_threads=8)
+        assert (mfma["status"] == plain["status"]).all() and (mfma["status"] == o["status"]).all()
+        ok = o["status"] != 2
+        assert ok.any()
+        assert np.abs(mfma["traj"] - plain["traj"])[ok].max() < 1e-9
+        assert np.abs(mfma["traj"] - o["traj"])[ok].max() < 1e-7
+        assert (np.abs(mfma["obj"] - o["obj"])[ok] / np.maximum(1.0, np.abs(o["obj"][ok]))).max() < 1e-6
