@@ -97,7 +97,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   env_int("HDSM_BOX_CUT", 0, 1, &c->box_cut);
   c->scanner = 1;
   env_int("HDSM_SCANNER", 0, 2, &c->scanner);
-  c->child_bound = 1, c->pad_child_bound = 0;
+  c->child_bound = 1, c->overlap_sweep = 1;
+  env_int("HDSM_OVERLAP_SWEEP", 0, 1, &c->overlap_sweep);
   env_int("HDSM_CHILD_BOUND", 0, 1, &c->child_bound);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;

@@ -167,6 +167,7 @@ struct Shm {
   int32_t wanted_raw;  // after a sweep that overflowed: ncand + ncold as counted past the capacity (before the clamp)
   int32_t nviol;  // rows found violated (> tol) by the last sweep
   int32_t warm_head;  // first word of the instance's warm-start record (count | WARM_CERT), fetched by the set-up
+  int32_t warm_ncand; // staged rows after the warm start has placed the rows of its guess (before a concurrent sweep adds its own)
   int32_t leaf_pick;  // result of the one-wavefront leaf test
   double* snap;       // this workgroup's snapshot scratch (global memory; kept here, not in a register pair across the active-set run)
   int32_t node_res;   // pass 2 of a split launch: nodes drawn from the instance's pool and not yet opened
@@ -1094,17 +1095,52 @@ struct Solver {
       sweep_all(s.ncand, s.ncold);
       if (s.fixed_bad) run = false;  // still gridlocked: infeasible whatever the choice
     }
+    bool swept_conc = false;
+    const bool overlap_ok = c.overlap_sweep != 0 && blockDim.x == 128 && a.l1_rows == nullptr && !warm_cert && c.presweep != 0 && (uni(s.warm_head) & ~WARM_CERT) > 0;
     if (run && item < 0 && a.warm != nullptr) {
 #ifdef HDSM_PROFILE
       const long long tw_ = clock64();
 #endif
       TL_T0
+      // Two-wave workgroups (the four-per-CU kernel of the bench line): the FIRST staging sweep runs on wave 1 WHILE wave 0 installs the
+      // guess — the two used to follow each other, 13 + 7 us of the slowest instances, with one of the two waves idle in either. The sweep
+      // cannot wait for the warm-start point, so it stages around the points every replan is expected to end near: the own previous
+      // plan, one step on (the positions the planes themselves are built from); those points become the reference of the displacement
+      // test, which decides at the end whether a verification sweep is needed, exactly as it does for a sweep at the warm-start point.
+      const bool conc = overlap_ok;
+      if (conc) {
+        PAR_FOR(k, 3 * (N + 1)) {
+          const int m = k / 3, ax = k % 3;
+          s.sw_ref[m][ax] = m == 0 ? s.st[0][ax] : (m <= c.pinned_steps ? s.fr[ax][m][0] : s.cprev[m - 1][ax]);
+        }
+        if (IS_T0) s.nviol = 0;
+        SYNC();
+      }
       if (HDSM_TX < 64) {
-        W::warm_start(s, c, a, R, inst, self, iters, wpre);
+        W::warm_start(s, c, a, R, inst, self, iters, wpre, conc);
         if (HDSM_TX == 0) s.iters_sh = iters;
+      } else if (conc) {
+        __syncthreads();  // (the guess's rows have their slots)
+        swept_conc = c.presweep == 1 || a.bounds == nullptr || s.ncand > 0;  // (the rule of the sequential pre-sweep below)
+        if (swept_conc) WaveGI<NV, CMAX, SMALL>::template sweep_planes<true>(s, c, a, self, c.cand_tau, true, (int)HDSM_TX & 63, &s.sw_ref[0][0], 3);
       }
       SYNC();
       iters = s.iters_sh;
+      if (conc) {
+        swept_conc = c.presweep == 1 || a.bounds == nullptr || s.warm_ncand > 0;  // (what wave 1 decided on: the count it saw)
+        if (swept_conc) {
+          if (s.overflow) {  // the staging area overflowed: as if no sweep had been made — the sequential path below shrinks the radius
+            SYNC();
+            if (IS_T0) s.ncand = s.warm_ncand, s.ncold = 0, s.overflow = 0, s.fixed_bad = 0;
+            SYNC();
+          } else {
+            ++sweeps;
+            if (IS_T0) s.sw_tau = c.cand_tau;
+            if (s.fixed_bad) run = false;  // a common row is violated at a pinned point: infeasible whatever the choice
+            SYNC();
+          }
+        }
+      }
       TL_ADD(tl_warm_)
 #ifdef HDSM_TIMELINE
       tl_warm_it_ = iters;

@@ -40,7 +40,7 @@ struct Consts {
                         // 2, development: as 1 but every pick of the scanner is confirmed by its exact evaluation)
   int32_t child_bound;  // 1 (default): a child of a branch-and-bound node whose lower bound f + v^2 / (2 a^T Z a) — v the violation of a row
                         // of its polyhedron at the node's minimiser — reaches the incumbent is not opened (HDSM_CHILD_BOUND=0: off). Exact.
-  int32_t pad_child_bound;
+  int32_t overlap_sweep;  // 1 (default): two-wave workgroups run the first staging sweep on wave 1 while wave 0 installs the warm start (HDSM_OVERLAP_SWEEP=0: one after the other)
   double tol, ftol_fixed, cand_tau, hot_tau;
   double mip_gap;  // relative gap at which a node is cut off against the incumbent (0 = exact)
   long long time_ticks;  // hdsm_params.time_limit_s in ticks of the device's constant-rate clock (0 = no time limit)

@@ -585,9 +585,18 @@ struct WaveGI {
   // Same planes as tasc_plane_eval (AC:1100-1205), organised for the workgroup: thread <-> (neighbour, step) pair, so
   // the dependent f64 chain of one plane (two reciprocal square roots) is walked once per thread and not N times.
   // For large swarms (a.bounds) the neighbours first pass a sphere test and only the survivors form pairs.
+  // SOLO: ONE wavefront sweeps (wave 1 of a two-wave workgroup, while wave 0 installs the warm start: hdsm_core.h) — `lane` is the lane
+  // of that wavefront, the barriers are wave-local. `pts` / `pstride`: the trajectory points the slacks are evaluated at (Shm::st with
+  // stride 9, or the reference points of the displacement test, Shm::sw_ref, stride 3).
+  template <bool SOLO = false>
   static __device__ __forceinline__ void sweep_planes(S& s, const Consts& c, const Args& a, int self, double thresh,
-                                                      bool check_fixed, int lane) {
-    const int N = c.N, n_rob = a.n_rob, nt = (int)blockDim.x;  // lane = thread of the WORKGROUP here (all waves sweep)
+                                                      bool check_fixed, int lane, const double* pts = nullptr, int pstride = 9) {
+    const int N = c.N, n_rob = a.n_rob, nt = SOLO ? 64 : (int)blockDim.x;  // lane = thread of the WORKGROUP (all waves sweep) unless SOLO
+    if (pts == nullptr) pts = &s.st[0][0];
+    auto bar = [&]() {
+      if constexpr (SOLO) wsync();
+      else __syncthreads();
+    };
     PROF_DECL
     const double radius = c.radius, k2m1 = c.k2m1, pert = c.pert, tol = c.tol, hot_tau = c.hot_tau;
     const int pinned = c.pinned_steps;
@@ -603,7 +612,8 @@ struct WaveGI {
                    mz = 0.5 * (s.cprev[0][2] + s.cprev[N - 1][2]);
       if (lane < 2 * N) {
         const int i = lane >> 1, m = i + (lane & 1);
-        const double ux = s.st[m][0] - s.cprev[i][0], uy = s.st[m][1] - s.cprev[i][1], uz = s.st[m][2] - s.cprev[i][2];
+        const double* pm0 = pts + m * pstride;
+        const double ux = pm0[0] - s.cprev[i][0], uy = pm0[1] - s.cprev[i][1], uz = pm0[2] - s.cprev[i][2];
         d2 = ux * ux + uy * uy + uz * uz;
         const double wx = s.cprev[i][0] - mx, wy = s.cprev[i][1] - my, wz = s.cprev[i][2] - mz;
         r2 = wx * wx + wy * wy + wz * wz;
@@ -617,7 +627,7 @@ struct WaveGI {
         s.nlist = 0;
       }
     }
-    __syncthreads();
+    bar();
     const double cull = s.sw[0], cull2 = cull * cull;
     SW_PROF(8)
     const int chunk = pre ? S::LC : n_rob;
@@ -642,7 +652,7 @@ struct WaveGI {
               s.list[atomicAdd(&s.nlist, 1)] = k;
           }
         }
-        __syncthreads();
+        bar();
         cnt = s.nlist;
         SW_PROF(9)
       }
@@ -673,7 +683,7 @@ struct WaveGI {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int m = i + e;
-            const double* pm = s.st[m];
+            const double* pm = pts + m * pstride;
             const double v = fx * pm[0] + fy * pm[1] + fz * pm[2] - rhs;
             if (m <= pinned) {  // a constant row (hdsm_core.h): within ftol_fixed it holds, beyond it nothing can satisfy it
               if (check_fixed && v > c.ftol_fixed) s.fixed_bad = 1;
@@ -697,12 +707,12 @@ struct WaveGI {
         SW_PROF(11)
       }
       if (pre && end < n_rob) {  // next chunk reuses the list
-        __syncthreads();
+        bar();
         if (lane == 0) s.nlist = 0;
-        __syncthreads();
+        bar();
       }
     }
-    __syncthreads();
+    bar();
     if (lane == 0 && s.ncand + s.ncold > CMAX) {  // rows that found no slot advanced the counters past the capacity: clamp
       s.overflow = 1;                             // (no slot is written twice, so everything below the clamped counts is complete)
       s.wanted_raw = s.ncand + s.ncold;
@@ -710,7 +720,7 @@ struct WaveGI {
       if (s.ncand > CMAX - cold) s.ncand = CMAX - cold;
       s.ncold = cold;
     }
-    __syncthreads();
+    bar();
     SW_PROF(12)
   }
 

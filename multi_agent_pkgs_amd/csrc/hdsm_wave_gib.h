@@ -320,12 +320,21 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
   // closed form  t = U^T v, lambda = U t, x_W = x0 + J1 t, f_W = f(x0) + |t|^2 / 2
   using WarmPre = typename Base::WarmPre;
   using Base::warm_prefetch;
+  // `conc`: wave 1 sweeps the neighbour rows while this wave installs the guess (hdsm_core.h): ONE workgroup barrier, on every path,
+  // right after the rows of the guess have taken their staging slots — from there on this function no longer touches the counters
+  // of the staging area, and the sweep may add its rows behind them.
   static __device__ __forceinline__ void warm_start(S& s, const Consts& c, const Args& a, Regs& R, int inst, int self, int& iters,
-                                                    const WarmPre& wpre) {
+                                                    const WarmPre& wpre, bool conc = false) {
     const int lane = (int)HDSM_TX;
     const int N = c.N, n = c.n;
     int nw = uni(wpre.head) & ~WARM_CERT;
-    if (nw <= 0) return;
+    if (nw <= 0) {
+      if (conc) {
+        if (lane == 0) s.warm_ncand = s.ncand;
+        __syncthreads();
+      }
+      return;
+    }
     if (nw > NV) nw = NV;
     PROF_DECL
     int pre = -1, my_m = 0, my_src = 0;  // pre: >= 0 a ready id, -2 a neighbour row held in my_row, -1 nothing usable
@@ -370,6 +379,10 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
         if (lane == 0) s.ncand = base + (cnt < room ? cnt : (room > 0 ? room : 0));
         wsync();
       }
+    }
+    if (conc) {
+      if (lane == 0) s.warm_ncand = s.ncand;
+      __syncthreads();
     }
     WS_PROF(16)
     for (int g = 0; g < nw && q < n; ++g) {

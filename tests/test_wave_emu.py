@@ -165,10 +165,13 @@ def test_node_budget_is_reported(wave, oracle):
     assert np.abs(e["traj"][ok] - o["traj"][ok]).max() < 1e-8
 
 
-def test_closed_loop_with_a_persistent_warm_start_store(wave, oracle):
+@pytest.mark.parametrize("threads,cmax", [(64, 0), (128, 256)], ids=["one-wave", "two-waves-small-lds"])
+def test_closed_loop_with_a_persistent_warm_start_store(wave, oracle, threads, cmax):
     """Consecutive rounds of a closed loop (host mirror around the solve): the device source, warm-started every round from
     the store it filled the round before (working sets moved one step towards the present, gridlock / certificate marks),
-    returns what the cold-started oracle returns on the same inputs, round after round."""
+    returns what the cold-started oracle returns on the same inputs, round after round. With two wavefronts (the shape of the
+    four-per-CU kernel, small LDS layout) wave 1 runs the first staging sweep — around the own previous plan — WHILE wave 0 installs
+    the guess (round 5); one wavefront keeps the sequential order."""
     from multi_agent_pkgs_amd import swarm
     n = 10
     prm = agile_params(10, max_rows_static=18)
@@ -177,7 +180,7 @@ def test_closed_loop_with_a_persistent_warm_start_store(wave, oracle):
 
     def solve(inp, plans, has):
         args = [inp[k] for k in ("agent_id", "state", "ref", "n_poly", "n_rows", "A", "b")] + [plans, has]
-        g = wave.replan(prm, *args, warm=store)
+        g = wave.replan(prm, *args, warm=store, threads=threads, cmax=cmax)
         o = oracle.replan(prm, *args, n_threads=8)
         compare(g, o, tol=1e-7)
         seen.append((int(g["qp_iters"].sum()), int((g["status"] == 2).sum())))
