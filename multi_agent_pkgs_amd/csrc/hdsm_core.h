@@ -1096,7 +1096,8 @@ struct Solver {
       if (s.fixed_bad) run = false;  // still gridlocked: infeasible whatever the choice
     }
     bool swept_conc = false;
-    const bool overlap_ok = c.overlap_sweep != 0 && blockDim.x == 128 && a.l1_rows == nullptr && !warm_cert && c.presweep != 0 && (uni(s.warm_head) & ~WARM_CERT) > 0;
+    // (n <= 30 only: a second copy of the sweep in the kernels of the larger factor costs them 170 bytes of spilled registers per lane)
+    const bool overlap_ok = NV == 32 && c.overlap_sweep != 0 && blockDim.x == 128 && a.l1_rows == nullptr && !warm_cert && c.presweep != 0 && (uni(s.warm_head) & ~WARM_CERT) > 0;
     if (run && item < 0 && a.warm != nullptr) {
 #ifdef HDSM_PROFILE
       const long long tw_ = clock64();
@@ -1122,7 +1123,9 @@ struct Solver {
       } else if (conc) {
         __syncthreads();  // (the guess's rows have their slots)
         swept_conc = c.presweep == 1 || a.bounds == nullptr || s.ncand > 0;  // (the rule of the sequential pre-sweep below)
-        if (swept_conc) WaveGI<NV, CMAX, SMALL>::template sweep_planes<true>(s, c, a, self, c.cand_tau, true, (int)HDSM_TX & 63, &s.sw_ref[0][0], 3);
+        if constexpr (NV == 32) {
+          if (swept_conc) WaveGI<NV, CMAX, SMALL>::template sweep_planes<true>(s, c, a, self, c.cand_tau, true, (int)HDSM_TX & 63, &s.sw_ref[0][0], 3);
+        }
       }
       SYNC();
       iters = s.iters_sh;
