@@ -379,29 +379,14 @@ struct Solver {
           double v0max = -DINF, v1max = -DINF;
           // rows on input-independent points only gate the choice
           const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
-          // Child bound. The node's minimiser x_p is optimal for the rows of the node; a child must also satisfy row r of the
-          // polyhedron it assigns, violated by v at x_p: every point that does is at least v / sqrt(a^T Z a) away from x_p in the
-          // metric of the problem, so the child's optimum is >= f + v^2 / (2 a^T Z a) (Z: inverse Hessian on the null space of
-          // the terminal equalities; a^T Z a = sum_ax n_ax^2 kap[m][ax] for a row on point m — the quantity behind the pick rule).
-          // The best such ratio over the rows and both end points is kept by cross-multiplication: one division per lane.
-          double bv2 = 0.0, bq = 1.0, bv = 0.0;
-          int bcode = -1;
-          const double k00 = s.kap[i][0], k01 = s.kap[i][1], k02 = s.kap[i][2];
-          const double k10 = s.kap[i + 1][0], k11 = s.kap[i + 1][1], k12 = s.kap[i + 1][2];
           for (int r = 0; r < rows; ++r) {
             const double* row = s.sp[j][r];
             const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
             const double v0 = r0 * ax_ + r1 * ay_ + r2 * az_ - r3, v1 = r0 * bx_ + r1 * by_ + r2 * bz_ - r3;
             v0max = v0 > v0max ? v0 : v0max, v1max = v1 > v1max ? v1 : v1max;
-            const double s0 = r0 * r0, s1 = r1 * r1, s2 = r2 * r2;
-            const double q0 = s0 * k00 + s1 * k01 + s2 * k02, q1 = s0 * k10 + s1 * k11 + s2 * k12;
-            if (!g0 && v0 > c.tol && q0 > 1e-60 && v0 * v0 * bq > bv2 * q0) bv2 = v0 * v0, bq = q0, bv = v0, bcode = r;
-            if (!g1 && v1 > c.tol && q1 > 1e-60 && v1 * v1 * bq > bv2 * q1) bv2 = v1 * v1, bq = q1, bv = v1, bcode = 64 | r;
           }
-          if (on) s.pk_at(lane) = c.child_bound != 0 ? bcode : -1, s.pv_at(lane) = bv;
           if ((g0 && v0max > c.ftol_fixed) || (g1 && v1max > c.ftol_fixed)) vmax = DINF;
           else vmax = g1 ? -DINF : (g0 ? v1max : (v0max > v1max ? v0max : v1max));
-          if (on) s.lb_at(lane) = c.child_bound != 0 ? 0.5 * (bv2 / bq) * (1.0 - 1e-9) : 0.0;  // (rounded towards "no bound")
         }
         if (on) s.keys[i][j] = vmax;
         const unsigned long long inside = __ballot(on && vmax <= c.tol);
@@ -419,6 +404,36 @@ struct Solver {
         const unsigned long long open = __ballot(lane < N && cont < 0);
         int pick = -1;
         if (open != 0ull) {
+          // Child bound — a second walk over the rows, only at a node that WILL branch (in open space no instance ever gets here).
+          // The node's minimiser x_p is optimal for the rows of the node; a child must also satisfy row r of the polyhedron it
+          // assigns, violated by v at x_p: every point that does is at least v / sqrt(a^T Z a) away from x_p in the metric of the
+          // problem, so the child's optimum is >= f + v^2 / (2 a^T Z a) (Z: inverse Hessian on the null space of the terminal
+          // equalities; a^T Z a = sum_ax n_ax^2 kap[m][ax] for a row on point m — the quantity behind the pick rule). The best such
+          // ratio over the rows and both end points is kept by cross-multiplication (one division per lane); the row that attains it
+          // is the child's first entering row.
+          if (on && ai < 0) {
+            const int rows = s.sp_rows[j];
+            const double* p0 = s.st[i];
+            const double* p1 = s.st[i + 1];
+            const double ax_ = p0[0], ay_ = p0[1], az_ = p0[2], bx_ = p1[0], by_ = p1[1], bz_ = p1[2];
+            const bool g0 = i <= c.pinned_steps, g1 = i + 1 <= c.pinned_steps;
+            double bv2 = 0.0, bq = 1.0, bv = 0.0;
+            int bcode = -1;
+            const double k00 = s.kap[i][0], k01 = s.kap[i][1], k02 = s.kap[i][2];
+            const double k10 = s.kap[i + 1][0], k11 = s.kap[i + 1][1], k12 = s.kap[i + 1][2];
+            for (int r = 0; r < rows; ++r) {
+              const double* row = s.sp[j][r];
+              const double r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+              const double v0 = r0 * ax_ + r1 * ay_ + r2 * az_ - r3, v1 = r0 * bx_ + r1 * by_ + r2 * bz_ - r3;
+              const double s0 = r0 * r0, s1 = r1 * r1, s2 = r2 * r2;
+              const double q0 = s0 * k00 + s1 * k01 + s2 * k02, q1 = s0 * k10 + s1 * k11 + s2 * k12;
+              if (!g0 && v0 > c.tol && q0 > 1e-60 && v0 * v0 * bq > bv2 * q0) bv2 = v0 * v0, bq = q0, bv = v0, bcode = r;
+              if (!g1 && v1 > c.tol && q1 > 1e-60 && v1 * v1 * bq > bv2 * q1) bv2 = v1 * v1, bq = q1, bv = v1, bcode = 64 | r;
+            }
+            s.pk_at(lane) = c.child_bound != 0 ? bcode : -1, s.pv_at(lane) = bv;
+            s.lb_at(lane) = c.child_bound != 0 ? 0.5 * (bv2 / bq) * (1.0 - 1e-9) : 0.0;  // (rounded towards "no bound")
+          }
+          wsync();
           if (c.branch_rule == 0) {
             pick = __ffsll((long long)open) - 1;  // the first in time
           } else {
@@ -430,15 +445,19 @@ struct Solver {
         // bounds the whole subtree: f + max_i min_j klb[i][j]. Kept as the largest and the second largest of those minima (and
         // whose step the largest is), so that a child of step i gets max(its own klb, the best of the OTHER steps).
         double mine = 0.0;
-        if (lane < N && cont < 0) {
+        if (open != 0ull && lane < N && cont < 0) {
           mine = DINF;
           for (int jj = 0; jj < np; ++jj)
             if (s.keys[lane][jj] < DINF) mine = s.lb_at(lane * np + jj) < mine ? s.lb_at(lane * np + jj) : mine;
           if (!(mine < DINF)) mine = 0.0;  // (no admissible polyhedron: the branching finds no child anyway)
         }
-        const double top1 = wave_max64(mine);
-        const int l1 = top1 > 0.0 ? __ffsll((long long)__ballot(mine == top1)) - 1 : -1;
-        const double top2 = wave_max64(lane == l1 ? 0.0 : mine);
+        double top1 = 0.0, top2 = 0.0;
+        int l1 = -1;
+        if (open != 0ull) {  // (wave-uniform)
+          top1 = wave_max64(mine);
+          l1 = top1 > 0.0 ? __ffsll((long long)__ballot(mine == top1)) - 1 : -1;
+          top2 = wave_max64(lane == l1 ? 0.0 : mine);
+        }
         if (lane == 0) s.leaf_pick = pick, s.lb_top1 = top1, s.lb_top2 = top2, s.lb_step = l1, s.leaf_lb = 1;
       }
       SYNC();
