@@ -717,7 +717,7 @@ struct Handle {
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int split_mode = 2, split_budget = 0, split_ttl = 0;  // split_budget 0: by batch size, see launch()
-  int rec_cap = 0, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32, item_min = 0, poll_sleep = 2;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
+  int rec_cap = 2048, rows_cap = 0, items_cap = 0, sub_slots_n = 0, pool_cap = 0, item_budget = 32, item_min = 0, poll_sleep = 2;  // hand-over records, staged rows per record, queue length, persistent workgroups of pass 2
   int32_t* h_ovf_flag = nullptr;    // pinned host word: an instance ended on a staging overflow (Args::ovf_flag), and its device alias
   int32_t* d_ovf_flag = nullptr;
   int rescue_ttl = 0;               // launches left that carry the rescue pass
@@ -1213,27 +1213,11 @@ hipError_t ensure_sub(Handle* h) {
   const bool two = h->threads == 256 && h->duo_min > 0;
   h->sub_slots_n = (two ? 2 : 1) * h->cus;
   h->rows_cap = h->n <= hdsm::SPLIT_N_MAX ? (two ? CMAX_DUO : CMAX30) : (two ? h->duo48_rows : CMAX48);
-  h->rec_cap = 2048;  // (records: one per instance that hands its search over + one per item that hands over again)
-  if (const char* ev = std::getenv("HDSM_SPLIT_RECORDS")) {
-    const long v = std::strtol(ev, nullptr, 10);
-    if (v >= 1 && v <= (1 << 20)) h->rec_cap = (int)v;
-  }
+  // (rec_cap — records: one per instance that hands its search over + one per item that hands over again — set by hdsm_create)
   h->items_cap = h->rec_cap * 16 < 4096 ? 4096 : h->rec_cap * 16;
   // snapshot scratch of pass 2: one slot per workgroup that can be resident + one per record (an item that hands over again leaves
   // its slot to its record for the rest of the launch)
   h->pool_cap = h->sub_slots_n + h->rec_cap;
-  if (const char* ev = std::getenv("HDSM_ITEM_BUDGET")) {
-    const long v = std::strtol(ev, nullptr, 10);
-    if (v >= 0 && v <= 100000) h->item_budget = (int)v;
-  }
-  if (const char* ev = std::getenv("HDSM_POLL_SLEEP")) {
-    const long v = std::strtol(ev, nullptr, 10);
-    if (v >= 1 && v <= 1000) h->poll_sleep = (int)v;
-  }
-  if (const char* ev = std::getenv("HDSM_ITEM_MIN")) {
-    const long v = std::strtol(ev, nullptr, 10);
-    if (v >= 1 && v <= 100000) h->item_min = (int)v;
-  }
   const size_t G = (size_t)h->items_cap, R = (size_t)h->rec_cap;
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) {
@@ -1375,7 +1359,12 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_DUO48_ROWS", 320, 720, &h->duo48_rows);
     env_int("HDSM_SETUP_MFMA", 0, 1, &h->setup_mfma);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
-    env_int("HDSM_SPLIT_BUDGET", 2, 100000, &h->split_budget);  // (unset: by batch size, see launch())
+    env_int("HDSM_SPLIT_BUDGET", 1, 100000, &h->split_budget);  // (unset: by batch size, see launch())
+    env_int("HDSM_ITEM_BUDGET", 0, 100000, &h->item_budget);    // pass 2: nodes after which an item hands over again (32; 0 = never)
+    env_int("HDSM_ITEM_MIN", 1, 100000, &h->item_min);          // ... or, while workgroups wait for items, this many (unset: by batch size)
+    env_int("HDSM_POLL_SLEEP", 1, 1000, &h->poll_sleep);
+    h->rec_cap = 8 * max_instances < 256 ? 256 : (8 * max_instances > 2048 ? 2048 : 8 * max_instances);
+    env_int("HDSM_SPLIT_RECORDS", 1, 1 << 20, &h->rec_cap);
     // more instances than can be resident at once (two workgroups per CU): launch the expensive ones first
     h->order_min = params->launch_order == 0 ? 2 * cus + 1 : (params->launch_order < 0 ? 0 : params->launch_order);
     env_int("HDSM_ORDER_MIN", 0, INT_MAX, &h->order_min);  // 0 = never

@@ -6,7 +6,8 @@ that runs into its budget, by its second search order (most infeasible step firs
 second order directly (the enumeration in step order needs minutes per instance there). An oracle answer with status
 LIMIT is never accepted as a verdict. Every case also goes through the OTHER launch forms the handle would pick for large
 batches or deep trees — the kernels that share a CU (reduced staging area, with the rescue pass for instances that overflow
-it) and the three-kernel subtree split with a two-node budget — forced here by the HDSM_* environment knobs."""
+it) and the split launch (hand-over records + item queue) with one- and two-node budgets, items that hand over again — forced here by
+the HDSM_* environment knobs."""
 import os
 
 import numpy as np
@@ -37,7 +38,9 @@ def _case(rng, case):
 FORMS = [dict(),                                                              # what the handle picks for the batch by itself
          dict(HDSM_DUO_MIN="1", HDSM_TRI_MIN="1", HDSM_ORDER_MIN="1", HDSM_BOUNDS_MIN="1"),  # what a large batch gets: shared-CU
                                                                               # kernels, launch order, sphere prefilter
-         dict(HDSM_SPLIT="1", HDSM_SPLIT_BUDGET="2")]                         # subtree split, poly_hor^3 sub-blocks per tree
+         dict(HDSM_SPLIT="1", HDSM_SPLIT_BUDGET="2"),                         # split launch: hand-over after two nodes, items of pass 2
+         dict(HDSM_SPLIT="1", HDSM_SPLIT_BUDGET="1", HDSM_ITEM_BUDGET="2", HDSM_ITEM_MIN="1",   # ... items that hand over again after two
+              HDSM_DUO_MIN="1", HDSM_TRI_MIN="1", HDSM_QUAD_MIN="1")]        # nodes (records chained per instance), four-per-CU kernel in pass 1
 
 
 def test_fuzz_every_device_answer_is_verified_by_the_oracle(oracle, monkeypatch):
