@@ -538,7 +538,13 @@ struct Solver {
     // (the per-lane addresses of a snapshot are formed here, when one is taken: hoisted out of the branch-and-bound loop they
     // were kept alive across the whole active-set run — 37 dwords per lane spilled to scratch by EVERY instance, tree or not)
     buf = keep_in_loop(buf);
-    if (HDSM_TX < 64) W::snapshot(s, R, buf, save, tid_here());
+    // (workgroups of two or more wavefronts: wave 1 moves U — LDS <-> global — while wave 0 moves J from / to its registers)
+    if (blockDim.x > 64) {
+      if (HDSM_TX < 64) W::template snapshot<false>(s, R, buf, save, tid_here());
+      else if (HDSM_TX < 128) W::snapshot_u(s, buf, save, tid_here() & 63);
+    } else if (HDSM_TX < 64) {
+      W::template snapshot<true>(s, R, buf, save, tid_here());
+    }
     SYNC();
   }
   // No point of the input box has an objective above f_box (set-up), and the dual method's f only grows: once it passes f_box the
@@ -590,19 +596,24 @@ struct Solver {
       if (level == 0) return false;
       const int L = level - 1;
       const int pos = s.br_pos[L];
-      if (pos < s.br_cnt[L] && !(s.br_f[L] >= cutoff(s, c))) {
-        if (s.br_lb[L][pos] >= cutoff(s, c)) {  // the child's lower bound (leaf_check) reaches the incumbent: neither opened nor counted
+      const double cut = cutoff(s, c);
+      if (pos < s.br_cnt[L] && !(s.br_f[L] >= cut)) {
+        if (s.br_lb[L][pos] >= cut) {  // the child's lower bound (leaf_check) reaches the incumbent: neither opened nor counted
           SYNC();
           if (IS_T0) s.br_pos[L] = pos + 1, ++s.lb_skipped;
           SYNC();
           continue;
         }
-        if (s.n_nogood > 0) {  // a child whose assignments contain a learned conflict is infeasible: not opened, not counted
-          unsigned long long cur = 1ull << (4 * s.br_step[L] + s.br_order[L][pos]);
-          for (int i = 0; i < c.N; ++i)
-            if (s.assign[i] >= 0 && i != s.br_step[L]) cur |= 1ull << (4 * i + s.assign[i]);
-          bool blocked = false;
-          for (int k = 0; k < s.n_nogood; ++k) blocked = blocked || (s.nogood[k] & ~cur) == 0ull;
+        const int n_ng = uni(s.n_nogood);
+        if (n_ng > 0) {  // a child whose assignments contain a learned conflict is infeasible: not opened, not counted
+          // (lane-parallel in every wavefront: the assignments of the child as a mask from four ballots — bit 16 j + i = polyhedron j
+          // at step i — and one learnt conflict per lane; one thread walking both lists was 4 k cycles of LDS round trips per node)
+          const int ln = tid_here() & 63, bs = uni(s.br_step[L]), bj = uni(s.br_order[L][pos]);
+          const int aj = ln < c.N ? (ln == bs ? bj : s.assign[ln]) : -1;
+          unsigned long long cur = 0ull;
+          for (int j = 0; j < 4; ++j) cur |= (__ballot(aj == j) & 0xffffull) << (16 * j);
+          const unsigned long long mine = ln < n_ng ? s.nogood[ln] : ~0ull;
+          const bool blocked = __ballot((mine & ~cur) == 0ull) != 0ull;
           if (blocked) {
             SYNC();
             if (IS_T0) s.br_pos[L] = pos + 1, ++s.ng_skipped;
@@ -1194,6 +1205,7 @@ struct Solver {
 #endif
       }
       last_rc = rc;
+      NODE_PROF(16)
       if (rc == GI_ITERLIM || rc == GI_TIMELIM) {
         limit = true;
         flags |= rc == GI_ITERLIM ? FLAG_ITER_LIMIT : FLAG_TIME_LIMIT;
@@ -1212,6 +1224,7 @@ struct Solver {
 #ifdef HDSM_PROFILE
         t_leaf_ += clock64() - tl_;
 #endif
+        NODE_PROF(17)
         if (bstep < 0) {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
@@ -1250,7 +1263,9 @@ struct Solver {
           // the node bound reaches the incumbent: no leaf below this node can beat it — closed without a snapshot, without a level
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level, bstep_own = bstep;
+          NODE_PROF(18)
           snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, true);
+          NODE_PROF(19)
           if (IS_T0) {
             const int bstep = bstep_own;
             int cnt = 0;
@@ -1275,6 +1290,7 @@ struct Solver {
           SYNC();
         }
       }
+      NODE_PROF(20)
       if (rc == GI_INFEASIBLE && c.P <= 4 && N <= 16) {
         // Conflict learning. The dual method stopped because row inf_id depends on the working set and no multiplier can
         // give way: working set + that row are infeasible TOGETHER. Apart from the rows of assigned polyhedra, everything
@@ -1288,7 +1304,7 @@ struct Solver {
             const int code = (k < s.q) ? s.act[k] : s.inf_id;
             if (id_kind(code) == K_P) {
               const int i = id_payload(code) >> 7;
-              if (s.assign[i] >= 0) m |= 1ull << (4 * i + s.assign[i]);
+              if (s.assign[i] >= 0) m |= 1ull << (16 * s.assign[i] + i);  // (bit 16 j + i: polyhedron j at step i)
             }
           }
           if (m == 0ull) {
@@ -1303,7 +1319,9 @@ struct Solver {
       }
       // node closed (incumbent recorded / infeasible / cut off) or level opened: go to the next child
       const bool lim_before = limit;
+      NODE_PROF(21)
       run = select_child(s, c, R, nodes, limit, inst, handed_over, rec_slot);
+      NODE_PROF(22)
       if (limit && !lim_before) flags |= FLAG_NODE_LIMIT;
     }
 
@@ -1356,7 +1374,7 @@ struct Solver {
         const double cut = cutoff(s, c);
         auto open_child = [&](int l, int x1, unsigned long long path) {  // still to be explored: bound below the incumbent, no learnt conflict
           if (s.br_lb[l][x1] >= cut) return false;
-          const unsigned long long cur = path | (1ull << (4 * s.br_step[l] + s.br_order[l][x1]));
+          const unsigned long long cur = path | (1ull << (16 * s.br_order[l][x1] + s.br_step[l]));
           bool blocked = false;
           if (c.P <= 4 && N <= 16)
             for (int k = 0; k < s.n_nogood; ++k) blocked = blocked || (s.nogood[k] & ~cur) == 0ull;
@@ -1366,7 +1384,7 @@ struct Solver {
         unsigned long long path = 0ull;
         for (int l = 0; l < lev; ++l) {
           for (int x1 = s.br_pos[l]; x1 < s.br_cnt[l]; ++x1) cnt += open_child(l, x1, path) ? 1 : 0;
-          if (l + 1 < lev) path |= 1ull << (4 * s.br_step[l] + s.assign[s.br_step[l]]);
+          if (l + 1 < lev) path |= 1ull << (16 * s.assign[s.br_step[l]] + s.br_step[l]);
         }
         // the items' places in the queue are RESERVED first ([5]: the reserved end), written, and then PUBLISHED in order ([1]: the
         // end of what the workgroups of pass 2 may draw) — an item is never drawn before it is there
@@ -1381,7 +1399,7 @@ struct Solver {
               a.item_status[first + w] = ST_PENDING;  // (an item no workgroup gets to — a grid or a queue too short — is reported as a limit)
               a.items[first + w++] = (rec_slot << 8) | (l << 3) | x1;
             }
-          if (l + 1 < lev) path |= 1ull << (4 * s.br_step[l] + s.assign[s.br_step[l]]);
+          if (l + 1 < lev) path |= 1ull << (16 * s.assign[s.br_step[l]] + s.br_step[l]);
         }
         // what pass 2 starts from: the incumbent found so far (objectives are >= 0: the bit patterns order) and the rest of the node budget
         if (item < 0) {

@@ -161,7 +161,15 @@ struct alignas(16) D2 {
 // -DHDSM_PROF_STAGE (with -DHDSM_PROFILE): slots 16..20 time the steps of the staging phase instead of the sweeps
 // -DHDSM_PROF_OP (with -DHDSM_PROFILE): slots 8..23 time the inside of a regular active-set operation (OP_PROF) instead of the
 // sweeps, the set-up and the warm start
-#if defined(HDSM_PROFILE) && defined(HDSM_PROF_OP)
+// -DHDSM_PROF_NODE (with -DHDSM_PROFILE): slots 16..23 time the node machinery of the branch and bound (NODE_PROF in hdsm_core.h)
+// instead of the warm start: 16 end of a run, 17 leaf test, 18 verification / incumbent, 19 snapshot, 20 level, 21 conflict, 22 next child
+#if defined(HDSM_PROFILE) && defined(HDSM_PROF_NODE)
+#define SW_PROF(k) PROF(k)
+#define ST_PROF(k)
+#define WS_PROF(k)
+#define OP_PROF(k)
+#define NODE_PROF(k) PROF(k)
+#elif defined(HDSM_PROFILE) && defined(HDSM_PROF_OP)
 #define SW_PROF(k)
 #define ST_PROF(k)
 #define WS_PROF(k)
@@ -178,6 +186,9 @@ struct alignas(16) D2 {
 #define ST_PROF(k)
 #define WS_PROF(k) PROF(k)
 #define OP_PROF(k)
+#endif
+#ifndef NODE_PROF
+#define NODE_PROF(k)
 #endif
 #if !defined(SC_PROF) && defined(HDSM_ISA_MARKS)
 #define SC_PROF_DECL

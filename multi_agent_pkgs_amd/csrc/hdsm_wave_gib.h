@@ -860,6 +860,22 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
 
   // snapshots: J slots from registers (layout [slot][lane]), U rows / multipliers / ids / x from LDS
   static constexpr int SNAP_DOUBLES = Base::SNAP_DOUBLES;
+  // the U part of a snapshot (LDS <-> global), any wavefront: `lane` = lane of that wavefront
+  static __device__ __forceinline__ void snapshot_u(S& s, double* buf, bool save, int lane) {
+    keep_in_loop(lane);
+    const int row = row_addr(lane), c0 = Base::col0_of(lane);
+    if (Base::row_ok(lane)) {
+      if (save) {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+      }
+    }
+  }
+  // WITH_U = false: the U part is taken by another wavefront at the same time (snapshot_u; hdsm_core.h, snapshot_io)
+  template <bool WITH_U = true>
   static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
     keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
     const int row = row_addr(lane), c0 = Base::col0_of(lane);
@@ -867,10 +883,16 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
     if (Base::row_ok(lane)) {
       if (save) {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) buf[j * JL + lane] = R.Jr[j], buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+        for (int j = 0; j < NC; ++j) {
+          buf[j * JL + lane] = R.Jr[j];
+          if constexpr (WITH_U) buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < NC; ++j) R.Jr[j] = buf[j * JL + lane], s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+        for (int j = 0; j < NC; ++j) {
+          R.Jr[j] = buf[j * JL + lane];
+          if constexpr (WITH_U) s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+        }
       }
     }
     if (lane < NV) {
