@@ -681,7 +681,9 @@ struct Solver {
         ++nodes;
         const int j = s.br_order[L][pos];
         SYNC();
+        NODE_PROF(22)
         if (pos > 0) snapshot_io(s, c, R, s.snap + (int64_t)L * SNAP_STRIDE, false);
+        NODE_PROF(23)
         if (IS_T0) {
           s.br_pos[L] = pos + 1;
           s.assign[s.br_step[L]] = j;

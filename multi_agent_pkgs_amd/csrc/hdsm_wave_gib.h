@@ -860,8 +860,19 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
 
   // snapshots: J slots from registers (layout [slot][lane]), U rows / multipliers / ids / x from LDS
   static constexpr int SNAP_DOUBLES = Base::SNAP_DOUBLES;
+  // (the snapshot buffer is GLOBAL memory, and said to be: through a generic pointer — it comes out of LDS, Shm::snap — every load of
+  // a restore was a flat_load that might alias the LDS store next to it, and the compiler waited for each one before the next:
+  // 48 memory round trips in a chain, 13 k cycles per restore, a sixth of the time of a deep tree)
+#if defined(__HIP_DEVICE_COMPILE__)
+  using GBuf = __attribute__((address_space(1))) double*;
+  static __device__ __forceinline__ GBuf as_global(double* p) { return (GBuf)p; }
+#else
+  using GBuf = double*;
+  static GBuf as_global(double* p) { return p; }
+#endif
   // the U part of a snapshot (LDS <-> global), any wavefront: `lane` = lane of that wavefront
-  static __device__ __forceinline__ void snapshot_u(S& s, double* buf, bool save, int lane) {
+  static __device__ __forceinline__ void snapshot_u(S& s, double* buf_generic, bool save, int lane) {
+    const GBuf buf = as_global(buf_generic);
     keep_in_loop(lane);
     const int row = row_addr(lane), c0 = Base::col0_of(lane);
     if (Base::row_ok(lane)) {
@@ -869,14 +880,18 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
 #pragma unroll
         for (int j = 0; j < NC; ++j) buf[(NV + c0 + j) * NV + row] = s.U[row * LDT + c0 + j];
       } else {
+        double t[NC];  // (every load requested before the first one is stored)
 #pragma unroll
-        for (int j = 0; j < NC; ++j) s.U[row * LDT + c0 + j] = buf[(NV + c0 + j) * NV + row];
+        for (int j = 0; j < NC; ++j) t[j] = buf[(NV + c0 + j) * NV + row];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) s.U[row * LDT + c0 + j] = t[j];
       }
     }
   }
   // WITH_U = false: the U part is taken by another wavefront at the same time (snapshot_u; hdsm_core.h, snapshot_io)
   template <bool WITH_U = true>
-  static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf, bool save, int lane) {
+  static __device__ __forceinline__ void snapshot(S& s, Regs& R, double* buf_generic, bool save, int lane) {
+    const GBuf buf = as_global(buf_generic);
     keep_in_loop(lane);  // (the per-lane offsets of a snapshot are formed when one is taken, not kept alive across the active-set run)
     const int row = row_addr(lane), c0 = Base::col0_of(lane);
     constexpr int JL = SPLIT ? 64 : NV;  // lanes that hold slots of J (NC JL = NV NV doubles)
