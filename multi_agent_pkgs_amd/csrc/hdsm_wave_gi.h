@@ -146,6 +146,25 @@ struct alignas(16) D2 {
   double x, y;
 };
 
+// A pointer the kernel KNOWS to address global memory. The launch arguments are kept in LDS (Shm::args), and a pointer that comes
+// out of LDS is a generic one: its loads are flat_load, which count on the LDS counter as well and may alias every LDS access near
+// them — the compiler orders them accordingly (a restore of a snapshot was 48 chained round trips, hdsm_wave_gib.h).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+using GPtr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ GPtr<const T> gptr(const T* p) { return (GPtr<const T>)p; }
+template <class T>
+__device__ __forceinline__ GPtr<T> gptr(T* p) { return (GPtr<T>)p; }
+#else
+template <class T>
+using GPtr = T*;
+template <class T>
+__device__ __host__ inline GPtr<const T> gptr(const T* p) { return p; }  // (the host pass of hipcc, and the CPU execution of the tests)
+template <class T>
+__device__ __host__ inline GPtr<T> gptr(T* p) { return p; }
+#endif
+
 #ifdef HDSM_PROFILE
 // cycle counters accumulated in LDS by lane 0 (keeps them out of the SGPR file)
 #define PROF_DECL if (HDSM_TX == 0) s.prof_last = clock64();
@@ -604,6 +623,8 @@ struct WaveGI {
                                                       bool check_fixed, int lane, const double* pts = nullptr, int pstride = 9) {
     const int N = c.N, n_rob = a.n_rob, nt = SOLO ? 64 : (int)blockDim.x;  // lane = thread of the WORKGROUP (all waves sweep) unless SOLO
     if (pts == nullptr) pts = &s.st[0][0];
+    const GPtr<const double> g_bounds = gptr(a.bounds), g_pos = gptr(a.pos);
+    const GPtr<const uint8_t> g_has = gptr(a.has_plan);
     auto bar = [&]() {
       if constexpr (SOLO) wsync();
       else __syncthreads();
@@ -653,7 +674,7 @@ struct WaveGI {
 #pragma unroll
           for (int f = 0; f < FB; ++f) {
             const int k = k0 + f * nt;
-            bk[f] = *reinterpret_cast<const double4*>(a.bounds + 4 * (int64_t)(k < end ? k : base));
+            bk[f] = *(GPtr<const double4>)(g_bounds + 4 * (int64_t)(k < end ? k : base));
           }
 #pragma unroll
           for (int f = 0; f < FB; ++f) {
@@ -675,9 +696,9 @@ struct WaveGI {
         const int j = in ? idx / N : 0, i = in ? idx - j * N : 0;
         const int k = in ? (pre ? s.list[j] : base + j) : 0;  // idle threads read agent 0's record (always there)
         // packed positions [n_rob][N][3]: consecutive threads of a neighbour read consecutive 24-B records
-        const double* op = a.pos + ((int64_t)k * N + i) * 3;
+        const GPtr<const double> op = g_pos + ((int64_t)k * N + i) * 3;
         const double ox = op[0], oy = op[1], oz = op[2];
-        const bool on = in && k != self && (pre || a.has_plan[k]);
+        const bool on = in && k != self && (pre || g_has[k]);
         SW_PROF(10)
         const double cx = s.cprev[i][0], cy = s.cprev[i][1], cz = s.cprev[i][2];
         const double dx = ox - cx, dy = oy - cy, dz = oz - cz;

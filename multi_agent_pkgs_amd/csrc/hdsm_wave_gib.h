@@ -868,7 +868,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
   static __device__ __forceinline__ GBuf as_global(double* p) { return (GBuf)p; }
 #else
   using GBuf = double*;
-  static GBuf as_global(double* p) { return p; }
+  static __device__ __host__ GBuf as_global(double* p) { return p; }
 #endif
   // the U part of a snapshot (LDS <-> global), any wavefront: `lane` = lane of that wavefront
   static __device__ __forceinline__ void snapshot_u(S& s, double* buf_generic, bool save, int lane) {
