@@ -39,6 +39,11 @@
 #endif
 
 #if defined(__clang__)
+#define CD_UNROLL _Pragma("unroll")  // loops over the four sides of a face: their small arrays must be registers on the device
+#else
+#define CD_UNROLL
+#endif
+#if defined(__clang__)
 #pragma clang fp contract(off)  // the plane offsets must come out bit-identical on the host and on the device
 #endif
 
@@ -62,9 +67,8 @@ CD_HD Cell neg(Cell a) { return {-a.x, -a.y, -a.z}; }
 CD_HD int dot(Cell a, Cell b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
 // outward normals in the order of the output rows (CD:17-18)
-CD_HD Cell normal_of(int f) {
-  const Cell n[6] = {{0, -1, 0}, {1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, 0, 1}, {0, 0, -1}};
-  return n[f];
+CD_HD Cell normal_of(int f) {  // (-y, +x, +y, -x, +z, -z), computed: an indexed table would live in scratch memory on the device
+  return Cell{(f == 1) - (f == 3), (f == 2) - (f == 0), (f == 4) - (f == 5)};
 }
 CD_HD int face_with_normal(Cell n) {
   for (int f = 0; f < 6; ++f)
@@ -73,8 +77,9 @@ CD_HD int face_with_normal(Cell n) {
 }
 // the two faces meeting in edge e (numbering of CD:28-31: it fixes the order of the chamfer rows)
 CD_HD int edge_face(int e, int which) {
-  const int t[12][2] = {{0, 1}, {0, 4}, {0, 3}, {0, 5}, {1, 5}, {1, 4}, {3, 4}, {3, 5}, {1, 2}, {2, 4}, {2, 3}, {2, 5}};
-  return t[e][which];
+  // {0,1} {0,4} {0,3} {0,5} {1,5} {1,4} {3,4} {3,5} {1,2} {2,4} {2,3} {2,5}, one nibble per edge (no table in scratch memory)
+  const unsigned long long first = 0x222133110000ull, second = 0x534254455341ull;
+  return (int)(((which ? second : first) >> (4 * e)) & 0xfull);
 }
 
 struct Frame {      // in-plane frame of a face and what lies across each of its four sides
@@ -94,6 +99,7 @@ CD_HD void build_frames(Frame fr[6]) {
     fr[f].side[0] = u, fr[f].side[1] = v, fr[f].side[2] = neg(u), fr[f].side[3] = neg(v);
   }
   for (int f = 0; f < 6; ++f)
+    CD_UNROLL
     for (int j = 0; j < 4; ++j) {
       const int g = face_with_normal(fr[f].side[j]);
       fr[f].face[j] = g;
@@ -101,6 +107,7 @@ CD_HD void build_frames(Frame fr[6]) {
       for (int e = 0; e < 12; ++e)
         if ((edge_face(e, 0) == f && edge_face(e, 1) == g) || (edge_face(e, 0) == g && edge_face(e, 1) == f)) fr[f].edge[j] = e;
       fr[f].back[j] = -1;
+      CD_UNROLL
       for (int k = 0; k < 4; ++k)
         if (same(fr[g].side[k], normal_of(f))) fr[f].back[j] = k;
     }
@@ -141,13 +148,14 @@ struct Layer {
   Cell far[4];          // border_limit_tmp
 };
 
-// everything one decomposition needs; ~45 KB, provided by the caller (heap on the host, global scratch on the device)
+// everything one decomposition needs; ~30 KB, provided by the caller (heap on the host, global scratch or LDS on the device)
 struct Work {
   Frame fr[6];
-  FaceState faces[6], faces_t[6];
+  FaceState faces[6], face_t;  // face_t: the face under trial with its new layer as outermost layer (CD:978-1066)
   Layer L, L2;
   CellDeque rim[4], moved, moved_real, edge_row;
   Edge edges[12], edges_t[12];
+  Cell anchor[6];  // a voxel of each face's outermost layer (gives the face plane)
   Cell seed;
   int overflow;
 };
@@ -164,13 +172,19 @@ struct WindowGrid {
   int ground_k;
   int mark;
   Cell seed;
-  uint32_t* bits;      // overlay over offsets [-OV, OV)^3 from the seed
-  // optional cache of the world under the overlay, 2 bits per voxel, same indexing (device corridor kernel: built by the
-  // whole wavefront in LDS, so that the one lane that runs the decomposition does not wait for a global read per voxel):
-  // 0 = free (any value below kOccupied), 1 = exactly kOccupied (also: below the ground, unknown), 2 = above kOccupied
-  const uint32_t* occ2 = nullptr;
-  static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32, OCC2_WORDS = OVW * OVW * OVW / 16;
+  uint32_t* bits;      // overlay over offsets [-OV, OV)^3 from the seed: word dy + OVW * dz, bit dx ("x-fast")
+  // optional (cooperative mode of the device: built by the whole wavefront in LDS, build_world_maps): bit maps of the world under
+  // the overlay, same indexing, for the offsets |d| <= map_r from the seed —
+  //   maps[0 .. WORDS)            FREE, x-fast: inside the local grid and a value below kOccupied
+  //   maps[WORDS .. 2 WORDS)      POS,  x-fast: outside the local grid or a value above 0 (what SideIsEmpty tests, CD:577-588)
+  //   maps[2 WORDS .. 3 WORDS)    FREE, y-fast: word dx + OVW * dz, bit dy
+  // and a y-fast copy of the overlay (bits_t). With them a whole plane of voxels is 32 words — one per lane (grow_layer_planes).
+  const uint32_t* maps = nullptr;
+  uint32_t* bits_t = nullptr;
+  int map_r = 0;
+  static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32, MAP_WORDS = 3 * WORDS;
   static constexpr bool kAtomicMarks = true;  // set_atomic / unset_atomic exist (cooperative mode)
+  static constexpr bool kHasPlanes = true;    // maps / bits_t may be there
   CD_HD int nx() const { return lnx; }
   CD_HD int ny() const { return lny; }
   CD_HD int nz() const { return lnz; }
@@ -191,36 +205,46 @@ struct WindowGrid {
     const int v = world[(size_t)gi + (size_t)gj * wnx + (size_t)gk * wnx * wny];
     return v < 0 ? kOccupied : v;
   }
-  CD_HD static uint32_t occ2_class(int v) { return v < kOccupied ? 0u : (v == kOccupied ? 1u : 2u); }
   CD_HD int value(Cell c) const {
-    const int b = bit_index(c);
-    if (b >= 0) {
-      if ((bits[b >> 5] >> (b & 31)) & 1u) return mark;
-      if (occ2) {  // (the decomposition only compares values with kOccupied and the mark: the class is enough)
-        const uint32_t cls = (occ2[b >> 4] >> ((b & 15) * 2)) & 3u;
-        return cls == 0 ? 0 : (cls == 1 ? kOccupied : kOccupied + 1);
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx >= 0 && dy >= 0 && dz >= 0 && dx < OVW && dy < OVW && dz < OVW) {
+      const int w = dy + OVW * dz;
+      if ((bits[w] >> dx) & 1u) return mark;
+      if (maps && dx >= OV - map_r && dx <= OV + map_r && dy >= OV - map_r && dy <= OV + map_r && dz >= OV - map_r && dz <= OV + map_r) {
+        // (the decomposition compares values with kOccupied, with 0 and with the mark only: the two bits are enough; callers test
+        // inside() before they look at a value, FREE already holds it)
+        if (!((maps[w] >> dx) & 1u)) return kOccupied;
+        return (maps[WORDS + w] >> dx) & 1u;
       }
     }
     return world_value(c);
   }
   CD_HD void set(Cell c, int) {
-    const int b = bit_index(c);
-    if (b >= 0) bits[b >> 5] |= 1u << (b & 31);
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
+    bits[dy + OVW * dz] |= 1u << dx;
+    if (bits_t) bits_t[dx + OVW * dz] |= 1u << dy;
   }
   CD_HD void trial_set(Cell c, int m) { set(c, m); }
   CD_HD void trial_unset(Cell c) {
-    const int b = bit_index(c);
-    if (b >= 0) bits[b >> 5] &= ~(1u << (b & 31));
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
+    bits[dy + OVW * dz] &= ~(1u << dx);
+    if (bits_t) bits_t[dx + OVW * dz] &= ~(1u << dy);
   }
-#if defined(__HIP_DEVICE_COMPILE__)
-  // cooperative mode (Ctx::coop): the lanes of a wavefront mark different voxels at once
+#if defined(__HIP_DEVICE_COMPILE__) || defined(CD_EMU_COOP)
+  // cooperative mode (Ctx::coop): the lanes of a wavefront mark different voxels at once, in both copies of the overlay
   __device__ void set_atomic(Cell c) const {
-    const int b = bit_index(c);
-    if (b >= 0) atomicOr(&bits[b >> 5], 1u << (b & 31));
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
+    atomicOr(&bits[dy + OVW * dz], 1u << dx);
+    if (bits_t) atomicOr(&bits_t[dx + OVW * dz], 1u << dy);
   }
   __device__ void unset_atomic(Cell c) const {
-    const int b = bit_index(c);
-    if (b >= 0) atomicAnd(&bits[b >> 5], ~(1u << (b & 31)));
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
+    atomicAnd(&bits[dy + OVW * dz], ~(1u << dx));
+    if (bits_t) atomicAnd(&bits_t[dx + OVW * dz], ~(1u << dy));
   }
 #endif
   CD_HD int count() const {
@@ -237,7 +261,7 @@ struct WindowGrid {
 // data — the control flow is uniform and every lane stores the same values — and the loops over the cells of a layer / a rim
 // (where one lane spent its time: a chain of LDS round trips per cell) are spread over the lanes, with ballots where the serial
 // loop stops at the first hit or appends in order. The results are those of the serial code, statement for statement.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CD_NO_COOP)
+#if (defined(__HIP_DEVICE_COMPILE__) || defined(CD_EMU_COOP)) && !defined(CD_NO_COOP)
 #define CD_HAS_COOP 1
 #define CD_COOP(cx) ((cx).coop)
 #define CD_SYNC() __syncthreads()
@@ -250,10 +274,33 @@ struct WindowGrid {
 // hipcc -O3 produced gfx950 code for the one-thread-per-seed kernel that faulted on some seeds (memory aperture violation;
 // fine at -O2, with -fno-unroll-loops or -fno-vectorize, with either function out of line, and the same source is clean on the
 // host under ASan / UBSan). The calls also keep the kernels a third of the size.
+// The COOPERATIVE instantiations (template parameter COOP) are inlined into their kernel instead: only then does the compiler
+// see that the workspace is LDS and the small arrays are registers — behind a call they were flat loads, and the allowance of a
+// layer a scratch (global-memory) load per rim move.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define CD_NOINLINE __attribute__((noinline))
+#define CD_INLINE __attribute__((always_inline))
 #else
 #define CD_NOINLINE
+#define CD_INLINE
+#endif
+
+// -DCD_PROFILE (development builds, scripts/gpu_corridor_profile.sh): cycles per phase of the cooperative decomposition,
+// accumulated by lane 0 into a device array that hdsm_corridor_profile() reads
+#if defined(CD_PROFILE) && defined(__HIPCC__)
+static __device__ unsigned long long g_cd_prof[16];
+#endif
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define CD_PROF_BEGIN() unsigned long long cd_t0_ = __builtin_readcyclecounter()
+#define CD_PROF(i)                                                  \
+  do {                                                              \
+    const unsigned long long cd_t1_ = __builtin_readcyclecounter(); \
+    if (cx.lane == 0) atomicAdd(&g_cd_prof[i], cd_t1_ - cd_t0_);     \
+    cd_t0_ = cd_t1_;                                                \
+  } while (0)
+#else
+#define CD_PROF_BEGIN() ((void)0)
+#define CD_PROF(i) ((void)0)
 #endif
 
 struct Ctx {
@@ -326,6 +373,7 @@ struct Ctx {
 
 // how far the next layer of face f may extend on each side, given the chamfers already started (CD:71-91)
 CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* edges, int allow[4], Edge trial[4]) {
+  CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     allow[j] = fs.reach[j];
     trial[j] = edges[fr[f].edge[j]];
@@ -337,12 +385,128 @@ CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* ed
   }
 }
 
+#if CD_HAS_COOP
+// The in-plane growth of a layer (the loop of grow_layer below) for the cooperative mode, WITHOUT the cell deques. What that loop
+// maintains is a rectangle: a side only ever moves as a whole line, its cells are the rectangle's edge in counter-clockwise
+// order ((+u: along +v, +v: along -u, -u: along -v, -v: along +u), and a line may move iff it stays inside the allowance and no
+// cell of it lies on top of the polyhedron without being free — a failure is final, the line only gets longer. So: lane r < 32
+// holds row r of two bit planes of the overlay's 32 x 32 cross-section at the layer's level (REAL: on top of the polyhedron and
+// free; BLK: on top of it and not free — three LDS words per lane, from the x-fast or y-fast copies so that the plane's rows
+// are words), a move along the bit axis is a ballot of one bit column, a move along the row axis a v_readlane of one row, both
+// masked to the rectangle; the layer's cells (the REAL cells of every line that moved, in the deque's order) are written by
+// the lanes that hold them, ranked by a popcount. At the end the four rim_real deques and `far` are written out as the serial
+// loop leaves them — every cell of rim_real[j] is a REAL cell of side j's final line and vice versa, far[j] is read only
+// through its coordinate along side j — so the caller goes on unchanged. ~100 cycles per move instead of ~2 k.
+template <class G>
+CD_INLINE __device__ inline void grow_layer_planes(const Ctx& cx, const G& g, int f, const int allow_in[4], Cell s2, Layer& L) {
+  Work& wk = *cx.wk;
+  const int allow[4] = {allow_in[0], allow_in[1], allow_in[2], allow_in[3]};
+  constexpr int OV = G::OV, OVW = G::OVW;
+  const int lane = cx.lane;
+  const Cell up = normal_of(f);
+  const Cell* sd = wk.fr[f].side;
+  const int aw = up.x ? 0 : (up.y ? 1 : 2);          // axis of the face's normal
+  const int ab = aw == 0 ? 1 : 0, ar = aw == 2 ? 1 : 2;  // axis along the bits of a row / across the rows
+  auto comp = [](Cell c, int a) { return a == 0 ? c.x : (a == 1 ? c.y : c.z); };
+  const int su = up.x + up.y + up.z;
+  const int sb = comp(cx.seed, ab), sr = comp(cx.seed, ar), sw = comp(cx.seed, aw);
+  const int lw = comp(s2, aw) - sw + OV, lb = lw - su;  // the layer's level and the one below it, as overlay indices
+  int b0 = comp(s2, ab) - sb + OV, r0 = comp(s2, ar) - sr + OV, b1 = b0, r1 = r0;
+  const int lo_ok = OV - g.map_r, hi_ok = OV + g.map_r;
+  L.cells.n = 1;
+  L.cells.c[0] = cx.pack(s2);
+  if (lw < lo_ok || lw > hi_ok || lb < lo_ok || lb > hi_ok || b0 < lo_ok || b0 > hi_ok || r0 < lo_ok || r0 > hi_ok) {
+    wk.overflow = 1;  // (beyond what build_world_maps classified: n_it too large for the overlay)
+    return;
+  }
+  CD_PROF_BEGIN();
+  uint32_t real = 0, blk = 0;
+  if (lane < OVW) {
+    const uint32_t* mk = aw == 0 ? g.bits_t : g.bits;
+    const uint32_t* fr = aw == 0 ? g.maps + 2 * G::WORDS : g.maps;
+    const int wt = aw == 2 ? lane + OVW * lw : lw + OVW * lane, wb = aw == 2 ? lane + OVW * lb : lb + OVW * lane;
+    const uint32_t below = mk[wb], free_t = mk[wt] | fr[wt];  // (a voxel of the polyhedron counts as free: its value is the mark)
+    real = below & free_t, blk = below & ~free_t;
+  }
+  bool bit_axis[4];
+  int sg[4];
+  CD_UNROLL
+  for (int j = 0; j < 4; ++j) bit_axis[j] = comp(sd[j], ab) != 0, sg[j] = comp(sd[j], ab) + comp(sd[j], ar);
+  bool alive[4] = {true, true, true, true}, nonempty[4] = {true, true, true, true};
+  int farc[4];
+  CD_UNROLL
+  for (int j = 0; j < 4; ++j) farc[j] = dot(s2, sd[j]);
+  int n = 1;
+  auto range_mask = [](int lo, int hi) { return (uint32_t)(((1ull << (hi + 1)) - 1ull) & ~((1ull << lo) - 1ull)); };
+  auto line_of = [&](bool along_bits, int at, uint32_t plane, int lo, int hi) {  // one line of a plane, indexed along the OTHER axis
+    const uint32_t m = along_bits ? (uint32_t)__ballot(lane < OVW && ((plane >> at) & 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)plane, at);
+    return m & range_mask(lo, hi);
+  };
+  auto write_line = [&](Packed* dst, int cap, bool along_bits, int at, uint32_t m, bool ascending) {
+    if (lane < OVW && ((m >> lane) & 1u)) {
+      const int rank = ascending ? __builtin_popcount(m & ((1u << lane) - 1u)) : __builtin_popcountll((unsigned long long)m >> (lane + 1));
+      int d[3];
+      d[aw] = lw - OV, d[ab] = (along_bits ? at : lane) - OV, d[ar] = (along_bits ? lane : at) - OV;
+      if (rank < cap) dst[rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2]};
+      else wk.overflow = 1;
+    }
+  };
+  CD_PROF(1);
+  while (alive[0] || alive[1] || alive[2] || alive[3]) {
+CD_UNROLL
+    for (int s = 0; s < 4; ++s) {
+      if (!alive[s]) continue;
+      const int nxt = (s + 1) & 3, prv = (s + 3) & 3;
+      const bool ba = bit_axis[s];
+      const int at = ba ? (sg[s] > 0 ? b1 + 1 : b0 - 1) : (sg[s] > 0 ? r1 + 1 : r0 - 1);
+      const int lo = ba ? r0 : b0, hi = ba ? r1 : b1;
+      bool ok = sg[s] * ((ba ? sb : sr) + at - OV) <= allow[s];
+      if (ok && (at < lo_ok || at > hi_ok)) wk.overflow = 1, ok = false;
+      uint32_t lr = 0;
+      if (ok) {
+        ok = line_of(ba, at, blk, lo, hi) == 0u;
+        lr = line_of(ba, at, real, lo, hi);
+      }
+      if (!ok) {
+        alive[s] = false;
+        continue;
+      }
+      const bool asc = sg[nxt] > 0;  // the line's cells in the deque's order: along side s + 1
+      write_line(L.cells.c + n, CELLS - n, ba, at, lr, asc);
+      n += __builtin_popcount(lr);
+      if (n > CELLS) n = CELLS;
+      if (ba) (sg[s] > 0 ? b1 : b0) = at;
+      else (sg[s] > 0 ? r1 : r0) = at;
+      nonempty[s] = lr != 0u;
+      if ((lr >> (asc ? lo : hi)) & 1u) nonempty[prv] = true;  // the corner cells join the neighbouring sides (if on top of the polyhedron)
+      if ((lr >> (asc ? hi : lo)) & 1u) nonempty[nxt] = true;
+CD_UNROLL
+      for (int j = 0; j < 4; ++j)
+        if (nonempty[j]) farc[j] = sg[j] * ((bit_axis[j] ? sb : sr) + (bit_axis[j] ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0)) - OV);
+    }
+  }
+  L.cells.n = n;
+  CD_PROF(2);
+CD_UNROLL
+  for (int j = 0; j < 4; ++j) {
+    const bool ba = bit_axis[j];
+    const int at = ba ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0);
+    const uint32_t m = line_of(ba, at, real, ba ? r0 : b0, ba ? r1 : b1);
+    write_line(L.rim_real[j].c + RIM0, RIM - RIM0, ba, at, m, sg[(j + 1) & 3] > 0);
+    L.rim_real[j].b = RIM0, L.rim_real[j].e = RIM0 + __builtin_popcount(m);
+    L.far[j] = Cell{sd[j].x * farc[j], sd[j].y * farc[j], sd[j].z * farc[j]};
+  }
+  CD_SYNC();
+  CD_PROF(3);
+}
+#endif
+
 // One layer on top of face f: a free 2-D seed above the current outer layer, inside the allowance and inside voxels
 // [1, dim - 1 - margin] (CD:94-116: margin 1; CD:700-723: margin 0), grown in its plane (CD:118-200).
 // Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v),
 // trial_set / trial_unset, and kAtomicMarks (true: set_atomic / unset_atomic for the cooperative mode).
 template <class G>
-CD_NOINLINE CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
   Work& wk = *cx.wk;
   const Frame* fr = wk.fr;
   L.found = 0;
@@ -354,10 +518,12 @@ CD_NOINLINE CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceSt
     if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx() - margin || t.y >= g.ny() - margin || t.z >= g.nz() - margin) return false;
     if (g.value(t) >= kOccupied) return false;
     bool in = true;
+    CD_UNROLL
     for (int k = 0; k < 4; ++k) in = in && dot(t, sd[k]) <= allow[k];
     return in;
   };
   bool found = false;
+  CD_PROF_BEGIN();
 #if CD_HAS_COOP
   if (cx.coop) {  // the first cell of the list that qualifies: 64 candidates per trip
     const int n = fs.outer.n;
@@ -377,13 +543,23 @@ CD_NOINLINE CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceSt
     }
   }
   L.found = found ? 1 : 0;
-  if (!found) return;
+  CD_PROF(0);
+  if (!found) return false;
+#if CD_HAS_COOP
+  if constexpr (G::kHasPlanes) {
+    if (cx.coop && g.maps) {
+      grow_layer_planes(cx, g, f, allow, s2, L);
+      return true;
+    }
+  }
+#endif
   // current outline of the layer per side: all cells (rim) / cells of the layer (rim_real)
+  CD_UNROLL
   for (int j = 0; j < 4; ++j) cx.assign1(wk.rim[j], s2), cx.assign1(L.rim_real[j], s2), L.far[j] = s2;
   cx.push(L.cells, s2);
   bool alive[4] = {true, true, true, true};
   for (int k = 0; alive[0] || alive[1] || alive[2] || alive[3]; ++k) {
-    if (wk.overflow) return;
+    if (wk.overflow) return true;
     const int s = k % 4, prev = (k + 3) % 4, next = (k + 1) % 4;
     cx.clear(wk.moved), cx.clear(wk.moved_real);
     bool ok = true;
@@ -466,9 +642,21 @@ CD_NOINLINE CD_HD void grow_layer(const Ctx& cx, const G& g, int f, const FaceSt
       if (same(cx.front(wk.moved), cx.front(wk.moved_real))) cx.push_back(L.rim_real[prev], cx.front(wk.moved));
       if (same(cx.back(wk.moved), cx.back(wk.moved_real))) cx.push_front(L.rim_real[next], cx.back(wk.moved));
     }
+    CD_UNROLL
     for (int j = 0; j < 4; ++j)
       if (!cx.empty(L.rim_real[j])) L.far[j] = cx.front(L.rim_real[j]);
   }
+  return true;
+}
+
+template <class G>
+CD_NOINLINE CD_HD bool grow_layer_call(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+  return grow_layer_impl(cx, g, f, fs, allow, mark, margin, L);
+}
+template <class G, bool COOP>
+CD_INLINE CD_HD bool grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+  if constexpr (COOP) return grow_layer_impl(cx, g, f, fs, allow, mark, margin, L);
+  else return grow_layer_call(cx, g, f, fs, allow, mark, margin, L);
 }
 
 CD_HD double dabs(double v) { return v < 0 ? -v : v; }
@@ -481,6 +669,7 @@ CD_HD double span_area(const int l[4]) {
 // side. A side without layer cells has no front in the reference (it reads an empty deque there); the last known
 // front (border_limit_tmp) stands in for it.
 CD_HD void layer_extent(const Ctx& cx, int f, const Layer& L, int ext[4]) {
+  CD_UNROLL
   for (int j = 0; j < 4; ++j) ext[j] = dot(cx.empty(L.rim_real[j]) ? L.far[j] : cx.front(L.rim_real[j]), cx.wk->fr[f].side[j]);
 }
 
@@ -508,26 +697,28 @@ CD_HD bool side_is_empty(const Ctx& cx, const G& g, const CellDeque& cells, Cell
 }
 
 // FindCorners, CD:378-564: a trial layer on face f from the given state; which square edges would become chamfers.
-template <class G>
-CD_NOINLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool growing[6], const FaceState* faces, const Edge* edges, int mark,
-                        bool& valid, Edge out[4]) {
-  if (!growing[f]) {
+template <class G, bool COOP>
+CD_INLINE CD_HD void find_corners_impl(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark,
+                                       bool& valid, Edge out[4]) {
+  if (!growing_f) {
     valid = false;
     return;
   }
   Work& wk = *cx.wk;
   int allow[4];
-  allowance(wk.fr, f, faces[f], edges, allow, out);
+  allowance(wk.fr, f, face, edges, allow, out);
   const double area = span_area(allow);
   Layer& L = wk.L2;
-  grow_layer(cx, g, f, faces[f], allow, mark, 0, L);
-  if (!L.found) return;
+  // (whether a seed was found is the function's value, not L.found: in the cooperative mode a lane must not depend on when
+  // another lane starts the next layer)
+  if (!grow_layer<G, COOP>(cx, g, f, face, allow, mark, 0, L)) return;
   int ext[4];
   layer_extent(cx, f, L, ext);
   if (span_area(ext) < area / 2) valid = false;
+  CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     if (cx.empty(L.rim_real[j])) continue;
-    const int gap = faces[f].reach[j] - dot(cx.front(L.rim_real[j]), wk.fr[f].side[j]);
+    const int gap = face.reach[j] - dot(cx.front(L.rim_real[j]), wk.fr[f].side[j]);
     if (out[j].slope == 0 && gap > 0) {
       out[j].slope = out[j].steps = gap;
       if (gap > 1) out[j].dir = f;
@@ -535,12 +726,24 @@ CD_NOINLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, const bool
   }
 }
 
+template <class G>
+CD_NOINLINE CD_HD void find_corners_call(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark,
+                                         bool& valid, Edge out[4]) {
+  find_corners_impl<G, false>(cx, g, f, growing_f, face, edges, mark, valid, out);
+}
+template <class G, bool COOP>
+CD_INLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark, bool& valid,
+                                  Edge out[4]) {
+  if constexpr (COOP) find_corners_impl<G, true>(cx, g, f, growing_f, face, edges, mark, valid, out);
+  else find_corners_call(cx, g, f, growing_f, face, edges, mark, valid, out);
+}
+
 // rows[max_rows][4] = (n, n . p); returns CD_OK, CD_CAPACITY (n_rows = needed count) or CD_WORK_OVERFLOW (a fixed-capacity
 // container of `wk` was too small for this grid: the caller falls back to a bigger workspace / reports it)
-template <class G>
+template <class G, bool COOP = false>
 CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, double res, int mark, const double origin[3], double* rows,
-                         int max_rows, int* n_rows, bool coop = false, int lane = 0) {
-  Ctx cx{&wk, coop, lane, seed};
+                         int max_rows, int* n_rows, int lane = 0) {
+  Ctx cx{&wk, COOP, lane, seed};
   // mark / unmark every cell of a list
   auto mark_cells = [&](const CellList& l, int how) {  // 0 set, 1 trial_set, 2 trial_unset
 #if CD_HAS_COOP
@@ -568,22 +771,23 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
   const bool aware = variant != 0;
   FaceState* faces = wk.faces;
   Edge* edges = wk.edges;
-  Cell anchor[6];              // a voxel of the outermost layer (gives the face plane)
-  bool growing[6];
+  Cell* anchor = wk.anchor;
+  unsigned growing = 0x3fu;     // faces that still grow, one bit each (indexed by the turn's face: no local array)
   for (int e = 0; e < 12; ++e) edges[e] = fresh_edge();
   for (int f = 0; f < 6; ++f) {
-    faces[f].outer.n = 0;
-    cx.push(faces[f].outer, seed);
+    faces[f].outer.n = 1;  // (stores of values, no read-modify-write: in the cooperative mode every lane executes them)
+    faces[f].outer.c[0] = cx.pack(seed);
     anchor[f] = seed;
-    growing[f] = true;
+    CD_UNROLL
     for (int j = 0; j < 4; ++j) faces[f].reach[j] = dot(seed, fr[f].side[j]);
   }
   g.set(seed, mark);
 
+  CD_PROF_BEGIN();
   for (int it = 0; it < n_it; ++it) {
     if (wk.overflow) return CD_WORK_OVERFLOW;
     const int f = it % 6;
-    if (!growing[f]) continue;
+    if (!((growing >> f) & 1u)) continue;
     const Cell up = normal_of(f);
     const Cell* sd = fr[f].side;
 
@@ -591,9 +795,11 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     Edge trial[4];
     allowance(fr, f, faces[f], edges, allow, trial);
     Layer& L = wk.L;
-    grow_layer(cx, g, f, faces[f], allow, mark, aware ? 0 : 1, L);
+    CD_PROF(4);
+    const bool layer_found = grow_layer<G, COOP>(cx, g, f, faces[f], allow, mark, aware ? 0 : 1, L);
     if (wk.overflow) return CD_WORK_OVERFLOW;
-    if (!L.found) continue;
+    CD_PROF(11);  // (the layer itself: phases 0..3 lie inside)
+    if (!layer_found) continue;
 
     bool soft = true;  // shape-aware variant: layer acceptable this turn
     if (aware) {
@@ -605,6 +811,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     // is the layer consistent with ONE plane through every edge? (CD:209-283 / CD:828-910)
     bool accept = true;
     int fresh[4] = {0, 0, 0, 0};  // corner_new_state: 1 = a one-voxel chamfer starts on this side, 2 = a longer one
+    CD_UNROLL
     for (int j = 0; j < 4 && accept; ++j) {
       if (cx.empty(L.rim_real[j])) continue;
       Edge e = trial[j];
@@ -650,75 +857,91 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       }
       if (accept) trial[j] = e;
     }
+    CD_PROF(5);
     if (!accept) {
-      growing[f] = false;
+      growing &= ~(1u << f);
       continue;
     }
     if (!soft) continue;
 
     if (aware) {  // CD:930-1066: does every chamfer that starts with this layer follow a real obstacle?
       bool expand = true;
+      CD_UNROLL
       for (int j = 0; j < 4; ++j) {
         if (!fresh[j]) continue;
         const bool first = side_is_empty(cx, g, L.rim_real[j], up);
         const int nbf = fr[f].face[j], ci = fr[f].back[j];
         bool second = true;
         if (fresh[j] == 1) {
-          cx.clear(wk.edge_row);  // the neighbouring face's cells along the shared edge
+          int e_end = RIM0;  // the neighbouring face's cells along the shared edge
           for (int q = 0; q < faces[nbf].outer.n; ++q) {
             const Cell c = cx.at(faces[nbf].outer, q);
-            if (dot(c, fr[nbf].side[ci]) == faces[nbf].reach[ci]) cx.push_back(wk.edge_row, c);
+            if (dot(c, fr[nbf].side[ci]) == faces[nbf].reach[ci]) {
+              if (e_end < RIM) wk.edge_row.c[e_end++] = cx.pack(c);
+              else wk.overflow = 1;
+            }
           }
+          wk.edge_row.b = RIM0, wk.edge_row.e = e_end;
+          CD_SYNC();
           second = side_is_empty(cx, g, wk.edge_row, normal_of(nbf));
         }
         expand = !(first && second);
         if (!expand) {
-          growing[f] = false;
+          growing &= ~(1u << f);
           break;
         }
       }
+      CD_PROF(6);
       if (expand && (fresh[0] || fresh[1] || fresh[2] || fresh[3])) {
         // trial: put the layer in, grow one more on top of it, take it out again (its cells were free voxels)
         mark_cells(L.cells, 1);
-        FaceState* faces_t = wk.faces_t;
-        for (int k = 0; k < 6; ++k) {
-          cx.copy(faces_t[k].outer, k == f ? L.cells : faces[k].outer);
-          for (int j = 0; j < 4; ++j) faces_t[k].reach[j] = (k == f) ? dot(L.far[j], sd[j]) : faces[k].reach[j];
-        }
+        FaceState& face_t = wk.face_t;  // (the other faces are what they are: the trial reads only the face it grows)
+        cx.copy(face_t.outer, L.cells);
+        CD_UNROLL
+        for (int j = 0; j < 4; ++j) face_t.reach[j] = dot(L.far[j], sd[j]);
         Edge* edges_t = wk.edges_t;
         for (int k = 0; k < 12; ++k) edges_t[k] = edges[k];
+        CD_UNROLL
         for (int j = 0; j < 4; ++j)
           if (!fresh[j]) edges_t[fr[f].edge[j]] = trial[j];
         bool valid = true;
         Edge fin[4];
-        find_corners(cx, g, f, growing, faces_t, edges_t, mark, valid, fin);
+        find_corners<G, COOP>(cx, g, f, ((growing >> f) & 1u) != 0, face_t, edges_t, mark, valid, fin);
         mark_cells(L.cells, 2);
         if (valid) {
+          CD_UNROLL
           for (int j = 0; j < 4; ++j)
             if (fresh[j] == 2 && fin[j].slope < trial[j].slope) {
               expand = false;
-              growing[f] = false;
+              growing &= ~(1u << f);
               break;
             }
           if (expand)
+            CD_UNROLL
             for (int j = 0; j < 4; ++j) {
               if (fresh[j] != 1) continue;
               const int nbf = fr[f].face[j];
               bool v2 = true;
               Edge fin2[4];
-              find_corners(cx, g, nbf, growing, faces_t, edges, mark, v2, fin2);
-              if (v2 && fin2[fr[f].back[j]].slope == 0 && fin[j].slope == 0) {
+              find_corners<G, COOP>(cx, g, nbf, ((growing >> nbf) & 1u) != 0, faces[nbf], edges, mark, v2, fin2);
+              int nb_slope = 0;  // fin2[fr[f].back[j]].slope without a dynamically indexed local array
+              CD_UNROLL
+              for (int k = 0; k < 4; ++k)
+                if (k == fr[f].back[j]) nb_slope = fin2[k].slope;
+              if (v2 && nb_slope == 0 && fin[j].slope == 0) {
                 expand = false;
                 break;
               }
             }
         }
       }
+      CD_PROF(7);
       if (wk.overflow) return CD_WORK_OVERFLOW;
       if (!expand) continue;
     }
 
     cx.copy(faces[f].outer, L.cells);
+    CD_UNROLL
     for (int j = 0; j < 4; ++j) {
       faces[f].reach[j] = dot(L.far[j], sd[j]);
       edges[fr[f].edge[j]] = trial[j];
@@ -726,11 +949,14 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       if (trial[j].slope == 0 && !cx.empty(L.rim_real[j]) && faces[f].reach[j] == dot(cx.front(L.rim_real[j]), sd[j])) {
         const int nbf = fr[f].face[j];
         cx.append(faces[nbf].outer, L.rim_real[j]);
-        faces[nbf].reach[fr[f].back[j]] += 1;
+        const int reach_nb = faces[nbf].reach[fr[f].back[j]] + 1;
+        CD_SYNC();
+        faces[nbf].reach[fr[f].back[j]] = reach_nb;
       }
     }
     anchor[f] = cx.at(L.cells, 0);
     mark_cells(L.cells, 0);
+    CD_PROF(8);
   }
   if (wk.overflow) return CD_WORK_OVERFLOW;
 
@@ -765,6 +991,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     ++n;
   }
   *n_rows = n;
+  CD_PROF(9);
   return n <= max_rows ? CD_OK : CD_CAPACITY;
 }
 

@@ -15,6 +15,7 @@ using namespace hdsm_cd;
 // a caller-owned int8 grid, marks written in place (the contract of hdsm_poly_octa3d)
 struct ArrayGrid {
   [[maybe_unused]] static constexpr bool kAtomicMarks = false;
+  [[maybe_unused]] static constexpr bool kHasPlanes = false;
   int8_t* data;
   int dx, dy, dz;
   std::vector<int8_t> saved;  // values under a trial layer (CD:989-1000), restored in the order they were taken

@@ -13,6 +13,7 @@
 
 #include "../../include/hdsm_swarm.h"
 #include "corridor_core.h"
+#include "corridor_wave.h"
 
 namespace {
 
@@ -55,13 +56,7 @@ __global__ __launch_bounds__(64) void k_poly_octa3d(Batch b) {
     rc = HDSM_ERR_BAD_ARG;
   } else {
     int variant = b.variant[t];
-    if (variant < 0) {  // AC:1385-1395: a seed pinched between two occupied voxels along an axis takes the shape-aware variant
-      auto occ = [&](int dx, int dy, int dz) {
-        const Cell c{seed.x + dx, seed.y + dy, seed.z + dz};
-        return g.inside(c) && g.value(c) == kOccupied;
-      };
-      variant = ((occ(-1, 0, 0) && occ(1, 0, 0)) || (occ(0, -1, 0) && occ(0, 1, 0)) || (occ(0, 0, -1) && occ(0, 0, 1))) ? 1 : 0;
-    }
+    if (variant < 0) variant = seed_is_pinched(g, seed) ? 1 : 0;  // AC:1385-1395
     const double org[3] = {b.origin[3 * t], b.origin[3 * t + 1], b.origin[3 * t + 2]};
     const int r = decompose_core(g, wk, variant, seed, b.n_it, b.res, -1, org, b.rows + (size_t)t * b.max_rows * 4, b.max_rows, &n);
     rc = (r == CD_OK) ? HDSM_OK : HDSM_ERR_CAPACITY;
@@ -71,48 +66,26 @@ __global__ __launch_bounds__(64) void k_poly_octa3d(Batch b) {
   if (b.cells) b.cells[t] = (rc == HDSM_ERR_BAD_ARG) ? 0 : g.count();
 }
 
-// The same batch with ONE WAVEFRONT per seed: workspace, overlay and a 2-bit classification of the world under the overlay in
-// LDS, the decomposition run cooperatively by the 64 lanes (corridor_core.h, Ctx::coop) — the form the device-resident swarm
-// loop uses inside its corridor kernel, where one agent's decompositions are a latency chain. Lower latency per seed, fewer
-// seeds in flight; same rows, bit for bit (tests/test_gpu_configs.py).
-constexpr size_t WORK_BYTES = ((sizeof(Work) + 15) / 16) * 16;
-constexpr size_t SLAB_LDS = WORK_BYTES + WindowGrid::WORDS * 4 + WindowGrid::OCC2_WORDS * 4;
-static_assert(SLAB_LDS + 1024 <= 64 * 1024, "k_poly_octa3d_wave: LDS exceeds the default 64 KB limit of a launch");
+// The same batch with ONE WAVEFRONT per seed: workspace, overlay and bit maps of the world under the overlay in LDS, the
+// decomposition run cooperatively by the 64 lanes (corridor_wave.h, corridor_core.h Ctx::coop) — the form the device-resident
+// swarm loop uses inside its corridor kernel, where one agent's decompositions are a latency chain. Lower latency per seed,
+// fewer seeds in flight; same rows, bit for bit (tests/test_gpu_configs.py).
+static_assert(WAVE_LDS_BYTES + 1024 <= 64 * 1024, "k_poly_octa3d_wave: LDS exceeds the default 64 KB limit of a launch");
 
 __global__ __launch_bounds__(64) void k_poly_octa3d_wave(Batch b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int t = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (t >= b.n) return;
-  Work& wk = *reinterpret_cast<Work*>(lds);
-  uint32_t* bits = reinterpret_cast<uint32_t*>(lds + WORK_BYTES);
-  uint32_t* occ2 = bits + WindowGrid::WORDS;
-  for (int w = lane; w < WindowGrid::WORDS; w += 64) bits[w] = 0u;
+  const WaveLds m(lds);
   const Cell seed{b.seed[3 * t], b.seed[3 * t + 1], b.seed[3 * t + 2]};
   WindowGrid g{b.world, b.wdim[0], b.wdim[1], b.wdim[2], b.off[3 * t], b.off[3 * t + 1], b.off[3 * t + 2],
-               b.ldim[0], b.ldim[1], b.ldim[2], b.ground[t], -1, seed, bits, occ2};
-  for (int w = lane; w < WindowGrid::OCC2_WORDS; w += 64) {  // the world under the overlay, 16 voxels along x per word
-    const int b0 = w * 16;
-    const int dx0 = b0 & (WindowGrid::OVW - 1), dy = (b0 / WindowGrid::OVW) & (WindowGrid::OVW - 1), dz = b0 / (WindowGrid::OVW * WindowGrid::OVW);
-    uint32_t word = 0;
-    for (int u = 0; u < 16; ++u)
-      word |= WindowGrid::occ2_class(g.world_value(Cell{seed.x + dx0 + u - WindowGrid::OV, seed.y + dy - WindowGrid::OV, seed.z + dz - WindowGrid::OV})) << (2 * u);
-    occ2[w] = word;
-  }
-  __syncthreads();
+               b.ldim[0], b.ldim[1], b.ldim[2], b.ground[t], -1, seed, m.bits};
   int rc = HDSM_OK, n = 0;
   if (!g.inside(seed)) {
     rc = HDSM_ERR_BAD_ARG;
   } else {
-    int variant = b.variant[t];
-    if (variant < 0) {
-      auto occ = [&](int dx, int dy, int dz) {
-        const Cell c{seed.x + dx, seed.y + dy, seed.z + dz};
-        return g.inside(c) && g.value(c) == kOccupied;
-      };
-      variant = ((occ(-1, 0, 0) && occ(1, 0, 0)) || (occ(0, -1, 0) && occ(0, 1, 0)) || (occ(0, 0, -1) && occ(0, 0, 1))) ? 1 : 0;
-    }
     const double org[3] = {b.origin[3 * t], b.origin[3 * t + 1], b.origin[3 * t + 2]};
-    const int r = decompose_core(g, wk, variant, seed, b.n_it, b.res, -1, org, b.rows + (size_t)t * b.max_rows * 4, b.max_rows, &n, true, lane);
+    const int r = wave_decompose(g, m, b.variant[t], b.n_it, b.res, org, b.rows + (size_t)t * b.max_rows * 4, b.max_rows, &n, lane);
     rc = (r == CD_OK) ? HDSM_OK : HDSM_ERR_CAPACITY;
   }
   __syncthreads();
@@ -134,6 +107,17 @@ extern "C" {
 
 const char* hdsm_corridor_last_error(void) { return g_err.c_str(); }
 
+#ifdef CD_PROFILE
+// development builds only: the phase counters of the cooperative decompositions launched from THIS file (read and cleared)
+int hdsm_corridor_profile(unsigned long long out[16]) {
+  if (hipDeviceSynchronize() != hipSuccess) return HDSM_ERR_DEVICE;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hdsm_cd::g_cd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return HDSM_ERR_DEVICE;
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(hdsm_cd::g_cd_prof), zero, sizeof zero) != hipSuccess) return HDSM_ERR_DEVICE;
+  return HDSM_OK;
+}
+#endif
+
 size_t hdsm_poly_octa3d_scratch_bytes(int32_t n) { return (size_t)(n > 0 ? n : 0) * SLAB; }
 
 static int launch_batch(bool wave, int32_t device, int32_t n, const int8_t* world, const int32_t wdim[3], const int32_t ldim[3],
@@ -151,7 +135,7 @@ static int launch_batch(bool wave, int32_t device, int32_t n, const int8_t* worl
   b.n = n, b.n_it = n_it, b.max_rows = max_rows, b.res = res;
   b.off = off, b.ground = ground_k, b.seed = seed, b.variant = variant, b.origin = origin;
   b.rows = rows, b.n_rows = n_rows, b.rc = rc, b.cells = cells, b.scratch = static_cast<unsigned char*>(scratch);
-  if (wave) hipLaunchKernelGGL(k_poly_octa3d_wave, dim3(n), dim3(64), SLAB_LDS, static_cast<hipStream_t>(hip_stream), b);
+  if (wave) hipLaunchKernelGGL(k_poly_octa3d_wave, dim3(n), dim3(64), WAVE_LDS_BYTES, static_cast<hipStream_t>(hip_stream), b);
   else hipLaunchKernelGGL(k_poly_octa3d, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(HDSM_ERR_DEVICE, std::string("k_poly_octa3d: ") + hipGetErrorString(e));

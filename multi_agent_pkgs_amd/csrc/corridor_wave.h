@@ -1,0 +1,93 @@
+// corridor_wave.h — the cooperative (one wavefront per seed) form of the voxel decomposition: what a wavefront does around
+// hdsm_cd::decompose_core. Device code, shared by k_poly_octa3d_wave (corridor_kernels.hip), k_corridor of the device-resident
+// loop (swarm_kernels.hip) and the CPU execution of the device source in the test-suite (tests/wave_emu).
+#pragma once
+#include "corridor_core.h"
+
+namespace hdsm_cd {
+
+// AC:1385-1395: a seed pinched between two occupied voxels along an axis takes the shape-aware variant (VoxelGrid::IsOccupied:
+// == 100, outside the grid: not occupied). Nothing is marked yet, so this is the world under the overlay.
+CD_HD bool seed_is_pinched(const WindowGrid& g, Cell s) {
+  auto occ = [&](int dx, int dy, int dz) {
+    const Cell c{s.x + dx, s.y + dy, s.z + dz};
+    return g.inside(c) && g.world_value(c) == kOccupied;
+  };
+  return (occ(-1, 0, 0) && occ(1, 0, 0)) || (occ(0, -1, 0) && occ(0, 1, 0)) || (occ(0, 0, -1) && occ(0, 0, 1));
+}
+
+#if defined(__HIPCC__) || defined(CD_EMU_COOP)
+// LDS of one cooperative decomposition: the workspace, the overlay in its two orientations, the world maps
+constexpr size_t WAVE_WORK_BYTES = ((sizeof(Work) + 15) / 16) * 16;
+constexpr int WAVE_ROWS = 32;  // room for the rows of one polyhedron (the swarm loop's corridor kernel collects them here)
+constexpr size_t WAVE_LDS_BYTES = WAVE_WORK_BYTES + (2 * WindowGrid::WORDS + WindowGrid::MAP_WORDS) * 4 + WAVE_ROWS * 4 * 8;
+struct WaveLds {
+  Work* wk;
+  double* rows;
+  uint32_t *bits, *bits_t, *maps;
+  __device__ explicit WaveLds(unsigned char* lds)
+      : wk(reinterpret_cast<Work*>(lds)), rows(reinterpret_cast<double*>(lds + WAVE_WORK_BYTES)),
+        bits(reinterpret_cast<uint32_t*>(lds + WAVE_WORK_BYTES + WAVE_ROWS * 4 * 8)), bits_t(bits + WindowGrid::WORDS), maps(bits_t + WindowGrid::WORDS) {}
+};
+
+// how far from the seed a decomposition of n_it turns looks: n_it / 6 layers per face (rounded up), the layer on top of the last
+// one, and SideIsEmpty one voxel beyond that; 0 = more than the overlay holds (no maps: the plain cooperative form runs)
+__device__ inline int wave_map_radius(int n_it) {
+  const int r = (n_it + 5) / 6 + 2;
+  return r <= WindowGrid::OV - 1 ? r : 0;
+}
+
+// Clears the overlay and classifies the world under it (WindowGrid::maps) for the offsets |d| <= r from the seed. Lanes 0..31
+// and 32..63 take two z-levels at once, a lane = one x: the byte loads of a row are contiguous, the x-fast words are the two
+// halves of a ballot, the y-fast words accumulate in the lane while it walks along y.
+__device__ inline void build_world_maps(const WindowGrid& g, const WaveLds& m, int r, int lane) {
+  constexpr int OV = WindowGrid::OV, OVW = WindowGrid::OVW, WORDS = WindowGrid::WORDS;
+  for (int w = lane; w < 2 * WORDS; w += 64) m.bits[w] = 0u;  // bits and bits_t are contiguous
+  if (r <= 0) return;
+  const int lx = lane & 31, half = lane >> 5;
+  const int cx = g.seed.x + lx - OV;
+  const bool x_in = lx >= OV - r && lx <= OV + r;
+  for (int dz0 = OV - r; dz0 <= OV + r; dz0 += 2) {
+    const int dz = dz0 + half;
+    const int cz = g.seed.z + dz - OV;
+    uint32_t fy = 0;
+    for (int dy = OV - r; dy <= OV + r; ++dy) {
+      const Cell c{cx, g.seed.y + dy - OV, cz};
+      bool fr = false, ps = true;
+      if (x_in && dz <= OV + r && g.inside(c)) {
+        const int v = g.world_value(c);
+        fr = v < kOccupied, ps = v > 0;
+      }
+      const unsigned long long bf = __ballot(fr), bp = __ballot(ps);
+      if (lx == 0 && dz <= OV + r) {
+        m.maps[dy + OVW * dz] = (uint32_t)(bf >> (32 * half));
+        m.maps[WORDS + dy + OVW * dz] = (uint32_t)(bp >> (32 * half));
+      }
+      fy |= (fr ? 1u : 0u) << dy;
+    }
+    if (dz <= OV + r) m.maps[2 * WORDS + lx + OVW * dz] = fy;
+  }
+}
+
+// One decomposition by the whole wavefront: `g` = the window without overlay / maps (filled in here), variant -1 = decide like
+// AC:1385-1395. Every lane returns the same code and the same rows.
+__device__ inline int wave_decompose(WindowGrid g, const WaveLds& m, int variant, int n_it, double res, const double origin[3], double* rows,
+                                     int max_rows, int* n_rows, int lane) {
+  const int r = wave_map_radius(n_it);
+  g.bits = m.bits;
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
+  build_world_maps(g, m, r, lane);
+  __syncthreads();
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+  if (lane == 0) atomicAdd(&g_cd_prof[10], __builtin_readcyclecounter() - t0), atomicAdd(&g_cd_prof[15], 1ull);
+#endif
+  if (r > 0) g.maps = m.maps, g.bits_t = m.bits_t, g.map_r = r;
+  if (variant < 0) variant = seed_is_pinched(g, g.seed) ? 1 : 0;
+  return decompose_core<WindowGrid, true>(g, *m.wk, variant, g.seed, n_it, res, g.mark, origin, rows, max_rows, n_rows, lane);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace hdsm_cd

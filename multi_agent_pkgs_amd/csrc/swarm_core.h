@@ -16,6 +16,7 @@
 
 #include "../../include/hdsm_swarm.h"
 #include "corridor_core.h"
+#include "corridor_wave.h"
 #include "hdsm_types.h"
 
 #if defined(__clang__)
@@ -171,7 +172,7 @@ CD_HD void free_space_poly(const Cfg& c, const V3& grid_origin, const int seed[3
 // (AC:1385-1397), every other seed the original one. `bits` = WindowGrid::WORDS words of scratch.
 
 // the agent's local grid as a window of the world, overlay centred on `seed`
-CD_HD WindowGrid make_window(const Cfg& c, const V3& grid_origin, const int seed[3], uint32_t* bits, const uint32_t* occ2) {
+CD_HD WindowGrid make_window(const Cfg& c, const V3& grid_origin, const int seed[3], uint32_t* bits) {
   const double vs = c.voxel_size;
   int dim[3], off[3];
   for (int ax = 0; ax < 3; ++ax) {
@@ -179,7 +180,7 @@ CD_HD WindowGrid make_window(const Cfg& c, const V3& grid_origin, const int seed
     off[ax] = (int)lround((grid_origin[ax] - c.worigin[ax]) / vs);  // local voxel 0 in world voxels
   }
   return WindowGrid{c.world, c.wdim[0], c.wdim[1], c.wdim[2], off[0], off[1], off[2], dim[0], dim[1], dim[2],
-                    (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9), -1, Cell{seed[0], seed[1], seed[2]}, bits, occ2};
+                    (int)ceil((c.grid_z_min - grid_origin[2]) / vs - 1e-9), -1, Cell{seed[0], seed[1], seed[2]}, bits};
 }
 CD_HD bool seed_in_grid(const Cfg& c, const int seed[3]) {
   for (int ax = 0; ax < 3; ++ax)
@@ -187,32 +188,8 @@ CD_HD bool seed_in_grid(const Cfg& c, const int seed[3]) {
   return true;
 }
 
-// `occ2`: optional cache of the world under the overlay (WindowGrid::occ2), already built for this seed
-// `coop`, `lane`: device only, the whole wavefront calls with the same arguments (corridor_core.h, cooperative mode)
-CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Work* wk, uint32_t* bits, Poly* out,
-                     const uint32_t* occ2 = nullptr, bool coop = false, int lane = 0) {
-  const double vs = c.voxel_size;
-  out->rows = 0;
-  if (!seed_in_grid(c, seed)) return HDSM_ERR_BAD_ARG;
-  if (coop) {
-    for (int w = lane; w < WindowGrid::WORDS; w += 64) bits[w] = 0u;
-    CD_SYNC();
-  } else {
-    for (int w = 0; w < WindowGrid::WORDS; ++w) bits[w] = 0u;
-  }
-  const Cell sc{seed[0], seed[1], seed[2]};
-  WindowGrid g = make_window(c, grid_origin, seed, bits, occ2);
-  auto occupied = [&](int dx, int dy, int dz) {  // VoxelGrid::IsOccupied: == 100, outside the grid: not occupied
-    const Cell q{sc.x + dx, sc.y + dy, sc.z + dz};
-    return g.inside(q) && g.value(q) == hdsm_cd::kOccupied;
-  };
-  const bool pinched = (occupied(-1, 0, 0) && occupied(1, 0, 0)) || (occupied(0, -1, 0) && occupied(0, 1, 0)) ||
-                       (occupied(0, 0, -1) && occupied(0, 0, 1));
-  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
-  double rows[HDSM_MAX_ROWS_STATIC * 4];
-  int n = 0;
-  const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
-  const int rc = hdsm_cd::decompose_core(g, *wk, (pinched || c.use_cvx_new) ? 1 : 0, sc, c.n_it_decomp, vs, -1, org, rows, cap, &n, coop, lane);
+// the rows of one decomposition into a polyhedron of the corridor
+CD_HD int poly_from_rows(int rc, const double* rows, int n, Poly* out) {
   if (rc != hdsm_cd::CD_OK) return HDSM_ERR_CAPACITY;
   out->rows = n;
   for (int r = 0; r < n; ++r) {
@@ -221,6 +198,48 @@ CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Wor
   }
   return HDSM_OK;
 }
+
+CD_HD int world_poly(const Cfg& c, const V3& grid_origin, const int seed[3], Work* wk, uint32_t* bits, Poly* out) {
+  out->rows = 0;
+  if (!seed_in_grid(c, seed)) return HDSM_ERR_BAD_ARG;
+  for (int w = 0; w < WindowGrid::WORDS; ++w) bits[w] = 0u;
+  const Cell sc{seed[0], seed[1], seed[2]};
+  WindowGrid g = make_window(c, grid_origin, seed, bits);
+  const bool pinched = hdsm_cd::seed_is_pinched(g, sc);  // AC:1385-1395
+  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
+  double rows[HDSM_MAX_ROWS_STATIC * 4];
+  int n = 0;
+  const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
+  const int rc = hdsm_cd::decompose_core(g, *wk, (pinched || c.use_cvx_new) ? 1 : 0, sc, c.n_it_decomp, c.voxel_size, -1, org, rows, cap, &n);
+  return poly_from_rows(rc, rows, n, out);
+}
+#if defined(__HIPCC__) || defined(CD_EMU_COOP)
+// the same by the whole wavefront (corridor_wave.h): same arguments and the same result in every lane
+__device__ inline int world_poly_wave(const Cfg& c, const V3& grid_origin, const int seed[3], const hdsm_cd::WaveLds& lds, Poly* out, int lane) {
+  if (!seed_in_grid(c, seed)) {
+    out->rows = 0;
+    return HDSM_ERR_BAD_ARG;
+  }
+  const WindowGrid g = make_window(c, grid_origin, seed, nullptr);
+  const double org[3] = {grid_origin[0], grid_origin[1], grid_origin[2]};
+  static_assert(HDSM_MAX_ROWS_STATIC <= hdsm_cd::WAVE_ROWS, "rows of a polyhedron: room in LDS");
+  int n = 0;
+  const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
+  const int rc = hdsm_cd::wave_decompose(g, lds, c.use_cvx_new ? 1 : -1, c.n_it_decomp, c.voxel_size, org, lds.rows, cap, &n, lane);
+  __syncthreads();
+  if (rc != hdsm_cd::CD_OK) {
+    out->rows = 0;
+    return HDSM_ERR_CAPACITY;
+  }
+  if (lane == 0) out->rows = n;  // (every lane holds the same rows: the copy into the agent's state is shared out)
+  for (int t = lane; t < 4 * n; t += 64) {
+    const int r = t >> 2, k = t & 3;
+    if (k < 3) out->A[r][k] = lds.rows[t];
+    else out->b[r] = lds.rows[t];
+  }
+  return HDSM_OK;
+}
+#endif
 
 // GenerateSafeCorridor, AC:1236-1447. `wk`, `bits`: scratch of the voxel decomposition (unused in free space).
 CD_HD void corridor_step(const Cfg& c, AgentS& ag, Work* wk, uint32_t* bits) {

@@ -51,8 +51,7 @@ constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline ha
 // scratch of one agent's voxel decompositions, in LDS (dynamic shared memory of k_corridor): the workspace, the overlay bits and
 // the 2-bit cache of the world under the overlay. The decomposition is one lane's chain of small dependent accesses — in global
 // memory every one of them was a round trip (33 ms per round for 256 agents in the pillar forest).
-constexpr size_t WORK_BYTES = ((sizeof(hdsm_cd::Work) + 15) / 16) * 16;
-constexpr size_t SLAB = WORK_BYTES + hdsm_cd::WindowGrid::WORDS * 4 + hdsm_cd::WindowGrid::OCC2_WORDS * 4;
+constexpr size_t SLAB = hdsm_cd::WAVE_LDS_BYTES;
 // k_corridor also has static __shared__ state (the walk's rows and flags, < 4 KB); together they must stay inside the 64 KB a
 // kernel may use without hipFuncAttributeMaxDynamicSharedMemorySize — a growth of Work / the overlay fails HERE, not at launch
 static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed the default 64 KB limit");
@@ -61,24 +60,9 @@ static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed
 // them per round) tests every sample against every row of the kept polyhedra; with one thread per agent each test was a chain of
 // global loads (1.3 ms per round for 1024 agents). Here the rows live in the registers of the 64 lanes (two rows per lane,
 // P * RS <= 128), a sample is tested against all of them at once and `inside` is a ballot; the walk state is computed redundantly
-// by every lane (wave-uniform), so the arithmetic — and the result — is exactly that of hdsm_sw::corridor_step. New polyhedra
-// (closed form in free space, voxel decomposition on a window of the world grid) are produced by lane 0 with the shared code.
-// the world under the overlay of `seed`, classified (WindowGrid::occ2): one word = 16 voxels along x, a word per lane and trip
-__device__ void build_occ2(const Cfg& c, const V3& origin, const int seed[3], uint32_t* occ2, int lane) {
-  using hdsm_cd::WindowGrid;
-  const WindowGrid g = hdsm_sw::make_window(c, origin, seed, nullptr, nullptr);
-  for (int w = lane; w < WindowGrid::OCC2_WORDS; w += 64) {
-    const int b0 = w * 16;
-    const int dx0 = b0 & (WindowGrid::OVW - 1), dy = (b0 / WindowGrid::OVW) & (WindowGrid::OVW - 1), dz = b0 / (WindowGrid::OVW * WindowGrid::OVW);
-    uint32_t word = 0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const hdsm_cd::Cell cell{seed[0] + dx0 + u - WindowGrid::OV, seed[1] + dy - WindowGrid::OV, seed[2] + dz - WindowGrid::OV};
-      word |= WindowGrid::occ2_class(g.world_value(cell)) << (2 * u);
-    }
-    occ2[w] = word;
-  }
-}
+// by every lane (wave-uniform), so the arithmetic — and the result — is exactly that of hdsm_sw::corridor_step. New polyhedra:
+// the closed form in free space (lane 0), the voxel decomposition on a window of the world grid by the whole wavefront
+// (corridor_wave.h: the world under the overlay classified into bit maps in LDS, layers grown as bit planes).
 
 // min over the 64 lanes of a double, in every lane: four DPP row rotations + four v_readlane (six __shfl_xor stages are twelve
 // ds_bpermute round trips)
@@ -98,7 +82,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return fmin(fmin(lane_of(v, 0), lane_of(v, 16)), fmin(lane_of(v, 32), lane_of(v, 48)));
 }
 
-__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits, uint32_t* occ2, V3* path, int lane) {
+__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::WaveLds& lds, V3* path, int lane) {
   using namespace hdsm_sw;
   const int P = c.P, N = c.N, RS = c.RS;
   __shared__ int sh_npath;
@@ -235,13 +219,9 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, 
         break;
       }
     if (previous_seed) continue;
-    if (c.has_world && hdsm_sw::seed_in_grid(c, seed)) {  // all lanes: the world around the seed -> LDS
-      build_occ2(c, origin, seed, occ2, lane);
-      __syncthreads();
-    }
     int rc = HDSM_OK;
-    if (c.has_world) {  // the whole wavefront, cooperatively (corridor_core.h): same arguments, same result in every lane
-      rc = world_poly(c, origin, seed, wk, bits, &ag.polys[n_poly], occ2, true, lane);
+    if (c.has_world) {  // the whole wavefront, cooperatively: same arguments, same result in every lane
+      rc = world_poly_wave(c, origin, seed, lds, &ag.polys[n_poly], lane);
       if (rc != HDSM_OK) ag.corridor_rc = rc;
       else ag.polys[n_poly].seed = seed_world;
     } else if (lane == 0) {
@@ -268,17 +248,11 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, d
   if (k >= n) return;
   AgentS& ag = agents[k];
   extern __shared__ __attribute__((aligned(16))) unsigned char slab[];  // SLAB bytes when there is a world, else none
-  hdsm_cd::Work* wk = nullptr;
-  uint32_t *bits = nullptr, *occ2 = nullptr;
-  if (c.has_world) {
-    wk = reinterpret_cast<hdsm_cd::Work*>(slab);
-    bits = reinterpret_cast<uint32_t*>(slab + WORK_BYTES);
-    occ2 = bits + hdsm_cd::WindowGrid::WORDS;
-  }
+  const hdsm_cd::WaveLds lds(slab);
   if (c.P * c.RS <= 128) {
-    corridor_step_wave(c, ag, wk, bits, occ2, path_s, lane);
+    corridor_step_wave(c, ag, lds, path_s, lane);
   } else if (lane == 0) {
-    hdsm_sw::corridor_step(c, ag, wk, bits);  // more rows than two per lane: the plain per-agent code
+    hdsm_sw::corridor_step(c, ag, lds.wk, lds.bits);  // more rows than two per lane: the plain per-agent code
   }
   __syncthreads();
   if (lane == 0) np_s = hdsm_sw::reference_polyline(ag, poly_s);

@@ -72,3 +72,25 @@ def solve(prm, state, ref, n_poly, n_rows, A, b, threads=64):
         raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
     out["rc"] = rc
     return out
+
+
+def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32):
+    """The cooperative voxel decomposition (corridor_wave.h: one wavefront per seed) run on the CPU; arguments and results of
+    multi_agent_pkgs_amd.lib.poly_octa3d_batch(..., wave=True)."""
+    L = lib()
+    world = np.ascontiguousarray(world, dtype=np.int8)
+    wdim = np.asarray(world.shape[::-1], dtype=np.int32)
+    ldim = np.asarray(ldim, dtype=np.int32)
+    i32a = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    off, seed, ground_k, variant = i32a(off), i32a(seed), i32a(ground_k), i32a(variant)
+    origin = np.ascontiguousarray(origin, dtype=np.float64)
+    n = off.shape[0]
+    rows = np.zeros((n, max_rows, 4))
+    n_rows, rc, cells = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+    i32, d = C.c_int32, C.c_double
+    r = L.wave_poly_octa3d_batch(C.c_int32(n), world.ctypes.data_as(C.POINTER(C.c_int8)), _p(wdim, i32), _p(ldim, i32), _p(off, i32),
+                                 _p(ground_k, i32), _p(seed, i32), _p(variant, i32), _p(origin, d), C.c_int32(n_it), C.c_double(res),
+                                 _p(rows, d), C.c_int32(max_rows), _p(n_rows, i32), _p(rc, i32), _p(cells, i32))
+    if r:
+        raise RuntimeError("wave emulation: %s" % L.wave_last_error().decode())
+    return rows, n_rows, rc, cells

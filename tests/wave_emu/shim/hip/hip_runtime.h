@@ -175,6 +175,16 @@ inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v)
 #define __hip_atomic_store(ptr, val, order, scope) (*(volatile decltype(ptr))(ptr) = (val))
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __threadfence() ((void)0)
+inline unsigned atomicOr(unsigned* p, unsigned v) {
+  const unsigned old = *p;
+  *p = old | v;
+  return old;
+}
+inline unsigned atomicAnd(unsigned* p, unsigned v) {
+  const unsigned old = *p;
+  *p = old & v;
+  return old;
+}
 inline unsigned atomicAdd(unsigned* p, unsigned v) {
   const unsigned old = *p;
   *p = old + v;
