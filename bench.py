@@ -488,9 +488,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dl = float(t.item())
         _, _, _, failed_d = dsw.download(states=False)
+        prof = None
+        if os.environ.get("HDSM_LIBRARY"):  # a -DCD_PROFILE development build: where the corridor kernel's cycles go
+            import ctypes
+            L = lib.load()
+            if hasattr(L, "hdsm_swarm_corridor_profile"):
+                cnt = (ctypes.c_ulonglong * 16)()
+                L.hdsm_swarm_corridor_profile(cnt)
+                names = ["seed search", "plane rows", "move loop", "rim / far write-out", "allowance", "edge state machine", "shape-aware side tests",
+                         "trial layers", "accept (copy, append, mark)", "rows", "world maps", "layer (0..3 inside)", "corridor step", "decompositions in it"]
+                ar = max(1, int(cnt[14]))
+                prof = {"agent_rounds": int(cnt[14]), "decompositions": int(cnt[15]), "cycles_per_agent_round": {names[i]: int(cnt[i]) / ar for i in range(14)}}
         res = {"rounds": f"{rec_to + 2}..{rec_to + 1 + K}", "ms_per_round": dl / K * 1e3, "agent_replans_per_s": n_rob * K / dl,
                "instances_without_solution_this_rank": int(failed_d), "ranks": world,
                "what": "hdsm_dswarm_round live: corridor (f2) -> reference (f1) -> replan -> commit -> publish -> exchange, one stream"}
+        if prof:
+            res["corridor_profile"] = prof
         dsw.close()
         return res
 

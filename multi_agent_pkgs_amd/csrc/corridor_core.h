@@ -91,13 +91,15 @@ struct Frame {      // in-plane frame of a face and what lies across each of its
 
 // u = normal of the next lateral face and v = +z for the four lateral faces; (-y, +x) / (-y, -x) for top / bottom
 // (CD:33-41). Everything else follows from that.
+CD_HD Cell frame_side(int f, int j) {  // side j (+u, +v, -u, -v) of face f
+  Cell u, v;
+  if (f < 4) u = normal_of((f + 1) % 4), v = Cell{0, 0, 1};
+  else u = normal_of(0), v = (f == 4) ? normal_of(1) : normal_of(3);
+  return j == 0 ? u : (j == 1 ? v : (j == 2 ? neg(u) : neg(v)));
+}
 CD_HD void build_frames(Frame fr[6]) {
-  for (int f = 0; f < 6; ++f) {
-    Cell u, v;
-    if (f < 4) u = normal_of((f + 1) % 4), v = Cell{0, 0, 1};
-    else u = normal_of(0), v = (f == 4) ? normal_of(1) : normal_of(3);
-    fr[f].side[0] = u, fr[f].side[1] = v, fr[f].side[2] = neg(u), fr[f].side[3] = neg(v);
-  }
+  for (int f = 0; f < 6; ++f)
+    for (int j = 0; j < 4; ++j) fr[f].side[j] = frame_side(f, j);
   for (int f = 0; f < 6; ++f)
     CD_UNROLL
     for (int j = 0; j < 4; ++j) {
@@ -124,7 +126,7 @@ CD_HD Edge fresh_edge() { return Edge{{0.0, 0.0, 0.0}, 0, -1, 0, 0}; }
 
 // cells are stored as offsets from the seed (a polyhedron never reaches further than n_it / 6 + 1 layers from it)
 struct Packed {
-  int8_t x, y, z;
+  int8_t x, y, z, pad;  // (four bytes: one LDS access per cell)
 };
 
 struct CellList {   // std::vector<Vec3i> with a fixed capacity
@@ -146,6 +148,9 @@ struct Layer {
   CellList cells;       // border_real_tmp
   CellDeque rim_real[4];  // borders_2d_real
   Cell far[4];          // border_limit_tmp
+  // cooperative mode: the layer's cells as rows of a bit plane of the overlay, normal axis and level index of that plane
+  uint32_t plane[32];
+  int plane_axis, plane_level;
 };
 
 // everything one decomposition needs; ~30 KB, provided by the caller (heap on the host, global scratch or LDS on the device)
@@ -156,6 +161,11 @@ struct Work {
   CellDeque rim[4], moved, moved_real, edge_row;
   Edge edges[12], edges_t[12];
   Cell anchor[6];  // a voxel of each face's outermost layer (gives the face plane)
+#ifdef CD_PROFILE
+  unsigned long long prof[16];  // cycles per phase of this decomposition (lane 0), added to g_cd_prof at its end: probes that hit
+                                // global memory themselves made every wait for memory look expensive
+#endif
+  uint32_t seed_plane[32];  // cooperative mode: where a 2-D seed may lie, rows of a bit plane (one word per lane)
   Cell seed;
   int overflow;
 };
@@ -240,6 +250,15 @@ struct WindowGrid {
     atomicOr(&bits[dy + OVW * dz], 1u << dx);
     if (bits_t) atomicOr(&bits_t[dx + OVW * dz], 1u << dy);
   }
+  // one copy only: the x-fast one (bits) or the y-fast one (bits_t)
+  __device__ void mark_atomic(Cell c, bool on, bool x_fast) const {
+    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
+    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
+    uint32_t* w = x_fast ? &bits[dy + OVW * dz] : &bits_t[dx + OVW * dz];
+    const uint32_t b = 1u << (x_fast ? dx : dy);
+    if (on) atomicOr(w, b);
+    else atomicAnd(w, ~b);
+  }
   __device__ void unset_atomic(Cell c) const {
     const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
     if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
@@ -295,7 +314,7 @@ static __device__ unsigned long long g_cd_prof[16];
 #define CD_PROF(i)                                                  \
   do {                                                              \
     const unsigned long long cd_t1_ = __builtin_readcyclecounter(); \
-    if (cx.lane == 0) atomicAdd(&g_cd_prof[i], cd_t1_ - cd_t0_);     \
+    if (cx.lane == 0) cx.wk->prof[i] += cd_t1_ - cd_t0_;            \
     cd_t0_ = cd_t1_;                                                \
   } while (0)
 #else
@@ -311,7 +330,7 @@ struct Ctx {
   CD_HD Packed pack(Cell c) const {
     const int dx = c.x - seed.x, dy = c.y - seed.y, dz = c.z - seed.z;
     if (dx < -127 || dx > 127 || dy < -127 || dy > 127 || dz < -127 || dz > 127) wk->overflow = 1;
-    return Packed{(int8_t)dx, (int8_t)dy, (int8_t)dz};
+    return Packed{(int8_t)dx, (int8_t)dy, (int8_t)dz, 0};
   }
   CD_HD Cell unpack(Packed p) const { return Cell{seed.x + p.x, seed.y + p.y, seed.z + p.z}; }
   CD_HD void push(CellList& l, Cell c) const {
@@ -386,9 +405,9 @@ CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* ed
 }
 
 #if CD_HAS_COOP
-// The in-plane growth of a layer (the loop of grow_layer below) for the cooperative mode, WITHOUT the cell deques. What that loop
-// maintains is a rectangle: a side only ever moves as a whole line, its cells are the rectangle's edge in counter-clockwise
-// order ((+u: along +v, +v: along -u, -u: along -v, -v: along +u), and a line may move iff it stays inside the allowance and no
+// One layer on top of face F in the cooperative mode, WITHOUT the cell deques of grow_layer_serial below. What that function's
+// loop maintains is a rectangle: a side only ever moves as a whole line, its cells are the rectangle's edge in counter-clockwise
+// order (+u: along +v, +v: along -u, -u: along -v, -v: along +u), and a line may move iff it stays inside the allowance and no
 // cell of it lies on top of the polyhedron without being free — a failure is final, the line only gets longer. So: lane r < 32
 // holds row r of two bit planes of the overlay's 32 x 32 cross-section at the layer's level (REAL: on top of the polyhedron and
 // free; BLK: on top of it and not free — three LDS words per lane, from the x-fast or y-fast copies so that the plane's rows
@@ -396,48 +415,109 @@ CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* ed
 // masked to the rectangle; the layer's cells (the REAL cells of every line that moved, in the deque's order) are written by
 // the lanes that hold them, ranked by a popcount. At the end the four rim_real deques and `far` are written out as the serial
 // loop leaves them — every cell of rim_real[j] is a REAL cell of side j's final line and vice versa, far[j] is read only
-// through its coordinate along side j — so the caller goes on unchanged. ~100 cycles per move instead of ~2 k.
-template <class G>
-CD_INLINE __device__ inline void grow_layer_planes(const Ctx& cx, const G& g, int f, const int allow_in[4], Cell s2, Layer& L) {
+// through its coordinate along side j — so the caller goes on unchanged. The 2-D seed (the first cell of the face's outer list
+// whose neighbour above qualifies) is looked up in the same plane: free, inside the allowance, inside the grid's margin.
+// F = the face, a template parameter: normals, axes and signs of the four sides are constants of each instantiation (with a
+// run-time face every rim move dragged select chains over them along; one wavefront per CU issues an instruction every 4-5
+// cycles, so the instruction count IS the time).
+template <class G, int F>
+CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, const FaceState& fs, const int allow_in[4], int margin, Layer& L) {
   Work& wk = *cx.wk;
-  const int allow[4] = {allow_in[0], allow_in[1], allow_in[2], allow_in[3]};
+  constexpr int f = F;
   constexpr int OV = G::OV, OVW = G::OVW;
+  const int allow[4] = {allow_in[0], allow_in[1], allow_in[2], allow_in[3]};
   const int lane = cx.lane;
   const Cell up = normal_of(f);
-  const Cell* sd = wk.fr[f].side;
+  const Cell sd[4] = {frame_side(f, 0), frame_side(f, 1), frame_side(f, 2), frame_side(f, 3)};
   const int aw = up.x ? 0 : (up.y ? 1 : 2);          // axis of the face's normal
   const int ab = aw == 0 ? 1 : 0, ar = aw == 2 ? 1 : 2;  // axis along the bits of a row / across the rows
   auto comp = [](Cell c, int a) { return a == 0 ? c.x : (a == 1 ? c.y : c.z); };
   const int su = up.x + up.y + up.z;
   const int sb = comp(cx.seed, ab), sr = comp(cx.seed, ar), sw = comp(cx.seed, aw);
-  const int lw = comp(s2, aw) - sw + OV, lb = lw - su;  // the layer's level and the one below it, as overlay indices
-  int b0 = comp(s2, ab) - sb + OV, r0 = comp(s2, ar) - sr + OV, b1 = b0, r1 = r0;
-  const int lo_ok = OV - g.map_r, hi_ok = OV + g.map_r;
-  L.cells.n = 1;
-  L.cells.c[0] = cx.pack(s2);
-  if (lw < lo_ok || lw > hi_ok || lb < lo_ok || lb > hi_ok || b0 < lo_ok || b0 > hi_ok || r0 < lo_ok || r0 > hi_ok) {
-    wk.overflow = 1;  // (beyond what build_world_maps classified: n_it too large for the overlay)
-    return;
-  }
-  CD_PROF_BEGIN();
-  uint32_t real = 0, blk = 0;
-  if (lane < OVW) {
-    const uint32_t* mk = aw == 0 ? g.bits_t : g.bits;
-    const uint32_t* fr = aw == 0 ? g.maps + 2 * G::WORDS : g.maps;
-    const int wt = aw == 2 ? lane + OVW * lw : lw + OVW * lane, wb = aw == 2 ? lane + OVW * lb : lb + OVW * lane;
-    const uint32_t below = mk[wb], free_t = mk[wt] | fr[wt];  // (a voxel of the polyhedron counts as free: its value is the mark)
-    real = below & free_t, blk = below & ~free_t;
-  }
+  const int lo_ok = OV - g.map_r, hi_ok = OV + g.map_r;  // what build_world_maps classified
   bool bit_axis[4];
   int sg[4];
   CD_UNROLL
   for (int j = 0; j < 4; ++j) bit_axis[j] = comp(sd[j], ab) != 0, sg[j] = comp(sd[j], ab) + comp(sd[j], ar);
+  auto range_mask = [](int lo, int hi) { return lo > hi ? 0u : (uint32_t)(((1ull << (hi + 1)) - 1ull) & ~((1ull << lo) - 1ull)); };
+  const uint32_t* mk = aw == 0 ? g.bits_t : g.bits;
+  const uint32_t* fr = aw == 0 ? g.maps + 2 * G::WORDS : g.maps;
+  uint32_t real = 0, blk = 0, free_t = 0;
+  auto load_rows = [&](int lw) {  // the planes at level lw (and the level below it)
+    real = blk = free_t = 0;
+    if (lane < OVW) {
+      const int lb = lw - su;
+      const int wt = aw == 2 ? lane + OVW * lw : lw + OVW * lane, wb = aw == 2 ? lane + OVW * lb : lb + OVW * lane;
+      const uint32_t below = mk[wb];
+      free_t = mk[wt] | fr[wt];  // (a voxel of the polyhedron counts as free: its value is the mark)
+      real = below & free_t, blk = below & ~free_t;
+    }
+  };
+  CD_PROF_BEGIN();
+  // ---- the 2-D seed
+  const int n_outer = fs.outer.n;
+  const Cell c0 = add(cx.at(fs.outer, 0), up);
+  int lw = comp(c0, aw) - sw + OV;
+  bool plane_ok = lw - su >= lo_ok && lw - su <= hi_ok && lw >= lo_ok && lw <= hi_ok;
+  if (plane_ok) {
+    load_rows(lw);
+    // rows / bits a seed may lie in: voxels [1, dim - 1 - margin] (CD:94-116 / 700-723), the allowance, the classified box
+    int lim_lo[2] = {1, 1}, lim_hi[2] = {(ab == 0 ? g.nx() : g.ny()) - margin - 1, (ar == 1 ? g.ny() : g.nz()) - margin - 1};
+    CD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      const int a = bit_axis[j] ? 0 : 1;
+      if (sg[j] > 0) lim_hi[a] = lim_hi[a] < allow[j] ? lim_hi[a] : allow[j];
+      else lim_lo[a] = lim_lo[a] > -allow[j] ? lim_lo[a] : -allow[j];
+    }
+    const int xw = sw + lw - OV, nw = aw == 0 ? g.nx() : (aw == 1 ? g.ny() : g.nz());
+    const bool level_in = xw >= 1 && xw < nw - margin;
+    const int ib_lo = lim_lo[0] - sb + OV, ib_hi = lim_hi[0] - sb + OV, ir_lo = lim_lo[1] - sr + OV, ir_hi = lim_hi[1] - sr + OV;
+    const uint32_t bits_ok = range_mask(ib_lo > lo_ok ? ib_lo : lo_ok, ib_hi < hi_ok ? ib_hi : hi_ok);
+    const bool row_ok = level_in && lane >= ir_lo && lane <= ir_hi;
+    if (lane < OVW) wk.seed_plane[lane] = row_ok ? (free_t & bits_ok) : 0u;
+    CD_SYNC();
+  }
+  auto seed_ok = [&](Cell t) {  // the general form (grow_layer_serial's), for cells outside the plane that was loaded
+    if (t.x < 1 || t.y < 1 || t.z < 1 || t.x >= g.nx() - margin || t.y >= g.ny() - margin || t.z >= g.nz() - margin) return false;
+    if (g.value(t) >= kOccupied) return false;
+    bool in = true;
+    CD_UNROLL
+    for (int k = 0; k < 4; ++k) in = in && dot(t, sd[k]) <= allow[k];
+    return in;
+  };
+  bool found = false;
+  Cell s2{0, 0, 0};
+  for (int base = 0; base < n_outer && !found; base += 64) {
+    const int q = base + lane;
+    bool hit = false;
+    if (q < n_outer) {
+      const Cell t = add(cx.at(fs.outer, q), up);
+      const int iw = comp(t, aw) - sw + OV, ib = comp(t, ab) - sb + OV, ir = comp(t, ar) - sr + OV;
+      if (plane_ok && iw == lw && ib >= lo_ok && ib <= hi_ok && ir >= lo_ok && ir <= hi_ok) hit = (wk.seed_plane[ir] >> ib) & 1u;
+      else hit = seed_ok(t);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m) s2 = add(cx.at(fs.outer, base + __ffsll((long long)m) - 1), up), found = true;
+  }
+  CD_PROF(0);
+  if (!found) return false;
+  // ---- the growth
+  int b0 = comp(s2, ab) - sb + OV, r0 = comp(s2, ar) - sr + OV, b1 = b0, r1 = r0;
+  L.cells.c[0] = cx.pack(s2);
+  {
+    const int lw2 = comp(s2, aw) - sw + OV;
+    if (lw2 - su < lo_ok || lw2 - su > hi_ok || lw2 < lo_ok || lw2 > hi_ok || b0 < lo_ok || b0 > hi_ok || r0 < lo_ok || r0 > hi_ok) {
+      wk.overflow = 1;  // (beyond what build_world_maps classified)
+      L.cells.n = 1;
+      return true;
+    }
+    if (!plane_ok || lw2 != lw) lw = lw2, load_rows(lw);
+  }
   bool alive[4] = {true, true, true, true}, nonempty[4] = {true, true, true, true};
   int farc[4];
   CD_UNROLL
   for (int j = 0; j < 4; ++j) farc[j] = dot(s2, sd[j]);
   int n = 1;
-  auto range_mask = [](int lo, int hi) { return (uint32_t)(((1ull << (hi + 1)) - 1ull) & ~((1ull << lo) - 1ull)); };
   auto line_of = [&](bool along_bits, int at, uint32_t plane, int lo, int hi) {  // one line of a plane, indexed along the OTHER axis
     const uint32_t m = along_bits ? (uint32_t)__ballot(lane < OVW && ((plane >> at) & 1u)) : (uint32_t)__builtin_amdgcn_readlane((int)plane, at);
     return m & range_mask(lo, hi);
@@ -447,13 +527,13 @@ CD_INLINE __device__ inline void grow_layer_planes(const Ctx& cx, const G& g, in
       const int rank = ascending ? __builtin_popcount(m & ((1u << lane) - 1u)) : __builtin_popcountll((unsigned long long)m >> (lane + 1));
       int d[3];
       d[aw] = lw - OV, d[ab] = (along_bits ? at : lane) - OV, d[ar] = (along_bits ? lane : at) - OV;
-      if (rank < cap) dst[rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2]};
+      if (rank < cap) dst[rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2], 0};
       else wk.overflow = 1;
     }
   };
   CD_PROF(1);
   while (alive[0] || alive[1] || alive[2] || alive[3]) {
-CD_UNROLL
+    CD_UNROLL
     for (int s = 0; s < 4; ++s) {
       if (!alive[s]) continue;
       const int nxt = (s + 1) & 3, prv = (s + 3) & 3;
@@ -480,14 +560,14 @@ CD_UNROLL
       nonempty[s] = lr != 0u;
       if ((lr >> (asc ? lo : hi)) & 1u) nonempty[prv] = true;  // the corner cells join the neighbouring sides (if on top of the polyhedron)
       if ((lr >> (asc ? hi : lo)) & 1u) nonempty[nxt] = true;
-CD_UNROLL
+      CD_UNROLL
       for (int j = 0; j < 4; ++j)
         if (nonempty[j]) farc[j] = sg[j] * ((bit_axis[j] ? sb : sr) + (bit_axis[j] ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0)) - OV);
     }
   }
   L.cells.n = n;
   CD_PROF(2);
-CD_UNROLL
+  CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     const bool ba = bit_axis[j];
     const int at = ba ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0);
@@ -496,8 +576,24 @@ CD_UNROLL
     L.rim_real[j].b = RIM0, L.rim_real[j].e = RIM0 + __builtin_popcount(m);
     L.far[j] = Cell{sd[j].x * farc[j], sd[j].y * farc[j], sd[j].z * farc[j]};
   }
+  // the layer's cells as plane rows (= the REAL cells inside the rectangle), for mark_cells: the overlay copy whose words are
+  // this plane's rows takes them with one OR per lane
+  if (lane < OVW) L.plane[lane] = (lane >= r0 && lane <= r1) ? (real & range_mask(b0, b1)) : 0u;
+  L.plane_axis = aw, L.plane_level = lw;
   CD_SYNC();
   CD_PROF(3);
+  return true;
+}
+template <class G>
+CD_INLINE __device__ inline bool grow_layer_wave(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int margin, Layer& L) {
+  switch (f) {
+    case 0: return grow_layer_wave_f<G, 0>(cx, g, fs, allow, margin, L);
+    case 1: return grow_layer_wave_f<G, 1>(cx, g, fs, allow, margin, L);
+    case 2: return grow_layer_wave_f<G, 2>(cx, g, fs, allow, margin, L);
+    case 3: return grow_layer_wave_f<G, 3>(cx, g, fs, allow, margin, L);
+    case 4: return grow_layer_wave_f<G, 4>(cx, g, fs, allow, margin, L);
+    default: return grow_layer_wave_f<G, 5>(cx, g, fs, allow, margin, L);
+  }
 }
 #endif
 
@@ -506,7 +602,7 @@ CD_UNROLL
 // Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v),
 // trial_set / trial_unset, and kAtomicMarks (true: set_atomic / unset_atomic for the cooperative mode).
 template <class G>
-CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
+CD_NOINLINE CD_HD bool grow_layer_serial(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
   Work& wk = *cx.wk;
   const Frame* fr = wk.fr;
   L.found = 0;
@@ -524,17 +620,6 @@ CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const Fac
   };
   bool found = false;
   CD_PROF_BEGIN();
-#if CD_HAS_COOP
-  if (cx.coop) {  // the first cell of the list that qualifies: 64 candidates per trip
-    const int n = fs.outer.n;
-    for (int base = 0; base < n && !found; base += 64) {
-      const int q = base + cx.lane;
-      const bool hit = q < n && seed_ok(add(cx.at(fs.outer, q < n ? q : 0), up));
-      const unsigned long long m = __ballot(hit);
-      if (m) s2 = add(cx.at(fs.outer, base + __ffsll((long long)m) - 1), up), found = true;
-    }
-  } else
-#endif
   for (int q = 0; q < fs.outer.n; ++q) {
     const Cell t = add(cx.at(fs.outer, q), up);
     if (seed_ok(t)) {
@@ -545,14 +630,6 @@ CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const Fac
   L.found = found ? 1 : 0;
   CD_PROF(0);
   if (!found) return false;
-#if CD_HAS_COOP
-  if constexpr (G::kHasPlanes) {
-    if (cx.coop && g.maps) {
-      grow_layer_planes(cx, g, f, allow, s2, L);
-      return true;
-    }
-  }
-#endif
   // current outline of the layer per side: all cells (rim) / cells of the layer (rim_real)
   CD_UNROLL
   for (int j = 0; j < 4; ++j) cx.assign1(wk.rim[j], s2), cx.assign1(L.rim_real[j], s2), L.far[j] = s2;
@@ -564,53 +641,6 @@ CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const Fac
     cx.clear(wk.moved), cx.clear(wk.moved_real);
     bool ok = true;
     const int cnt = cx.size(wk.rim[s]);
-#if CD_HAS_COOP
-    if (cx.coop) {
-      // every cell of the side at once: a cell that stops the serial loop stops the side (what was pushed before it is
-      // discarded there too); otherwise `moved` takes all the cells and `moved_real` those on top of the polyhedron, in order
-      const int rb = wk.rim[s].b;
-      int n_real = 0;
-      for (int base = 0; base < cnt && ok; base += 64) {
-        const int q = base + cx.lane;
-        const bool act = q < cnt;
-        const Cell t = add(cx.unpack(wk.rim[s].c[rb + (act ? q : 0)]), sd[s]);
-        bool fail = false, real = false;
-        if (act) {
-          if (dot(t, sd[s]) > allow[s]) {
-            fail = true;
-          } else {
-            const Cell below = sub(t, up);
-            if (g.inside(below) && g.value(below) == mark) {
-              if (g.inside(t) && g.value(t) < kOccupied) real = true;
-              else fail = true;
-            }
-          }
-        }
-        if (__ballot(fail)) {
-          ok = false;
-          break;
-        }
-        const unsigned long long rm = __ballot(real);
-        if (act) {
-          const Packed pk = cx.pack(t);
-          if (RIM0 + q < RIM) wk.moved.c[RIM0 + q] = pk;
-          else wk.overflow = 1;
-          if (real) {
-            const int rpos = RIM0 + n_real + __popcll(rm & ((1ull << cx.lane) - 1ull));
-            if (rpos < RIM) wk.moved_real.c[rpos] = pk;
-            else wk.overflow = 1;
-          }
-        }
-        n_real += __popcll(rm);
-      }
-      CD_SYNC();
-      if (ok) {
-        wk.moved.b = RIM0, wk.moved.e = RIM0 + cnt < RIM ? RIM0 + cnt : RIM;
-        wk.moved_real.b = RIM0, wk.moved_real.e = RIM0 + n_real < RIM ? RIM0 + n_real : RIM;
-      }
-      CD_SYNC();
-    } else
-#endif
     for (int q = 0; q < cnt; ++q) {
       const Cell t = add(cx.get(wk.rim[s], q), sd[s]);
       if (dot(t, sd[s]) > allow[s]) {
@@ -649,14 +679,12 @@ CD_INLINE CD_HD bool grow_layer_impl(const Ctx& cx, const G& g, int f, const Fac
   return true;
 }
 
-template <class G>
-CD_NOINLINE CD_HD bool grow_layer_call(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
-  return grow_layer_impl(cx, g, f, fs, allow, mark, margin, L);
-}
 template <class G, bool COOP>
 CD_INLINE CD_HD bool grow_layer(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
-  if constexpr (COOP) return grow_layer_impl(cx, g, f, fs, allow, mark, margin, L);
-  else return grow_layer_call(cx, g, f, fs, allow, mark, margin, L);
+#if CD_HAS_COOP
+  if constexpr (COOP) return grow_layer_wave(cx, g, f, fs, allow, margin, L);
+#endif
+  return grow_layer_serial(cx, g, f, fs, allow, mark, margin, L);
 }
 
 CD_HD double dabs(double v) { return v < 0 ? -v : v; }
@@ -726,16 +754,12 @@ CD_INLINE CD_HD void find_corners_impl(const Ctx& cx, const G& g, int f, bool gr
   }
 }
 
-template <class G>
-CD_NOINLINE CD_HD void find_corners_call(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark,
-                                         bool& valid, Edge out[4]) {
-  find_corners_impl<G, false>(cx, g, f, growing_f, face, edges, mark, valid, out);
-}
+// (out of line in the cooperative mode too: a trial layer is rare, and two more inlined copies of the six per-face layer
+// functions would push the loop of decompose_core out of the instruction cache)
 template <class G, bool COOP>
-CD_INLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark, bool& valid,
-                                  Edge out[4]) {
-  if constexpr (COOP) find_corners_impl<G, true>(cx, g, f, growing_f, face, edges, mark, valid, out);
-  else find_corners_call(cx, g, f, growing_f, face, edges, mark, valid, out);
+CD_NOINLINE CD_HD void find_corners(const Ctx& cx, const G& g, int f, bool growing_f, const FaceState& face, const Edge* edges, int mark, bool& valid,
+                                    Edge out[4]) {
+  find_corners_impl<G, COOP>(cx, g, f, growing_f, face, edges, mark, valid, out);
 }
 
 // rows[max_rows][4] = (n, n . p); returns CD_OK, CD_CAPACITY (n_rows = needed count) or CD_WORK_OVERFLOW (a fixed-capacity
@@ -745,17 +769,22 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
                          int max_rows, int* n_rows, int lane = 0) {
   Ctx cx{&wk, COOP, lane, seed};
   // mark / unmark every cell of a list
-  auto mark_cells = [&](const CellList& l, int how) {  // 0 set, 1 trial_set, 2 trial_unset
+  auto mark_cells = [&](const Layer& layer, int how) {  // 0 set, 1 trial_set, 2 trial_unset
+    const CellList& l = layer.cells;
 #if CD_HAS_COOP
-    if constexpr (G::kAtomicMarks) {
-      if (cx.coop) {
-        for (int q = cx.lane; q < l.n; q += 64) {
-          if (how == 2) g.unset_atomic(cx.at(l, q));
-          else g.set_atomic(cx.at(l, q));
-        }
-        CD_SYNC();
-        return;
+    if constexpr (COOP) {
+      // the copy of the overlay whose words are rows of the layer's plane takes the layer with one word per lane, the other
+      // copy cell by cell
+      const int aw = layer.plane_axis, lw = layer.plane_level;
+      if (cx.lane < G::OVW) {
+        uint32_t* copy = aw == 0 ? g.bits_t : g.bits;
+        const int w = aw == 2 ? cx.lane + G::OVW * lw : lw + G::OVW * cx.lane;
+        const uint32_t row = layer.plane[cx.lane];
+        if (row) copy[w] = how == 2 ? (copy[w] & ~row) : (copy[w] | row);
       }
+      for (int q = cx.lane; q < l.n; q += 64) g.mark_atomic(cx.at(l, q), how != 2, aw == 0);
+      CD_SYNC();
+      return;
     }
 #endif
     for (int q = 0; q < l.n; ++q) {
@@ -811,8 +840,10 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     // is the layer consistent with ONE plane through every edge? (CD:209-283 / CD:828-910)
     bool accept = true;
     int fresh[4] = {0, 0, 0, 0};  // corner_new_state: 1 = a one-voxel chamfer starts on this side, 2 = a longer one
+    bool stop = false;  // (the reference's loop ends at !accept or at a break: written so that the loop unrolls and trial[] stays in registers)
     CD_UNROLL
-    for (int j = 0; j < 4 && accept; ++j) {
+    for (int j = 0; j < 4; ++j) {
+      if (!accept || stop) continue;
       if (cx.empty(L.rim_real[j])) continue;
       Edge e = trial[j];
       const Cell c = cx.front(L.rim_real[j]);
@@ -834,7 +865,10 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       } else if (e.fixed) {
         if (e.dir == f || e.dir == -1) {
           if (gap > e.slope) {
-            if (aware) break;  // CD:875-878: the scan of the edges ends here, this and the later sides keep their state
+            if (aware) {  // CD:875-878: the scan of the edges ends here, this and the later sides keep their state
+              stop = true;
+              continue;
+            }
             accept = false;
           }
         } else if (e.steps >= e.slope) {  // the other face has finished a stair: we may step in by one, once
@@ -882,7 +916,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
             }
           }
           wk.edge_row.b = RIM0, wk.edge_row.e = e_end;
-          CD_SYNC();
+          if constexpr (COOP) CD_SYNC();
           second = side_is_empty(cx, g, wk.edge_row, normal_of(nbf));
         }
         expand = !(first && second);
@@ -894,7 +928,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       CD_PROF(6);
       if (expand && (fresh[0] || fresh[1] || fresh[2] || fresh[3])) {
         // trial: put the layer in, grow one more on top of it, take it out again (its cells were free voxels)
-        mark_cells(L.cells, 1);
+        mark_cells(L, 1);
         FaceState& face_t = wk.face_t;  // (the other faces are what they are: the trial reads only the face it grows)
         cx.copy(face_t.outer, L.cells);
         CD_UNROLL
@@ -906,8 +940,12 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
           if (!fresh[j]) edges_t[fr[f].edge[j]] = trial[j];
         bool valid = true;
         Edge fin[4];
-        find_corners<G, COOP>(cx, g, f, ((growing >> f) & 1u) != 0, face_t, edges_t, mark, valid, fin);
-        mark_cells(L.cells, 2);
+        // (the out-of-line calls get copies of the context and the grid: the originals stay in registers instead of moving to
+        // the stack for good)
+        const Ctx cx_call = cx;
+        const G g_call = g;
+        find_corners<G, COOP>(cx_call, g_call, f, ((growing >> f) & 1u) != 0, face_t, edges_t, mark, valid, fin);
+        mark_cells(L, 2);
         if (valid) {
           CD_UNROLL
           for (int j = 0; j < 4; ++j)
@@ -916,23 +954,23 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
               growing &= ~(1u << f);
               break;
             }
-          if (expand)
-            CD_UNROLL
+          if (expand) {
+            // (this loop stays a loop — its body holds a whole trial layer — so nothing in it indexes a local array with j:
+            // on the device such an array would live in scratch memory)
+            auto pick = [](int j, int a0, int a1, int a2, int a3) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)); };
             for (int j = 0; j < 4; ++j) {
-              if (fresh[j] != 1) continue;
+              if (pick(j, fresh[0], fresh[1], fresh[2], fresh[3]) != 1) continue;
               const int nbf = fr[f].face[j];
               bool v2 = true;
               Edge fin2[4];
-              find_corners<G, COOP>(cx, g, nbf, ((growing >> nbf) & 1u) != 0, faces[nbf], edges, mark, v2, fin2);
-              int nb_slope = 0;  // fin2[fr[f].back[j]].slope without a dynamically indexed local array
-              CD_UNROLL
-              for (int k = 0; k < 4; ++k)
-                if (k == fr[f].back[j]) nb_slope = fin2[k].slope;
-              if (v2 && nb_slope == 0 && fin[j].slope == 0) {
+              find_corners<G, COOP>(cx_call, g_call, nbf, ((growing >> nbf) & 1u) != 0, faces[nbf], edges, mark, v2, fin2);
+              const int nb_slope = pick(fr[f].back[j], fin2[0].slope, fin2[1].slope, fin2[2].slope, fin2[3].slope);
+              if (v2 && nb_slope == 0 && pick(j, fin[0].slope, fin[1].slope, fin[2].slope, fin[3].slope) == 0) {
                 expand = false;
                 break;
               }
             }
+          }
         }
       }
       CD_PROF(7);
@@ -950,12 +988,12 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
         const int nbf = fr[f].face[j];
         cx.append(faces[nbf].outer, L.rim_real[j]);
         const int reach_nb = faces[nbf].reach[fr[f].back[j]] + 1;
-        CD_SYNC();
+        if constexpr (COOP) CD_SYNC();
         faces[nbf].reach[fr[f].back[j]] = reach_nb;
       }
     }
     anchor[f] = cx.at(L.cells, 0);
-    mark_cells(L.cells, 0);
+    mark_cells(L, 0);
     CD_PROF(8);
   }
   if (wk.overflow) return CD_WORK_OVERFLOW;

@@ -47,25 +47,48 @@ __device__ inline void build_world_maps(const WindowGrid& g, const WaveLds& m, i
   const int lx = lane & 31, half = lane >> 5;
   const int cx = g.seed.x + lx - OV;
   const bool x_in = lx >= OV - r && lx <= OV + r;
+  const size_t wsize = (size_t)g.wnx * g.wny * g.wnz;
+  // the class of one voxel, 1 = free | 2 = positive, without a branch around the load (its address is clamped into the world): the
+  // loads of a batch of rows are then in flight together instead of one global round trip per row
+  auto load = [&](Cell c, bool wanted, int& raw) {
+    const int gi = c.x + g.ox, gj = c.y + g.oy, gk = c.z + g.oz;
+    const bool in_world = gi >= 0 && gj >= 0 && gk >= 0 && gi < g.wnx && gj < g.wny && gk < g.wnz;
+    const size_t idx = (size_t)gi + (size_t)gj * g.wnx + (size_t)gk * g.wnx * g.wny;
+    raw = g.world[(wanted && in_world && idx < wsize) ? idx : 0];
+    return in_world;
+  };
+  auto classify = [&](Cell c, bool wanted, bool in_world, int raw) {
+    if (!(wanted && g.inside(c))) return 2u;                       // not free, "positive" (GetVoxel outside the grid: occupied)
+    const int v = c.z < g.ground_k ? kOccupied : (!in_world ? 0 : (raw < 0 ? kOccupied : raw));  // WindowGrid::world_value
+    return (v < kOccupied ? 1u : 0u) | (v > 0 ? 2u : 0u);
+  };
+  constexpr int B = 8;  // rows per batch
   for (int dz0 = OV - r; dz0 <= OV + r; dz0 += 2) {
     const int dz = dz0 + half;
     const int cz = g.seed.z + dz - OV;
+    const bool z_in = dz <= OV + r;
     uint32_t fy = 0;
-    for (int dy = OV - r; dy <= OV + r; ++dy) {
-      const Cell c{cx, g.seed.y + dy - OV, cz};
-      bool fr = false, ps = true;
-      if (x_in && dz <= OV + r && g.inside(c)) {
-        const int v = g.world_value(c);
-        fr = v < kOccupied, ps = v > 0;
+    for (int dy0 = OV - r; dy0 <= OV + r; dy0 += B) {
+      int raw[B];
+      bool inw[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) inw[u] = load(Cell{cx, g.seed.y + dy0 + u - OV, cz}, x_in && z_in && dy0 + u <= OV + r, raw[u]);
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        const int dy = dy0 + u;
+        const bool wanted = x_in && z_in && dy <= OV + r;
+        const uint32_t cls = classify(Cell{cx, g.seed.y + dy - OV, cz}, wanted, inw[u], raw[u]);
+        const unsigned long long bf = __ballot(cls & 1u), bp = __ballot(cls & 2u);
+        if (dy <= OV + r) {
+          if (lx == 0 && z_in) {
+            m.maps[dy + OVW * dz] = (uint32_t)(bf >> (32 * half));
+            m.maps[WORDS + dy + OVW * dz] = (uint32_t)(bp >> (32 * half));
+          }
+          fy |= (cls & 1u) << dy;
+        }
       }
-      const unsigned long long bf = __ballot(fr), bp = __ballot(ps);
-      if (lx == 0 && dz <= OV + r) {
-        m.maps[dy + OVW * dz] = (uint32_t)(bf >> (32 * half));
-        m.maps[WORDS + dy + OVW * dz] = (uint32_t)(bp >> (32 * half));
-      }
-      fy |= (fr ? 1u : 0u) << dy;
     }
-    if (dz <= OV + r) m.maps[2 * WORDS + lx + OVW * dz] = fy;
+    if (z_in) m.maps[2 * WORDS + lx + OVW * dz] = fy;
   }
 }
 
@@ -77,15 +100,35 @@ __device__ inline int wave_decompose(WindowGrid g, const WaveLds& m, int variant
   g.bits = m.bits;
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long t0 = __builtin_readcyclecounter();
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) m.wk->prof[i] = 0;
 #endif
   build_world_maps(g, m, r, lane);
   __syncthreads();
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-  if (lane == 0) atomicAdd(&g_cd_prof[10], __builtin_readcyclecounter() - t0), atomicAdd(&g_cd_prof[15], 1ull);
+  if (lane == 0) m.wk->prof[10] = __builtin_readcyclecounter() - t0, m.wk->prof[15] = 1;
 #endif
-  if (r > 0) g.maps = m.maps, g.bits_t = m.bits_t, g.map_r = r;
   if (variant < 0) variant = seed_is_pinched(g, g.seed) ? 1 : 0;
-  return decompose_core<WindowGrid, true>(g, *m.wk, variant, g.seed, n_it, res, g.mark, origin, rows, max_rows, n_rows, lane);
+  if (r <= 0) {
+    // more turns than the overlay's planes hold (n_it > 78): the plain form, by lane 0 (rows: the caller's array must then be
+    // memory every lane sees — global memory or LDS)
+    if (lane == 0) {
+      int n = 0;
+      WindowGrid g_plain = g;  // (its address goes into out-of-line calls: a copy, so that `g` itself stays in registers)
+      const int rc = decompose_core<WindowGrid, false>(g_plain, *m.wk, variant, g.seed, n_it, res, g.mark, origin, rows, max_rows, &n);
+      m.wk->seed_plane[0] = (uint32_t)rc, m.wk->seed_plane[1] = (uint32_t)n;
+    }
+    __syncthreads();
+    *n_rows = (int)m.wk->seed_plane[1];
+    return (int)m.wk->seed_plane[0];
+  }
+  g.maps = m.maps, g.bits_t = m.bits_t, g.map_r = r;
+  const int rc_wave = decompose_core<WindowGrid, true>(g, *m.wk, variant, g.seed, n_it, res, g.mark, origin, rows, max_rows, n_rows, lane);
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+  __syncthreads();
+  if (lane < 16 && lane != 12 && lane != 13 && lane != 14) atomicAdd(&g_cd_prof[lane], m.wk->prof[lane]);
+#endif
+  return rc_wave;
 }
 
 #endif  // __HIPCC__

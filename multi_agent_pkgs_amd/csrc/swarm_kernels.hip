@@ -25,6 +25,18 @@
 extern "C" int hdsm_internal_defer_done(void* handle, int on);
 extern "C" int hdsm_internal_record_done(void* handle, void* hip_stream);
 
+#ifdef CD_PROFILE
+// development builds only: the phase counters of the corridor kernel's decompositions (read and cleared); [12] cycles of the whole
+// corridor step, [13] of its decompositions, [14] agent-rounds, [15] decompositions
+extern "C" int hdsm_swarm_corridor_profile(unsigned long long out[16]) {
+  if (hipDeviceSynchronize() != hipSuccess) return HDSM_ERR_DEVICE;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hdsm_cd::g_cd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return HDSM_ERR_DEVICE;
+  unsigned long long zero[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(hdsm_cd::g_cd_prof), zero, sizeof zero) != hipSuccess) return HDSM_ERR_DEVICE;
+  return HDSM_OK;
+}
+#endif
+
 extern "C" int hdsm_swarm_export_state(void* swarm, void* agents_out, int32_t* n_local, int32_t* n_rob, int32_t* first_id,
                                        hdsm_params* prm, hdsm_swarm_config* cfg, const int8_t** world, int32_t wdim[3],
                                        double worigin[3]);
@@ -82,7 +94,9 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return fmin(fmin(lane_of(v, 0), lane_of(v, 16)), fmin(lane_of(v, 32), lane_of(v, 48)));
 }
 
-__device__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::WaveLds& lds, V3* path, int lane) {
+// (inlined into the kernel: only there does the compiler know that the workspace is LDS — behind a call every access of the
+// decomposition was a flat load)
+__device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::WaveLds& lds, V3* path, int lane) {
   using namespace hdsm_sw;
   const int P = c.P, N = c.N, RS = c.RS;
   __shared__ int sh_npath;
@@ -221,7 +235,13 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::Wave
     if (previous_seed) continue;
     int rc = HDSM_OK;
     if (c.has_world) {  // the whole wavefront, cooperatively: same arguments, same result in every lane
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+      const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
       rc = world_poly_wave(c, origin, seed, lds, &ag.polys[n_poly], lane);
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+      if (lane == 0) atomicAdd(&hdsm_cd::g_cd_prof[13], __builtin_readcyclecounter() - tp0);
+#endif
       if (rc != HDSM_OK) ag.corridor_rc = rc;
       else ag.polys[n_poly].seed = seed_world;
     } else if (lane == 0) {
@@ -237,6 +257,10 @@ __device__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::Wave
   if (lane == 0) ag.n_poly = n_poly;
 }
 
+__device__ __attribute__((noinline)) void corridor_step_plain(const Cfg& c, AgentS& ag, hdsm_cd::Work* wk, uint32_t* bits) {
+  hdsm_sw::corridor_step(c, ag, wk, bits);
+}
+
 // (the solver's inputs that do not depend on the reference — id, state, the corridor just built — leave with this kernel: a kernel
 // of their own cost 5 us per round in the live loop)
 __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, double* path, int32_t* n_path, int32_t* agent_id,
@@ -250,9 +274,16 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, d
   extern __shared__ __attribute__((aligned(16))) unsigned char slab[];  // SLAB bytes when there is a world, else none
   const hdsm_cd::WaveLds lds(slab);
   if (c.P * c.RS <= 128) {
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long tp0 = __builtin_readcyclecounter();
+#endif
     corridor_step_wave(c, ag, lds, path_s, lane);
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (lane == 0) atomicAdd(&hdsm_cd::g_cd_prof[12], __builtin_readcyclecounter() - tp0), atomicAdd(&hdsm_cd::g_cd_prof[14], 1ull);
+#endif
   } else if (lane == 0) {
-    hdsm_sw::corridor_step(c, ag, lds.wk, lds.bits);  // more rows than two per lane: the plain per-agent code
+    const Cfg c_call = c;  // (a copy for the call: the kernel's own stays in registers)
+    corridor_step_plain(c_call, ag, lds.wk, lds.bits);  // more rows than two per lane: the plain per-agent code
   }
   __syncthreads();
   if (lane == 0) np_s = hdsm_sw::reference_polyline(ag, poly_s);

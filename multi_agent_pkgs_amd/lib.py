@@ -12,7 +12,7 @@ import numpy as np
 from .params import HdsmParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libhdsm.so")
+SO_PATH = os.environ.get("HDSM_LIBRARY") or os.path.join(_HERE, "libhdsm.so")  # (HDSM_LIBRARY: a development build, e.g. -DCD_PROFILE)
 
 HDSM_OK, HDSM_ERR_BAD_ARG, HDSM_ERR_NO_DEVICE, HDSM_ERR_DEVICE, HDSM_ERR_CAPACITY, HDSM_ERR_COMM = 0, -1, -2, -3, -4, -5
 HDSM_FLAG_NODE_LIMIT, HDSM_FLAG_ITER_LIMIT, HDSM_FLAG_TIME_LIMIT, HDSM_FLAG_STAGING_OVERFLOW = 1, 2, 4, 8
