@@ -109,11 +109,17 @@ typedef struct hdsm_params {
                                                                                                     HDSM_ORDER_MIN    */
   double stage_radius;          /* [m] slack below which a neighbour row is staged (default 0.6)     HDSM_CAND_TAU     */
   /* (Environment only, for A/B scripts. HDSM_SPLIT 0 / 1 / 2 = never / always / automatically (default) run a launch whose
-   * predecessors met a deep branch-and-bound tree (32 nodes) as three kernels — budgeted solve; poly_hor^D workgroups for
-   * every instance that exceeded the budget, each searching the subtree its index selects at the first D branching levels;
-   * merge. HDSM_SPLIT_BUDGET = that budget in nodes (default 8 for batches that leave CUs idle, 96 beyond),
-   * HDSM_SPLIT_DEPTH = D (1 .. 3, default 3). max_nodes stays the budget of an INSTANCE: its sub-searches start with equal
-   * shares and pass what they do not use on to the others. HDSM_PICK_RULE 1 (default) / 0: the row that enters the working
+   * predecessors met a deep branch-and-bound tree (32 nodes) as three kernels — a budgeted solve in which an instance that
+   * exceeds the budget hands its search over (a record of its open levels; one queue item per unexplored child); persistent
+   * workgroups that draw the items and continue inside their subtrees, handing over again when a subtree grows large
+   * (HDSM_ITEM_BUDGET nodes, default 32; HDSM_ITEM_MIN while workgroups wait for items); the merge. HDSM_SPLIT_BUDGET = the
+   * budget of the first kernel in nodes (default by batch size: 8 for batches that leave CUs idle, 96 beyond). max_nodes stays
+   * the budget of an INSTANCE: its items draw from one pool. HDSM_CHILD_BOUND 1 (default) / 0: children of a branching node
+   * get a lower bound and their first entering row from the node's leaf test / neither. HDSM_SETUP_MFMA 1 (default) / 0: the
+   * set-up map of all instances of a launch is one product on the matrix cores in the pre-pass kernel / every instance applies
+   * it itself. HDSM_OVERLAP_SWEEP 1 (default) / 0: two-wave workgroups run the first staging sweep during the warm-start
+   * install / after it.
+   * HDSM_PICK_RULE 1 (default) / 0: the row that enters the working
    * set next is the most violated one in the metric of the problem (violation / sqrt(a' Z a)) / the most violated one.
    * HDSM_BOX_CUT 1 (default) / 0: a dual objective above the largest objective any point of the input box can have ends an
    * active-set run as infeasible / only the formal proof does.
