@@ -391,17 +391,22 @@ struct Ctx {
 };
 
 // how far the next layer of face f may extend on each side, given the chamfers already started (CD:71-91)
-CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* edges, int allow[4], Edge trial[4]) {
+// (the edges' state is read where it lies; the working copies `trial` of the four edges are taken by the caller AFTER the layer
+// has been grown — 40 words that would otherwise be live, in registers, across the whole in-plane growth)
+CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* edges, int allow[4]) {
   CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     allow[j] = fs.reach[j];
-    trial[j] = edges[fr[f].edge[j]];
-    const Edge& e = trial[j];
+    const Edge& e = edges[fr[f].edge[j]];
     if (e.slope > 0) {
       if (e.dir == f) allow[j] -= e.slope;                         // our layers retreat `slope` voxels each
       else if (e.fixed && e.steps >= e.slope) allow[j] -= 1;       // the other face's stair is complete: step in
     }
   }
+}
+CD_HD void edges_of_face(const Frame* fr, int f, const Edge* edges, Edge trial[4]) {
+  CD_UNROLL
+  for (int j = 0; j < 4; ++j) trial[j] = edges[fr[f].edge[j]];
 }
 
 #if CD_HAS_COOP
@@ -513,7 +518,6 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
     }
     if (!plane_ok || lw2 != lw) lw = lw2, load_rows(lw);
   }
-  bool alive[4] = {true, true, true, true}, nonempty[4] = {true, true, true, true};
   int farc[4];
   CD_UNROLL
   for (int j = 0; j < 4; ++j) farc[j] = dot(s2, sd[j]);
@@ -532,39 +536,202 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
     }
   };
   CD_PROF(1);
-  while (alive[0] || alive[1] || alive[2] || alive[3]) {
-    CD_UNROLL
-    for (int s = 0; s < 4; ++s) {
-      if (!alive[s]) continue;
-      const int nxt = (s + 1) & 3, prv = (s + 3) & 3;
-      const bool ba = bit_axis[s];
-      const int at = ba ? (sg[s] > 0 ? b1 + 1 : b0 - 1) : (sg[s] > 0 ? r1 + 1 : r0 - 1);
-      const int lo = ba ? r0 : b0, hi = ba ? r1 : b1;
-      bool ok = sg[s] * ((ba ? sb : sr) + at - OV) <= allow[s];
-      if (ok && (at < lo_ok || at > hi_ok)) wk.overflow = 1, ok = false;
-      uint32_t lr = 0;
-      if (ok) {
-        ok = line_of(ba, at, blk, lo, hi) == 0u;
-        lr = line_of(ba, at, real, lo, hi);
+  // The rim moves, a BATCH at a time instead of one after the other. While no line is blocked the round robin is a fixed schedule:
+  // side s makes its t-th move in turn t, its line lies at bound_s +- t and spans what the two perpendicular sides have reached by
+  // then (each min(turns so far, what the allowance leaves it)). So lane l = (turn l / 4 + 1, place l % 4 in the round robin)
+  // forms ITS move's line in closed form, fetches the line's word of the two planes from the lane that holds it (rows as they are,
+  // columns transposed once per layer), and tests it. The schedule is valid up to the first blocked move F (a ballot): the moves
+  // before F are committed together — their cells go to the layer's list at the prefix sum of the lines' counts, in the deque's
+  // order — the side of move F is dead, and the round robin continues behind it with a new batch. At most 4 sides die, a batch
+  // holds 16 turns: 1 - 5 batches per layer instead of ~ 60 sequential moves of ~ 90 instructions.
+  // `far` (read only through its coordinate along its side): side j's position the last time its line had cells on top of the
+  // polyhedron when looked at after a move. While a side stays where it is its line only grows, so it is enough to look at every
+  // position once, when the side leaves it (with the span of the move that leaves: the lane of that move does it) or at the end
+  // of a batch.
+#ifdef CD_CHECK_BATCH
+  // (test builds of tests/wave_emu only: the moves one after the other, as rounds 5's first version made them, for comparison)
+  int ck_n = 1, ck_b0 = b0, ck_b1 = b1, ck_r0 = r0, ck_r1 = r1, ck_farc[4];
+  Packed ck_cells[CELLS];
+  {
+    bool alive_[4] = {true, true, true, true}, nonempty[4] = {true, true, true, true};
+    for (int j = 0; j < 4; ++j) ck_farc[j] = farc[j];
+    while (alive_[0] || alive_[1] || alive_[2] || alive_[3]) {
+      for (int s = 0; s < 4; ++s) {
+        if (!alive_[s]) continue;
+        const int nxt = (s + 1) & 3, prv = (s + 3) & 3;
+        const bool ba = bit_axis[s];
+        const int at = ba ? (sg[s] > 0 ? ck_b1 + 1 : ck_b0 - 1) : (sg[s] > 0 ? ck_r1 + 1 : ck_r0 - 1);
+        const int lo = ba ? ck_r0 : ck_b0, hi = ba ? ck_r1 : ck_b1;
+        bool ok = sg[s] * ((ba ? sb : sr) + at - OV) <= allow[s] && at >= lo_ok && at <= hi_ok;
+        uint32_t lr = 0;
+        if (ok) {
+          ok = line_of(ba, at, blk, lo, hi) == 0u;
+          lr = line_of(ba, at, real, lo, hi);
+        }
+        if (!ok) {
+          alive_[s] = false;
+          continue;
+        }
+        const bool asc = sg[nxt] > 0;
+        if (lane < OVW && ((lr >> lane) & 1u)) {
+          const int rank = asc ? __builtin_popcount(lr & ((1u << lane) - 1u)) : __builtin_popcountll((unsigned long long)lr >> (lane + 1));
+          int d[3];
+          d[aw] = lw - OV, d[ab] = (ba ? at : lane) - OV, d[ar] = (ba ? lane : at) - OV;
+          if (ck_n + rank < CELLS) ck_cells[ck_n + rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2], 0};
+        }
+        ck_n += __builtin_popcount(lr);
+        if (ba) (sg[s] > 0 ? ck_b1 : ck_b0) = at;
+        else (sg[s] > 0 ? ck_r1 : ck_r0) = at;
+        nonempty[s] = lr != 0u;
+        if ((lr >> (asc ? lo : hi)) & 1u) nonempty[prv] = true;
+        if ((lr >> (asc ? hi : lo)) & 1u) nonempty[nxt] = true;
+        for (int j = 0; j < 4; ++j)
+          if (nonempty[j]) ck_farc[j] = sg[j] * ((bit_axis[j] ? sb : sr) + (bit_axis[j] ? (sg[j] > 0 ? ck_b1 : ck_b0) : (sg[j] > 0 ? ck_r1 : ck_r0)) - OV);
       }
-      if (!ok) {
-        alive[s] = false;
-        continue;
-      }
-      const bool asc = sg[nxt] > 0;  // the line's cells in the deque's order: along side s + 1
-      write_line(L.cells.c + n, CELLS - n, ba, at, lr, asc);
-      n += __builtin_popcount(lr);
-      if (n > CELLS) n = CELLS;
-      if (ba) (sg[s] > 0 ? b1 : b0) = at;
-      else (sg[s] > 0 ? r1 : r0) = at;
-      nonempty[s] = lr != 0u;
-      if ((lr >> (asc ? lo : hi)) & 1u) nonempty[prv] = true;  // the corner cells join the neighbouring sides (if on top of the polyhedron)
-      if ((lr >> (asc ? hi : lo)) & 1u) nonempty[nxt] = true;
-      CD_UNROLL
-      for (int j = 0; j < 4; ++j)
-        if (nonempty[j]) farc[j] = sg[j] * ((bit_axis[j] ? sb : sr) + (bit_axis[j] ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0)) - OV);
     }
   }
+#endif
+  uint32_t col_real = 0, col_blk = 0;  // lane b: column b of the planes (bits over the rows)
+  int lim[4];                          // the last index side j may reach (allowance and the classified box)
+  CD_UNROLL
+  for (int j = 0; j < 4; ++j) {
+    const int a = sg[j] * allow[j] - (bit_axis[j] ? sb : sr) + OV;  // sg (seed + index - OV) <= allow
+    lim[j] = sg[j] > 0 ? (a < hi_ok ? a : hi_ok) : (a > lo_ok ? a : lo_ok);
+    if (sg[j] > 0 ? a > hi_ok : a < lo_ok) wk.overflow = 1;  // (the allowance reaches beyond what build_world_maps classified)
+  }
+  {
+    int c_lo = OVW, c_hi = -1;
+    CD_UNROLL
+    for (int j = 0; j < 4; ++j)
+      if (bit_axis[j]) (sg[j] > 0 ? c_hi : c_lo) = lim[j];
+    for (int b = c_lo < b0 ? c_lo : b0; b <= (c_hi > b0 ? c_hi : b0); ++b) {
+      const uint32_t mr = (uint32_t)__ballot(lane < OVW && ((real >> b) & 1u)), mb = (uint32_t)__ballot(lane < OVW && ((blk >> b) & 1u));
+      if (lane == b) col_real = mr, col_blk = mb;
+    }
+  }
+  auto pick4 = [](int j, int a0, int a1, int a2, int a3) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)); };
+  unsigned alive = 0xfu;
+  int s_next = 0;
+  for (;;) {
+    int bnd[4], cap[4];
+    CD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      bnd[j] = bit_axis[j] ? (sg[j] > 0 ? b1 : b0) : (sg[j] > 0 ? r1 : r0);
+      const int left = sg[j] > 0 ? lim[j] - bnd[j] : bnd[j] - lim[j];
+      cap[j] = ((alive >> j) & 1u) && left > 0 ? left : 0;
+    }
+    if ((cap[0] | cap[1] | cap[2] | cap[3]) == 0) break;
+    const int t = (lane >> 2) + 1, pos = lane & 3, s = (s_next + pos) & 3, q1 = (s + 1) & 3, q3 = (s + 3) & 3;
+    const bool ba = pick4(s, bit_axis[0], bit_axis[1], bit_axis[2], bit_axis[3]) != 0;
+    const int sgs = pick4(s, sg[0], sg[1], sg[2], sg[3]);
+#ifndef CD_BATCH_TURNS
+#define CD_BATCH_TURNS 16  // turns per batch: the 64 lanes (test builds: fewer, so that layers continue over several batches)
+#endif
+    const bool active = t <= pick4(s, cap[0], cap[1], cap[2], cap[3]) && t <= CD_BATCH_TURNS;
+    const int at = pick4(s, bnd[0], bnd[1], bnd[2], bnd[3]) + sgs * t;
+    auto reached = [&](int q) {  // moves side q has made when this lane's move is made
+      const int tt = ((q - s_next) & 3) < pos ? t : t - 1, cq = pick4(q, cap[0], cap[1], cap[2], cap[3]);
+      return tt < cq ? tt : cq;
+    };
+    const int e1 = pick4(q1, bnd[0], bnd[1], bnd[2], bnd[3]) + pick4(q1, sg[0], sg[1], sg[2], sg[3]) * reached(q1);
+    const int e3 = pick4(q3, bnd[0], bnd[1], bnd[2], bnd[3]) + pick4(q3, sg[0], sg[1], sg[2], sg[3]) * reached(q3);
+    const int lo = e1 < e3 ? e1 : e3, hi = e1 < e3 ? e3 : e1;
+    const uint32_t span = range_mask(lo, hi);
+    const int src = active ? at : 0, src_prev = active ? at - sgs : 0;
+    // (every lane takes part in every shuffle: both orientations are fetched, then one is kept)
+    const uint32_t cr = (uint32_t)__shfl((int)col_real, src), rr = (uint32_t)__shfl((int)real, src);
+    const uint32_t cb = (uint32_t)__shfl((int)col_blk, src), rb = (uint32_t)__shfl((int)blk, src);
+    const uint32_t cp = (uint32_t)__shfl((int)col_real, src_prev), rp = (uint32_t)__shfl((int)real, src_prev);
+    const uint32_t w_real = ba ? cr : rr, w_blk = ba ? cb : rb, w_prev = ba ? cp : rp;
+    const uint32_t lr = w_real & span;
+    const unsigned long long blocked = __ballot(active && (w_blk & span) != 0u);
+    const int first_blocked = blocked ? __ffsll((long long)blocked) - 1 : 64;
+    const bool com = active && lane < first_blocked;
+    const int cnt = com ? __builtin_popcount(lr) : 0;
+    int incl = cnt;  // inclusive prefix sum over the lanes
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    const int total = __shfl(incl, 63);
+    if (com) {  // the line's cells in the deque's order: along side s + 1
+      const bool asc = pick4(q1, sg[0], sg[1], sg[2], sg[3]) > 0;
+      uint32_t w = lr;
+      int k = n + incl - cnt;
+      while (w) {
+        const int i = asc ? __builtin_ctz(w) : 31 - __builtin_clz(w);
+        w &= ~(1u << i);
+        int d[3];
+        d[aw] = lw - OV, d[ab] = (ba ? at : i) - OV, d[ar] = (ba ? i : at) - OV;
+        if (k < CELLS) L.cells.c[k] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2], 0};
+        else wk.overflow = 1;
+        ++k;
+      }
+    }
+    n = n + total < CELLS ? n + total : CELLS;
+    // positions left in this batch that had cells on top of the polyhedron when they were left; the sides' new positions
+    int moved[4];
+    CD_UNROLL
+    for (int p = 0; p < 4; ++p) {
+      const int j = (s_next + p) & 3;
+      const unsigned long long mine = __ballot(com && pos == p), left_full = __ballot(com && pos == p && (w_prev & span) != 0u);
+      const int mv = __popcll(mine);
+      if (left_full) {
+        const int turn = ((63 - __builtin_clzll(left_full)) >> 2) + 1;  // the latest of them: the position before that turn's move
+        const int idx = pick4(j, bnd[0], bnd[1], bnd[2], bnd[3]) + pick4(j, sg[0], sg[1], sg[2], sg[3]) * (turn - 1);
+        const int val = pick4(j, sg[0], sg[1], sg[2], sg[3]) * ((pick4(j, bit_axis[0], bit_axis[1], bit_axis[2], bit_axis[3]) ? sb : sr) + idx - OV);
+        CD_UNROLL
+        for (int jj = 0; jj < 4; ++jj)
+          if (jj == j) farc[jj] = val;
+      }
+      CD_UNROLL
+      for (int jj = 0; jj < 4; ++jj)
+        if (jj == j) moved[jj] = mv;
+    }
+    CD_UNROLL
+    for (int j = 0; j < 4; ++j) {
+      if (bit_axis[j]) (sg[j] > 0 ? b1 : b0) += sg[j] * moved[j];
+      else (sg[j] > 0 ? r1 : r0) += sg[j] * moved[j];
+    }
+    if (first_blocked < 64) {
+      const int pf = first_blocked & 3;
+      alive &= ~(1u << ((s_next + pf) & 3));
+      s_next = (s_next + pf + 1) & 3;
+    }
+    // ... and the positions the sides are in now (lanes 0..3 look at sides 0..3)
+    {
+      const int j = lane & 3;
+      const bool bj = pick4(j, bit_axis[0], bit_axis[1], bit_axis[2], bit_axis[3]) != 0;
+      const int sj = pick4(j, sg[0], sg[1], sg[2], sg[3]);
+      const int idx = bj ? (sj > 0 ? b1 : b0) : (sj > 0 ? r1 : r0);
+      const uint32_t wc = (uint32_t)__shfl((int)col_real, idx), wr = (uint32_t)__shfl((int)real, idx);
+      const uint32_t w = bj ? wc : wr;
+      const bool full = (w & (bj ? range_mask(r0, r1) : range_mask(b0, b1))) != 0u;
+      const unsigned long long now_full = __ballot(lane < 4 && full);
+      CD_UNROLL
+      for (int jj = 0; jj < 4; ++jj)
+        if ((now_full >> jj) & 1ull) farc[jj] = sg[jj] * ((bit_axis[jj] ? sb : sr) + (bit_axis[jj] ? (sg[jj] > 0 ? b1 : b0) : (sg[jj] > 0 ? r1 : r0)) - OV);
+    }
+  }
+#ifdef CD_CHECK_BATCH
+  CD_SYNC();
+  {
+    bool bad = ck_n != n || ck_b0 != b0 || ck_b1 != b1 || ck_r0 != r0 || ck_r1 != r1;
+    for (int j = 0; j < 4; ++j) bad = bad || ck_farc[j] != farc[j];
+    int bad_cell = -1;
+    if (lane < OVW)
+      for (int q = 1; q < ck_n && q < n; ++q) {  // (each lane wrote its own cells of the check list: compare those)
+        const Packed a = L.cells.c[q];
+        if (a.x == 0 && a.y == 0 && a.z == 0) continue;
+      }
+    if (bad && lane == 0)
+      fprintf(stderr, "BATCH MISMATCH F %d: n %d / %d, b [%d %d] / [%d %d], r [%d %d] / [%d %d], far %d %d %d %d / %d %d %d %d allow %d %d %d %d s2idx b %d r %d\n", F, n, ck_n, b0, b1, ck_b0,
+              ck_b1, r0, r1, ck_r0, ck_r1, farc[0], farc[1], farc[2], farc[3], ck_farc[0], ck_farc[1], ck_farc[2], ck_farc[3], allow[0], allow[1], allow[2], allow[3],
+              comp(s2, ab) - sb + OV, comp(s2, ar) - sr + OV);
+    (void)bad_cell;
+    if (bad) wk.overflow = 1;  // (the decomposition then fails, and the test with it)
+  }
+#endif
   L.cells.n = n;
   CD_PROF(2);
   CD_UNROLL
@@ -734,12 +901,14 @@ CD_INLINE CD_HD void find_corners_impl(const Ctx& cx, const G& g, int f, bool gr
   }
   Work& wk = *cx.wk;
   int allow[4];
-  allowance(wk.fr, f, face, edges, allow, out);
+  allowance(wk.fr, f, face, edges, allow);
   const double area = span_area(allow);
   Layer& L = wk.L2;
   // (whether a seed was found is the function's value, not L.found: in the cooperative mode a lane must not depend on when
   // another lane starts the next layer)
-  if (!grow_layer<G, COOP>(cx, g, f, face, allow, mark, 0, L)) return;
+  const bool layer_found = grow_layer<G, COOP>(cx, g, f, face, allow, mark, 0, L);
+  edges_of_face(wk.fr, f, edges, out);
+  if (!layer_found) return;
   int ext[4];
   layer_extent(cx, f, L, ext);
   if (span_area(ext) < area / 2) valid = false;
@@ -822,13 +991,14 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
 
     int allow[4];
     Edge trial[4];
-    allowance(fr, f, faces[f], edges, allow, trial);
+    allowance(fr, f, faces[f], edges, allow);
     Layer& L = wk.L;
     CD_PROF(4);
     const bool layer_found = grow_layer<G, COOP>(cx, g, f, faces[f], allow, mark, aware ? 0 : 1, L);
     if (wk.overflow) return CD_WORK_OVERFLOW;
     CD_PROF(11);  // (the layer itself: phases 0..3 lie inside)
     if (!layer_found) continue;
+    edges_of_face(fr, f, edges, trial);
 
     bool soft = true;  // shape-aware variant: layer acceptable this turn
     if (aware) {

@@ -1541,8 +1541,37 @@ HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int la
   unsigned flags = 0;
   const bool own = (a.split_info[2 * inst] & 2) != 0;  // pass 1 left an incumbent in the instance's own outputs
   double obj = DINF;
-  for (int r = a.split_info[2 * inst + 1]; r >= 0; r = a.recs[r].next) {  // the record of pass 1 and those of the items that handed over again
+  // The records of this instance — the one of pass 1 and those of the items that handed over again — are a chain through
+  // SplitRec::next: walking it is one dependent global round trip per record (0.1 - 0.2 ms per launch in the pillar forest, where an
+  // instance leaves dozens of records). On the device the lanes look at ALL records of the launch instead (their `inst` words: independent
+  // loads), list the matching ones in LDS, and only then go through them; the chain is walked when the list does not fit.
+  constexpr int LIST = 256;
+  int n_list = -1;  // -1: walk the chain
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ int32_t rec_list[LIST];
+  if (lanes == 64) {
+    const int taken = a.rec_count[0], R = taken < a.rec_cap ? taken : a.rec_cap;
+    n_list = 0;
+    for (int base = 0; base < R && n_list <= LIST; base += 64) {
+      const int r = base + lane;
+      const bool mine = r < R && a.recs[r].inst == inst;
+      const unsigned long long m = __ballot(mine);
+      if (mine) {
+        const int at = n_list + __popcll(m & ((1ull << lane) - 1ull));
+        if (at < LIST) rec_list[at] = r;
+      }
+      n_list += __popcll(m);
+    }
+    __syncthreads();
+    if (n_list > LIST) n_list = -1;
+  }
+#endif
+  for (int q = 0, r = n_list < 0 ? a.split_info[2 * inst + 1] : -1; n_list < 0 ? r >= 0 : q < n_list; ++q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (n_list >= 0) r = rec_list[q];
+#endif
     const SplitRec& rc = a.recs[r];
+    const int r_next = n_list < 0 ? rc.next : -1;
     if (rc.truncated) lim = 1, flags |= (unsigned)FLAG_NODE_LIMIT;
     for (int g = rc.first_item + lane; g < rc.first_item + rc.n_items; g += lanes) {
       const int st = b.status[g];
@@ -1557,6 +1586,7 @@ HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int la
       lim |= st == ST_LIMIT || (b.st_flags[g] & (FLAG_NODE_LIMIT | FLAG_ITER_LIMIT | FLAG_TIME_LIMIT | FLAG_STAGING_OVERFLOW)) != 0;
       if (st != ST_NO_SOLUTION && (b.obj[g] < obj || (b.obj[g] == obj && best >= 0 && g < best))) obj = b.obj[g], best = g;
     }
+    r = r_next;
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (lanes > 1) {

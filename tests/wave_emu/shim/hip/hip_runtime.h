@@ -217,6 +217,20 @@ inline int __shfl_xor(int v, int mask, int width = 64) {
   const int src = me ^ mask;
   return (src / width == me / width) ? wemu::my_wave().xi[p][src] : v;
 }
+inline int __shfl(int v, int src, int width = 64) {
+  wemu::Wave& w = wemu::my_wave();
+  const int me = wemu::lane();
+  w.xi[w.parity][me] = v;
+  const int p = wemu::rendezvous(4);
+  return wemu::my_wave().xi[p][(me & ~(width - 1)) | (src & (width - 1))];
+}
+inline int __shfl_up(int v, int delta, int width = 64) {
+  wemu::Wave& w = wemu::my_wave();
+  const int me = wemu::lane();
+  w.xi[w.parity][me] = v;
+  const int p = wemu::rendezvous(4);
+  return (me & (width - 1)) >= delta ? wemu::my_wave().xi[p][me - delta] : v;
+}
 inline double __shfl_xor(double v, int mask, int width = 64) {
   wemu::Wave& w = wemu::my_wave();
   const int me = wemu::lane();
