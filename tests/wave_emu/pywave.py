@@ -74,10 +74,19 @@ def solve(prm, state, ref, n_poly, n_rows, A, b, threads=64):
     return out
 
 
-def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32):
+_lib_t2 = None
+
+
+def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42, res=0.3, max_rows=32, short_batches=False):
     """The cooperative voxel decomposition (corridor_wave.h: one wavefront per seed) run on the CPU; arguments and results of
-    multi_agent_pkgs_amd.lib.poly_octa3d_batch(..., wave=True)."""
+    multi_agent_pkgs_amd.lib.poly_octa3d_batch(..., wave=True). short_batches: the build whose rim-move batches hold two turns."""
+    global _lib_t2
     L = lib()
+    if short_batches:
+        if _lib_t2 is None:
+            _lib_t2 = C.CDLL(os.path.join(_HERE, "libhdsm_corridor_emu_t2.so"))
+            _lib_t2.wave_last_error.restype = C.c_char_p
+        L = _lib_t2
     world = np.ascontiguousarray(world, dtype=np.int8)
     wdim = np.asarray(world.shape[::-1], dtype=np.int32)
     ldim = np.asarray(ldim, dtype=np.int32)
