@@ -393,20 +393,22 @@ struct Ctx {
 // how far the next layer of face f may extend on each side, given the chamfers already started (CD:71-91)
 // (the edges' state is read where it lies; the working copies `trial` of the four edges are taken by the caller AFTER the layer
 // has been grown — 40 words that would otherwise be live, in registers, across the whole in-plane growth)
-CD_HD void allowance(const Frame* fr, int f, const FaceState& fs, const Edge* edges, int allow[4]) {
+// (`fv`: the frame of face f BY VALUE — the caller reads it once per turn, all twenty-four words together, instead of a chain of
+// dependent LDS reads frame -> edge index -> edge at every use)
+CD_HD void allowance(const Frame& fv, int f, const FaceState& fs, const Edge* edges, int allow[4]) {
   CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     allow[j] = fs.reach[j];
-    const Edge& e = edges[fr[f].edge[j]];
+    const Edge& e = edges[fv.edge[j]];
     if (e.slope > 0) {
       if (e.dir == f) allow[j] -= e.slope;                         // our layers retreat `slope` voxels each
       else if (e.fixed && e.steps >= e.slope) allow[j] -= 1;       // the other face's stair is complete: step in
     }
   }
 }
-CD_HD void edges_of_face(const Frame* fr, int f, const Edge* edges, Edge trial[4]) {
+CD_HD void edges_of_face(const Frame& fv, const Edge* edges, Edge trial[4]) {
   CD_UNROLL
-  for (int j = 0; j < 4; ++j) trial[j] = edges[fr[f].edge[j]];
+  for (int j = 0; j < 4; ++j) trial[j] = edges[fv.edge[j]];
 }
 
 #if CD_HAS_COOP
@@ -863,9 +865,9 @@ CD_HD double span_area(const int l[4]) {
 // extents of the grown layer as the reference reads them for its area test (CD:816-820): the front cell of every
 // side. A side without layer cells has no front in the reference (it reads an empty deque there); the last known
 // front (border_limit_tmp) stands in for it.
-CD_HD void layer_extent(const Ctx& cx, int f, const Layer& L, int ext[4]) {
+CD_HD void layer_extent(const Ctx& cx, const Frame& fv, const Layer& L, int ext[4]) {
   CD_UNROLL
-  for (int j = 0; j < 4; ++j) ext[j] = dot(cx.empty(L.rim_real[j]) ? L.far[j] : cx.front(L.rim_real[j]), cx.wk->fr[f].side[j]);
+  for (int j = 0; j < 4; ++j) ext[j] = dot(cx.empty(L.rim_real[j]) ? L.far[j] : cx.front(L.rim_real[j]), fv.side[j]);
 }
 
 // SideIsEmpty, CD:577-588 (GetVoxel: outside the grid = occupied; any positive value, potential field included, counts)
@@ -900,22 +902,23 @@ CD_INLINE CD_HD void find_corners_impl(const Ctx& cx, const G& g, int f, bool gr
     return;
   }
   Work& wk = *cx.wk;
+  const Frame fv = wk.fr[f];
   int allow[4];
-  allowance(wk.fr, f, face, edges, allow);
+  allowance(fv, f, face, edges, allow);
   const double area = span_area(allow);
   Layer& L = wk.L2;
   // (whether a seed was found is the function's value, not L.found: in the cooperative mode a lane must not depend on when
   // another lane starts the next layer)
   const bool layer_found = grow_layer<G, COOP>(cx, g, f, face, allow, mark, 0, L);
-  edges_of_face(wk.fr, f, edges, out);
+  edges_of_face(fv, edges, out);
   if (!layer_found) return;
   int ext[4];
-  layer_extent(cx, f, L, ext);
+  layer_extent(cx, fv, L, ext);
   if (span_area(ext) < area / 2) valid = false;
   CD_UNROLL
   for (int j = 0; j < 4; ++j) {
     if (cx.empty(L.rim_real[j])) continue;
-    const int gap = face.reach[j] - dot(cx.front(L.rim_real[j]), wk.fr[f].side[j]);
+    const int gap = face.reach[j] - dot(cx.front(L.rim_real[j]), fv.side[j]);
     if (out[j].slope == 0 && gap > 0) {
       out[j].slope = out[j].steps = gap;
       if (gap > 1) out[j].dir = f;
@@ -987,23 +990,24 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     const int f = it % 6;
     if (!((growing >> f) & 1u)) continue;
     const Cell up = normal_of(f);
-    const Cell* sd = fr[f].side;
+    const Frame fv = fr[f];  // (by value: see allowance)
+    const Cell* sd = fv.side;
 
     int allow[4];
     Edge trial[4];
-    allowance(fr, f, faces[f], edges, allow);
+    allowance(fv, f, faces[f], edges, allow);
     Layer& L = wk.L;
     CD_PROF(4);
     const bool layer_found = grow_layer<G, COOP>(cx, g, f, faces[f], allow, mark, aware ? 0 : 1, L);
     if (wk.overflow) return CD_WORK_OVERFLOW;
     CD_PROF(11);  // (the layer itself: phases 0..3 lie inside)
     if (!layer_found) continue;
-    edges_of_face(fr, f, edges, trial);
+    edges_of_face(fv, edges, trial);
 
     bool soft = true;  // shape-aware variant: layer acceptable this turn
     if (aware) {
       int ext[4];
-      layer_extent(cx, f, L, ext);
+      layer_extent(cx, fv, L, ext);
       if (span_area(ext) < span_area(allow) / 2) soft = false;
     }
 
@@ -1020,7 +1024,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       const int gap = faces[f].reach[j] - dot(c, sd[j]);  // voxels this layer falls short of the last one
       if (e.slope == 0) {
         if (gap > 0) {  // a chamfer starts here: a point of its plane, between this layer and the neighbouring face
-          const Cell nb = normal_of(fr[f].face[j]);
+          const Cell nb = normal_of(fv.face[j]);
           const double extra = aware ? res / 2 : 0.0;  // (CD:836-848 adds res/2 twice)
           // (written as the reference writes it: products first, then left-to-right sums; no contraction)
           const double h = res / 2;
@@ -1049,7 +1053,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
           else e.steps += 1;
         }
       } else if (e.dir == -1) {           // slope 1 so far, long direction still open
-        if (gap == 0) e.dir = fr[f].face[j], e.steps += 1, e.slope += 1;
+        if (gap == 0) e.dir = fv.face[j], e.steps += 1, e.slope += 1;
         else if (gap == 1) e.fixed = 1;
         else accept = false;
       } else if (e.dir == f) {            // first layer after our own multi-voxel retreat fixes the slope
@@ -1074,7 +1078,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       for (int j = 0; j < 4; ++j) {
         if (!fresh[j]) continue;
         const bool first = side_is_empty(cx, g, L.rim_real[j], up);
-        const int nbf = fr[f].face[j], ci = fr[f].back[j];
+        const int nbf = fv.face[j], ci = fv.back[j];
         bool second = true;
         if (fresh[j] == 1) {
           int e_end = RIM0;  // the neighbouring face's cells along the shared edge
@@ -1107,7 +1111,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
         for (int k = 0; k < 12; ++k) edges_t[k] = edges[k];
         CD_UNROLL
         for (int j = 0; j < 4; ++j)
-          if (!fresh[j]) edges_t[fr[f].edge[j]] = trial[j];
+          if (!fresh[j]) edges_t[fv.edge[j]] = trial[j];
         bool valid = true;
         Edge fin[4];
         // (the out-of-line calls get copies of the context and the grid: the originals stay in registers instead of moving to
@@ -1130,11 +1134,11 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
             auto pick = [](int j, int a0, int a1, int a2, int a3) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3)); };
             for (int j = 0; j < 4; ++j) {
               if (pick(j, fresh[0], fresh[1], fresh[2], fresh[3]) != 1) continue;
-              const int nbf = fr[f].face[j];
+              const int nbf = fv.face[j];
               bool v2 = true;
               Edge fin2[4];
               find_corners<G, COOP>(cx_call, g_call, nbf, ((growing >> nbf) & 1u) != 0, faces[nbf], edges, mark, v2, fin2);
-              const int nb_slope = pick(fr[f].back[j], fin2[0].slope, fin2[1].slope, fin2[2].slope, fin2[3].slope);
+              const int nb_slope = pick(fv.back[j], fin2[0].slope, fin2[1].slope, fin2[2].slope, fin2[3].slope);
               if (v2 && nb_slope == 0 && pick(j, fin[0].slope, fin[1].slope, fin[2].slope, fin[3].slope) == 0) {
                 expand = false;
                 break;
@@ -1152,14 +1156,14 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     CD_UNROLL
     for (int j = 0; j < 4; ++j) {
       faces[f].reach[j] = dot(L.far[j], sd[j]);
-      edges[fr[f].edge[j]] = trial[j];
+      edges[fv.edge[j]] = trial[j];
       // full-width side on a square edge: these voxels are now also the outermost layer of the neighbouring face
       if (trial[j].slope == 0 && !cx.empty(L.rim_real[j]) && faces[f].reach[j] == dot(cx.front(L.rim_real[j]), sd[j])) {
-        const int nbf = fr[f].face[j];
+        const int nbf = fv.face[j];
         cx.append(faces[nbf].outer, L.rim_real[j]);
-        const int reach_nb = faces[nbf].reach[fr[f].back[j]] + 1;
+        const int reach_nb = faces[nbf].reach[fv.back[j]] + 1;
         if constexpr (COOP) CD_SYNC();
-        faces[nbf].reach[fr[f].back[j]] = reach_nb;
+        faces[nbf].reach[fv.back[j]] = reach_nb;
       }
     }
     anchor[f] = cx.at(L.cells, 0);

@@ -62,7 +62,7 @@ __device__ inline void build_world_maps(const WindowGrid& g, const WaveLds& m, i
     const int v = c.z < g.ground_k ? kOccupied : (!in_world ? 0 : (raw < 0 ? kOccupied : raw));  // WindowGrid::world_value
     return (v < kOccupied ? 1u : 0u) | (v > 0 ? 2u : 0u);
   };
-  constexpr int B = 8;  // rows per batch
+  constexpr int B = 10;  // rows per batch (19 rows for n_it = 42: two batches; every slot costs its instructions whether a row is wanted or not, and larger batches were slower)
   for (int dz0 = OV - r; dz0 <= OV + r; dz0 += 2) {
     const int dz = dz0 + half;
     const int cz = g.seed.z + dz - OV;
