@@ -193,7 +193,6 @@ struct WindowGrid {
   uint32_t* bits_t = nullptr;
   int map_r = 0;
   static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32, MAP_WORDS = 3 * WORDS;
-  static constexpr bool kAtomicMarks = true;  // set_atomic / unset_atomic exist (cooperative mode)
   static constexpr bool kHasPlanes = true;    // maps / bits_t may be there
   CD_HD int nx() const { return lnx; }
   CD_HD int ny() const { return lny; }
@@ -243,13 +242,7 @@ struct WindowGrid {
     if (bits_t) bits_t[dx + OVW * dz] &= ~(1u << dy);
   }
 #if defined(__HIP_DEVICE_COMPILE__) || defined(CD_EMU_COOP)
-  // cooperative mode (Ctx::coop): the lanes of a wavefront mark different voxels at once, in both copies of the overlay
-  __device__ void set_atomic(Cell c) const {
-    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
-    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
-    atomicOr(&bits[dy + OVW * dz], 1u << dx);
-    if (bits_t) atomicOr(&bits_t[dx + OVW * dz], 1u << dy);
-  }
+  // cooperative mode: the lanes of a wavefront mark different voxels of a layer at once (decompose_core, mark_cells) —
   // one copy only: the x-fast one (bits) or the y-fast one (bits_t)
   __device__ void mark_atomic(Cell c, bool on, bool x_fast) const {
     const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
@@ -258,12 +251,6 @@ struct WindowGrid {
     const uint32_t b = 1u << (x_fast ? dx : dy);
     if (on) atomicOr(w, b);
     else atomicAnd(w, ~b);
-  }
-  __device__ void unset_atomic(Cell c) const {
-    const int dx = c.x - seed.x + OV, dy = c.y - seed.y + OV, dz = c.z - seed.z + OV;
-    if (dx < 0 || dy < 0 || dz < 0 || dx >= OVW || dy >= OVW || dz >= OVW) return;
-    atomicAnd(&bits[dy + OVW * dz], ~(1u << dx));
-    if (bits_t) atomicAnd(&bits_t[dx + OVW * dz], ~(1u << dy));
   }
 #endif
   CD_HD int count() const {
@@ -554,6 +541,7 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
   // (test builds of tests/wave_emu only: the moves one after the other, as rounds 5's first version made them, for comparison)
   int ck_n = 1, ck_b0 = b0, ck_b1 = b1, ck_r0 = r0, ck_r1 = r1, ck_farc[4];
   Packed ck_cells[CELLS];
+  bool ck_mine[CELLS] = {false};
   {
     bool alive_[4] = {true, true, true, true}, nonempty[4] = {true, true, true, true};
     for (int j = 0; j < 4; ++j) ck_farc[j] = farc[j];
@@ -579,7 +567,7 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
           const int rank = asc ? __builtin_popcount(lr & ((1u << lane) - 1u)) : __builtin_popcountll((unsigned long long)lr >> (lane + 1));
           int d[3];
           d[aw] = lw - OV, d[ab] = (ba ? at : lane) - OV, d[ar] = (ba ? lane : at) - OV;
-          if (ck_n + rank < CELLS) ck_cells[ck_n + rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2], 0};
+          if (ck_n + rank < CELLS) ck_cells[ck_n + rank] = Packed{(int8_t)d[0], (int8_t)d[1], (int8_t)d[2], 0}, ck_mine[ck_n + rank] = true;
         }
         ck_n += __builtin_popcount(lr);
         if (ba) (sg[s] > 0 ? ck_b1 : ck_b0) = at;
@@ -720,17 +708,18 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
   {
     bool bad = ck_n != n || ck_b0 != b0 || ck_b1 != b1 || ck_r0 != r0 || ck_r1 != r1;
     for (int j = 0; j < 4; ++j) bad = bad || ck_farc[j] != farc[j];
-    int bad_cell = -1;
+    // (the cells of the check list: every lane wrote the ones of its own rows / columns, and compares those)
     if (lane < OVW)
-      for (int q = 1; q < ck_n && q < n; ++q) {  // (each lane wrote its own cells of the check list: compare those)
-        const Packed a = L.cells.c[q];
-        if (a.x == 0 && a.y == 0 && a.z == 0) continue;
+      for (int q = 1; q < ck_n && q < n && q < CELLS; ++q) {
+        const Packed a = L.cells.c[q], b = ck_cells[q];
+        const int own = lane - OV;  // this lane's row or column offset
+        if ((b.x == own || b.y == own || b.z == own) && ck_mine[q] && (a.x != b.x || a.y != b.y || a.z != b.z)) bad = true;
       }
+    bad = __ballot(bad) != 0ull;
     if (bad && lane == 0)
       fprintf(stderr, "BATCH MISMATCH F %d: n %d / %d, b [%d %d] / [%d %d], r [%d %d] / [%d %d], far %d %d %d %d / %d %d %d %d allow %d %d %d %d s2idx b %d r %d\n", F, n, ck_n, b0, b1, ck_b0,
               ck_b1, r0, r1, ck_r0, ck_r1, farc[0], farc[1], farc[2], farc[3], ck_farc[0], ck_farc[1], ck_farc[2], ck_farc[3], allow[0], allow[1], allow[2], allow[3],
               comp(s2, ab) - sb + OV, comp(s2, ar) - sr + OV);
-    (void)bad_cell;
     if (bad) wk.overflow = 1;  // (the decomposition then fails, and the test with it)
   }
 #endif
@@ -769,7 +758,7 @@ CD_INLINE __device__ inline bool grow_layer_wave(const Ctx& cx, const G& g, int 
 // One layer on top of face f: a free 2-D seed above the current outer layer, inside the allowance and inside voxels
 // [1, dim - 1 - margin] (CD:94-116: margin 1; CD:700-723: margin 0), grown in its plane (CD:118-200).
 // Grid G: nx(), ny(), nz(), inside(Cell), value(Cell) (the voxel, `mark` where the polyhedron already is), set(Cell, v),
-// trial_set / trial_unset, and kAtomicMarks (true: set_atomic / unset_atomic for the cooperative mode).
+// trial_set / trial_unset, and kHasPlanes (true: the cooperative mode's bit maps and mark_atomic may be there).
 template <class G>
 CD_NOINLINE CD_HD bool grow_layer_serial(const Ctx& cx, const G& g, int f, const FaceState& fs, const int allow[4], int mark, int margin, Layer& L) {
   Work& wk = *cx.wk;

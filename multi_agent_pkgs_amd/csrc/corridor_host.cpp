@@ -14,7 +14,6 @@ using namespace hdsm_cd;
 
 // a caller-owned int8 grid, marks written in place (the contract of hdsm_poly_octa3d)
 struct ArrayGrid {
-  [[maybe_unused]] static constexpr bool kAtomicMarks = false;
   [[maybe_unused]] static constexpr bool kHasPlanes = false;
   int8_t* data;
   int dx, dy, dz;
