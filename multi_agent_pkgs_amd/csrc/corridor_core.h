@@ -52,8 +52,9 @@ namespace hdsm_cd {
 constexpr int kOccupied = 100;  // CVX_DCMP_OCC (convex_decomp.hpp:11): values below it are free
 constexpr int CELLS = 768;      // capacity of a face's outermost layer (a layer is at most (2 n_it / 6 + 1)^2 voxels plus the
                                 // rows neighbouring faces hand over: 435 for n_it = 42, 700 for n_it = 54)
-constexpr int RIM = 160;        // capacity of one side of a growing layer (deque with room at both ends)
-constexpr int RIM0 = 64;        // where an empty deque starts inside its buffer
+constexpr int RIM = 96;         // capacity of one side of a growing layer (deque with room at both ends: a side is at most 2 n_it / 6 + 1
+                                // cells long and grows by as much at either end — 31 + 2 x 31 for n_it = 78, beyond which CELLS overflows first)
+constexpr int RIM0 = 32;        // where an empty deque starts inside its buffer
 
 enum { CD_OK = 0, CD_BAD_ARG = -1, CD_CAPACITY = -4, CD_WORK_OVERFLOW = -6 };
 
@@ -158,7 +159,7 @@ struct Work {
   Frame fr[6];
   FaceState faces[6], face_t;  // face_t: the face under trial with its new layer as outermost layer (CD:978-1066)
   Layer L, L2;
-  CellDeque rim[4], moved, moved_real, edge_row;
+  CellDeque edge_row;
   Edge edges[12], edges_t[12];
   Cell anchor[6];  // a voxel of each face's outermost layer (gives the face plane)
 #ifdef CD_PROFILE
@@ -168,6 +169,9 @@ struct Work {
   uint32_t seed_plane[32];  // cooperative mode: where a 2-D seed may lie, rows of a bit plane (one word per lane)
   Cell seed;
   int overflow;
+  // the serial form's rim deques, LAST: the cooperative form does not use them, and its LDS layout puts the y-fast copy of the
+  // overlay over them (corridor_wave.h, WaveLds)
+  CellDeque rim[4], moved, moved_real;
 };
 
 // The local voxel grid of one agent as a window into a WORLD grid (what env_builder's GenerateVoxelGridMSG cuts out,
@@ -185,11 +189,13 @@ struct WindowGrid {
   uint32_t* bits;      // overlay over offsets [-OV, OV)^3 from the seed: word dy + OVW * dz, bit dx ("x-fast")
   // optional (cooperative mode of the device: built by the whole wavefront in LDS, build_world_maps): bit maps of the world under
   // the overlay, same indexing, for the offsets |d| <= map_r from the seed —
-  //   maps[0 .. WORDS)            FREE, x-fast: inside the local grid and a value below kOccupied
-  //   maps[WORDS .. 2 WORDS)      POS,  x-fast: outside the local grid or a value above 0 (what SideIsEmpty tests, CD:577-588)
-  //   maps[2 WORDS .. 3 WORDS)    FREE, y-fast: word dx + OVW * dz, bit dy
+  //   maps       FREE, x-fast: inside the local grid and a value below kOccupied
+  //   maps_pos   POS,  x-fast: outside the local grid or a value above 0 (what SideIsEmpty tests, CD:577-588)
+  //   maps_t     FREE, y-fast: word dx + OVW * dz, bit dy
+  // (each array holds the 2 map_r + 1 z-levels that are classified only; the pointers are moved back by the words of the levels
+  // below them, so that the index is the overlay's — never dereferenced outside those levels)
   // and a y-fast copy of the overlay (bits_t). With them a whole plane of voxels is 32 words — one per lane (grow_layer_planes).
-  const uint32_t* maps = nullptr;
+  const uint32_t *maps = nullptr, *maps_pos = nullptr, *maps_t = nullptr;
   uint32_t* bits_t = nullptr;
   int map_r = 0;
   static constexpr int OV = 16, OVW = 32, WORDS = OVW * OVW * OVW / 32, MAP_WORDS = 3 * WORDS;
@@ -223,7 +229,7 @@ struct WindowGrid {
         // (the decomposition compares values with kOccupied, with 0 and with the mark only: the two bits are enough; callers test
         // inside() before they look at a value, FREE already holds it)
         if (!((maps[w] >> dx) & 1u)) return kOccupied;
-        return (maps[WORDS + w] >> dx) & 1u;
+        return (maps_pos[w] >> dx) & 1u;
       }
     }
     return world_value(c);
@@ -435,11 +441,11 @@ CD_INLINE __device__ inline bool grow_layer_wave_f(const Ctx& cx, const G& g, co
   for (int j = 0; j < 4; ++j) bit_axis[j] = comp(sd[j], ab) != 0, sg[j] = comp(sd[j], ab) + comp(sd[j], ar);
   auto range_mask = [](int lo, int hi) { return lo > hi ? 0u : (uint32_t)(((1ull << (hi + 1)) - 1ull) & ~((1ull << lo) - 1ull)); };
   const uint32_t* mk = aw == 0 ? g.bits_t : g.bits;
-  const uint32_t* fr = aw == 0 ? g.maps + 2 * G::WORDS : g.maps;
+  const uint32_t* fr = aw == 0 ? g.maps_t : g.maps;
   uint32_t real = 0, blk = 0, free_t = 0;
   auto load_rows = [&](int lw) {  // the planes at level lw (and the level below it)
     real = blk = free_t = 0;
-    if (lane < OVW) {
+    if (lane < OVW && (aw == 2 || (lane >= lo_ok && lane <= hi_ok))) {  // (aw != 2: the lane is the row's z-level — only classified levels exist)
       const int lb = lw - su;
       const int wt = aw == 2 ? lane + OVW * lw : lw + OVW * lane, wb = aw == 2 ? lane + OVW * lb : lb + OVW * lane;
       const uint32_t below = mk[wb];

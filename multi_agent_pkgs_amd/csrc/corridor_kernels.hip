@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_poly_octa3d(Batch b) {
 // decomposition run cooperatively by the 64 lanes (corridor_wave.h, corridor_core.h Ctx::coop) — the form the device-resident
 // swarm loop uses inside its corridor kernel, where one agent's decompositions are a latency chain. Lower latency per seed,
 // fewer seeds in flight; same rows, bit for bit (tests/test_gpu_configs.py).
-static_assert(WAVE_LDS_BYTES + 1024 <= 64 * 1024, "k_poly_octa3d_wave: LDS exceeds the default 64 KB limit of a launch");
+static_assert(WAVE_LDS_MAX + 1024 <= 64 * 1024, "k_poly_octa3d_wave: LDS exceeds the default 64 KB limit of a launch");
 
 __global__ __launch_bounds__(64) void k_poly_octa3d_wave(Batch b) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -135,7 +135,7 @@ static int launch_batch(bool wave, int32_t device, int32_t n, const int8_t* worl
   b.n = n, b.n_it = n_it, b.max_rows = max_rows, b.res = res;
   b.off = off, b.ground = ground_k, b.seed = seed, b.variant = variant, b.origin = origin;
   b.rows = rows, b.n_rows = n_rows, b.rc = rc, b.cells = cells, b.scratch = static_cast<unsigned char*>(scratch);
-  if (wave) hipLaunchKernelGGL(k_poly_octa3d_wave, dim3(n), dim3(64), WAVE_LDS_BYTES, static_cast<hipStream_t>(hip_stream), b);
+  if (wave) hipLaunchKernelGGL(k_poly_octa3d_wave, dim3(n), dim3(64), wave_lds_bytes(wave_map_radius(n_it)), static_cast<hipStream_t>(hip_stream), b);
   else hipLaunchKernelGGL(k_poly_octa3d, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(hip_stream), b);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(HDSM_ERR_DEVICE, std::string("k_poly_octa3d: ") + hipGetErrorString(e));

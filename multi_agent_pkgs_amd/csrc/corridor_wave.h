@@ -17,22 +17,30 @@ CD_HD bool seed_is_pinched(const WindowGrid& g, Cell s) {
 }
 
 #if defined(__HIPCC__) || defined(CD_EMU_COOP)
-// LDS of one cooperative decomposition: the workspace, the overlay in its two orientations, the world maps
-constexpr size_t WAVE_WORK_BYTES = ((sizeof(Work) + 15) / 16) * 16;
-constexpr int WAVE_ROWS = 32;  // room for the rows of one polyhedron (the swarm loop's corridor kernel collects them here)
-constexpr size_t WAVE_LDS_BYTES = WAVE_WORK_BYTES + (2 * WindowGrid::WORDS + WindowGrid::MAP_WORDS) * 4 + WAVE_ROWS * 4 * 8;
+// LDS of one cooperative decomposition: the workspace with the y-fast copy of the overlay laid over its last members (the serial
+// form's rim deques, which the cooperative form does not use), the rows of one polyhedron, the overlay, and the world maps for the
+// 2 r + 1 z-levels a decomposition of n_it turns looks at.
+constexpr int WAVE_ROWS = 32;  // room for the rows of one polyhedron (HDSM_MAX_ROWS_STATIC) (the swarm loop's corridor kernel collects them here)
+constexpr size_t WAVE_BITS_T_AT = offsetof(Work, rim);
+static_assert(WAVE_BITS_T_AT % 16 == 0 || WAVE_BITS_T_AT % 4 == 0, "the overlay copy starts on a word");
+constexpr size_t WAVE_HEAD_BYTES = (((WAVE_BITS_T_AT + WindowGrid::WORDS * 4 > sizeof(Work) ? WAVE_BITS_T_AT + WindowGrid::WORDS * 4 : sizeof(Work)) + 15) / 16) * 16;
+constexpr size_t wave_lds_bytes(int r) {  // r = wave_map_radius(n_it); 0: no maps (the plain form on lane 0)
+  return WAVE_HEAD_BYTES + WAVE_ROWS * 4 * 8 + WindowGrid::WORDS * 4 + (size_t)(r > 0 ? 3 * (2 * r + 1) * WindowGrid::OVW * 4 : 0);
+}
+constexpr size_t WAVE_LDS_MAX = wave_lds_bytes(WindowGrid::OV - 1);
 struct WaveLds {
   Work* wk;
   double* rows;
-  uint32_t *bits, *bits_t, *maps;
+  uint32_t *bits, *bits_t, *maps;  // maps: 3 x (2 r + 1) x OVW words, in the order FREE x-fast, POS x-fast, FREE y-fast
   __device__ explicit WaveLds(unsigned char* lds)
-      : wk(reinterpret_cast<Work*>(lds)), rows(reinterpret_cast<double*>(lds + WAVE_WORK_BYTES)),
-        bits(reinterpret_cast<uint32_t*>(lds + WAVE_WORK_BYTES + WAVE_ROWS * 4 * 8)), bits_t(bits + WindowGrid::WORDS), maps(bits_t + WindowGrid::WORDS) {}
+      : wk(reinterpret_cast<Work*>(lds)), rows(reinterpret_cast<double*>(lds + WAVE_HEAD_BYTES)),
+        bits(reinterpret_cast<uint32_t*>(lds + WAVE_HEAD_BYTES + WAVE_ROWS * 4 * 8)), bits_t(reinterpret_cast<uint32_t*>(lds + WAVE_BITS_T_AT)),
+        maps(bits + WindowGrid::WORDS) {}
 };
 
 // how far from the seed a decomposition of n_it turns looks: n_it / 6 layers per face (rounded up), the layer on top of the last
 // one, and SideIsEmpty one voxel beyond that; 0 = more than the overlay holds (no maps: the plain cooperative form runs)
-__device__ inline int wave_map_radius(int n_it) {
+__host__ __device__ inline int wave_map_radius(int n_it) {
   const int r = (n_it + 5) / 6 + 2;
   return r <= WindowGrid::OV - 1 ? r : 0;
 }
@@ -42,8 +50,13 @@ __device__ inline int wave_map_radius(int n_it) {
 // halves of a ballot, the y-fast words accumulate in the lane while it walks along y.
 __device__ inline void build_world_maps(const WindowGrid& g, const WaveLds& m, int r, int lane) {
   constexpr int OV = WindowGrid::OV, OVW = WindowGrid::OVW, WORDS = WindowGrid::WORDS;
-  for (int w = lane; w < 2 * WORDS; w += 64) m.bits[w] = 0u;  // bits and bits_t are contiguous
-  if (r <= 0) return;
+  for (int w = lane; w < WORDS; w += 64) m.bits[w] = 0u;
+  if (r <= 0) return;  // (no maps and no second copy of the overlay: where it would lie the plain form keeps its deques)
+  for (int w = lane; w < WORDS; w += 64) m.bits_t[w] = 0u;
+  const int levels = 2 * r + 1;
+  uint32_t* const map_free = m.maps - OVW * (OV - r);  // indexed like the overlay, see WindowGrid
+  uint32_t* const map_pos = map_free + OVW * levels;
+  uint32_t* const map_free_t = map_pos + OVW * levels;
   const int lx = lane & 31, half = lane >> 5;
   const int cx = g.seed.x + lx - OV;
   const bool x_in = lx >= OV - r && lx <= OV + r;
@@ -81,14 +94,14 @@ __device__ inline void build_world_maps(const WindowGrid& g, const WaveLds& m, i
         const unsigned long long bf = __ballot(cls & 1u), bp = __ballot(cls & 2u);
         if (dy <= OV + r) {
           if (lx == 0 && z_in) {
-            m.maps[dy + OVW * dz] = (uint32_t)(bf >> (32 * half));
-            m.maps[WORDS + dy + OVW * dz] = (uint32_t)(bp >> (32 * half));
+            map_free[dy + OVW * dz] = (uint32_t)(bf >> (32 * half));
+            map_pos[dy + OVW * dz] = (uint32_t)(bp >> (32 * half));
           }
           fy |= (cls & 1u) << dy;
         }
       }
     }
-    if (z_in) m.maps[2 * WORDS + lx + OVW * dz] = fy;
+    if (z_in) map_free_t[lx + OVW * dz] = fy;
   }
 }
 
@@ -122,7 +135,8 @@ __device__ inline int wave_decompose(WindowGrid g, const WaveLds& m, int variant
     *n_rows = (int)m.wk->seed_plane[1];
     return (int)m.wk->seed_plane[0];
   }
-  g.maps = m.maps, g.bits_t = m.bits_t, g.map_r = r;
+  g.maps = m.maps - WindowGrid::OVW * (WindowGrid::OV - r), g.maps_pos = g.maps + WindowGrid::OVW * (2 * r + 1), g.maps_t = g.maps_pos + WindowGrid::OVW * (2 * r + 1);
+  g.bits_t = m.bits_t, g.map_r = r;
   const int rc_wave = decompose_core<WindowGrid, true>(g, *m.wk, variant, g.seed, n_it, res, g.mark, origin, rows, max_rows, n_rows, lane);
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
   __syncthreads();

@@ -63,7 +63,7 @@ constexpr int PTS = hdsm_sw::PATH_PTS + 1;  // points of a reference polyline ha
 // scratch of one agent's voxel decompositions, in LDS (dynamic shared memory of k_corridor): the workspace, the overlay bits and
 // the 2-bit cache of the world under the overlay. The decomposition is one lane's chain of small dependent accesses — in global
 // memory every one of them was a round trip (33 ms per round for 256 agents in the pillar forest).
-constexpr size_t SLAB = hdsm_cd::WAVE_LDS_BYTES;
+constexpr size_t SLAB = hdsm_cd::WAVE_LDS_MAX;  // (the launch asks for what its n_it needs: wave_lds_bytes)
 // k_corridor also has static __shared__ state (the walk's rows and flags, < 4 KB); together they must stay inside the 64 KB a
 // kernel may use without hipFuncAttributeMaxDynamicSharedMemorySize — a growth of Work / the overlay fails HERE, not at launch
 static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed the default 64 KB limit");
@@ -606,7 +606,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
     }
   } done_once(d->solver, st);
   if (n > 0) {
-    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? SLAB : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath, d->d_id, d->d_state,
+    hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? hdsm_cd::wave_lds_bytes(hdsm_cd::wave_map_radius(d->c.n_it_decomp)) : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath, d->d_id, d->d_state,
                        d->d_npoly, d->d_nrows, d->d_A, d->d_b);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {

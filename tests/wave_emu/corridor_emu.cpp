@@ -58,11 +58,15 @@ extern "C" int wave_poly_octa3d_batch(int32_t n, const int8_t* world, const int3
                                       const int32_t* ground_k, const int32_t* seed, const int32_t* variant, const double* origin,
                                       int32_t n_it, double res, double* rows, int32_t max_rows, int32_t* n_rows, int32_t* rc,
                                       int32_t* cells) {
-  std::vector<unsigned char> lds(WAVE_LDS_BYTES + 16);
+  const size_t bytes = wave_lds_bytes(wave_map_radius(n_it)), guard = 4096;  // what the launch asks for, between two guard zones
+  std::vector<unsigned char> mem(guard + bytes + guard);
+  unsigned char* lds_base = mem.data() + guard;
   for (int t = 0; t < n; ++t) {
-    for (auto& v : lds) v = 0xA5;  // uninitialised LDS
-    Job j{world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, max_rows, res, rows, n_rows, rc, cells, lds.data(), t};
+    for (auto& v : mem) v = 0xA5;  // uninitialised LDS
+    Job j{world, wdim, ldim, off, ground_k, seed, variant, origin, n_it, max_rows, res, rows, n_rows, rc, cells, lds_base, t};
     if (!wemu::run_block(body, &j, t, 64)) return -100;
+    for (size_t i = 0; i < guard; ++i)
+      if (mem[i] != 0xA5 || mem[guard + bytes + i] != 0xA5) return -101;  // a store outside the LDS of the launch
   }
   return 0;
 }

@@ -100,6 +100,8 @@ def poly_octa3d_batch(world, ldim, off, ground_k, seed, variant, origin, n_it=42
     r = L.wave_poly_octa3d_batch(C.c_int32(n), world.ctypes.data_as(C.POINTER(C.c_int8)), _p(wdim, i32), _p(ldim, i32), _p(off, i32),
                                  _p(ground_k, i32), _p(seed, i32), _p(variant, i32), _p(origin, d), C.c_int32(n_it), C.c_double(res),
                                  _p(rows, d), C.c_int32(max_rows), _p(n_rows, i32), _p(rc, i32), _p(cells, i32))
+    if r == -101:
+        raise RuntimeError("wave emulation: a store outside the LDS the launch asks for (guard zone overwritten)")
     if r:
         raise RuntimeError("wave emulation: %s" % L.wave_last_error().decode())
     return rows, n_rows, rc, cells
