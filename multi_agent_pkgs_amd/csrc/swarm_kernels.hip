@@ -68,6 +68,18 @@ constexpr size_t SLAB = hdsm_cd::WAVE_LDS_MAX;  // (the launch asks for what its
 // kernel may use without hipFuncAttributeMaxDynamicSharedMemorySize — a growth of Work / the overlay fails HERE, not at launch
 static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed the default 64 KB limit");
 
+// The polyhedra an agent's last decompositions produced, with what they depend on besides the (constant) world and configuration:
+// the seed voxel (Poly::seed, its centre in world coordinates) and the origin of the local grid the decomposition ran in. The
+// corridor keeps only the polyhedra the last plan used, so the ones further down the path are dropped and asked for again round
+// after round — with the same seed, and, until the agent crosses a voxel boundary, the same local grid: the same rows, bit for
+// bit. Those are copied from here instead of being grown again (the host mirror grows them again: same result).
+constexpr int CACHE_POLYS = 6;
+struct PolyCache {
+  hdsm_sw::Poly poly[CACHE_POLYS];
+  V3 origin[CACHE_POLYS];
+  int32_t n, next;
+};
+
 // GenerateSafeCorridor (AC:1236-1447), ONE WAVEFRONT PER AGENT. The walk along the path (steps of voxel / 10: hundreds of
 // them per round) tests every sample against every row of the kept polyhedra; with one thread per agent each test was a chain of
 // global loads (1.3 ms per round for 1024 agents). Here the rows live in the registers of the 64 lanes (two rows per lane,
@@ -96,7 +108,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
 
 // (inlined into the kernel: only there does the compiler know that the workspace is LDS — behind a call every access of the
 // decomposition was a flat load)
-__device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::WaveLds& lds, V3* path, int lane) {
+__device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, const hdsm_cd::WaveLds& lds, V3* path, int lane, PolyCache* pc) {
   using namespace hdsm_sw;
   const int P = c.P, N = c.N, RS = c.RS;
   __shared__ int sh_npath;
@@ -234,16 +246,36 @@ __device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, con
       }
     if (previous_seed) continue;
     int rc = HDSM_OK;
-    if (c.has_world) {  // the whole wavefront, cooperatively: same arguments, same result in every lane
+    if (c.has_world) {
+      int hit = -1;
+      if (pc != nullptr)
+        for (int k = 0; k < pc->n && hit < 0; ++k)
+          if (pc->poly[k].seed[0] == seed_world[0] && pc->poly[k].seed[1] == seed_world[1] && pc->poly[k].seed[2] == seed_world[2] &&
+              pc->origin[k][0] == origin[0] && pc->origin[k][1] == origin[1] && pc->origin[k][2] == origin[2])
+            hit = k;
+      if (hit >= 0) {  // grown before from this seed in this local grid: the same rows
+        copy_poly(&ag.polys[n_poly], &pc->poly[hit]);
+      } else {  // the whole wavefront, cooperatively: same arguments, same result in every lane
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-      const unsigned long long tp0 = __builtin_readcyclecounter();
+        const unsigned long long tp0 = __builtin_readcyclecounter();
 #endif
-      rc = world_poly_wave(c, origin, seed, lds, &ag.polys[n_poly], lane);
+        rc = world_poly_wave(c, origin, seed, lds, &ag.polys[n_poly], lane);
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-      if (lane == 0) atomicAdd(&hdsm_cd::g_cd_prof[13], __builtin_readcyclecounter() - tp0);
+        if (lane == 0) atomicAdd(&hdsm_cd::g_cd_prof[13], __builtin_readcyclecounter() - tp0);
 #endif
-      if (rc != HDSM_OK) ag.corridor_rc = rc;
-      else ag.polys[n_poly].seed = seed_world;
+        if (rc != HDSM_OK) {
+          ag.corridor_rc = rc;
+        } else {
+          ag.polys[n_poly].seed = seed_world;
+          if (pc != nullptr) {
+            __syncthreads();  // (the rows just written by the lanes)
+            const int slot = pc->next;
+            copy_poly(&pc->poly[slot], &ag.polys[n_poly]);
+            __syncthreads();
+            if (lane == 0) pc->origin[slot] = origin, pc->next = (slot + 1) % CACHE_POLYS, pc->n = pc->n < CACHE_POLYS ? pc->n + 1 : CACHE_POLYS;
+          }
+        }
+      }
     } else if (lane == 0) {
       free_space_poly(c, origin, seed, &ag.polys[n_poly]);
       ag.polys[n_poly].seed = seed_world;
@@ -264,7 +296,7 @@ __device__ __attribute__((noinline)) void corridor_step_plain(const Cfg& c, Agen
 // (the solver's inputs that do not depend on the reference — id, state, the corridor just built — leave with this kernel: a kernel
 // of their own cost 5 us per round in the live loop)
 __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, double* path, int32_t* n_path, int32_t* agent_id,
-                                                 double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A, double* b) {
+                                                 double* state_curr, int32_t* n_poly, int32_t* n_rows, double* A, double* b, PolyCache* cache) {
   __shared__ V3 path_s[hdsm_sw::PATH_PTS + 2];
   __shared__ V3 poly_s[PTS];
   __shared__ int np_s;
@@ -277,7 +309,7 @@ __global__ __launch_bounds__(64) void k_corridor(Cfg c, int n, AgentS* agents, d
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     const unsigned long long tp0 = __builtin_readcyclecounter();
 #endif
-    corridor_step_wave(c, ag, lds, path_s, lane);
+    corridor_step_wave(c, ag, lds, path_s, lane, cache != nullptr ? cache + k : nullptr);
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if (lane == 0) atomicAdd(&hdsm_cd::g_cd_prof[12], __builtin_readcyclecounter() - tp0), atomicAdd(&hdsm_cd::g_cd_prof[14], 1ull);
 #endif
@@ -456,6 +488,7 @@ struct DSwarm {
   hdsm_ref_config rcfg{};
   Cfg c{};
   AgentS* d_agents = nullptr;
+  PolyCache* d_cache = nullptr;  // [n_local], worlds only (HDSM_POLY_CACHE=0: none)
   int8_t* d_world = nullptr;
   double *d_cap = nullptr, *d_path = nullptr, *d_ref_full = nullptr, *d_ref = nullptr, *d_pv = nullptr, *d_state = nullptr, *d_A = nullptr, *d_b = nullptr,
          *d_traj = nullptr, *d_ctrl = nullptr, *d_obj = nullptr, *d_local = nullptr, *d_plans = nullptr;
@@ -472,7 +505,7 @@ hipError_t dalloc(T** p, size_t count) {
 }
 
 void free_all(DSwarm* d) {
-  void* ptrs[] = {d->d_cap, d->d_agents, d->d_world, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
+  void* ptrs[] = {d->d_cap, d->d_agents, d->d_cache, d->d_world, d->d_path, d->d_ref_full, d->d_ref, d->d_pv, d->d_state, d->d_A, d->d_b, d->d_traj,
                   d->d_ctrl, d->d_obj, d->d_local, d->d_plans, d->d_npath, d->d_id, d->d_npoly, d->d_nrows, d->d_status, d->d_fails,
                   d->d_used, d->d_has};
   for (void* p : ptrs)
@@ -539,6 +572,9 @@ int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_
   ok(dalloc(&d->d_agents, n));
   if (hworld) {
     ok(dalloc(&d->d_world, (size_t)wdim[0] * wdim[1] * wdim[2]));
+    bool cache_on = true;  // development switch (A/B): HDSM_POLY_CACHE=0 grows every polyhedron again
+    if (const char* pcenv = std::getenv("HDSM_POLY_CACHE")) cache_on = !(pcenv[0] == '0' && pcenv[1] == 0);
+    if (cache_on) ok(dalloc(&d->d_cache, n));
   }
   ok(dalloc(&d->d_path, n * PTS * 3)), ok(dalloc(&d->d_npath, n)), ok(dalloc(&d->d_ref_full, n * (N + 1) * 6)), ok(dalloc(&d->d_ref, n * N * 6));
   ok(dalloc(&d->d_cap, n)), ok(dalloc(&d->d_pv, n)), ok(dalloc(&d->d_id, n)), ok(dalloc(&d->d_state, n * 9)), ok(dalloc(&d->d_npoly, n)), ok(dalloc(&d->d_nrows, n * P));
@@ -607,7 +643,7 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
   } done_once(d->solver, st);
   if (n > 0) {
     hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? hdsm_cd::wave_lds_bytes(hdsm_cd::wave_map_radius(d->c.n_it_decomp)) : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath, d->d_id, d->d_state,
-                       d->d_npoly, d->d_nrows, d->d_A, d->d_b);
+                       d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_cache);
     HIP_TRY(hipGetLastError());
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_vel_cap, dim3((unsigned)n), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
