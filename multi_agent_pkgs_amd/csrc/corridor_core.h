@@ -125,6 +125,67 @@ struct Edge {      // Corner3D (convex_decomp.hpp:21-36)
 };
 CD_HD Edge fresh_edge() { return Edge{{0.0, 0.0, 0.0}, 0, -1, 0, 0}; }
 
+// Where a chamfer's point came from (kept beside the edges, written when a layer that starts a chamfer is accepted): the voxel, the
+// face that was growing, the neighbouring face and whether the shape-aware half voxel was added. With the anchors of the faces and
+// the edges' slopes this is the polyhedron as INTEGERS — its rows can be formed again for another origin of the local grid,
+// with the arithmetic a decomposition in that grid would use (PolyStruct, rows_from_structure).
+struct EdgeSrc {
+  Cell c;
+  int f, nbf, extra;
+};
+// the point of a chamfer's plane, between the layer and the neighbouring face (CD:322-373 / 836-848; written as the reference writes
+// it: products first, then left-to-right sums; no contraction)
+CD_HD void edge_point(Cell c, Cell up, Cell nb, double res, bool half_more, double pos[3]) {
+  const double extra = half_more ? res / 2 : 0.0;  // (CD:836-848 adds res/2 twice)
+  const double h = res / 2;
+  pos[0] = (((c.x * res - up.x * res / 2) + nb.x * res / 2) + h) + extra;
+  pos[1] = (((c.y * res - up.y * res / 2) + nb.y * res / 2) + h) + extra;
+  pos[2] = (((c.z * res - up.z * res / 2) + nb.z * res / 2) + h) + extra;
+}
+// the half-space of chamfered edge e: normal = slope * long-face normal + other-face normal
+CD_HD void edge_row(int e, int slope, int dir, const double pos[3], const double origin[3], double r[4]) {
+  const int fa = edge_face(e, 0), fb = edge_face(e, 1);
+  const int lng = (dir == fa) ? fa : fb, oth = (dir == fa) ? fb : fa;
+  const Cell nl = normal_of(lng), no = normal_of(oth);
+  const double nrm[3] = {(double)(slope * nl.x + no.x), (double)(slope * nl.y + no.y), (double)(slope * nl.z + no.z)};
+  const double p[3] = {pos[0] + origin[0], pos[1] + origin[1], pos[2] + origin[2]};
+  r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
+  r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
+}
+// the half-space of face f through the outer side of voxel `anchor`
+CD_HD void face_row(int f, Cell anchor, double res, const double origin[3], double r[4]) {
+  const Cell nf = normal_of(f);
+  const double nrm[3] = {(double)nf.x, (double)nf.y, (double)nf.z};
+  const double h = res / 2;
+  const double p[3] = {((anchor.x * res + nf.x * res / 2) + h) + origin[0], ((anchor.y * res + nf.y * res / 2) + h) + origin[1],
+                       ((anchor.z * res + nf.z * res / 2) + h) + origin[2]};
+  r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
+  r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
+}
+// A finished polyhedron as integers, voxels relative to the seed
+struct PolyStruct {
+  int32_t slope[12], dir[12], f[12], nbf[12], extra[12];
+  Cell c[12];
+  Cell anchor[6];
+};
+// rows[max_rows][4] of a polyhedron with this structure grown from `seed` (a voxel of the local grid whose voxel (0,0,0) lies at
+// `origin`): what decompose_core writes for it. Returns the number of rows (may exceed max_rows: CD_CAPACITY for the caller).
+CD_HD int rows_from_structure(const PolyStruct& ps, Cell seed, double res, const double origin[3], double* rows, int max_rows) {
+  int n = 0;
+  for (int e = 0; e < 12; ++e) {
+    if (ps.slope[e] <= 0) continue;
+    double pos[3];
+    edge_point(add(seed, ps.c[e]), normal_of(ps.f[e]), normal_of(ps.nbf[e]), res, ps.extra[e] != 0, pos);
+    if (n < max_rows) edge_row(e, ps.slope[e], ps.dir[e], pos, origin, rows + 4 * n);
+    ++n;
+  }
+  for (int f = 0; f < 6; ++f) {
+    if (n < max_rows) face_row(f, add(seed, ps.anchor[f]), res, origin, rows + 4 * n);
+    ++n;
+  }
+  return n;
+}
+
 // cells are stored as offsets from the seed (a polyhedron never reaches further than n_it / 6 + 1 layers from it)
 struct Packed {
   int8_t x, y, z, pad;  // (four bytes: one LDS access per cell)
@@ -161,6 +222,7 @@ struct Work {
   Layer L, L2;
   CellDeque edge_row;
   Edge edges[12], edges_t[12];
+  EdgeSrc esrc[12];  // (see EdgeSrc)
   Cell anchor[6];  // a voxel of each face's outermost layer (gives the face plane)
 #ifdef CD_PROFILE
   unsigned long long prof[16];  // cycles per phase of this decomposition (lane 0), added to g_cd_prof at its end: probes that hit
@@ -1009,6 +1071,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     // is the layer consistent with ONE plane through every edge? (CD:209-283 / CD:828-910)
     bool accept = true;
     int fresh[4] = {0, 0, 0, 0};  // corner_new_state: 1 = a one-voxel chamfer starts on this side, 2 = a longer one
+    Cell fresh_c[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // ... from this voxel
     bool stop = false;  // (the reference's loop ends at !accept or at a break: written so that the loop unrolls and trial[] stays in registers)
     CD_UNROLL
     for (int j = 0; j < 4; ++j) {
@@ -1019,13 +1082,8 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
       const int gap = faces[f].reach[j] - dot(c, sd[j]);  // voxels this layer falls short of the last one
       if (e.slope == 0) {
         if (gap > 0) {  // a chamfer starts here: a point of its plane, between this layer and the neighbouring face
-          const Cell nb = normal_of(fv.face[j]);
-          const double extra = aware ? res / 2 : 0.0;  // (CD:836-848 adds res/2 twice)
-          // (written as the reference writes it: products first, then left-to-right sums; no contraction)
-          const double h = res / 2;
-          e.pos[0] = (((c.x * res - up.x * res / 2) + nb.x * res / 2) + h) + extra;
-          e.pos[1] = (((c.y * res - up.y * res / 2) + nb.y * res / 2) + h) + extra;
-          e.pos[2] = (((c.z * res - up.z * res / 2) + nb.z * res / 2) + h) + extra;
+          edge_point(c, up, normal_of(fv.face[j]), res, aware, e.pos);
+          fresh_c[j] = c;
           e.slope = e.steps = gap;
           if (gap > 1) e.dir = f;
           fresh[j] = gap > 1 ? 2 : 1;
@@ -1152,6 +1210,7 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
     for (int j = 0; j < 4; ++j) {
       faces[f].reach[j] = dot(L.far[j], sd[j]);
       edges[fv.edge[j]] = trial[j];
+      if (fresh[j]) wk.esrc[fv.edge[j]] = EdgeSrc{fresh_c[j], f, fv.face[j], aware ? 1 : 0};
       // full-width side on a square edge: these voxels are now also the outermost layer of the neighbouring face
       if (trial[j].slope == 0 && !cx.empty(L.rim_real[j]) && faces[f].reach[j] == dot(cx.front(L.rim_real[j]), sd[j])) {
         const int nbf = fv.face[j];
@@ -1171,30 +1230,11 @@ CD_HD int decompose_core(G& g, Work& wk, int variant, Cell seed, int n_it, doubl
   int n = 0;
   for (int e = 0; e < 12; ++e) {
     if (edges[e].slope <= 0) continue;
-    const int fa = edge_face(e, 0), fb = edge_face(e, 1);
-    const int lng = (edges[e].dir == fa) ? fa : fb, oth = (edges[e].dir == fa) ? fb : fa;
-    const Cell nl = normal_of(lng), no = normal_of(oth);
-    const double nrm[3] = {(double)(edges[e].slope * nl.x + no.x), (double)(edges[e].slope * nl.y + no.y),
-                           (double)(edges[e].slope * nl.z + no.z)};
-    const double p[3] = {edges[e].pos[0] + origin[0], edges[e].pos[1] + origin[1], edges[e].pos[2] + origin[2]};
-    if (n < max_rows) {
-      double* r = rows + 4 * n;
-      r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
-      r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
-    }
+    if (n < max_rows) edge_row(e, edges[e].slope, edges[e].dir, edges[e].pos, origin, rows + 4 * n);
     ++n;
   }
   for (int f = 0; f < 6; ++f) {
-    const Cell nf = normal_of(f);
-    const double nrm[3] = {(double)nf.x, (double)nf.y, (double)nf.z};
-    const double h = res / 2;
-    const double p[3] = {((anchor[f].x * res + nf.x * res / 2) + h) + origin[0], ((anchor[f].y * res + nf.y * res / 2) + h) + origin[1],
-                         ((anchor[f].z * res + nf.z * res / 2) + h) + origin[2]};
-    if (n < max_rows) {
-      double* r = rows + 4 * n;
-      r[0] = nrm[0], r[1] = nrm[1], r[2] = nrm[2];
-      r[3] = (nrm[0] * p[0] + nrm[1] * p[1]) + nrm[2] * p[2];
-    }
+    if (n < max_rows) face_row(f, anchor[f], res, origin, rows + 4 * n);
     ++n;
   }
   *n_rows = n;

@@ -145,6 +145,20 @@ __device__ inline int wave_decompose(WindowGrid g, const WaveLds& m, int variant
   return rc_wave;
 }
 
+// The structure of the polyhedron the last wave_decompose of this workgroup produced (PolyStruct: what its rows are made of, as
+// integers relative to the seed), written by the lanes to `out` (any memory).
+__device__ inline void wave_poly_structure(const WaveLds& m, Cell seed, PolyStruct* out, int lane) {
+  const Work& wk = *m.wk;
+  if (lane < 12) {
+    const int e = lane, sl = wk.edges[e].slope;
+    out->slope[e] = sl, out->dir[e] = wk.edges[e].dir;
+    out->f[e] = sl > 0 ? wk.esrc[e].f : 0, out->nbf[e] = sl > 0 ? wk.esrc[e].nbf : 0, out->extra[e] = sl > 0 ? wk.esrc[e].extra : 0;
+    out->c[e] = sl > 0 ? sub(wk.esrc[e].c, seed) : Cell{0, 0, 0};
+  } else if (lane < 18) {
+    out->anchor[lane - 12] = sub(wk.anchor[lane - 12], seed);
+  }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace hdsm_cd

@@ -26,6 +26,9 @@ extern "C" int hdsm_internal_defer_done(void* handle, int on);
 extern "C" int hdsm_internal_record_done(void* handle, void* hip_stream);
 
 #ifdef CD_PROFILE
+namespace {
+__device__ unsigned long long g_cache_stat[4];  // polyhedra asked for, found in the cache with (seed, origin), with the seed alone
+}
 // development builds only: the phase counters of the corridor kernel's decompositions (read and cleared); [12] cycles of the whole
 // corridor step, [13] of its decompositions, [14] agent-rounds, [15] decompositions
 extern "C" int hdsm_swarm_corridor_profile(unsigned long long out[16]) {
@@ -33,6 +36,10 @@ extern "C" int hdsm_swarm_corridor_profile(unsigned long long out[16]) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hdsm_cd::g_cd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return HDSM_ERR_DEVICE;
   unsigned long long zero[16] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(hdsm_cd::g_cd_prof), zero, sizeof zero) != hipSuccess) return HDSM_ERR_DEVICE;
+  unsigned long long cs[4] = {0};
+  if (hipMemcpyFromSymbol(cs, HIP_SYMBOL(g_cache_stat), sizeof cs) != hipSuccess) return HDSM_ERR_DEVICE;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_cache_stat), zero, sizeof cs) != hipSuccess) return HDSM_ERR_DEVICE;
+  out[6] = cs[0], out[7] = cs[1], out[9] = cs[2];  // (the slots of the rare phases: polyhedra asked for / found in the cache / seed seen before)
   return HDSM_OK;
 }
 #endif
@@ -68,15 +75,20 @@ constexpr size_t SLAB = hdsm_cd::WAVE_LDS_MAX;  // (the launch asks for what its
 // kernel may use without hipFuncAttributeMaxDynamicSharedMemorySize — a growth of Work / the overlay fails HERE, not at launch
 static_assert(SLAB + 4096 <= 64 * 1024, "k_corridor: dynamic + static LDS exceed the default 64 KB limit");
 
-// The polyhedra an agent's last decompositions produced, with what they depend on besides the (constant) world and configuration:
-// the seed voxel (Poly::seed, its centre in world coordinates) and the origin of the local grid the decomposition ran in. The
-// corridor keeps only the polyhedra the last plan used, so the ones further down the path are dropped and asked for again round
-// after round — with the same seed, and, until the agent crosses a voxel boundary, the same local grid: the same rows, bit for
-// bit. Those are copied from here instead of being grown again (the host mirror grows them again: same result).
+// The polyhedra an agent's last decompositions produced. The corridor keeps only the polyhedra the last plan used, so the ones
+// further down the path are dropped and asked for again round after round with the same seed voxel — more than half of all
+// decompositions of a forest flight. What a decomposition yields depends on the (constant) world and configuration, on the seed,
+// and on the local grid only where the growth meets the grid's border or the ground plane moves; so an entry holds the
+// polyhedron as INTEGERS relative to the seed (hdsm_cd::PolyStruct) with the seed's world voxel, the grid's offset in the world,
+// the ground plane's world level and whether everything a decomposition can look at (the seed +- wave_map_radius) lay inside the
+// grid's interior in x and y. A request for the same world voxel from a grid at the same height with that property too (or from
+// the same grid) gets its rows
+// formed from the entry — with the arithmetic a decomposition in ITS grid would use, origin included (rows_from_structure), so the
+// host mirror, which grows the polyhedron again, gets the same bits.
 constexpr int CACHE_POLYS = 6;
 struct PolyCache {
-  hdsm_sw::Poly poly[CACHE_POLYS];
-  V3 origin[CACHE_POLYS];
+  hdsm_cd::PolyStruct ps[CACHE_POLYS];
+  int32_t seed_w[CACHE_POLYS][3], off[CACHE_POLYS][3], ground_w[CACHE_POLYS], interior[CACHE_POLYS];
   int32_t n, next;
 };
 
@@ -247,14 +259,41 @@ __device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, con
     if (previous_seed) continue;
     int rc = HDSM_OK;
     if (c.has_world) {
+      // (the local grid of this agent in world voxels, as make_window forms it)
+      const hdsm_cd::WindowGrid wg = hdsm_sw::make_window(c, origin, seed, nullptr);
+      const int seed_w[3] = {seed[0] + wg.ox, seed[1] + wg.oy, seed[2] + wg.oz}, off_w[3] = {wg.ox, wg.oy, wg.oz}, ground_w = wg.ground_k + wg.oz;
+      const int rad = hdsm_cd::wave_map_radius(c.n_it_decomp);
+      // (in x and y: the local grid is 66 voxels wide there, 20 in z — in z the growth does meet the border, so a request must come
+      // from a grid at the same height; an agent changes its z voxel rarely, its x / y voxel every other round)
+      const bool interior = rad > 0 && hdsm_sw::seed_in_grid(c, seed) && seed[0] - rad >= 1 && seed[1] - rad >= 1 && seed[0] + rad <= wg.lnx - 2 &&
+                            seed[1] + rad <= wg.lny - 2;
       int hit = -1;
       if (pc != nullptr)
-        for (int k = 0; k < pc->n && hit < 0; ++k)
-          if (pc->poly[k].seed[0] == seed_world[0] && pc->poly[k].seed[1] == seed_world[1] && pc->poly[k].seed[2] == seed_world[2] &&
-              pc->origin[k][0] == origin[0] && pc->origin[k][1] == origin[1] && pc->origin[k][2] == origin[2])
-            hit = k;
-      if (hit >= 0) {  // grown before from this seed in this local grid: the same rows
-        copy_poly(&ag.polys[n_poly], &pc->poly[hit]);
+        for (int k = 0; k < pc->n && hit < 0; ++k) {
+          const bool same_voxel = pc->seed_w[k][0] == seed_w[0] && pc->seed_w[k][1] == seed_w[1] && pc->seed_w[k][2] == seed_w[2];
+          const bool same_grid = pc->off[k][0] == off_w[0] && pc->off[k][1] == off_w[1] && pc->off[k][2] == off_w[2];
+          if (same_voxel && (same_grid || (interior && pc->interior[k] != 0 && pc->off[k][2] == off_w[2] && pc->ground_w[k] == ground_w))) hit = k;
+        }
+#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+      if (lane == 0 && pc != nullptr) atomicAdd(&g_cache_stat[0], 1ull), atomicAdd(&g_cache_stat[1], hit >= 0 ? 1ull : 0ull);
+#endif
+      if (hit >= 0) {  // grown before from this voxel: the rows from the integers, in this grid's arithmetic
+        const double org[3] = {origin[0], origin[1], origin[2]};
+        const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
+        const int n = hdsm_cd::rows_from_structure(pc->ps[hit], hdsm_cd::Cell{seed[0], seed[1], seed[2]}, c.voxel_size, org, lds.rows, cap);
+        __syncthreads();
+        if (n > cap) {
+          rc = HDSM_ERR_CAPACITY, ag.polys[n_poly].rows = 0, ag.corridor_rc = rc;
+        } else {
+          Poly* out = &ag.polys[n_poly];
+          if (lane == 0) out->rows = n;
+          for (int t = lane; t < 4 * n; t += 64) {
+            const int r = t >> 2, q = t & 3;
+            if (q < 3) out->A[r][q] = lds.rows[t];
+            else out->b[r] = lds.rows[t];
+          }
+          out->seed = seed_world;
+        }
       } else {  // the whole wavefront, cooperatively: same arguments, same result in every lane
 #if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
         const unsigned long long tp0 = __builtin_readcyclecounter();
@@ -267,12 +306,15 @@ __device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, con
           ag.corridor_rc = rc;
         } else {
           ag.polys[n_poly].seed = seed_world;
-          if (pc != nullptr) {
-            __syncthreads();  // (the rows just written by the lanes)
+          if (pc != nullptr && rad > 0) {  // (rad = 0: the plain form ran; it keeps no chamfer sources)
             const int slot = pc->next;
-            copy_poly(&pc->poly[slot], &ag.polys[n_poly]);
+            hdsm_cd::wave_poly_structure(lds, hdsm_cd::Cell{seed[0], seed[1], seed[2]}, &pc->ps[slot], lane);
+            if (lane < 3) pc->seed_w[slot][lane] = seed_w[lane], pc->off[slot][lane] = off_w[lane];
             __syncthreads();
-            if (lane == 0) pc->origin[slot] = origin, pc->next = (slot + 1) % CACHE_POLYS, pc->n = pc->n < CACHE_POLYS ? pc->n + 1 : CACHE_POLYS;
+            if (lane == 0) {
+              pc->ground_w[slot] = ground_w, pc->interior[slot] = interior ? 1 : 0;
+              pc->next = (slot + 1) % CACHE_POLYS, pc->n = pc->n < CACHE_POLYS ? pc->n + 1 : CACHE_POLYS;
+            }
           }
         }
       }
