@@ -356,7 +356,7 @@ def test_cooperative_voxel_decomposition_matches_the_host_bit_for_bit(wave, wnam
     import decomp_cases as dc
     rng = np.random.default_rng(100 + n_it)
     occ2, origin = dc.world(wname, potential=True, rng=rng)
-    off, seed, ground, variant, org = dc.cases(occ2, origin, 80, rng)
+    off, seed, ground, variant, org = dc.cases(occ2, origin, 50, rng)
     rows, n_rows, rc, cells = wave.poly_octa3d_batch(occ2, dc.LDIM, off, ground, seed, variant, org, n_it=n_it, res=0.3, max_rows=32, short_batches=short)
     chamfered = 0
     for t in range(len(off)):
@@ -369,4 +369,4 @@ def test_cooperative_voxel_decomposition_matches_the_host_bit_for_bit(wave, wnam
         assert np.array_equal(rows[t, : n_rows[t]], want), (wname, t)
         assert cells[t] == voxels, (wname, t)
         chamfered += len(want) > 6
-    assert chamfered >= 5
+    assert chamfered >= 3
