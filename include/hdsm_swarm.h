@@ -168,7 +168,10 @@ int hdsm_swarm_prepare_corridor(void* swarm);
  * hdsm_comm (NULL when world_size == 1). hdsm_dswarm_round is asynchronous on hip_stream. hdsm_dswarm_download synchronises
  * and copies out what the caller asks for (any pointer may be NULL): the agent states back into the host mirror `swarm`
  * (so that every hdsm_swarm_* diagnostic works on them), the all-gathered plans [world_size * per][N+1][9] and flags, the
- * statuses of the last round, the number of instances without solution so far. */
+ * statuses of the last round, the number of instances without solution so far.
+ * The world and the configuration are those of the host mirror at hdsm_dswarm_create and stay fixed for the dswarm's life (the
+ * device corridor keeps each agent's last polyhedra and forms the rows of one that is asked for again from them instead of
+ * growing it again — same rows, bit for bit; environment HDSM_POLY_CACHE=0 switches that off, for A/B runs). */
 int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_size, void** dswarm);
 /* the all-gathered plans [n_rob][N+1][9] and flags [n_rob] the next round starts from (a swarm taken over in mid-flight) */
 int hdsm_dswarm_upload_plans(void* dswarm, const double* plans_all, const uint8_t* has_plan);
