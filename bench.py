@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--device-loop-multi", action="store_true", help="(kept for old command lines: the device-resident-loop pass now runs "
                     "with --gpus > 1 by default, last and under a watchdog)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline-corridor", action="store_true", help="skip the orc_safe_corridor comparison of the device-loop pass")
     ap.add_argument("--save-recording", default="", help="development: write the recorded rounds (solver inputs) to this .npz")
     ap.add_argument("--load-recording", default="", help="development: replay the rounds of a --save-recording file instead of flying "
                     "the set-up flight (A/B of execution knobs on IDENTICAL inputs; implies --no-event-pass)")
@@ -112,6 +113,9 @@ def main():
                     "8 per round) with the CPU oracle -> parity_on_timed_rounds (what the secondary workloads of the default line run with; "
                     "the default circle line compares EVERY timed instance in its cpu_baseline leg instead)")
     ap.add_argument("--parity-seconds", type=float, default=40.0, help="wall-clock budget of the --parity-sample pass (rounds beyond it are skipped)")
+    ap.add_argument("--device-loop", action="store_true", help="run the device-resident-loop pass (hdsm_dswarm_round live, with its per-phase "
+                    "HIP-event shares and, in obstacle worlds, a bounded orc_safe_corridor comparison) even with --no-event-pass: what the "
+                    "forest / fwf secondary records of the default line carry")
     ap.add_argument("--second-window", type=int, default=-1, help="first round of a second timed window recorded in the same set-up flight "
                     "(default: 100 for the 1024-agent circle line - rounds in which every instance has a solution - else none; 0 = none)")
     args = ap.parse_args()
@@ -165,19 +169,52 @@ def main():
     solver = lib.Solver(prm, max(n_local, 1), max(n_rob, world * per), device=dev.index)
     stream = torch.cuda.current_stream()
     comm = None
+    exchange_error = None
     if world > 1 and args.dist_backend == "rccl":
-        # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line
+        # RCCL prints a version banner on stdout when a communicator is created: keep stdout for the ONE JSON line.
+        # hdsm_comm_create (ncclCommInitRank) may FAIL (e.g. ncclInvalidUsage: two ranks on one device) or never come back (a rank
+        # that died before the bootstrap): it runs in a thread with a budget, the ranks agree on the outcome through the launcher's
+        # gloo group, and without a communicator the line is still produced — host-staged exchange, `exchange_error` says why.
+        import threading
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
+        box = {}
         try:
             uid = [lib.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            comm = lib.Comm(solver, uid[0], rank, world)
+
+            def make_comm():
+                try:
+                    box["comm"] = lib.Comm(solver, uid[0], rank, world)
+                except BaseException as e:  # noqa: BLE001
+                    box["error"] = repr(e)[:300]
+
+            th_c = threading.Thread(target=make_comm, daemon=True)
+            th_c.start()
+            th_c.join(float(os.environ.get("HDSM_BENCH_COMM_BUDGET_S", "120")))
+            if th_c.is_alive():
+                box["error"] = "hdsm_comm_create did not return within its budget (HDSM_BENCH_COMM_BUDGET_S)"
+        except BaseException as e:  # noqa: BLE001
+            box["error"] = repr(e)[:300]
         finally:
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-        assert comm.world == world and comm.rank == rank
+        errs = [None] * world
+        dist.all_gather_object(errs, box.get("error"))
+        if any(e is not None for e in errs):
+            exchange_error = {"ranks_failed": [k for k, e in enumerate(errs) if e is not None], "first_error": next(e for e in errs if e is not None),
+                              "consequence": "no RCCL communicator: the exchange of this line is the host-staged gloo all-gather (flow only); "
+                                             "rccl_ranks is null and the weak-scaling record / device loop over RCCL are skipped"}
+            if "comm" in box and not th_c.is_alive():
+                try:
+                    box["comm"].close()
+                except Exception:
+                    pass
+            comm = None
+        else:
+            comm = box["comm"]
+            assert comm.world == world and comm.rank == rank
 
     # ---------------------------------------------------------------- set-up: closed-loop flight, recording
     def allgather_np(local):  # set-up flight only (host arrays): through the launcher's process group
@@ -330,23 +367,35 @@ def main():
 
     # N > 1: the exchange alone (HIP events on the launch stream around hdsm_exchange_device, nothing else queued in between)
     exchange_ms = None
-    if world > 1 and comm is not None:
-        evx = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(K, 20))]
+    if world > 1:
+        n_x = max(K, 20)
         for _ in range(3):
             exchange()
         barrier()
-        for a_, b_ in evx:
-            a_.record(stream)
-            exchange()
-            b_.record(stream)
-        barrier()
-        xs = np.array([a_.elapsed_time(b_) for a_, b_ in evx])
+        if comm is not None:
+            evx = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_x)]
+            for a_, b_ in evx:
+                a_.record(stream)
+                exchange()
+                b_.record(stream)
+            barrier()
+            xs = np.array([a_.elapsed_time(b_) for a_, b_ in evx])
+            how = ("hdsm_exchange_device alone (ONE ncclAllGather of the plan records + the flag kernel), HIP events on the launch "
+                   "stream, back to back; p50 / p95 = max over the ranks")
+        else:   # host-staged (gloo): wall clock per call, device synchronised on both sides — a flow check, not a figure of the product path
+            xs = []
+            for _ in range(n_x):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                exchange()
+                torch.cuda.synchronize()
+                xs.append((time.perf_counter() - t1) * 1e3)
+            xs = np.array(xs)
+            how = "host-staged gloo all-gather (D2H, all_gather_into_tensor, H2D), wall clock per call: the flow check of a box with fewer GPUs than ranks, NOT the product's exchange"
         t = torch.tensor([float(np.percentile(xs, 50)), float(np.percentile(xs, 95))], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exchange_ms = {"p50": float(t[0]), "p95": float(t[1]), "this_rank_p50": float(np.percentile(xs, 50)), "samples": len(xs),
-                       "bytes_per_rank": per * (N + 1) * 9 * 8,
-                       "what": "hdsm_exchange_device alone (ONE ncclAllGather of the plan records + the flag kernel), HIP events on the launch "
-                               "stream, back to back; p50 / p95 = max over the ranks"}
+                       "bytes_per_rank": per * (N + 1) * 9 * 8, "backend": "rccl" if comm is not None else "gloo-host-staged", "what": how}
 
     # the second window of the same flight (rounds before the squeeze: every instance has a solution), same timing contract
     second = None
@@ -488,6 +537,58 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dl = float(t.item())
         _, _, _, failed_d = dsw.download(states=False)
+        # where the round goes: a few MORE rounds with HIP events between the launches (hdsm_dswarm_set_phase_timing; never the rounds
+        # ms_per_round is taken from: every event record is a barrier packet in front of the next kernel)
+        phases = None
+        try:
+            dsw.set_phase_timing(True)
+            acc, n_t = {}, max(4, min(K, 8))
+            for _ in range(n_t):
+                dsw.round(comm, stream)
+                for k_, v_ in dsw.phase_ms().items():
+                    acc[k_] = acc.get(k_, 0.0) + v_ / n_t
+            dsw.set_phase_timing(False)
+            tot = sum(acc.values())
+            phases = {"rounds_timed": n_t, "ms": acc, "share": {k_: (v_ / tot if tot > 0 else 0.0) for k_, v_ in acc.items()}, "ms_sum": tot,
+                      "what": "HIP events on the round's stream between the launches of hdsm_dswarm_round, mean over rounds_timed further rounds"}
+        except Exception as e:  # noqa: BLE001 (a secondary record)
+            phases = {"error": repr(e)[:200]}
+        _, _, status_d, failed_d2 = dsw.download(states=False)
+        cache = None
+        try:
+            cache = dsw.cache_stats()
+        except Exception as e:  # noqa: BLE001
+            cache = {"error": repr(e)[:200]}
+        # obstacle worlds, one rank: a bounded comparison of the device corridor (k_corridor) with the literal restatement of
+        # GenerateSafeCorridor (oracle/hdsm_oracle.c: orc_safe_corridor, AC:1236-1447) on a sample of agents of two further live rounds
+        corridor = None
+        if world == 1 and world_occ is not None and rank == 0 and not args.no_cpu_baseline_corridor:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import corridor_oracle as co
+                from oracle import pyoracle as orc_c
+                rng_c = np.random.default_rng(5)
+                n_chk = n_same = n_stop = 0
+                t_c = time.perf_counter()
+                for _ in range(2):
+                    dsw.download(states=True)
+                    pre, prm_s, cfg_s, w_s, wo_s = co.export_agents(loop.shard)
+                    dsw.round(comm, stream)
+                    dsw.download(states=True)
+                    post = co.export_agents(loop.shard)[0]
+                    for a_ in rng_c.choice(n_local, min(24, n_local), replace=False):
+                        rc_o, want = co.oracle_corridor(orc_c.lib(), prm_s, cfg_s, w_s, wo_s, pre[int(a_)])
+                        n_chk += 1
+                        if rc_o != 0 or post[int(a_)].corridor_rc != 0:
+                            n_stop += 1
+                            n_same += int(rc_o != 0 and post[int(a_)].corridor_rc != 0)
+                        else:
+                            n_same += int(co.same_corridor(co.product_corridor(post[int(a_)]), want))
+                corridor = {"agents_compared": n_chk, "identical_bit_for_bit": n_same, "stopped_in_both": n_stop, "seconds": time.perf_counter() - t_c,
+                            "what": "k_corridor of two further live rounds against orc_safe_corridor (oracle/hdsm_oracle.c, the literal restatement of "
+                                    "AC:1236-1447) on the same pre-round agent states: polyhedra, rows and seeds bit for bit"}
+            except Exception as e:  # noqa: BLE001
+                corridor = {"error": repr(e)[:300]}
         prof = None
         if os.environ.get("HDSM_LIBRARY"):  # a -DCD_PROFILE development build: where the corridor kernel's cycles go
             import ctypes
@@ -500,15 +601,20 @@ def main():
                 ar = max(1, int(cnt[14]))
                 prof = {"agent_rounds": int(cnt[14]), "decompositions": int(cnt[15]), "cycles_per_agent_round": {names[i]: int(cnt[i]) / ar for i in range(14)}}
         res = {"rounds": f"{rec_to + 2}..{rec_to + 1 + K}", "ms_per_round": dl / K * 1e3, "agent_replans_per_s": n_rob * K / dl,
-               "instances_without_solution_this_rank": int(failed_d), "ranks": world,
+               "instances_without_solution_this_rank": int(failed_d), "instances_without_solution_last_round": int((status_d == 2).sum()),
+               "instances_on_a_budget_last_round": int((status_d == 1).sum()), "ranks": world,
+               "phases": phases, "polyhedron_cache": cache, "corridor_parity": corridor,
                "what": "hdsm_dswarm_round live: corridor (f2) -> reference (f1) -> replan -> commit -> publish -> exchange, one stream"}
         if prof:
             res["corridor_profile"] = prof
         dsw.close()
         return res
 
-    if not args.no_event_pass and world == 1:
-        dloop = device_loop_pass()
+    if (not args.no_event_pass or args.device_loop) and world == 1 and not args.load_recording:
+        try:
+            dloop = device_loop_pass()
+        except Exception as e:  # noqa: BLE001 (a secondary record must not cost the line)
+            dloop = {"error": repr(e)[:300]}
 
     # ---------------------------------------------------------------- N > 1: secondary WEAK-scaling record
     # The line above shards the SAME 1024 agents over the ranks (strong scaling: a round cannot end before its slowest instance,
@@ -517,8 +623,8 @@ def main():
     # one RCCL all-gather of the new plans per round. Early rounds of the flight (the squeeze of a ring that large is thousands of
     # rounds away); same timing contract.
     weak = None
-    if world > 1 and comm is not None and args.scenario == "circle" and not args.no_weak_record:
-        per_w = 1024
+    if world > 1 and args.scenario == "circle" and not args.no_weak_record:
+        per_w = int(os.environ.get("HDSM_BENCH_WEAK_PER_GPU", "1024"))
         n_w = per_w * world
         first_w = 25
         solver_w = lib.Solver(prm, per_w, n_w, device=dev.index)
@@ -554,7 +660,12 @@ def main():
         def step_w(r):
             solver_w.replan_device(w_agent[r], w_state[r], w_ref[r], w_npoly[r], w_nrows[r], w_A[r], w_b[r], w_plans[r], w_has[r],
                                    w_traj, w_ctrl, w_used, w_status, w_obj, stream=stream)
-            comm.exchange_device(w_traj, w_next, w_next_has, stream=stream)
+            if comm is not None:
+                comm.exchange_device(w_traj, w_next, w_next_has, stream=stream)
+            else:   # gloo: host-staged (flow check only)
+                f_w = torch.empty(w_next.shape, dtype=w_next.dtype)
+                dist.all_gather_into_tensor(f_w, w_traj.cpu())
+                w_next.copy_(f_w)
 
         reps_w = []
         for _ in range(max(1, args.repeats)):
@@ -573,6 +684,7 @@ def main():
                 "unit": "agent-replans/s", "ms_per_step": el_w / K * 1e3, "ms_per_step_repeats": [e / K * 1e3 for e in reps_w],
                 "steps": K, "warmup": W, "rounds": f"{first_w}..{first_w + K - 1}",
                 "exchange_bytes_per_rank_per_round": per_w * (N + 1) * 9 * 8,
+                "exchange": "RCCL all-gather (hdsm_exchange_device)" if comm is not None else "host-staged gloo all-gather (flow check only)",
                 "what": f"{per_w} agents per GPU on a ring of {n_w} (R = n / 2 pi): every rank solves its {per_w} instances against "
                         f"all {n_w} plans + ONE RCCL all-gather per round; same barrier / max-over-ranks contract as the line"}
         solver_w.close()
@@ -688,14 +800,47 @@ def main():
                     o[k][again] = o2[k]
             return o
 
+        # Two legs. (1) EVERY answer the device returned without a proof — the instances that ended on a work budget (their incumbent must
+        # not beat, and is expected to equal, the oracle's PROVEN optimum) and the instances it called infeasible (the oracle must prove
+        # that too) — of every timed round, as far as --parity-seconds goes (2/3 of the budget at most); checked / total are in the record.
+        # (2) a random sample of the proven answers per round with what is left.
         t_par = time.perf_counter()
-        n_cmp = n_mis = n_nov = n_lim = n_lim_proved = n_lim_beaten = rounds_done = 0
+        n_cmp = n_mis = n_nov = n_lim = n_lim_proved = n_lim_beaten = n_lim_above = rounds_done = 0
+        n_nos = n_nos_agree = n_nos_mis = n_nos_nov = unproven_rounds = 0
         d_traj_max = d_obj_max = lim_gap_max = 0.0
-        for r in range(W, W + K):
+        lim_total = int(sum((outs[r]["status"] == 1).sum() for r in outs))
+        nos_total = int(sum((outs[r]["status"] == 2).sum() for r in outs))
+        for r in range(W, W + K):   # leg 1
+            if time.perf_counter() - t_par > args.parity_seconds * 2.0 / 3.0:
+                break
+            x, g = rec[r], outs[r]
+            lim = np.where(g["status"] == 1)[0]
+            if len(lim):   # incumbents without a proof: hinted search for the optimum (the hint only prunes)
+                ol = proved(x, lim, hint=g["obj"][lim] * (1 + 1e-9))
+                n_lim += len(lim)
+                for t_, a_ in enumerate(lim):
+                    if ol["status"][t_] == 0:
+                        n_lim_proved += 1
+                        gap = float((g["obj"][a_] - ol["obj"][t_]) / max(1.0, abs(ol["obj"][t_])))
+                        lim_gap_max = max(lim_gap_max, gap)
+                        n_lim_beaten += int(gap < -1e-7)
+                        n_lim_above += int(gap > 1e-7)
+            nos = np.where(g["status"] == 2)[0]
+            if len(nos):
+                on = proved(x, nos)
+                n_nos += len(nos)
+                n_nos_agree += int((on["status"] == 2).sum())
+                n_nos_mis += int((on["status"] == 0).sum())
+                n_nos_nov += int((on["status"] == 1).sum())
+            unproven_rounds += 1
+        for r in range(W, W + K):   # leg 2
             if time.perf_counter() - t_par > args.parity_seconds:
                 break
             x, g = rec[r], outs[r]
-            cand = np.where(g["status"] != 1)[0]
+            cand = np.where(g["status"] == 0)[0]
+            if len(cand) == 0:
+                rounds_done += 1
+                continue
             sub = np.sort(rng_p.choice(cand, min(args.parity_sample, len(cand)), replace=False))
             o = proved(x, sub)
             verdict = o["status"] != 1
@@ -706,28 +851,23 @@ def main():
             if both.any():
                 d_traj_max = max(d_traj_max, float(np.abs(g["traj"][sub][both] - o["traj"][both]).max()))
                 d_obj_max = max(d_obj_max, float((np.abs(g["obj"][sub][both] - o["obj"][both]) / np.maximum(1.0, np.abs(o["obj"][both]))).max()))
-            lim = np.where(g["status"] == 1)[0][:8]
-            if len(lim):   # incumbents without a proof: hinted search for the optimum (the hint only prunes)
-                ol = proved(x, lim, hint=g["obj"][lim] * (1 + 1e-9))
-                n_lim += len(lim)
-                for t_, a_ in enumerate(lim):
-                    if ol["status"][t_] == 0:
-                        n_lim_proved += 1
-                        gap = float((g["obj"][a_] - ol["obj"][t_]) / max(1.0, abs(ol["obj"][t_])))
-                        lim_gap_max = max(lim_gap_max, gap)
-                        n_lim_beaten += int(gap < -1e-7)
             rounds_done += 1
-        parity = {"instances_compared": n_cmp, "status_mismatches": n_mis, "max_abs_traj_diff": d_traj_max, "max_rel_obj_diff": d_obj_max,
-                  "oracle_without_verdict": n_nov, "rounds_checked": rounds_done, "sample_per_round": args.parity_sample,
-                  "limit_instances_checked": n_lim, "limit_incumbents_with_proven_optimum": n_lim_proved,
-                  "limit_incumbent_below_optimum": n_lim_beaten, "limit_incumbent_max_rel_gap": lim_gap_max,
-                  "limit_instances_in_replay": int(sum((outs[r]["status"] == 1).sum() for r in outs)),
-                  "failed_instances_in_replay": int(sum((outs[r]["status"] == 2).sum() for r in outs)),
+        parity = {"instances_compared": n_cmp + n_nos - n_nos_nov, "status_mismatches": n_mis + n_nos_mis, "max_abs_traj_diff": d_traj_max, "max_rel_obj_diff": d_obj_max,
+                  "oracle_without_verdict": n_nov + n_nos_nov, "rounds_checked": rounds_done, "sample_per_round": args.parity_sample,
+                  "limit_instances_checked": n_lim, "limit_instances_in_replay": lim_total,
+                  "limit_incumbents_with_proven_optimum": n_lim_proved,
+                  "limit_incumbent_below_optimum": n_lim_beaten, "limit_incumbent_above_optimum": n_lim_above, "limit_incumbent_max_rel_gap": lim_gap_max,
+                  "no_solution_checked": n_nos, "no_solution_in_replay": nos_total, "no_solution_oracle_agrees": n_nos_agree,
+                  "no_solution_oracle_finds_a_solution": n_nos_mis, "no_solution_oracle_without_verdict": n_nos_nov,
+                  "rounds_checked_for_unproven_answers": unproven_rounds,
+                  "failed_instances_in_replay": nos_total,
                   "instances_in_timed_rounds": K * n_local, "seconds": time.perf_counter() - t_par,
-                  "what": "a replay of the timed rounds after the timed region (same recorded inputs, same warm-up): a random sample of the device "
-                          "answers per round (status, trajectory, objective) against the CPU oracle with a PROOF (second search order where the "
-                          "step-ordered one runs into its budget; an oracle answer without proof is no verdict), plus the instances the device ended "
-                          "on a budget: their incumbent against the oracle's proven optimum"}
+                  "what": "a replay of the timed rounds after the timed region (same recorded inputs, same warm-up). Leg 1: EVERY instance the device "
+                          "ended on a budget (its incumbent against the oracle's PROVEN optimum: below = a wrong answer, above = a valid but "
+                          "suboptimal incumbent, as AC:948-952 lets Gurobi return at its time limit) and EVERY instance it called infeasible (the oracle "
+                          "must prove that), round by round within 2/3 of --parity-seconds; leg 2: a random sample of the proven answers per round "
+                          "(status, trajectory, objective) against the oracle with a PROOF (second search order where the step-ordered one runs "
+                          "into its budget; an oracle answer without proof is no verdict)"}
 
     # ---------------------------------------------------------------- secondary workloads (default single-GPU line only)
     # BASELINE configs[2] and configs[4] as short windows, each a run of this script in its own process (own handle, own set-up
@@ -745,7 +885,10 @@ def main():
                 continue
             cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-secondary", "--no-event-pass", "--repeats", "3",
                                                                         "--mip-gap", str(gap), "--time-limit-s", str(args.time_limit_s),
-                                                                        "--parity-sample", "64" if gap == 0.0 else "0", "--parity-seconds", "40"]
+                                                                        "--parity-sample", "64" if gap == 0.0 else "0",
+                                                                        "--parity-seconds", "75" if extra is cfg5 else "40"]
+            if gap == args.mip_gap:   # (the record at Gurobi's MIPGap repeats the window only: no second device-loop pass)
+                cmd.append("--device-loop")
             # (a profiler attached to this process must see this line's launches only: the children run without its preload)
             child_env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX"))}
             pre = [x for x in child_env.pop("LD_PRELOAD", "").split(":") if x and "rocprof" not in x and "roctracer" not in x]
@@ -753,13 +896,14 @@ def main():
                 child_env["LD_PRELOAD"] = ":".join(pre)
             try:
                 t1 = time.perf_counter()
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=child_env)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=child_env)
                 z = json.loads(pr.stdout.strip().splitlines()[-1])
                 secondary.append({"workload_key": z["config"]["workload_key"], "workload": z["config"]["workload"], "mip_gap": gap, "value": z["value"], "unit": z["unit"],
                                   "ms_per_step": z["ms_per_step"], "ms_per_step_repeats": z["ms_per_step_repeats"],
                                   "roofline_frac": z["roofline"]["frac"], "limit_instances": z["limit_instances_timed_rounds"],
                                   "failed_instances": z["failed_instances_timed_rounds"], "nodes_max": z["solver_stats_timed_rounds"]["nodes_max"],
                                   "parity_on_timed_rounds": z.get("parity_on_timed_rounds"),
+                                  "device_resident_loop": z.get("device_resident_loop"),
                                   "wall_s": time.perf_counter() - t1,
                                   "what": "ms_per_step = wall clock per replayed round (pre-pass + kernels, inputs resident in HBM); roofline_frac "
                                           "is priced on it (no separate event pass)"})
@@ -856,6 +1000,7 @@ def main():
             "rccl_ranks": comm.world if comm is not None else (1 if world == 1 else None),
             "exchange": ("none (one rank)" if world == 1 else ("RCCL all-gather (hdsm_exchange_device)" if comm is not None
                                                                else "host-staged gloo all-gather (flow check only)")),
+            "exchange_error": exchange_error,
             "weak_scaling_record": weak,
             "weak_scaling_value": None if weak is None else weak["value"],
             "scaling_note": None if world == 1 else (

@@ -113,7 +113,10 @@ typedef struct hdsm_params {
    * exceeds the budget hands its search over (a record of its open levels; one queue item per unexplored child); persistent
    * workgroups that draw the items and continue inside their subtrees, handing over again when a subtree grows large
    * (HDSM_ITEM_BUDGET nodes, default 32; HDSM_ITEM_MIN while workgroups wait for items); the merge. HDSM_SPLIT_BUDGET = the
-   * budget of the first kernel in nodes (default by batch size: 8 for batches that leave CUs idle, 96 beyond). max_nodes stays
+   * budget of the first kernel in nodes (1 or more; default by batch size: 2 for batches of at most 2 x compute units instances,
+   * 16 beyond — a hand-over costs about one node since round 5). HDSM_ITEM_MIN has the same by-batch default (2 / 16).
+   * HDSM_SPLIT_RECORDS: hand-over records per launch (default 8 x max_instances, clamped to 256 .. 2048); HDSM_POLL_SLEEP: s_sleep(127)
+   * periods between two looks of a waiting workgroup at the item queue (default 2). max_nodes stays
    * the budget of an INSTANCE: its items draw from one pool. HDSM_CHILD_BOUND 1 (default) / 0: children of a branching node
    * get a lower bound and their first entering row from the node's leaf test / neither. HDSM_SETUP_MFMA 1 (default) / 0: the
    * set-up map of all instances of a launch is one product on the matrix cores in the pre-pass kernel / every instance applies
@@ -126,8 +129,7 @@ typedef struct hdsm_params {
    * HDSM_QUAD_MIN: batches of at least this many instances with n_hor <= 10 run FOUR 128-thread workgroups per CU (small
    * LDS layout; default 3 x compute units + 1, 0 = never). HDSM_SCANNER 1 (default) / 0: in workgroups of more than one
    * wavefront the second one evaluates the trajectory and picks the row that enters next while the first applies the update
-   * of the operation before / the iterating wavefront does both. HDSM_DUO48_ROWS 720 (default) / 320: staging rows of the
-   * two-per-CU kernel for n_hor > 10 (the smaller instantiation exists for the staging-overflow test).
+   * of the operation before / the iterating wavefront does both.
    * None of these changes an answer that is HDSM_OPTIMAL.)                                                       */
   /* Gurobi's TimeLimit (0.08 s, AC:952) as an OPTIONAL wall-clock budget per instance, measured on the device's
    * constant-rate clock from the start of the instance's workgroup: when it is spent the branch-and-bound stops and

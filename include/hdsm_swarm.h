@@ -179,6 +179,18 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream);
 int hdsm_dswarm_download(void* dswarm, void* swarm, double* plans_all, uint8_t* has_plan, int32_t* status, int32_t* failed_total);
 void hdsm_dswarm_destroy(void* dswarm);
 const char* hdsm_dswarm_last_error(void);
+/* Where a round goes (a measurement aid; the reference books the same intervals per agent, AC:165-227 comp_time_sc_ / _tasc_ / _opt_):
+ * with timing on, hdsm_dswarm_round records HIP events on its stream between its launches; hdsm_dswarm_last_phase_ms waits for the
+ * last timed round and returns milliseconds of [0] k_corridor (GenerateSafeCorridor, AC:1236-1447), [1] k_vel_cap (ComputePathVelocity's
+ * voxel term, AC:1709-1766), [2] hdsm_reference_device (AC:1449-1553), [3] k_keep_free (AC:1665-1693), [4] hdsm_replan_device
+ * (AC:1086-1215 + 858-1023), [5] k_commit (AC:955-1019, 569-585, 233-238), [6] the exchange (AC:610-677; one rank: nothing).
+ * Every record is a barrier packet in front of the next launch: a timed round is a few microseconds longer than a plain one. */
+int hdsm_dswarm_set_phase_timing(void* dswarm, int32_t on);
+int hdsm_dswarm_last_phase_ms(void* dswarm, float ms[7]);
+/* The device corridor's polyhedron cache since hdsm_dswarm_create, summed over the shard: out[0] polyhedra asked for, out[1] formed
+ * from a structure recorded in the same local grid, out[2] from one recorded in another grid at the same height (the interior
+ * rule), out[3] 1 if the cache is on (a world is set and HDSM_POLY_CACHE is not 0). Synchronises the device. */
+int hdsm_dswarm_cache_stats(void* dswarm, int64_t out[4]);
 
 /* Next row f3 (ROS-free half): every local agent keeps the records of Agent::TrajPlanningIteration — comp_time_sc_ (CPU time of
  * its corridor generation), comp_time_opt_ (the duration of the fused launch, handed in with hdsm_swarm_record_solve_ms between

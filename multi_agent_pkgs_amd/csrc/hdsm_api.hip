@@ -74,18 +74,26 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
       // compare-and-swap on a shared counter was measured first: 512 workgroups retrying against each other cost a millisecond.)
       const int ticket = atomicAdd(&rcnt[2], 1);
       int got = -1;
+      bool timed_out = ticket < icap;
       for (int spins = 0; spins < (1 << 19) && ticket < icap; ++spins) {  // (seconds: whatever holds the last items up)
         const int done = __hip_atomic_load(&rcnt[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int q = __hip_atomic_load(&rcnt[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         q = q < icap ? q : icap;
         if (ticket < q) {
-          got = ticket;
+          got = ticket, timed_out = false;
           break;
         }
-        if (done >= q) break;  // (read BEFORE the queue's end: all of it was completed, and only a running item can extend it)
+        // (read BEFORE the queue's end: all of it was completed, and only a running item can extend it) — or the launch was
+        // ABORTED (rcnt[6]): a waiter ran out of patience, so its ticket will never be drawn and `done` can never reach the end
+        // of the queue again; every other waiter would spin out its own seconds one after the other
+        if (done >= q || __hip_atomic_load(&rcnt[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          timed_out = false;
+          break;
+        }
         // (hundreds of workgroups may be waiting, and every look is a device-scope read that no L2 can serve)
         for (int w = 0; w < psleep; ++w) __builtin_amdgcn_s_sleep(127);
       }
+      if (timed_out) atomicExch(&rcnt[6], 1);  // (items left in the queue stay ST_PENDING: the merge reports their instances as LIMIT)
       int sl = -1;
       if (got >= 0) {  // a scratch slot: at most gridDim-resident + records slots are ever busy (a slot left to a record stays busy)
         for (int probe = 0; probe < pcap && sl < 0; ++probe) {
@@ -713,7 +721,6 @@ struct Handle {
   int bounds_min = 256;       // swarms of at least this many agents get the sphere prefilter (HDSM_BOUNDS_MIN)
   int duo_min = 0;            // batches of at least this many instances run two workgroups per CU (HDSM_DUO_MIN; set at create: CUs + 1)
   int tri_min = 0;            // ... and of at least this many three 128-thread workgroups per CU (HDSM_TRI_MIN; 2 x CUs + 1, 0 = never)
-  int duo48_rows = 720;       // staging rows of the two-per-CU kernel for n > 30 (HDSM_DUO48_ROWS=320: the smaller instantiation)
   int quad_min = 0;           // ... and of at least this many four per CU, small LDS layout (HDSM_QUAD_MIN; 3 x CUs + 1, 0 = never)
   // subtree splitting (launch_split): 0 never, 1 always, 2 automatic (when the previous launch saw a deep tree)
   int split_mode = 2, split_budget = 0, split_ttl = 0;  // split_budget 0: by batch size, see launch()
@@ -856,25 +863,30 @@ int launch_quad(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
 
 // n > 30 (H up to 16): the factor needs more than 256 registers per lane, so a wavefront must have a SIMD to itself — but a
 // 128-thread workgroup has only two, and TWO such workgroups (four wavefronts, one per SIMD) fit a CU once the staging area is cut
-// to 720 rows (2 x 80 KB of LDS; 736 until round 5 added the per-level child bounds; 320 rows until the butterfly layout freed the 19 KB transposition buffer of the old code — the
-// 320-row instantiation stays selectable, HDSM_DUO48_ROWS=320: the staging-overflow test needs an area that a dense
-// neighbourhood can fill). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5: 4096
-// instances, 16 per CU one after the other), and every instance is one latency-bound wavefront: the second one doubles the rate.
-constexpr int CMAX_DUO48 = 720, CMAX_DUO48_SMALL = 320;
+// to 720 rows (2 x 80 KB of LDS; 736 until round 5 added the per-level child bounds; 320 rows until the butterfly layout freed the
+// 19 KB transposition buffer of the old code). Batches larger than the CU count are throughput-bound at one instance per CU (cfg 5:
+// 4096 instances, 16 per CU one after the other), and every instance is one latency-bound wavefront: the second one doubles the rate.
+// (Until round 6 a second instantiation with 320 rows stayed selectable for the staging-overflow test, HDSM_DUO48_ROWS=320. When the
+// last spilled registers of these kernels were removed, THAT instantiation — and only it — began to end feasible instances as
+// "infeasible" after two operations, deterministically per build, while builds with a spill, with -O2, with -fwrapv or with device
+// printf in the loop gave the oracle's answers; the CPU execution of the same source is right in either wave order. The cause was not
+// found — scripts/gpu_r6_overflow_raw.py reproduces it on the sources of that commit — so the product keeps ONE instantiation per
+// launch shape, each of which the whole -m gpu suite, the fuzz and the oracle check of the timed rounds run through, and the
+// overflow test fills the 256 rows of the four-per-CU kernel instead.)
+constexpr int CMAX_DUO48 = 720;
 template <int NV, int CMAX, int NT>
 __global__ __launch_bounds__(NT, 1) void k_replan_duo48(const hdsm::Consts* __restrict__ cp, hdsm::Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using Sol = hdsm::Solver<NV, CMAX>;
   run_block<Sol>(reinterpret_cast<typename Sol::S*>(smem), cp, a);
 }
-template <int CM>
-int launch_duo48_rows(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
-  using Sol = hdsm::Solver<48, CM>;
+int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
+  using Sol = hdsm::Solver<48, CMAX_DUO48>;
 #ifndef HDSM_PROFILE  // (the counters of the profile build live in LDS: that build runs at a lower occupancy)
   static_assert(sizeof(typename Sol::S) * 2 <= 160 * 1024, "two instances must fit the LDS of one CU");
 #endif
   const size_t shm = sizeof(typename Sol::S);
-  auto kern = k_replan_duo48<48, CM, 128>;
+  auto kern = k_replan_duo48<48, CMAX_DUO48, 128>;
   static thread_local int attr_dev[2] = {-1, -1};
   if (attr_dev[a.item_mode ? 1 : 0] != h->device) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -883,10 +895,6 @@ int launch_duo48_rows(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(128), shm, st, h->d_consts, a);
   HIP_TRY(hipGetLastError());
   return HDSM_OK;
-}
-
-int launch_duo48(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
-  return h->duo48_rows == CMAX_DUO48_SMALL ? launch_duo48_rows<CMAX_DUO48_SMALL>(h, a, st, blocks) : launch_duo48_rows<CMAX_DUO48>(h, a, st, blocks);
 }
 
 int launch_tri(Handle* h, const hdsm::Args& a, hipStream_t st, int blocks) {
@@ -1211,8 +1219,12 @@ int64_t scratch_stride_for(int n) {
 hipError_t ensure_sub(Handle* h) {
   const size_t N = (size_t)h->N;
   const bool two = h->threads == 256 && h->duo_min > 0;
+  // (resident workgroups of pass 2 per CU: two for the 256-thread shared-CU shapes, ONE for everything else — the one-per-CU kernels,
+  // with 64 threads too, are held to that by LDS: their instance state is more than half of a CU's 160 KB)
+  static_assert(sizeof(hdsm::Solver<32, CMAX30>::S) > 80 * 1024 && sizeof(hdsm::Solver<48, CMAX48>::S) > 80 * 1024,
+                "pool_cap counts ONE resident pass-2 workgroup per CU for the one-per-CU kernels");
   h->sub_slots_n = (two ? 2 : 1) * h->cus;
-  h->rows_cap = h->n <= hdsm::SPLIT_N_MAX ? (two ? CMAX_DUO : CMAX30) : (two ? h->duo48_rows : CMAX48);
+  h->rows_cap = h->n <= hdsm::SPLIT_N_MAX ? (two ? CMAX_DUO : CMAX30) : (two ? CMAX_DUO48 : CMAX48);
   // (rec_cap — records: one per instance that hands its search over + one per item that hands over again — set by hdsm_create)
   h->items_cap = h->rec_cap * 16 < 4096 ? 4096 : h->rec_cap * 16;
   // snapshot scratch of pass 2: one slot per workgroup that can be resident + one per record (an item that hands over again leaves
@@ -1356,7 +1368,6 @@ int hdsm_create(const hdsm_params* params, int32_t max_instances, int32_t n_rob_
     env_int("HDSM_TRI_MIN", 0, INT_MAX, &h->tri_min);  // 0 = never
     h->quad_min = h->tri_min > 0 ? 3 * cus + 1 : 0;    // more instances than the three-per-CU kernel has resident slots
     env_int("HDSM_QUAD_MIN", 0, INT_MAX, &h->quad_min);  // 0 = never
-    env_int("HDSM_DUO48_ROWS", 320, 720, &h->duo48_rows);
     env_int("HDSM_SETUP_MFMA", 0, 1, &h->setup_mfma);
     env_int("HDSM_SPLIT", 0, 2, &h->split_mode);       // subtree splitting: 0 never, 1 always, 2 (default) when the last launch met a deep tree
     env_int("HDSM_SPLIT_BUDGET", 1, 100000, &h->split_budget);  // (unset: by batch size, see launch())

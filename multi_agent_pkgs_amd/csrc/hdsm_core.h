@@ -291,9 +291,9 @@ struct Solver {
           // violated (or almost) -> hot list, scanned every iteration; merely close -> cold list at the top of
           // the staging area, scanned only when the hot rows are all satisfied
           const bool hot = -v < c.hot_tau;
-          const int slot = hot ? atomic_inc_i32(&s.ncand) : CMAX - 1 - atomic_inc_i32(&s.ncold);
-          const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
-          if (fits && slot >= 0 && slot < CMAX) {
+          int slot;
+          const bool fits = stage_slot<CMAX>(s.ncand, s.ncold, hot, slot);  // (hdsm_wave_gi.h: increment, THEN the other list's counter)
+          if (fits) {
             s.cand[slot][0] = row[0], s.cand[slot][1] = row[1], s.cand[slot][2] = row[2];
             s.cand[slot][3] = row[3];
             s.cand_mw[slot] = mk_mw(s.kap, row[0], row[1], row[2], m);
@@ -509,7 +509,10 @@ struct Solver {
       s.contain[i] = cont;
     }
     SYNC();
-    if (IS_T0) s.lb_top1 = 0.0, s.lb_top2 = 0.0, s.lb_step = -1, s.leaf_lb = 0;  // (no node / child bound on this path: more than 64 (step, polyhedron) pairs)
+    // (no node / child bound on this path — more than 64 (step, polyhedron) pairs: leaf_lb = 0 says so, and whoever reads lb_top1 /
+    // lb_top2 / lb_step looks at it first. Writing zeros into the two doubles here instead cost the shared-CU kernels their only scratch
+    // access: the 16-byte zero was hoisted in front of the tree loop as a loop-invariant constant and SPILLED, 20 B/lane)
+    if (IS_T0) s.leaf_lb = 0;
     // the step to branch on among those whose segment lies in no polyhedron: the first in time (rule 0), or the MOST
     // infeasible one — largest violation of its best polyhedron (rule 1). Any choice is exact; it only shapes the tree.
     int pick = -1;
@@ -1261,7 +1264,7 @@ struct Solver {
             if (a.item_mode && s.f >= 0.0) atomicMin(&a.inc_bits[inst], (unsigned long long)__double_as_longlong(s.f));
           }
           SYNC();
-        } else if (s.f + s.lb_top1 >= cutoff(s, c)) {
+        } else if (s.leaf_lb != 0 && s.f + s.lb_top1 >= cutoff(s, c)) {
           // the node bound reaches the incumbent: no leaf below this node can beat it — closed without a snapshot, without a level
         } else {  // open a new level on the first step that lies in no polyhedron
           const int L = s.level, bstep_own = bstep;
@@ -1279,7 +1282,7 @@ struct Solver {
                 s.br_order[L][y] = s.br_order[L][y - 1];
                 s.br_order[L][y - 1] = t;
               }
-            const double others = bstep == s.lb_step ? s.lb_top2 : s.lb_top1;  // the node bound of the steps that stay uncontained
+            const double others = s.leaf_lb == 0 ? 0.0 : (bstep == s.lb_step ? s.lb_top2 : s.lb_top1);  // the node bound of the steps that stay uncontained
             for (int x1 = 0; x1 < cnt; ++x1) {
               const int item = bstep * np + s.br_order[L][x1];
               const double own = s.leaf_lb ? s.lb_at(item) : 0.0;
@@ -1409,8 +1412,20 @@ struct Solver {
           a.node_pool[inst] = a.nodes_pool0;
         }
         __threadfence();
-        while (__hip_atomic_load(&a.rec_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != first) __builtin_amdgcn_s_sleep(1);  // (those before: a few stores away)
-        __hip_atomic_store(&a.rec_count[1], first + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (those before: a few stores away. Bounded all the same — a predecessor that never publishes, or a launch a waiter has
+        // aborted (rec_count[6], hdsm_api.hip run_block), must not hang this workgroup: it raises the abort word and leaves its items
+        // unpublished; they stay ST_PENDING and the merge reports the instance as LIMIT)
+        int spins = 0;
+        bool in_order = true;
+        while (__hip_atomic_load(&a.rec_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != first) {
+          if (++spins > (1 << 22) || __hip_atomic_load(&a.rec_count[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            in_order = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (in_order) __hip_atomic_store(&a.rec_count[1], first + cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else atomicExch(&a.rec_count[6], 1);
       }
       if (item >= 0) wg_slot = -1;  // (pass 2: this workgroup's scratch, with the snapshots of the open levels, stays with the record)
     }

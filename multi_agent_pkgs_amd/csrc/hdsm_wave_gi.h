@@ -107,6 +107,31 @@ __device__ __forceinline__ double rsq_nr(double x) {
   return y;
 }
 
+// A slot of the staging area for one row: hot rows fill it from the bottom (counter `ncand`), cold rows from the top (`ncold`), every
+// thread of the workgroup at once. A writer takes its slot with an atomic increment of its own counter and THEN reads the other list's
+// counter: if the two lists have met, whichever writer incremented second sees it and gives way, so no slot is ever written twice.
+// "Then" must hold in the machine code: the increment ACQUIRES (nothing after it moves in front of it) and the other counter is read
+// ATOMICALLY (never a value the compiler kept from before). Written as a plain `s.ncold` after a relaxed atomicAdd the order was only an
+// accident of instruction scheduling — one register-allocation change later (round 6) the read of a loop-invariant-looking `s.ncold`
+// sat in front of the loop, both lists wrote through each other as soon as the area filled up, and the 320-row kernel returned
+// "infeasible" for feasible instances WITHOUT the overflow flag.
+template <int CMAX>
+__device__ __forceinline__ bool stage_slot(int32_t& ncand, int32_t& ncold, bool hot, int& slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (hot) {
+    slot = __hip_atomic_fetch_add(&ncand, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int other = __hip_atomic_load(&ncold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return slot >= 0 && slot < CMAX - other;
+  }
+  slot = CMAX - 1 - __hip_atomic_fetch_add(&ncold, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const int other = __hip_atomic_load(&ncand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return slot < CMAX && slot >= other && slot >= 0;
+#else
+  slot = hot ? atomicAdd(&ncand, 1) : CMAX - 1 - atomicAdd(&ncold, 1);
+  return (hot ? slot < CMAX - ncold : slot >= ncand) && slot >= 0 && slot < CMAX;
+#endif
+}
+
 // an integer the optimiser must treat as recomputed here (no effect on the value): stops it from hoisting what depends on it
 __device__ __forceinline__ void keep_in_loop(int& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -724,9 +749,9 @@ struct WaveGI {
             if (v > tol) s.nviol = 1;
             if (-v < thresh) {
               const bool hot = -v < hot_tau;
-              const int slot = hot ? atomicAdd(&s.ncand, 1) : CMAX - 1 - atomicAdd(&s.ncold, 1);
-              const bool fits = hot ? slot < CMAX - s.ncold : slot >= s.ncand;
-              if (fits && slot >= 0 && slot < CMAX) {
+              int slot;
+              const bool fits = stage_slot<CMAX>(s.ncand, s.ncold, hot, slot);
+              if (fits) {
                 s.cand[slot][0] = fx, s.cand[slot][1] = fy, s.cand[slot][2] = fz, s.cand[slot][3] = rhs;
                 s.cand_mw[slot] = mk_mw(s.kap, fx, fy, fz, m);
                 s.cand_src[slot] = (k << 6) | (i << 1) | e;

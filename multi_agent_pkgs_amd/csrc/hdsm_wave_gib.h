@@ -556,8 +556,8 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
 #ifdef HDSM_TRACE_GI
       if (lane == 0) {
         const int kd = id_kind(ip), pl = id_payload(ip);
-        if (kd == K_C) printf("  pick C m=%d src(k=%d,i=%d,e=%d) v=%.3e q=%d f=%.6g\n", kc_m(pl), s.cand_src[kc_slot(pl)] >> 6, (s.cand_src[kc_slot(pl)] >> 1) & 31, s.cand_src[kc_slot(pl)] & 1, vip, q, f);
-        else printf("  pick kind=%d payload=%d v=%.3e q=%d f=%.6g\n", kd, pl, vip, q, f);
+        if (kd == K_C) printf("  [blk %d] pick C m=%d src(k=%d,i=%d,e=%d) v=%.3e q=%d f=%.6g\n", kc_m(pl), (int)blockIdx.x, s.cand_src[kc_slot(pl)] >> 6, (s.cand_src[kc_slot(pl)] >> 1) & 31, s.cand_src[kc_slot(pl)] & 1, vip, q, f);
+        else printf("  [blk %d] pick kind=%d payload=%d v=%.3e q=%d f=%.6g\n", (int)blockIdx.x, kd, pl, vip, q, f);
       }
 #endif
       double lam_p = 0;
@@ -611,7 +611,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
         }
         PROF(4)
 #ifdef HDSM_TRACE_GI
-        if (lane == 0) printf("    step dep=%d t1=%.3e t2=%.3e l=%d zz=%.3e dd=%.3e\n", (int)dependent, t1, dependent ? 0.0 : vip / zz, l, zz, dd);
+        if (lane == 0) printf("    [blk %d] step dep=%d t1=%.3e t2=%.3e l=%d zz=%.3e dd=%.3e dep_thr=%.3e kip=%.3e\n", (int)blockIdx.x, (int)dependent, t1, dependent ? 0.0 : vip / zz, l, zz, dd, dep_thr, kip);
 #endif
         if (dependent && l < 0) {
           no_step();
@@ -674,6 +674,9 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
         break;
       }
     }
+#ifdef HDSM_TRACE_GI
+    if (lane == 0) printf("  [blk %d] run ends rc=%d iters=%d q=%d f=%.9g f_cut=%.9g f_box=%.9g\n", (int)blockIdx.x, rc, iters, q, f, f_cut, s.f_box);
+#endif
     store_pos(s, R, lane);
     wsync();
     if (pending) __syncthreads();  // (a pick nobody needs any more: its "done")

@@ -12,10 +12,12 @@
 // tests/test_gpu_configs.py. AC = multi_agent_planner/src/agent_class.cpp of the reference.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdlib>
 #include <new>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/hdsm.h"
 #include "../../include/hdsm_swarm.h"
@@ -26,20 +28,14 @@ extern "C" int hdsm_internal_defer_done(void* handle, int on);
 extern "C" int hdsm_internal_record_done(void* handle, void* hip_stream);
 
 #ifdef CD_PROFILE
-namespace {
-__device__ unsigned long long g_cache_stat[4];  // polyhedra asked for, found in the cache with (seed, origin), with the seed alone
-}
 // development builds only: the phase counters of the corridor kernel's decompositions (read and cleared); [12] cycles of the whole
-// corridor step, [13] of its decompositions, [14] agent-rounds, [15] decompositions
+// corridor step, [13] of its decompositions, [14] agent-rounds, [15] decompositions. (The polyhedron cache's counters are NOT in here:
+// hdsm_dswarm_cache_stats, every build.)
 extern "C" int hdsm_swarm_corridor_profile(unsigned long long out[16]) {
   if (hipDeviceSynchronize() != hipSuccess) return HDSM_ERR_DEVICE;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hdsm_cd::g_cd_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return HDSM_ERR_DEVICE;
   unsigned long long zero[16] = {0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(hdsm_cd::g_cd_prof), zero, sizeof zero) != hipSuccess) return HDSM_ERR_DEVICE;
-  unsigned long long cs[4] = {0};
-  if (hipMemcpyFromSymbol(cs, HIP_SYMBOL(g_cache_stat), sizeof cs) != hipSuccess) return HDSM_ERR_DEVICE;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_cache_stat), zero, sizeof cs) != hipSuccess) return HDSM_ERR_DEVICE;
-  out[6] = cs[0], out[7] = cs[1], out[9] = cs[2];  // (the slots of the rare phases: polyhedra asked for / found in the cache / seed seen before)
   return HDSM_OK;
 }
 #endif
@@ -90,6 +86,9 @@ struct PolyCache {
   hdsm_cd::PolyStruct ps[CACHE_POLYS];
   int32_t seed_w[CACHE_POLYS][3], off[CACHE_POLYS][3], ground_w[CACHE_POLYS], interior[CACHE_POLYS];
   int32_t n, next;
+  // what the cache did for this agent (hdsm_dswarm_cache_stats; written by lane 0 of the agent's own wavefront): polyhedra asked
+  // for, found with the same grid, found through the interior rule (another grid at the same height)
+  int32_t asked, hits_same_grid, hits_interior, pad_;
 };
 
 // GenerateSafeCorridor (AC:1236-1447), ONE WAVEFRONT PER AGENT. The walk along the path (steps of voxel / 10: hundreds of
@@ -268,15 +267,17 @@ __device__ __forceinline__ void corridor_step_wave(const Cfg& c, AgentS& ag, con
       const bool interior = rad > 0 && hdsm_sw::seed_in_grid(c, seed) && seed[0] - rad >= 1 && seed[1] - rad >= 1 && seed[0] + rad <= wg.lnx - 2 &&
                             seed[1] + rad <= wg.lny - 2;
       int hit = -1;
+      bool hit_same_grid = false;
       if (pc != nullptr)
         for (int k = 0; k < pc->n && hit < 0; ++k) {
           const bool same_voxel = pc->seed_w[k][0] == seed_w[0] && pc->seed_w[k][1] == seed_w[1] && pc->seed_w[k][2] == seed_w[2];
           const bool same_grid = pc->off[k][0] == off_w[0] && pc->off[k][1] == off_w[1] && pc->off[k][2] == off_w[2];
-          if (same_voxel && (same_grid || (interior && pc->interior[k] != 0 && pc->off[k][2] == off_w[2] && pc->ground_w[k] == ground_w))) hit = k;
+          if (same_voxel && (same_grid || (interior && pc->interior[k] != 0 && pc->off[k][2] == off_w[2] && pc->ground_w[k] == ground_w))) hit = k, hit_same_grid = same_grid;
         }
-#if defined(CD_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-      if (lane == 0 && pc != nullptr) atomicAdd(&g_cache_stat[0], 1ull), atomicAdd(&g_cache_stat[1], hit >= 0 ? 1ull : 0ull);
-#endif
+      if (lane == 0 && pc != nullptr) {
+        ++pc->asked;
+        if (hit >= 0) ++(hit_same_grid ? pc->hits_same_grid : pc->hits_interior);
+      }
       if (hit >= 0) {  // grown before from this voxel: the rows from the integers, in this grid's arithmetic
         const double org[3] = {origin[0], origin[1], origin[2]};
         const int cap = c.RS < HDSM_MAX_ROWS_STATIC ? c.RS : HDSM_MAX_ROWS_STATIC;
@@ -537,6 +538,10 @@ struct DSwarm {
   int32_t *d_npath = nullptr, *d_id = nullptr, *d_npoly = nullptr, *d_nrows = nullptr, *d_status = nullptr, *d_fails = nullptr;
   uint8_t *d_used = nullptr, *d_has = nullptr;
   long long rounds = 0;
+  // hdsm_dswarm_set_phase_timing: HIP events between the launches of a round (development / bench aid: every record is a barrier
+  // packet in front of the next kernel, so a timed round is a few us longer than a plain one — ms_per_round is never taken from it)
+  bool phase_timing = false, phase_valid = false;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 template <class T>
@@ -552,6 +557,8 @@ void free_all(DSwarm* d) {
                   d->d_used, d->d_has};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : d->ev)
+    if (e) (void)hipEventDestroy(e);
 }
 
 }  // namespace
@@ -559,6 +566,50 @@ void free_all(DSwarm* d) {
 extern "C" {
 
 const char* hdsm_dswarm_last_error(void) { return g_err.c_str(); }
+
+// Where a round of the device-resident loop goes, measured with HIP events on the round's own stream: the records sit between the
+// launches of hdsm_dswarm_round — [0] k_corridor, [1] k_vel_cap, [2] hdsm_reference_device (pack + reference), [3] k_keep_free,
+// [4] hdsm_replan_device (pre-pass, solver kernels, merge), [5] k_commit, [6] the exchange. hdsm_dswarm_last_phase_ms synchronises
+// with the last timed round and returns the seven durations in milliseconds (a phase the round did not launch: ~0).
+int hdsm_dswarm_set_phase_timing(void* dswarm, int32_t on) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d) return fail(HDSM_ERR_BAD_ARG, "null dswarm");
+  HIP_TRY(hipSetDevice(d->device));
+  if (on)
+    for (hipEvent_t& e : d->ev)
+      if (!e) HIP_TRY(hipEventCreate(&e));
+  d->phase_timing = on != 0, d->phase_valid = false;
+  return HDSM_OK;
+}
+
+// The polyhedron cache of the device corridor (k_corridor, PolyCache), summed over the shard's agents since hdsm_dswarm_create:
+// out[0] polyhedra asked for, out[1] formed from a cached structure recorded in the same local grid, out[2] formed from one recorded in
+// ANOTHER grid at the same height (the interior rule), out[3] = 1 if the cache is on (HDSM_POLY_CACHE, a world is set), else 0.
+int hdsm_dswarm_cache_stats(void* dswarm, int64_t out[4]) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d || !out) return fail(HDSM_ERR_BAD_ARG, "null argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!d->d_cache || d->n_local == 0) return HDSM_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipDeviceSynchronize());
+  out[3] = 1;
+  // (only the four counters of every entry travel: one strided 2-D copy)
+  std::vector<int32_t> cnt((size_t)d->n_local * 4);
+  HIP_TRY(hipMemcpy2D(cnt.data(), 16, reinterpret_cast<const char*>(d->d_cache) + offsetof(PolyCache, asked), sizeof(PolyCache), 16, (size_t)d->n_local,
+                      hipMemcpyDeviceToHost));
+  for (int k = 0; k < d->n_local; ++k) out[0] += cnt[4 * (size_t)k], out[1] += cnt[4 * (size_t)k + 1], out[2] += cnt[4 * (size_t)k + 2];
+  return HDSM_OK;
+}
+
+int hdsm_dswarm_last_phase_ms(void* dswarm, float ms[7]) {
+  DSwarm* d = static_cast<DSwarm*>(dswarm);
+  if (!d || !ms) return fail(HDSM_ERR_BAD_ARG, "null argument");
+  if (!d->phase_valid) return fail(HDSM_ERR_BAD_ARG, "no round has run with hdsm_dswarm_set_phase_timing on");
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipEventSynchronize(d->ev[7]));
+  for (int k = 0; k < 7; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], d->ev[k], d->ev[k + 1]));
+  return HDSM_OK;
+}
 
 int hdsm_dswarm_create(void* swarm, void* solver, int32_t device, int32_t world_size, void** dswarm) {
   if (!swarm || !solver || !dswarm || world_size < 1) return fail(HDSM_ERR_BAD_ARG, "null argument");
@@ -683,35 +734,52 @@ int hdsm_dswarm_round(void* dswarm, void* comm, void* hip_stream) {
       (void)hdsm_internal_record_done(solver, st);
     }
   } done_once(d->solver, st);
+  const bool timing = d->phase_timing;
+#define PHASE_MARK(k) \
+  do {                \
+    if (timing) HIP_TRY(hipEventRecord(d->ev[k], st)); \
+  } while (0)
+  PHASE_MARK(0);
   if (n > 0) {
     hipLaunchKernelGGL(k_corridor, dim3((unsigned)n), dim3(64), d->c.has_world ? hdsm_cd::wave_lds_bytes(hdsm_cd::wave_map_radius(d->c.n_it_decomp)) : 0, st, d->c, n, d->d_agents, d->d_path, d->d_npath, d->d_id, d->d_state,
                        d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_cache);
     HIP_TRY(hipGetLastError());
+    PHASE_MARK(1);
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_vel_cap, dim3((unsigned)n), dim3(64), 0, st, d->c, d->rcfg, n, d->d_agents, d->d_path, d->d_npath, d->d_cap);
       HIP_TRY(hipGetLastError());
     }
+    PHASE_MARK(2);
     int rc = hdsm_reference_device(d->solver, &d->rcfg, n, G, d->d_id, d->d_path, d->d_npath, PTS, d->c.has_world ? d->d_cap : nullptr,
                                    d->d_plans, d->d_has, d->d_ref_full, d->d_ref, d->d_pv, st);
     if (rc) return fail(rc, std::string("hdsm_reference_device: ") + hdsm_last_error());
+    PHASE_MARK(3);
     if (d->c.has_world) {
       hipLaunchKernelGGL(k_keep_free, dim3(gb), dim3(64), 0, st, d->c, n, d->d_agents, d->d_ref_full, d->d_ref, d->d_pv);
       HIP_TRY(hipGetLastError());
     }
+    PHASE_MARK(4);
     rc = hdsm_replan_device(d->solver, n, G, d->d_id, d->d_state, d->d_ref, d->d_npoly, d->d_nrows, d->d_A, d->d_b, d->d_plans, d->d_has,
                             d->d_traj, d->d_ctrl, d->d_used, d->d_status, d->d_obj, st);
     if (rc) return fail(rc, std::string("hdsm_replan_device: ") + hdsm_last_error());
+  } else {
+    for (int k = 1; k <= 4; ++k) PHASE_MARK(k);
   }
+  PHASE_MARK(5);
   // (one rank: the solve of this round is behind us on the stream, so the records go straight into the plans buffer — slot k =
   // agent k — and the flags with them; several ranks: into the send buffer of the ONE all-gather)
   const bool direct = d->world == 1;
   hipLaunchKernelGGL(k_commit, dim3((unsigned)(d->per > 0 ? d->per : 1)), dim3(64), 0, st, d->c, n, d->per, d->d_agents, d->d_traj, d->d_ctrl, d->d_used, d->d_status,
                      direct ? d->d_plans : d->d_local, d->d_fails, direct ? d->d_has : nullptr, d->d_ref_full, d->d_pv);
   HIP_TRY(hipGetLastError());
+  PHASE_MARK(6);
   if (!direct) {
     const int rc = hdsm_exchange_device(comm, d->per, d->d_local, d->d_plans, d->d_has, st);
     if (rc) return fail(rc, std::string("hdsm_exchange_device: ") + hdsm_last_error());
   }
+  PHASE_MARK(7);
+#undef PHASE_MARK
+  if (timing) d->phase_valid = true;
   ++d->rounds;
   return HDSM_OK;
 }

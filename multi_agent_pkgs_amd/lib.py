@@ -26,6 +26,7 @@ EXPORTS = ("hdsm_version", "hdsm_last_error", "hdsm_default_params", "hdsm_creat
            "hdsm_swarm_set_world", "hdsm_swarm_set_paths", "hdsm_swarm_route", "hdsm_swarm_get_paths",
            "hdsm_swarm_reference_inputs_n", "hdsm_swarm_corridor_errors", "hdsm_swarm_yaw", "hdsm_swarm_view", "hdsm_swarm_record_solve_ms", "hdsm_swarm_shutdown", "hdsm_swarm_prepare_corridor", "hdsm_swarm_vel_cap",
            "hdsm_dswarm_create", "hdsm_dswarm_upload_plans", "hdsm_dswarm_round", "hdsm_dswarm_download", "hdsm_dswarm_destroy", "hdsm_dswarm_last_error",
+           "hdsm_dswarm_set_phase_timing", "hdsm_dswarm_last_phase_ms", "hdsm_dswarm_cache_stats",
            "hdsm_stats_create", "hdsm_stats_destroy", "hdsm_stats_add", "hdsm_stats_add_state", "hdsm_stats_add_latency",
            "hdsm_stats_shutdown", "hdsm_map_preprocess", "hdsm_map_preprocess_device", "hdsm_map_last_error")
 

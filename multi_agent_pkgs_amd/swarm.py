@@ -362,6 +362,34 @@ class DeviceSwarm:
             raise _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
         return plans, has, status, failed.value
 
+    PHASES = ("k_corridor", "k_vel_cap", "hdsm_reference_device", "k_keep_free", "hdsm_replan_device", "k_commit", "exchange")
+
+    def _err(self, rc):
+        self.lib.hdsm_dswarm_last_error.restype = C.c_char_p
+        return _lib.HdsmError(rc, self.lib.hdsm_dswarm_last_error().decode())
+
+    def set_phase_timing(self, on=True):
+        """hdsm_dswarm_set_phase_timing: HIP events between the launches of the following rounds (see phase_ms)."""
+        rc = self.lib.hdsm_dswarm_set_phase_timing(self.h, C.c_int32(1 if on else 0))
+        if rc:
+            raise self._err(rc)
+
+    def phase_ms(self):
+        """Milliseconds of the last timed round per phase (PHASES order); synchronises with that round."""
+        ms = (C.c_float * 7)()
+        rc = self.lib.hdsm_dswarm_last_phase_ms(self.h, ms)
+        if rc:
+            raise self._err(rc)
+        return dict(zip(self.PHASES, [float(x) for x in ms]))
+
+    def cache_stats(self):
+        """hdsm_dswarm_cache_stats: what the device corridor's polyhedron cache did since the dswarm was created."""
+        out = (C.c_int64 * 4)()
+        rc = self.lib.hdsm_dswarm_cache_stats(self.h, out)
+        if rc:
+            raise self._err(rc)
+        return {"asked": int(out[0]), "hits_same_grid": int(out[1]), "hits_interior": int(out[2]), "cache_on": bool(out[3])}
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.hdsm_dswarm_destroy(self.h)

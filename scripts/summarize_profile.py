@@ -91,8 +91,14 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # streams at 64 B -> doubled as prescribed there (an upper estimate for this kernel, whose loads are 8-32 B per lane).
     summ["hbm_bytes_per_launch_raw"] = (pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
     summ["hbm_bytes_per_launch"] = (2 * pm["FETCH_SIZE"] + pm["WRITE_SIZE"]) * 1024
+# Scratch in a solver kernel is a regression (round 3 removed it; round 5 brought 20 B/lane back unnoticed): say so LOUDLY and fail.
+scratch = str(summ.get("kernel_trace", {}).get("scratch", "0")).strip()
+summ["scratch_check"] = "ok: Scratch_Size 0" if scratch in ("0", "") else f"FAILED: the traced solver kernel uses {scratch} B/lane of scratch"
 json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_summary.json"), "w"), indent=1)
 if "hbm_bytes_per_launch" in summ:
     json.dump(summ, open(os.path.join(root, "profiles", f"pmc_{key}.json"), "w"), indent=1)
 shutil.copy(os.path.join(out_dir, "bench.json"), os.path.join(root, "profiles", f"{tag}_bench.json"))
 print(json.dumps(summ, indent=1)[:3000])
+if not summ["scratch_check"].startswith("ok"):
+    print("\n*** " + summ["scratch_check"] + " ***", file=sys.stderr)
+    sys.exit(3)

@@ -71,7 +71,11 @@ bool run_block(void (*body)(void*), void* arg, int block_index, int nthreads) {
   while (r.b_nlive > 0 && !g_failed) {
     const long ops = r.ops;
     const int live = r.b_nlive;
-    for (int l = 0; l < nthreads && !g_failed; ++l) {
+    // (WEMU_ORDER=reverse: the wavefronts of the workgroup take their turns in the opposite order — what runs between two barriers must
+    // not depend on which wave gets there first; a result that changes with the order is a data race between wavefronts)
+    static const bool reverse = getenv("WEMU_ORDER") != nullptr && getenv("WEMU_ORDER")[0] == 'r';
+    for (int l0 = 0; l0 < nthreads && !g_failed; ++l0) {
+      const int nw = nthreads / W, l = reverse ? ((nw - 1 - l0 / W) * W + l0 % W) : l0;
       if (g_done[l]) continue;
       r.cur = l;
       swapcontext(&g_main, &g_ctx[l]);
