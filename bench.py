@@ -133,7 +133,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        local_rank = local_rank % max(1, torch.cuda.device_count()) if args.dist_backend == "gloo" else local_rank
+        # (ranks share devices: the gloo flow check of a box with fewer GPUs than ranks; HDSM_BENCH_SAME_DEVICE=1: the test of the
+        # line's behaviour when RCCL refuses the communicator — two ranks on one device)
+        if args.dist_backend == "gloo" or os.environ.get("HDSM_BENCH_SAME_DEVICE") == "1":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         # torch.distributed is the LAUNCHER-side plumbing only (rendezvous, broadcast of the RCCL unique id, the barrier
         # and the max-over-ranks of the contract); the data path is hdsm_exchange_device

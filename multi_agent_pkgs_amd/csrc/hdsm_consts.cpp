@@ -100,6 +100,8 @@ int build_consts(const hdsm_params* prm, Consts* c, const char** err) {
   c->child_bound = 1, c->overlap_sweep = 1;
   env_int("HDSM_OVERLAP_SWEEP", 0, 1, &c->overlap_sweep);
   env_int("HDSM_CHILD_BOUND", 0, 1, &c->child_bound);
+  c->dominance = 1;
+  env_int("HDSM_DOMINANCE", 0, 1, &c->dominance);
   c->mip_gap = prm->mip_gap;
   c->leaf_mfma = 1;
   env_int("HDSM_LEAF_MFMA", 0, 1, &c->leaf_mfma);

@@ -169,6 +169,11 @@ struct Shm {
   int32_t warm_head;  // first word of the instance's warm-start record (count | WARM_CERT), fetched by the set-up
   int32_t warm_ncand; // staged rows after the warm start has placed the rows of its guess (before a concurrent sweep adds its own)
   int32_t leaf_pick;  // result of the one-wavefront leaf test
+  // Dominated polyhedra (bit j): polyhedron j lies inside another polyhedron of the instance, so it is never offered as a choice and
+  // never counts as the container of a segment (its dominator does). Computed ONCE, by the first leaf test that finds an uncontained
+  // step (dom_done) — an instance that never has to branch never pays for it; an item of pass 2 takes it from its record.
+  int32_t sp_dom, dom_done;
+  int32_t forced;  // 1: steps were assigned outside the tree (one polyhedron left, leaf_check): assigned rows exist although level == 0
   double* snap;       // this workgroup's snapshot scratch (global memory; kept here, not in a register pair across the active-set run)
   int32_t node_res;   // pass 2 of a split launch: nodes drawn from the instance's pool and not yet opened
   int32_t rc, iters_sh;  // device build: results of wave 0's active-set run, shared with the other waves
@@ -311,8 +316,59 @@ struct Solver {
     SYNC();
   }
 
+  // ---- dominated polyhedra (one wavefront, `lane` = its lane; every lane returns the mask) ---------------------------------
+  // P_j is CONTAINED in P_k when every row (a, b) of P_k is implied by a row (a2, b2) of P_j with the same direction:
+  // a = t a2, t > 0 and t b2 <= b — then a . p = t a2 . p <= t b2 <= b wherever P_j's row holds. (A sufficient test — no vertex
+  // enumeration — that finds what actually occurs: the corridor of an agent that is held up keeps seeding polyhedra from
+  // neighbouring voxels, which grow into the SAME chamfers and faces with one or two faces shifted; BASELINE cfg 5's instances
+  // that ended on the node budget had two or three such copies among their four polyhedra and enumerated 3^12 equivalent
+  // assignments: 2366 -> 13 nodes, 2353 -> 19, 2368 -> 9 on the dumped cases, same optimum.) A trajectory that is feasible with the
+  // smaller polyhedron at a step is feasible with the larger one there, so the MIQP optimum does not need the smaller one:
+  // polyhedron j is dominated if it is contained in some k and (k is not contained in j, or k < j — of two copies the first stays).
+  // Directions are compared exactly up to 1e-12 (rows of the voxel decomposition carry small integers), right-hand sides with
+  // 1e-10 max(1, |b|): a tenth of the solver's own feasibility tolerance.
+  static HD unsigned dominated_mask(const S& s, int np, int lane) {
+    // item = (ordered pair (j, k), row r of k), 32 items per pair: two pairs per trip of the wavefront
+    unsigned long long sub = 0ull;  // bit j * np + k: P_j is contained in P_k
+    const int pairs = np * np;
+    for (int p0 = 0; p0 < pairs; p0 += 2) {
+      const int p = p0 + (lane >> 5), r = lane & 31;
+      const int j = p < pairs ? p / np : 0, k = p < pairs ? p - j * np : 0;
+      const int rows_k = s.sp_rows[k], rows_j = s.sp_rows[j];
+      bool implied = true;
+      if (p < pairs && j != k && r < rows_k) {
+        const double a0 = s.sp[k][r][0], a1 = s.sp[k][r][1], a2 = s.sp[k][r][2], b = s.sp[k][r][3];
+        const double amax = fmax(fabs(a0), fmax(fabs(a1), fabs(a2)));
+        implied = amax == 0.0 && b >= 0.0;  // (a zero row 0 . p <= b holds everywhere)
+        const double bb = b + 1e-10 * fmax(1.0, fabs(b));
+        for (int q = 0; q < rows_j && !implied; ++q) {
+          const double c0 = s.sp[j][q][0], c1 = s.sp[j][q][1], c2 = s.sp[j][q][2], d = s.sp[j][q][3];
+          const double cmax = fmax(fabs(c0), fmax(fabs(c1), fabs(c2)));
+          const double x0 = a1 * c2 - a2 * c1, x1 = a2 * c0 - a0 * c2, x2 = a0 * c1 - a1 * c0;
+          const double dot = a0 * c0 + a1 * c1 + a2 * c2, cc = c0 * c0 + c1 * c1 + c2 * c2;
+          const bool parallel = fmax(fabs(x0), fmax(fabs(x1), fabs(x2))) <= 1e-12 * amax * cmax && dot > 0.0;
+          implied = parallel && dot * d <= bb * cc;  // t = dot / cc:  t d <= b (+ tolerance)
+        }
+      }
+      if (p >= pairs || j == k) implied = false;
+      const unsigned long long ok = __ballot(implied || (p < pairs && j != k && r >= rows_k));  // (rows beyond the polyhedron's count: nothing to imply)
+      for (int h = 0; h < 2; ++h) {
+        const int ph = p0 + h;
+        if (ph < pairs && ph / np != ph % np && (unsigned)(ok >> (32 * h)) == 0xffffffffu && s.sp_rows[ph % np] > 0 && s.sp_rows[ph / np] > 0) sub |= 1ull << ph;
+      }
+    }
+    unsigned dom = 0u;
+    for (int j = 0; j < np; ++j)
+      for (int k = 0; k < np; ++k)
+        if (k != j && ((sub >> (j * np + k)) & 1ull) && (!((sub >> (k * np + j)) & 1ull) || k < j)) dom |= 1u << j;
+    if (dom == (1u << np) - 1u) dom = 0u;  // (cannot happen with a consistent containment relation: never leave an instance without a choice)
+    return dom;
+  }
+
   // ---- leaf test: which unassigned steps lie in no polyhedron -----------------------------------------------
   // keys[i][j] = max row violation of polyhedron j on (p_i, p_{i+1}); DINF if an input-independent end point is outside.
+  // Returns the step to branch on, -1: every step lies in a polyhedron (a leaf), -2: steps were ASSIGNED here (one polyhedron is left
+  // after the dominated ones are gone: every uncontained step must take it) — the node's run continues with their rows.
   static HD int leaf_check(S& s, const Consts& c) {
     const int N = c.N, np = s.n_poly;
 #ifdef HDSM_LEAF_MFMA
@@ -371,7 +427,10 @@ struct Solver {
         const int i = on ? (int)(((float)lane + 0.5f) * (1.0f / (float)np)) : 0, j = on ? lane - i * np : 0;
         const int ai = s.assign[i];
         double vmax = -DINF;
-        if (on && ai < 0) {
+        unsigned dom = (unsigned)uni(s.sp_dom);
+        if (on && ai < 0 && ((dom >> j) & 1u)) {
+          vmax = DINF;  // a dominated polyhedron: neither a container nor a choice
+        } else if (on && ai < 0) {
           const int rows = s.sp_rows[j];
           const double* p0 = s.st[i];
           const double* p1 = s.st[i + 1];
@@ -388,20 +447,48 @@ struct Solver {
           if ((g0 && v0max > c.ftol_fixed) || (g1 && v1max > c.ftol_fixed)) vmax = DINF;
           else vmax = g1 ? -DINF : (g0 ? v1max : (v0max > v1max ? v0max : v1max));
         }
-        if (on) s.keys[i][j] = vmax;
-        const unsigned long long inside = __ballot(on && vmax <= c.tol);
         // lane i < N: its step
         const int my_a = lane < N ? s.assign[lane] : 0;
-        const unsigned fits = lane < N ? (unsigned)((inside >> (lane * np)) & ((1ull << np) - 1ull)) : 1u;
-        const int cont = (lane < N) ? (my_a >= 0 ? my_a : (fits != 0u ? __builtin_ffs((int)fits) - 1 : -1)) : 0;
-        if (lane < N) s.contain[lane] = cont;
-        wsync();
+        int cont = 0;
         double best = -DINF;  // smallest violation among the polyhedra of an uncontained step (-DINF: contained / no step)
-        if (lane < N && cont < 0) {
-          best = DINF;
-          for (int jj = 0; jj < np; ++jj) best = s.keys[lane][jj] < best ? s.keys[lane][jj] : best;
+        unsigned long long open = 0ull;
+        for (int pass = 0;; ++pass) {
+          if (on) s.keys[i][j] = vmax;
+          const unsigned long long inside = __ballot(on && vmax <= c.tol);
+          const unsigned fits = lane < N ? (unsigned)((inside >> (lane * np)) & ((1ull << np) - 1ull)) : 1u;
+          cont = (lane < N) ? (my_a >= 0 ? my_a : (fits != 0u ? __builtin_ffs((int)fits) - 1 : -1)) : 0;
+          if (lane < N) s.contain[lane] = cont;
+          wsync();
+          best = -DINF;
+          if (lane < N && cont < 0) {
+            best = DINF;
+            for (int jj = 0; jj < np; ++jj) best = s.keys[lane][jj] < best ? s.keys[lane][jj] : best;
+          }
+          open = __ballot(lane < N && cont < 0);
+          // the first time this instance would have to branch: which polyhedra are contained in another one (dominated_mask)
+          if (pass > 0 || open == 0ull || np < 2 || c.dominance == 0 || uni(s.dom_done) != 0) break;
+          dom = dominated_mask(s, np, lane);
+          wsync();
+          if (lane == 0) s.dom_done = 1, s.sp_dom = (int32_t)dom;
+          if (dom == 0u) break;
+          if (on && ai < 0 && ((dom >> j) & 1u)) vmax = DINF;  // (what lies in a dominated polyhedron lies in its dominator: `open` stays as it is)
+          wsync();
         }
-        const unsigned long long open = __ballot(lane < N && cont < 0);
+        // ONE polyhedron left: every uncontained step has to take it — assigned here, all at once, without a level and without a node
+        // (the assignment holds at every node of the instance; it is made at the root, where the mask is computed, or found again by an item)
+        const unsigned alive = ~dom & ((1u << np) - 1u);
+        bool forced = false;  // (wave-uniform)
+        if (open != 0ull && dom != 0u && (alive & (alive - 1u)) == 0u) {
+          const int j0 = __builtin_ffs((int)alive) - 1;
+          // (a step whose pinned end point lies outside j0 has no admissible polyhedron at all: the ordinary path below reports it — no child)
+          const bool admissible = __ballot(lane < N && cont < 0 && !(s.keys[lane][j0] < DINF)) == 0ull;
+          if (admissible) {
+            if (lane < N && cont < 0) s.assign[lane] = j0;
+            if (lane == 0) s.leaf_pick = -2, s.leaf_lb = 0, s.first_id = -1, s.forced = 1;
+            wsync();
+            open = 0ull, forced = true;
+          }
+        }
         int pick = -1;
         if (open != 0ull) {
           // Child bound — a second walk over the rows, only at a node that WILL branch (in open space no instance ever gets here).
@@ -458,7 +545,7 @@ struct Solver {
           l1 = top1 > 0.0 ? __ffsll((long long)__ballot(mine == top1)) - 1 : -1;
           top2 = wave_max64(lane == l1 ? 0.0 : mine);
         }
-        if (lane == 0) s.leaf_pick = pick, s.lb_top1 = top1, s.lb_top2 = top2, s.lb_step = l1, s.leaf_lb = 1;
+        if (lane == 0 && !forced) s.leaf_pick = pick, s.lb_top1 = top1, s.lb_top2 = top2, s.lb_step = l1, s.leaf_lb = 1;
       }
       SYNC();
       return s.leaf_pick;
@@ -913,6 +1000,7 @@ struct Solver {
         s.n_poly = np, s.q = 6, s.neq_done = 6, s.ncand = 0, s.level = 0, s.have_inc = 0;
         s.fixed_bad = 0, s.overflow = 0, s.inc_f = DINF, s.ncold = 0, s.rc = 0, s.iters_sh = 0;
         s.warm_head = wpre.head;
+        s.sp_dom = 0, s.dom_done = 0, s.forced = 0;
         s.st_sph = 0, s.st_pairs = 0, s.n_nogood = 0, s.ng_skipped = 0, s.ng_global = 0, s.lb_skipped = 0, s.first_id = -1, s.inc_shared = DINF, s.node_res = 0;  // (pass 2: every node after the item's own is drawn from the instance's pool)
         s.t_start = c.time_ticks > 0 ? (long long)wall_clock64() : 0;
       }
@@ -1053,6 +1141,7 @@ struct Solver {
       }
       if (IS_T0) {
         s.ncand = nh, s.ncold = ncl, s.n_nogood = rc.n_nogood, s.sw_tau = rc.sw_tau, s.level = L + 1;
+        s.sp_dom = rc.sp_dom, s.dom_done = 1;  // (the search that handed over had branched: it had looked)
         const int code = rc.br_pk[L][pos];
         s.first_id = code >= 0 ? mk_id(K_P, (rc.br_step[L] << 7) | code) : -1, s.first_v = rc.br_pv[L][pos];
         const unsigned long long bits = __hip_atomic_load(&a.inc_bits[inst], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1230,6 +1319,7 @@ struct Solver {
         t_leaf_ += clock64() - tl_;
 #endif
         NODE_PROF(17)
+        if (bstep == -2) continue;  // steps were assigned by the leaf test (one polyhedron left): the run goes on with their rows, same node
         if (bstep < 0) {
           // every step lies in a polyhedron: before accepting, re-check ALL neighbour rows
           const int before = s.ncand;
@@ -1373,7 +1463,7 @@ struct Solver {
       SYNC();
       if (IS_T0) {
         rc.inst = inst, rc.level = lev, rc.ncand = nh, rc.ncold = ncl, rc.n_nogood = s.n_nogood, rc.sw_tau = s.sw_tau;
-        rc.nodes_done = nodes, rc.sweeps_done = sweeps, rc.snap = s.snap;
+        rc.nodes_done = nodes, rc.sweeps_done = sweeps, rc.snap = s.snap, rc.sp_dom = s.sp_dom;
         // (an item that hands over again: its record goes in front of the instance's chain, and the workgroup moves to a fresh scratch slot)
         rc.next = item >= 0 ? atomicExch(&a.split_info[2 * inst + 1], rec_slot) : -1;
         const double cut = cutoff(s, c);

@@ -52,7 +52,9 @@ struct Consts {
   double g[3][3][MAXH];          // impulse responses: g[ax][s][lag] = (Ad^lag Bd)[s]
   int32_t pinned_steps;          // positions p_1 .. p_pinned do not depend on the inputs at all (the impulse response of the
                                  // position is zero for that many lags: 2 with jerk inputs and the Euler model)
-  int32_t pad_pinned;
+  int32_t dominance;             // 1 (default): the first time an instance has to branch, polyhedra CONTAINED in another polyhedron of the
+                                 // instance are taken out of the choice (hdsm_core.h, dominated_mask): whatever lies in the smaller one lies in
+                                 // the larger one, so offering both only multiplies the tree (HDSM_DOMINANCE=0: off). Exact.
   double phi[3][MAXH + 1][3][3]; // Ad^i
   double Hinv[MAXNV * MAXNV];    // inverse Hessian, dense n x n, row-major with stride n
   double J0[MAXNV * MAXNV];      // L^{-T}, H = L L^T
@@ -89,7 +91,8 @@ constexpr int ITEMS_PER_REC = 64;   // items an instance can queue when it hands
 // What an instance writes when it hands its search over to pass 2 of a split launch (Args::recs; see Args).
 struct SplitRec {
   int32_t inst, level, ncand, ncold, n_nogood, first_item, n_items, nodes_done, sweeps_done, truncated;
-  int32_t next, pad_next;  // the next record of the same instance (-1: none): an item of pass 2 that hands over again chains its record in
+  int32_t next;            // the next record of the same instance (-1: none): an item of pass 2 that hands over again chains its record in
+  int32_t sp_dom;          // dominated polyhedra of the instance (Shm::sp_dom: bit j; the search that wrote the record had computed it)
   const double* snap;      // snapshots of the open levels (level l at snap + l * SNAP_STRIDE): the scratch the search was using
   double sw_tau;
   int32_t br_step[MAXH], br_cnt[MAXH], br_pos[MAXH], assign[MAXH];

@@ -515,7 +515,7 @@ struct WaveGI {
       }
     }
     OP_PROF(8)
-    if (MODE != 2 && uni(s.level) > 0) scan_assigned(s, lane, N, tol, norm, pk, c.pinned_steps);  // rows of the polyhedra assigned on the current branch
+    if (MODE != 2 && (uni(s.level) | uni(s.forced)) != 0) scan_assigned(s, lane, N, tol, norm, pk, c.pinned_steps);  // rows of the polyhedra assigned on the current branch
     const int nc = MODE != 2 ? uni(s.ncand) : 0;
     const bool mw = SHARE && blockDim.x > 64 && nc > 256;  // worth waking the helper waves (two barriers)
     if (mw) {
@@ -600,7 +600,11 @@ struct WaveGI {
       row = s.cand[kc_slot(p)];
       m = kc_m(p);
     }
-    return (kk < m) ? row[ax] * s.gz[ax][0][MAXH + m - 1 - kk] : 0.0;
+    // (the lane's axis as a value formed HERE: the byte offsets 8 ax / 24 MAXH ax that the two reads below add were hoisted in front of
+    // the branch-and-bound loop as loop invariants and, in the two-per-CU kernel, spilled — its only scratch access)
+    int axl = ax;
+    keep_in_loop(axl);
+    return (kk < m) ? row[axl] * s.gz[axl][0][MAXH + m - 1 - kk] : 0.0;
   }
 
   static __device__ __forceinline__ double resid(const S& s, const Consts& c, int id, int N) {

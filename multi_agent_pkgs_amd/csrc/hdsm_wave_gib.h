@@ -741,7 +741,7 @@ struct WaveGIB : WaveGI<NVT, CMAX, SMALL> {
       bool answered = false;
       if (cmd == CMD_PREP) {
         // ---- phase 1: everything that needs x and z but not the step
-        const int nc = uni(s.ncand), level = uni(s.level);
+        const int nc = uni(s.ncand), level = uni(s.level) | uni(s.forced);  // (> 0: rows of assigned polyhedra exist)
         double xk[HH], zk[HH], gk[HH];
 #pragma unroll
         for (int k = 0; k < HH; ++k) xk[k] = xx[k], zk[k] = zx[k], gk[k] = gp[-k];

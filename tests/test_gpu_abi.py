@@ -274,6 +274,57 @@ def test_bench_self_launches_two_ranks_and_reports_rccl_ranks():
     assert max(z["ms_per_step_per_rank"]) <= z["ms_per_step"] * 1.5
 
 
+def _run_bench_two_ranks(extra, env_extra=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--agents", "128",
+                        "--first-round", "20", "--repeats", "1", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_host_staged_exchange_carries_every_multi_gpu_key():
+    """The N > 1 flow of bench.py end to end on a box with ONE GPU (what every box of this build has been): `--gpus 2 --dist-backend
+    gloo` starts two ranks that share device 0, shards the swarm, runs the timed region with the barrier / max-over-ranks contract
+    and a host-staged all-gather in place of hdsm_exchange_device. Every key the multi-GPU line carries must be there and sane
+    (`rccl_ranks` null because no RCCL communicator exists; the exchange figures are labelled as the flow check they are) — so that
+    the first run on a multi-GPU node can only differ in the exchange itself."""
+    z = _run_bench_two_ranks(["--dist-backend", "gloo"], {"HDSM_BENCH_WEAK_PER_GPU": "64"})
+    assert z["n_gpus"] == 2 and z["scaling"] == "strong" and z["value"] > 0 and z["steps"] == 5 and z["warmup"] == 2
+    assert z["rccl_ranks"] is None and z["exchange_error"] is None and "gloo" in z["exchange"]
+    assert z["config"]["agents"] == 128 and z["config"]["agents_per_gpu"] == 64
+    assert len(z["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in z["ms_per_step_per_rank"])
+    assert max(z["ms_per_step_per_rank"]) <= z["ms_per_step"] * 1.5
+    assert z["exchange_ms_p50"] > 0 and z["exchange_ms"]["backend"] == "gloo-host-staged" and z["exchange_ms"]["bytes_per_rank"] == 64 * 11 * 9 * 8
+    w = z["weak_scaling_record"]
+    assert w["scaling"] == "weak" and w["agents_per_gpu"] == 64 and w["agents"] == 128 and w["value"] > 0 and z["weak_scaling_value"] == w["value"]
+    assert "gloo" in w["exchange"]
+    assert z["roofline"]["frac"] > 0 and z["kernel_ms_mean"] > 0 and z["failed_instances_timed_rounds"] >= 0
+
+
+@pytest.mark.skipif(_device_count() != 1, reason="two ranks on ONE device: the box must have exactly one GPU")
+def test_bench_survives_a_communicator_that_cannot_be_created():
+    """`python bench.py --gpus 2` on a one-GPU box: both ranks land on device 0 and RCCL refuses the communicator (duplicate GPU,
+    ncclInvalidUsage — or never answers: the creation runs under a budget). The ranks agree on the failure, fall back to the
+    host-staged exchange and rank 0 still prints the ONE JSON line, with `exchange_error` saying what happened — a dead rank and
+    no line is what this used to produce."""
+    import torch  # noqa: F401
+    z = _run_bench_two_ranks(["--no-weak-record"], {"HDSM_BENCH_COMM_BUDGET_S": "60", "HDSM_BENCH_SAME_DEVICE": "1"})
+    assert z["n_gpus"] == 2 and z["value"] > 0 and z["rccl_ranks"] is None
+    err = z["exchange_error"]
+    assert err is not None and len(err["ranks_failed"]) >= 1 and err["first_error"]
+    assert "gloo" in z["exchange"] and z["weak_scaling_record"] is None
+    assert len(z["ms_per_step_per_rank"]) == 2
+
+
 def test_two_ros_nodes_exchange_traj_full_on_the_in_memory_bus():
     """ros/hdsm_agent_node.cpp (compiled against the API-shaped rclcpp of tests/ros_shim): two nodes in one process, each hosting
     four agents of an eight-agent ring, timers fired in lock step; every plan a node knows about the OTHER node's agents arrived

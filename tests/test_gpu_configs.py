@@ -421,4 +421,10 @@ def test_device_corridor_kernel_matches_the_reference_restatement(hdsm, oracle, 
             carried += sum(1 for g in got if any(np.array_equal(g[3], h[3]) for h in old))
             made += len(got)
     assert made - carried > n_rob and carried > n_rob   # polyhedra were generated AND carried over
+    # ... and a good part of the generated ones were NOT grown but formed from the polyhedron cache (hdsm_dswarm_cache_stats) — through
+    # the same-grid rule and, mostly, through the interior rule (same world voxel asked for from another local grid at the same
+    # height): the oracle above grows every polyhedron, so every cache hit of these rounds was compared with a grown one bit for bit
+    cs = dsw.cache_stats()
+    assert cs["cache_on"] and cs["asked"] >= made - carried, cs
+    assert cs["hits_interior"] > 0 and cs["hits_same_grid"] + cs["hits_interior"] > cs["asked"] // 10, cs
     dsw.close()

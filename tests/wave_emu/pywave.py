@@ -63,11 +63,12 @@ def solve(prm, state, ref, n_poly, n_rows, A, b, threads=64):
     state, ref, A, b, n_poly, n_rows = f64(state), f64(ref), f64(A), f64(b), i32(n_poly), i32(n_rows)
     n_inst, r_max = state.shape[0], A.shape[3]
     out = dict(traj=np.zeros((n_inst, N + 1, 9)), ctrl=np.zeros((n_inst, N, 3)), used=np.zeros((n_inst, P), dtype=np.uint8),
-               status=np.zeros(n_inst, dtype=np.int32), obj=np.zeros(n_inst))
+               status=np.zeros(n_inst, dtype=np.int32), obj=np.zeros(n_inst), qp_iters=np.zeros(n_inst, dtype=np.int32),
+               nodes=np.zeros(n_inst, dtype=np.int32))
     d, i, u = C.c_double, C.c_int32, C.c_uint8
     rc = lib().wave_solve(C.byref(prm), n_inst, r_max, _p(state, d), _p(ref, d), _p(n_poly, i), _p(n_rows, i), _p(A, d), _p(b, d),
                           _p(out["traj"], d), _p(out["ctrl"], d), _p(out["used"], u), _p(out["status"], i), _p(out["obj"], d),
-                          C.c_int32(threads))
+                          C.c_int32(threads), _p(out["qp_iters"], i), _p(out["nodes"], i))
     if rc == -100:
         raise RuntimeError("wavefront emulation: " + lib().wave_last_error().decode())
     out["rc"] = rc

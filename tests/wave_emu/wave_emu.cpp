@@ -249,7 +249,8 @@ extern "C" int wave_replan(const hdsm_params* prm, int32_t n_inst, int32_t n_rob
 // Level 1 (fully formed per-step polyhedra, hdsm_solve) through the product's host-side split and the device source
 extern "C" int wave_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max, const double* state_curr, const double* traj_ref,
                           const int32_t* n_poly, const int32_t* n_rows, const double* A, const double* b, double* traj_out,
-                          double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj, int32_t threads) {
+                          double* ctrl_out, uint8_t* poly_used, int32_t* status, double* obj, int32_t threads, int32_t* qp_iters,
+                          int32_t* nodes) {
   if (threads != 64 && threads != 128 && threads != 256) return -1;
   auto c = std::make_unique<hdsm::Consts>();
   const char* err = nullptr;
@@ -266,6 +267,7 @@ extern "C" int wave_solve(const hdsm_params* prm, int32_t n_inst, int32_t r_max,
   a.n_poly = sp.n_poly.data(), a.n_rows = sp.n_rows_static.data(), a.A = sp.A_static.data(), a.b = sp.b_static.data();
   a.plans = dummy_plans, a.has_plan = &zero, a.traj = traj_out, a.ctrl = ctrl_out, a.used = poly_used;
   a.status = status, a.obj = obj, a.l1_rows = sp.common.data(), a.l1_nrows = sp.n_common.data(), a.l1_rmax = sp.rc_max;
+  a.st_iters = qp_iters, a.st_nodes = nodes;  // (may be null)
   if (c->n <= hdsm::SPLIT_N_MAX) return run_all<32, 1536>(*c, a, threads);
   return run_all<48, 1024>(*c, a, threads);
 }
