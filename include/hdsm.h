@@ -114,10 +114,12 @@ typedef struct hdsm_params {
    * workgroups that draw the items and continue inside their subtrees, handing over again when a subtree grows large
    * (HDSM_ITEM_BUDGET nodes, default 32; HDSM_ITEM_MIN while workgroups wait for items); the merge. HDSM_SPLIT_BUDGET = the
    * budget of the first kernel in nodes (1 or more; default by batch size: 2 for batches of at most 2 x compute units instances,
-   * 16 beyond — a hand-over costs about one node since round 5). HDSM_ITEM_MIN has the same by-batch default (2 / 16).
+   * 8 beyond — a hand-over costs about one node since round 5). HDSM_ITEM_MIN has the same by-batch default (2 / 8).
    * HDSM_SPLIT_RECORDS: hand-over records per launch (default 8 x max_instances, clamped to 256 .. 2048); HDSM_POLL_SLEEP: s_sleep(127)
    * periods between two looks of a waiting workgroup at the item queue (default 2). max_nodes stays
-   * the budget of an INSTANCE: its items draw from one pool. HDSM_CHILD_BOUND 1 (default) / 0: children of a branching node
+   * the budget of an INSTANCE: its items draw from one pool. HDSM_DOMINANCE 1 (default) / 0: the first time an instance has
+   * to branch, polyhedra that lie inside another polyhedron of the instance are taken out of the choice (one left: its rows
+   * are assigned to every uncontained step at once) / every polyhedron is offered. HDSM_CHILD_BOUND 1 (default) / 0: children of a branching node
    * get a lower bound and their first entering row from the node's leaf test / neither. HDSM_SETUP_MFMA 1 (default) / 0: the
    * set-up map of all instances of a launch is one product on the matrix cores in the pre-pass kernel / every instance applies
    * it itself. HDSM_OVERLAP_SWEEP 1 (default) / 0: two-wave workgroups run the first staging sweep during the warm-start

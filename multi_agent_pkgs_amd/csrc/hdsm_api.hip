@@ -187,11 +187,20 @@ __device__ void setup_map_tile(const SetupMapArgs& m, int tile) {
   const double* st = m.state + (int64_t)(inst_on ? inst : 0) * 9;
   const double* rf = m.ref + (int64_t)(inst_on ? inst : 0) * 6 * m.N;
   v4d acc = {0.0, 0.0, 0.0, 0.0};
-  for (int k0 = 0; k0 < nvt; k0 += 4) {
-    const int j = k0 + kk;
-    const double aop = (row_on && j < nvt) ? m.c->KT[(int64_t)j * hdsm::KROWS + row] : 0.0;
-    const double bop = (inst_on && j < nvt) ? (j < 9 ? st[j] : rf[j - 9]) : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+  // (the operands of NINE k-steps are requested before the first product is formed: with one step per trip the tile was a chain of 18 - 25
+  // dependent round trips to memory, and the tile workgroups — not the packing ones — set the duration of the pre-pass kernel: 6.9 -> 11 us
+  // in round 5; two or three trips now)
+  constexpr int CH = 9;
+  for (int k0 = 0; k0 < nvt; k0 += 4 * CH) {
+    double av[CH], bv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int j = k0 + 4 * u + kk;
+      av[u] = (row_on && j < nvt) ? m.c->KT[(int64_t)j * hdsm::KROWS + row] : 0.0;
+      bv[u] = (inst_on && j < nvt) ? (j < 9 ? st[j] : rf[j - 9]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
   }
   const int col = lane & 15, oi = it * 16 + col;
   if (oi < m.n_inst) {
@@ -1082,7 +1091,9 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
   // instances, 2 / 4 / 8 / 16 nodes -> 0.65 / 0.70 / 0.84 / 0.93 ms per round; cfg 5, 4096 instances, 16 / 24 / 32 / 48 / 96 nodes ->
   // 8.1 / 8.4 / 8.9 / 9.4 / 11.3 ms)
   const bool roomy = a.n_inst <= 2 * h->cus;
-  const int budget = h->split_budget > 0 ? h->split_budget : (roomy ? 2 : 16);
+  // (round 6, after the dominance rule made the trees small — cfg 5: 77 k -> 23 k nodes per round: 8 / 8 instead of 16 / 16 for full
+  // batches, 4.18 -> 3.51 ms on rounds 8..13 and 7.24 -> 5.86 ms on rounds 30..35, scripts/gpu_r6_cfg5_sweep.sh; cfg 3 is flat in both knobs)
+  const int budget = h->split_budget > 0 ? h->split_budget : (roomy ? 2 : 8);
   a.tree_mark = budget > hdsm::TREE_MARK ? budget : hdsm::TREE_MARK;
   // Subtree splitting. A launch lasts as long as its slowest instance, and in obstacle worlds that is one agent between pillars
   // whose branch and bound needs hundreds of nodes while the other workgroups have been idle for milliseconds. When the last
@@ -1125,7 +1136,7 @@ int launch(Handle* h, hdsm::Args a, hipStream_t st) {
     b.split_budget = h->item_budget;  // an item whose subtree outgrows this many nodes hands over again (0: never)
     // ... or, while workgroups are waiting for items, this many: 2 in a batch that leaves CUs idle (cfg 3: 0.84 ms against 1.14 without),
     // 16 in one that fills the GPU (every look at the queue is two device-scope reads per node: cfg 5 8.15 ms with 2 - 4, 7.5 with >= 8)
-    b.split_min = h->item_min > 0 ? h->item_min : (roomy ? 2 : 16);
+    b.split_min = h->item_min > 0 ? h->item_min : (roomy ? 2 : 8);
     b.poll_sleep = h->poll_sleep;
     int32_t* ss = h->d_sub_stats;
     const size_t GI = (size_t)h->items_cap;
