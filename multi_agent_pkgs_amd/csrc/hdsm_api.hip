@@ -1247,7 +1247,7 @@ hipError_t ensure_sub(Handle* h) {
     if (e == hipSuccess) e = r;
   };
   ok(dmalloc(&h->d_recs, R)), ok(dmalloc(&h->d_rec_cand, R * h->rows_cap * 4)), ok(dmalloc(&h->d_rec_mw, R * h->rows_cap)), ok(dmalloc(&h->d_rec_src, R * h->rows_cap));
-  ok(dmalloc(&h->d_rec_count, 8)), ok(dmalloc(&h->d_items, G)), ok(dmalloc(&h->d_slot_busy, (size_t)h->pool_cap));
+  ok(dmalloc(&h->d_rec_count, 8 + R)), ok(dmalloc(&h->d_items, G)), ok(dmalloc(&h->d_slot_busy, (size_t)h->pool_cap));
   ok(dmalloc(&h->d_split, 2 * (size_t)h->max_inst)), ok(dmalloc(&h->d_inc, (size_t)h->max_inst)), ok(dmalloc(&h->d_node_pool, (size_t)h->max_inst));
   ok(dmalloc(&h->d_sub_stats, 8 * G)), ok(dmalloc(&h->d_sub_warm, (hdsm::MAXNV + 2) * G)), ok(dmalloc(&h->d_sub_status, G));
   ok(dmalloc(&h->d_sub_traj, G * (N + 1) * 9)), ok(dmalloc(&h->d_sub_ctrl, G * N * 3)), ok(dmalloc(&h->d_sub_obj, G)), ok(dmalloc(&h->d_sub_used, G * h->P));

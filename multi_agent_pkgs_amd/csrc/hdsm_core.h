@@ -1462,6 +1462,7 @@ struct Solver {
       __threadfence();  // (pass 2 draws items while it runs: the record must be visible before its items are)
       SYNC();
       if (IS_T0) {
+        a.rec_count[8 + rec_slot] = inst;  // (the merge's lanes look for an instance's records HERE: consecutive words, not one per 1.6-KB record)
         rc.inst = inst, rc.level = lev, rc.ncand = nh, rc.ncold = ncl, rc.n_nogood = s.n_nogood, rc.sw_tau = s.sw_tau;
         rc.nodes_done = nodes, rc.sweeps_done = sweeps, rc.snap = s.snap, rc.sp_dom = s.sp_dom;
         // (an item that hands over again: its record goes in front of the instance's chain, and the workgroup moves to a fresh scratch slot)
@@ -1659,7 +1660,7 @@ HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int la
     n_list = 0;
     for (int base = 0; base < R && n_list <= LIST; base += 64) {
       const int r = base + lane;
-      const bool mine = r < R && a.recs[r].inst == inst;
+      const bool mine = r < R && a.rec_count[8 + r] == inst;
       const unsigned long long m = __ballot(mine);
       if (mine) {
         const int at = n_list + __popcll(m & ((1ull << lane) - 1ull));

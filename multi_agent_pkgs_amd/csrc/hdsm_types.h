@@ -172,7 +172,8 @@ struct Args {
   int32_t* rec_src;       // [rec_cap][rows_cap] their origins (Shm::cand_src)
   int32_t* rec_count;     // [0] records taken, [1] items queued (published), [2] tickets taken by the workgroups of pass 2 (ticket k = item k),
                           // [4] items completed, [5] places of the queue reserved, [6] abort word: a waiter of pass 2 or a publisher ran out of
-                          // patience — nobody waits any longer, unpublished / undrawn items stay pending (zeroed before pass 1)
+                          // patience — nobody waits any longer, unpublished / undrawn items stay pending (zeroed before pass 1);
+                          // [8 + r] the instance of record r (what SplitRec::inst says, packed for the merge's search)
   int32_t pool_cap;       // pass 2: snapshot-scratch slots (Args::scratch), taken by the workgroup of an item for its lifetime
   int32_t* slot_busy;     // [pool_cap] 0 / 1; an item that hands over again leaves its slot (busy) to its record
   int32_t* item_total;    // host-visible word: the merge leaves the number of items this launch queued

@@ -10,7 +10,7 @@ import sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
-KEEP = ("value", "ms_per_step", "ms_per_step_repeats", "config", "solver_stats_timed_rounds", "failed_instances_timed_rounds",
+KEEP = ("value", "ms_per_step", "ms_per_step_repeats", "config", "solver_stats_timed_rounds", "failed_instances_timed_rounds", "limit_instances_timed_rounds",
         "device_resident_loop", "kernel_ms_mean", "p50_solve_latency_ms", "p95_solve_latency_ms", "host_buffer_path")
 lines = {}
 for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
@@ -21,7 +21,8 @@ for path in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     lines[os.path.basename(path)[len("bench_"):-len(".json")]] = {k: d[k] for k in KEEP if k in d}
 json.dump({"what": f"secondary bench lines of the round (scripts/gpu_round_evidence.sh {tag}): BASELINE configs 2, 3, 5 and a 4096-agent circle at "
                    "H = 15 on one MI355X, plus the A/B lines of the round's knobs: '_unsplit' = HDSM_SPLIT=0 (one-kernel launches), '_depth1' = "
-                   "HDSM_SPLIT_DEPTH=1, '_raw_pick_rule' = HDSM_PICK_RULE=0, '_cold_start' = hdsm_params.warm_start = 0. Forest flights do not "
+                   "HDSM_SPLIT_DEPTH=1, '_raw_pick_rule' = HDSM_PICK_RULE=0, '_cold_start' = hdsm_params.warm_start = 0, '_no_dominance' = HDSM_DOMINANCE=0 "
+                   "(round 6), '_round5_settings' = HDSM_DOMINANCE=0 with the split budget / item minimum of round 5 (16 / 16). Forest flights do not "
                    "repeat bit for bit from run to run (DESIGN section 4); A/Bs on identical recorded rounds: scripts/gpu_ab_env.sh",
            "lines": lines}, open(os.path.join(root, "profiles", f"{tag}_workloads.json"), "w"), indent=1)
 
@@ -30,6 +31,9 @@ def parse(line):
     return {k: float(v) for k, v in re.findall(r"(\w+)=(-?\d+)", line)}
 
 
+if not os.path.exists(os.path.join(src, "prof_bench.log")):   # (round 6: no -DHDSM_PROFILE pass in the evidence run)
+    print("wrote", len(lines), "bench lines (no phase counters in this run)")
+    sys.exit(0)
 log = open(os.path.join(src, "prof_bench.log")).read().splitlines()
 worst = [ln for ln in log if ln.startswith("HDSM_PROFILE worst")]
 mean = [ln for ln in log if ln.startswith("HDSM_PROFILE mean")]

@@ -6,7 +6,8 @@
 TAG=${1:-r05}; shift
 ARGS=${@:-"--scenario fwf --agents 4096 --horizon 15 --first-round 8 --steps 6 --warmup 2"}
 cd $GRAFT_REPO_ROOT
-OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_cfg5
+NAME=${NAME:-cfg5}   # (round 6: NAME=cfg3 with the forest arguments gives profiles/<tag>_cfg3_roofline.json + pmc_forest_*.json)
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_${NAME}
 mkdir -p $OUT
 export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-secondary --no-event-pass --repeats 1"
@@ -19,4 +20,4 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py $ARGS $COMMON > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err)
   ls $OUT/pmc_$N | head -3
 done
-python scripts/summarize_cfg5_profile.py $TAG
+python scripts/summarize_cfg5_profile.py $TAG $NAME

@@ -14,8 +14,9 @@ import os
 import sys
 
 tag = sys.argv[1]
+name = sys.argv[2] if len(sys.argv) > 2 else "cfg5"   # cfg5 (default) or cfg3: which secondary workload of the line was profiled
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(root, "gpurun_out", tag + "_cfg5")
+out_dir = os.path.join(root, "gpurun_out", tag + "_" + name)
 line = json.loads(open(os.path.join(out_dir, "trace_bench.json")).read().strip().splitlines()[-1])
 plain = json.loads(open(os.path.join(out_dir, "bench.json")).read().strip().splitlines()[-1])
 K = line["steps"]
@@ -45,7 +46,7 @@ def rounds_of(path, value_of):
     return res, rows
 
 
-summ = {"tag": tag, "workload_key": key, "workload": line["config"]["workload"], "kernel": "k_replan_duo48<48,720,128> (pass 1: all instances; pass 2: the item queue)",
+summ = {"tag": tag, "workload_key": key, "workload": line["config"]["workload"], "kernel": "k_replan shapes of a split launch (pass 1: all instances; pass 2: the item queue) - kernel_trace.kernel_names",
         "kernel_source_sha16": line["roofline"]["kernel_source_sha16"], "timed_rounds": K,
         "bench_line_plain": {k: plain[k] for k in ("value", "ms_per_step", "limit_instances_timed_rounds", "failed_instances_timed_rounds")},
         "bench_line_of_the_traced_run": {k: line[k] for k in ("value", "ms_per_step")}}
@@ -62,7 +63,7 @@ if tr:
     summ["kernel_trace"] = {"pass1_ms_mean": sum(p1) / len(p1) / 1e6, "pass2_ms_mean": sum(p2) / len(p2) / 1e6, "rescue_or_other_ms_mean": sum(ot) / len(ot) / 1e6,
                             "solver_kernels_ms_per_round": t_round_ns / 1e6, "pass1_ms": [x / 1e6 for x in p1], "pass2_ms": [x / 1e6 for x in p2],
                             "k_replan_dispatches_per_round": [x["n_replan"] for x in rr], "grids_last_round": rr[-1]["grid"],
-                            "kernel_name": first["Kernel_Name"][:90], "VGPR": first["VGPR_Count"], "AGPR": first["Accum_VGPR_Count"], "SGPR": first["SGPR_Count"],
+                            "kernel_name": first["Kernel_Name"][:90], "kernel_names": sorted({r["Kernel_Name"].split("(")[0][-60:] for r in rows if "k_replan" in r["Kernel_Name"]}), "VGPR": first["VGPR_Count"], "AGPR": first["Accum_VGPR_Count"], "SGPR": first["SGPR_Count"],
                             "LDS": first["LDS_Block_Size"], "scratch": first["Scratch_Size"], "workgroup": first["Workgroup_Size_X"]}
 pm = {}
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "*counter_collection.csv")):
@@ -97,7 +98,7 @@ if "SQ_INSTS_VALU" in v and t_round_ns:
     roof["valu_issue_utilisation"] = v["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * t_round_ns * 1e-9)
 summ["roofline"] = roof
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_cfg5_roofline.json"), "w"), indent=1)
+json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_{name}_roofline.json"), "w"), indent=1)
 if "hbm_bytes_per_launch" in summ:
     json.dump(summ, open(os.path.join(root, "profiles", f"pmc_{key}.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1)[:4000])

@@ -122,7 +122,7 @@ int run_all(const hdsm::Consts& c, hdsm::Args& a, int nthreads) {
   // every queued item (own outputs, the instance's shared incumbent word and node pool, the snapshots of pass 1 read from its
   // scratch), then the merge (hdsm::split_merge, the body of k_split_merge)
   const int rec_cap = a.n_inst * 64 < 256 ? 256 : a.n_inst * 64, rows_cap = CMAX, items_cap = rec_cap * 8;
-  std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, rec_count(8, 0), items, rec_src, node_pool;
+  std::vector<int32_t> split_info, sub_status, sub_stats, sub_warm, rec_count(8 + rec_cap, 0), items, rec_src, node_pool;
   std::vector<unsigned long long> inc_bits;
   std::vector<double> sub_traj, sub_ctrl, sub_obj, rec_cand, all_scratch;
   std::vector<long long> rec_mw;
