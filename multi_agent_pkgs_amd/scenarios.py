@@ -112,6 +112,24 @@ def _listed_to_occupied(listed):
     return occ
 
 
+def cylinder_voxels(cx, cy, cz, z_lo, z_hi, nx, ny, nz, vox=VOX):
+    """Voxel columns (i, j) and the z range [k0, k1) a vertical cylinder of radius 0.05 m and height 20 m centred at (cx, cy, cz) lists
+    (Cylinder.occupy_voxels, shapes.py:243-264, clipped by its RandomVolume): the mesh circle of radius 0.05 m is taken at its four
+    bounding-square corners. Against the reference's own run on its own 90 centres (tests/golden/shapes_cylinders.npz, minted by
+    tests/golden/make_shapes_golden.py): no voxel the reference lists is missing; 4 of ~150 columns are extra (a corner of the
+    square lies 0.07 m from the axis, the circle 0.05 m) and 3 of 90 pillars are one voxel taller (the reference's last z sample lies
+    0.05 m below the clipped top) - tests/test_scenarios.py::test_cylinders_against_the_reference_run."""
+    k0 = max(0, int(np.floor((max(z_lo, cz - 10.0) - z_lo) / vox)))
+    k1 = min(nz, int(np.ceil((min(z_hi, cz + 10.0) - z_lo) / vox)))
+    cols = []
+    for sx in (-0.05, 0.05):                  # the mesh circle of radius 0.05 m
+        for sy in (-0.05, 0.05):
+            i, j = int(np.floor((cx + sx) / vox)), int(np.floor((cy + sy) / vox))
+            if 0 <= i < nx and 0 <= j < ny and (i, j) not in cols:
+                cols.append((i, j))
+    return cols, k0, k1
+
+
 def forest_wall_forest(tiles_y=1, tiles_z=1, seed=0, n_cyl=(90, 180), vox=VOX):
     """generate_random_grid.py:57-115: a 100 x 30 x 15 m grid at origin (0, 0, -6); a wall at x = 48 (0.3 m thick, meshed at
     vox/2) with fifteen square gaps; 90 vertical cylinders of radius 0.05 m in x in [3, 33] and 180 in x in [63, 93], full
@@ -148,13 +166,9 @@ def forest_wall_forest(tiles_y=1, tiles_z=1, seed=0, n_cyl=(90, 180), vox=VOX):
     for (x_lo, cnt) in ((3.0, n_cyl[0]), (63.0, n_cyl[1])):
         for _ in range(int(round(cnt * scale))):
             cx, cy, cz = rng.uniform(x_lo, x_lo + 30.0), rng.uniform(0.0, 30.0 * tiles_y), rng.uniform(z_lo, z_hi)
-            k0 = max(0, int(np.floor((max(z_lo, cz - 10.0) - z_lo) / vox)))
-            k1 = min(nz, int(np.ceil((min(z_hi, cz + 10.0) - z_lo) / vox)))
-            for sx in (-0.05, 0.05):                  # the mesh circle of radius 0.05 m
-                for sy in (-0.05, 0.05):
-                    i, j = int(np.floor((cx + sx) / vox)), int(np.floor((cy + sy) / vox))
-                    if 0 <= i < nx and 0 <= j < ny:
-                        listed[k0:k1, j, i] = True
+            cols, k0, k1 = cylinder_voxels(cx, cy, cz, z_lo, z_hi, nx, ny, nz, vox)
+            for (i, j) in cols:
+                listed[k0:k1, j, i] = True
     occ = _listed_to_occupied(listed)
     return (occ.astype(np.int8) * 100), np.array([0.0, 0.0, -6.0])
 

@@ -208,3 +208,32 @@ def test_corridor_maintenance_matches_the_reference_restatement(oracle):
             new_polys += len(got)
         loop.step()
     assert new_polys - kept > n and kept > n   # polyhedra were generated AND carried over
+
+
+def test_cylinders_against_the_reference_run():
+    """The reference's own generator, RUN (env_builder/scripts/shapes.py imported in the build container by
+    tests/golden/make_shapes_golden.py; the fixture holds data only): the 90 cylinder centres its RNG draws for the first forest block
+    of cfg 5's world (generate_random_grid.py:93-100, Python `random` seed 0) and the voxels Cylinder.occupy_voxels marks for each.
+    scenarios.cylinder_voxels - what forest_wall_forest lists per pillar - on the SAME centres: every voxel of the reference is
+    there; the differences are the ones its docstring names (a few extra columns at the corners of the bounding square, a pillar one
+    voxel taller where the reference's last z sample falls short of the clipped top). The pillar POSITIONS of scenarios.py come from
+    numpy's generator, not Python's: worlds are equivalent in distribution, not voxel for voxel (not required)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shapes_cylinders.npz"))
+    c, cnt, v = z["centres"], z["counts"], z["voxels"]
+    nx, ny, nz = (int(x) for x in z["grid_size"])
+    assert (nx, ny, nz) == (333, 100, 50) and len(c) == 90   # (the reference truncates 100 / 0.3: 333 columns; scenarios.py lists 334)
+    off = np.r_[0, np.cumsum(cnt)]
+    extra_cols = cols_ref_total = taller = 0
+    for n in range(len(c)):
+        vv = v[off[n]:off[n + 1]]
+        ref_cols = {(int(i), int(j)) for i, j in vv[:, :2]}
+        cols, k0, k1 = sc.cylinder_voxels(c[n][0], c[n][1], c[n][2], -6.0, 9.0, nx, ny, nz)
+        assert ref_cols <= set(cols), (n, ref_cols, cols)                         # nothing the reference lists is missing
+        # every listed column spans the same z range in the reference: a full prism
+        for col in ref_cols:
+            ks = np.sort(vv[(vv[:, 0] == col[0]) & (vv[:, 1] == col[1]), 2])
+            assert ks[0] == k0 and ks[-1] in (k1 - 1, k1 - 2) and len(ks) == ks[-1] - ks[0] + 1, (n, col, ks[0], ks[-1], k0, k1)
+            taller += int(ks[-1] == k1 - 2)
+        extra_cols += len(set(cols) - ref_cols)
+        cols_ref_total += len(ref_cols)
+    assert extra_cols <= 0.05 * cols_ref_total and taller <= 0.1 * cols_ref_total, (extra_cols, taller, cols_ref_total)
