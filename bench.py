@@ -543,7 +543,10 @@ def main():
         # where the round goes: a few MORE rounds with HIP events between the launches (hdsm_dswarm_set_phase_timing; never the rounds
         # ms_per_round is taken from: every event record is a barrier packet in front of the next kernel)
         phases = None
+        plain = os.environ.get("HDSM_BENCH_DLOOP_PLAIN") == "1"   # (scripts/gpu_dloop_trace.sh: a kernel trace of the live rounds only - no event records, no downloads behind them)
         try:
+            if plain:
+                raise RuntimeError("skipped: HDSM_BENCH_DLOOP_PLAIN=1")
             dsw.set_phase_timing(True)
             acc, n_t = {}, max(4, min(K, 8))
             for _ in range(n_t):
@@ -565,7 +568,7 @@ def main():
         # obstacle worlds, one rank: a bounded comparison of the device corridor (k_corridor) with the literal restatement of
         # GenerateSafeCorridor (oracle/hdsm_oracle.c: orc_safe_corridor, AC:1236-1447) on a sample of agents of two further live rounds
         corridor = None
-        if world == 1 and world_occ is not None and rank == 0 and not args.no_cpu_baseline_corridor:
+        if world == 1 and world_occ is not None and rank == 0 and not args.no_cpu_baseline_corridor and not plain:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import corridor_oracle as co

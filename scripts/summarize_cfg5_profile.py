@@ -14,9 +14,9 @@ import os
 import sys
 
 tag = sys.argv[1]
-name = sys.argv[2] if len(sys.argv) > 2 else "cfg5"   # cfg5 (default) or cfg3: which secondary workload of the line was profiled
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else "cfg5"   # cfg5 (default) or cfg3: which secondary workload of the line was profiled
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(root, "gpurun_out", tag + "_" + name)
+out_dir = os.path.join(root, "gpurun_out", tag + "_" + cfg_name)
 line = json.loads(open(os.path.join(out_dir, "trace_bench.json")).read().strip().splitlines()[-1])
 plain = json.loads(open(os.path.join(out_dir, "bench.json")).read().strip().splitlines()[-1])
 K = line["steps"]
@@ -98,7 +98,7 @@ if "SQ_INSTS_VALU" in v and t_round_ns:
     roof["valu_issue_utilisation"] = v["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * t_round_ns * 1e-9)
 summ["roofline"] = roof
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
-json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_{name}_roofline.json"), "w"), indent=1)
+json.dump(summ, open(os.path.join(root, "profiles", f"{tag}_{cfg_name}_roofline.json"), "w"), indent=1)
 if "hbm_bytes_per_launch" in summ:
     json.dump(summ, open(os.path.join(root, "profiles", f"pmc_{key}.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1)[:4000])

@@ -370,3 +370,64 @@ def test_cooperative_voxel_decomposition_matches_the_host_bit_for_bit(wave, wnam
         assert cells[t] == voxels, (wname, t)
         chamfered += len(want) > 6
     assert chamfered >= 3
+
+
+def _with_contained_copies(sn, P, RS):
+    """Every instance gets, next to each of its polyhedra, a COPY with its first row pulled in by 0.05 (contained in the original),
+    up to P polyhedra: [P0, P1] -> [P0, P1, P0', P1']. The MIQP optimum cannot change: whatever lies in a copy lies in its original."""
+    out = dict(sn)
+    n_poly, n_rows, A, b = sn["n_poly"].copy(), sn["n_rows"].copy(), sn["A"].copy(), sn["b"].copy()
+    for a in range(len(n_poly)):
+        k0 = int(n_poly[a])
+        for j in range(k0):
+            if n_poly[a] >= P:
+                break
+            jn = int(n_poly[a])
+            r = int(n_rows[a, j])
+            A[a, jn, :r], b[a, jn, :r] = A[a, j, :r], b[a, j, :r]
+            b[a, jn, 0] -= 0.05 * np.linalg.norm(A[a, j, 0])
+            n_rows[a, jn] = r
+            n_poly[a] = jn + 1
+    out.update(n_poly=n_poly, n_rows=n_rows, A=A, b=b)
+    return out
+
+
+def test_dominated_polyhedra_are_taken_out_of_the_choice(wave, oracle, monkeypatch):
+    """Round 6 (hdsm_core.h, dominated_mask): a polyhedron contained in another polyhedron of the instance is neither a container nor a
+    choice. Instances whose corridors force branching, each polyhedron accompanied by a slightly smaller copy of itself: the answer is
+    the oracle's answer for the ORIGINAL polyhedra (and for the padded ones: the oracle does not know the rule), with the rule and
+    without it (HDSM_DOMINANCE=0), and with the rule the trees are no larger than those of the original instances — without it every
+    copy multiplies them. A corridor of ONE polyhedron and its copy is a pure QP: one node (the copy is dominated, the survivor's rows
+    are assigned to every uncontained step at once)."""
+    prm = make_params(n_hor=10, max_rows_static=18, poly_hor=4)
+    tot = {"orig": 0, "on": 0, "off": 0}
+    for seed in (3, 5, 21):
+        sn = problems.swarm_snapshot(prm, 10, seed, narrow=True, turn=True, chamfer=(seed % 2 == 1))
+        sn["n_poly"] = np.minimum(sn["n_poly"], 2)          # two polyhedra + their two copies
+        pad = _with_contained_copies(sn, prm.poly_hor, prm.max_rows_static)
+        assert (pad["n_poly"] == 2 * sn["n_poly"]).all()
+        o = oracle.replan(prm, *[sn[k] for k in ARG_KEYS], n_threads=8)
+        compare(oracle.replan(prm, *[pad[k] for k in ARG_KEYS], n_threads=8), o)   # (the copies change nothing: the oracle agrees)
+        e0 = wave.replan(prm, *[sn[k] for k in ARG_KEYS])
+        compare(e0, o)
+        e1 = wave.replan(prm, *[pad[k] for k in ARG_KEYS])
+        compare(e1, o)
+        monkeypatch.setenv("HDSM_DOMINANCE", "0")
+        e2 = wave.replan(prm, *[pad[k] for k in ARG_KEYS])
+        monkeypatch.delenv("HDSM_DOMINANCE")
+        compare(e2, o)
+        # a copy is never the polyhedron an answer names (its original contains the segment too, and comes first)
+        assert not e1["used"][:, 2:].any() or (e1["nodes"] == 1).all()
+        tot["orig"] += int(e0["nodes"].sum())
+        tot["on"] += int(e1["nodes"].sum())
+        tot["off"] += int(e2["nodes"].sum())
+    assert tot["orig"] > 3 * 10, tot                         # the cases do branch
+    assert tot["on"] <= tot["orig"] and tot["off"] > tot["on"], tot
+    # one polyhedron + its copy: no tree at all
+    sn = problems.swarm_snapshot(prm, 10, 5, narrow=True, turn=True, chamfer=True)
+    sn["n_poly"] = np.minimum(sn["n_poly"], 1)
+    pad = _with_contained_copies(sn, prm.poly_hor, prm.max_rows_static)
+    o = oracle.replan(prm, *[sn[k] for k in ARG_KEYS], n_threads=8)
+    e = wave.replan(prm, *[pad[k] for k in ARG_KEYS])
+    compare(e, o)
+    assert (e["nodes"] == 1).all(), e["nodes"].tolist()
