@@ -891,8 +891,8 @@ def main():
                 continue
             cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-secondary", "--no-event-pass", "--repeats", "3",
                                                                         "--mip-gap", str(gap), "--time-limit-s", str(args.time_limit_s),
-                                                                        "--parity-sample", "64" if gap == 0.0 else "0",
-                                                                        "--parity-seconds", "75" if extra is cfg5 else "40"]
+                                                                        "--parity-sample", "128" if gap == 0.0 else "0",
+                                                                        "--parity-seconds", "75" if extra is cfg5 else "60"]
             if gap == args.mip_gap:   # (the record at Gurobi's MIPGap repeats the window only: no second device-loop pass)
                 cmd.append("--device-loop")
             # (a profiler attached to this process must see this line's launches only: the children run without its preload)

@@ -478,7 +478,8 @@ struct Solver {
         // (the assignment holds at every node of the instance; it is made at the root, where the mask is computed, or found again by an item)
         const unsigned alive = ~dom & ((1u << np) - 1u);
         bool forced = false;  // (wave-uniform)
-        if (open != 0ull && dom != 0u && (alive & (alive - 1u)) == 0u) {
+        // (also when the instance came with one polyhedron: step-by-step branching with one child per level was a node per step)
+        if (open != 0ull && c.dominance != 0 && (alive & (alive - 1u)) == 0u) {
           const int j0 = __builtin_ffs((int)alive) - 1;
           // (a step whose pinned end point lies outside j0 has no admissible polyhedron at all: the ordinary path below reports it — no child)
           const bool admissible = __ballot(lane < N && cont < 0 && !(s.keys[lane][j0] < DINF)) == 0ull;
@@ -1594,6 +1595,11 @@ struct Solver {
       if (IS_T0) wp[0] = cnt | ((certificate || gridlock) ? WARM_CERT : 0);
     }
 #ifdef HDSM_TIMELINE
+    if (HDSM_TX == 64 && a.prof) {  // ... and where its second wavefront (the scanner) sat (scripts/timeline_simd.py)
+      unsigned hw1;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw1));
+      a.prof[(int64_t)inst * 32 + 30] = (long long)hw1;
+    }
     if (IS_T0 && a.prof) {  // development aid (scripts/gpu_timeline.sh): when and where this instance ran
       long long* pr = a.prof + (int64_t)inst * 32;
       unsigned hw;
@@ -1623,7 +1629,15 @@ struct Solver {
         // longest of the launch, and starting a short one early costs nothing
         // (+ 9 units per row of the final working set: next to the duration, the size of the active set is what predicts the
         // next replan's length best on the crossing rounds — list-scheduling replay of recorded launches, profiles/README.md)
-        const long long ticks = (((long long)wall_clock64() - tl_begin_) >> 6) + 9 * s.q;
+        // (n > 30: instances last hundreds of microseconds — in 0.64-us units every one of them beyond 163 us carried the SAME key, 254, and
+        // the long ones of a cfg 5 launch started in arbitrary order: 19 of 20 launches were set by a late starter, span 1.37 ms against
+        // 0.90 ms for the slowest instance. 2.56-us units there: 650 us before the key saturates, and still 30 levels for the 85-us instances of an open-space H = 15 round)
+#ifdef HDSM_OLD_KEY
+        constexpr int KEY_SHIFT = 6;
+#else
+        constexpr int KEY_SHIFT = NV > 32 ? 8 : 6;
+#endif
+        const long long ticks = (((long long)wall_clock64() - tl_begin_) >> KEY_SHIFT) + ((9 * s.q) >> (KEY_SHIFT - 6));
         a.st_key[out] = status == ST_NO_SOLUTION ? 255 : (int)(ticks < 0 ? 0 : (ticks > 254 ? 254 : ticks));
       }
       if (a.ovf_flag != nullptr && (flags & FLAG_STAGING_OVERFLOW)) *a.ovf_flag = 1;
@@ -1730,7 +1744,13 @@ HD void split_merge(int N, int P, const Args& a, const Args& b, int inst, int la
     a.st_iters[inst] = iters, a.st_nodes[inst] = nodes, a.st_sweeps[inst] = sweeps, a.st_cand[inst] = cand;
     if (a.st_sph) a.st_sph[inst] = sph, a.st_pairs[inst] = pairs;
     a.st_flags[inst] = flags;
+#ifdef HDSM_OLD_KEY
     if (a.st_key) a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : 254;  // a deep tree: launch it first next time
+#else
+    // a deep tree: early next time — among the handed-over instances in the order of what pass 1 spent on them (its own key stays: what
+    // the next pass 1 will spend is what the launch order has to predict; 254 for all of them left their order to chance)
+    if (a.st_key) a.st_key[inst] = status == ST_NO_SOLUTION ? 255 : (a.st_key[inst] > 128 ? a.st_key[inst] : 128);
+#endif
   }
 }
 

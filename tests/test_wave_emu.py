@@ -431,3 +431,7 @@ def test_dominated_polyhedra_are_taken_out_of_the_choice(wave, oracle, monkeypat
     e = wave.replan(prm, *[pad[k] for k in ARG_KEYS])
     compare(e, o)
     assert (e["nodes"] == 1).all(), e["nodes"].tolist()
+    # ... and so is a corridor that comes with one polyhedron (step-by-step branching with one child per level was a node per step)
+    e = wave.replan(prm, *[sn[k] for k in ARG_KEYS])
+    compare(e, o)
+    assert (e["nodes"] == 1).all(), e["nodes"].tolist()
