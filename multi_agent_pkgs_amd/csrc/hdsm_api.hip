@@ -90,7 +90,8 @@ __device__ __forceinline__ void run_block(typename Sol::S* sp, const hdsm::Const
           timed_out = false;
           break;
         }
-        // (hundreds of workgroups may be waiting, and every look is a device-scope read that no L2 can serve)
+        // (hundreds of workgroups may be waiting, and every look is a device-scope read that no L2 can serve. Letting the few whose
+        // tickets come next look without sleeping was measured in round 6: no difference on cfg 3 or cfg 5 — scripts/gpu_r6_poll_ab.sh)
         for (int w = 0; w < psleep; ++w) __builtin_amdgcn_s_sleep(127);
       }
       if (timed_out) atomicExch(&rcnt[6], 1);  // (items left in the queue stay ST_PENDING: the merge reports their instances as LIMIT)
@@ -284,13 +285,23 @@ __device__ void launch_order_block(int n_inst, const int32_t* __restrict__ key_p
     atomicAdd(&bucket[255 - (it < 0 ? 0 : (it > 255 ? 255 : it))], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int b = 0; b < 256; ++b) {
-      const int c = bucket[b];
-      bucket[b] = run;
-      run += c;
+  // exclusive prefix over the 256 buckets, a bucket per thread (every launch of this block has 256 threads): scan inside the wavefront,
+  // then the totals of the wavefronts before. (One thread walked the buckets before round 6, 256 dependent LDS round trips; the bench line
+  // does not see the difference — the pre-pass launch is as long as its set-up map tiles.)
+  {
+    __shared__ int wave_total[4];
+    const int c = bucket[tid & 255];
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if ((tid & 63) >= off) incl += v;
     }
+    if ((tid & 63) == 63) wave_total[(tid >> 6) & 3] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < ((tid >> 6) & 3); ++w) base += wave_total[w];
+    if (tid < 256) bucket[tid] = base + incl - c;
   }
   __syncthreads();
   for (int k = tid; k < n_inst; k += nt) {

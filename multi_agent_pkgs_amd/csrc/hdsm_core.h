@@ -1120,7 +1120,6 @@ struct Solver {
     // search had accumulated: staged rows in their slots (the working set of the snapshot names them), conflicts, the displacement
     // reference of the sweeps, the assignments of the path down to the item's level; the snapshot of that level is the solver state.
     bool item_run = false;
-    int sweeps0 = 0;
     if (item >= 0) {
       const SplitRec& rc = a.recs[item >> 8];
       const int L = (item >> 3) & 15, pos = item & 7;
@@ -1153,7 +1152,7 @@ struct Solver {
       if (item_run) snapshot_io(s, c, R, const_cast<double*>(rc.snap) + (int64_t)L * SNAP_STRIDE, false);
       if (IS_T0) s.neq_done = 6;
       run = item_run;
-      sweeps = sweeps0 = rc.sweeps_done;  // (a staging sweep that pass 1 has made is not made again: the rows are here)
+      sweeps = rc.sweeps_done;  // (a staging sweep that pass 1 has made is not made again: the rows are here)
       nodes = item_run ? 1 : 0;
     }
     SYNC();
@@ -1618,7 +1617,8 @@ struct Solver {
       a.status[out] = status;
       if (a.st_iters) a.st_iters[out] = iters;
       if (a.st_nodes) a.st_nodes[out] = nodes;
-      if (a.st_sweeps) a.st_sweeps[out] = sweeps - sweeps0;
+      // (the sweeps pass 1 had made come from the record again: carried in a register from the hand-over to here they were one more value to spill)
+      if (a.st_sweeps) a.st_sweeps[out] = sweeps - (item >= 0 ? a.recs[item >> 8].sweeps_done : 0);
       if (a.st_cand) a.st_cand[out] = s.ncand + s.ncold;
       if (a.st_sph) a.st_sph[out] = s.st_sph;
       if (a.st_pairs) a.st_pairs[out] = s.st_pairs;

@@ -73,6 +73,17 @@ for name, num, den in (("us_per_regular_op", 4, 3), ("us_per_warm_op", 6, 5)):
             c = np.linalg.lstsq(A, R[m, num], rcond=None)[0]
             res["overlap %.2f..%.2f" % (lo, hi)] = {"n": int(m.sum()), "const_us": round(float(c[0]), 3), "per_op_us": round(float(c[1]), 3)}
     out[name + "_by_mate_overlap"] = res
+# the slowest instance of every launch: operations against what is left in the working set at the end
+B = ev
+slow_rows = []
+for b in B:
+    j = int(np.argmax(b[:, 1] - b[:, 0]))
+    slow_rows.append((float((b[j, 1] - b[j, 0]) * 0.01), int(b[j, 4]), int(b[j, 18]), int(b[j, 13]), int(b[j, 6]), int(b[j, 7]), int(b[j, 10])))
+out["slowest_instance_per_launch (us, operations, warm operations, final working set, sweeps, staged rows, status)"] = slow_rows
+allb = np.vstack(B)
+long_ = (allb[:, 1] - allb[:, 0]) * 0.01 > 50.0
+out["instances_longer_than_50us"] = {"n": int(long_.sum()), "operations_mean": float(allb[long_, 4].mean()), "warm_operations_mean": float(allb[long_, 18].mean()),
+                                      "final_working_set_mean": float(allb[long_, 13].mean()), "status_counts": {int(k): int(v) for k, v in zip(*np.unique(allb[long_, 10], return_counts=True))}}
 print(json.dumps(out, indent=1))
 for e in examples:
     print(e)
